@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE's own nn code (build container only).
+
+    python tests/golden/generate_golden.py          # writes tests/golden/*.npz
+
+The reference (`/root/reference/src/torch_m3gnet`) imports four third-party packages that are
+absent from this image (torch_scatter, torchtyping, torch_geometric, pymatgen).  The tiny stand-ins
+under tests/golden/_shims/ (our code, annotations/containers/index-add only) let its nn modules
+import unchanged; every number written here is produced by the reference's forward/backward code.
+The reference never travels to the GPU box: only the .npz fixtures (data) and this script do.
+
+Cases:
+  cu32   BASELINE config 1: jittered 32-atom fcc Cu, default model (cutoff 5/4, l=n=3, D=64, 3 blocks)
+  tio    Ti8O24 cell of the reference's tests/conftest.py:45-86, default model
+  alna   Al-fcc(4)+Na-bcc(2) batch of tests/conftest.py:89-115, perturbed as tests/test_model.py:90-95,
+         small test model (l_max=2, n_max=3, 93 types, dim 17, 2 blocks)
+  mix    two random-species cells batched, non-unit length/energy scales and elemental energies
+Each case is stored in two `factors` modes:
+  ref    NormalizedSphericalBessel.factors exactly as the reference constructs them
+  doc    factors overwritten by the documented normalisation 1/(sqrt(2/rc^3)/|j_{l+1}(z_ln)|)
+         (docs/architecture.md:127-132) so the three-body path is numerically visible.
+"""
+from __future__ import annotations
+
+import importlib.util
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(HERE / "_shims"))
+sys.path.insert(1, "/root/reference/src")
+
+from torch_geometric.data import Batch  # noqa: E402  (stand-in container)
+from torch_m3gnet.data import MaterialGraphKey as K  # noqa: E402  (REFERENCE package)
+from torch_m3gnet.data.material_graph import compute_threebody  # noqa: E402
+from torch_m3gnet.model.build import build_model  # noqa: E402
+from torch_m3gnet.nn.interaction import SPHERICAL_BESSEL_ZEROS, spherical_bessel  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "m3g_neighbors", REPO / "torch-m3gnet_amd" / "torch_m3gnet" / "data" / "neighbors.py"
+)
+nb = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(nb)
+
+
+# ------------------------------------------------------------------ structures
+def fcc_cu(nx, ny, nz, a=3.61, jitter=0.025, seed=0):
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    g = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"), -1)
+    frac = (g.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a
+    rng = np.random.default_rng(seed)
+    pos = frac + rng.uniform(-jitter, jitter, frac.shape)
+    return np.diag([nx * a, ny * a, nz * a]).astype(float), pos, np.full(len(pos), 29)
+
+
+def ti8o24():
+    a = 8.01
+    coords = np.array(
+        [
+            [0.005698, 7.903250, 7.975364], [7.962333, 0.031776, 4.087014], [7.987993, 4.053572, 7.916418],
+            [7.972553, 3.990096, 3.904352], [3.901632, 0.009469, 0.015298], [4.061435, 7.980741, 3.923483],
+            [4.075226, 3.974756, 0.060859], [3.997434, 3.997462, 3.900065], [0.002131, 2.089909, 2.043724],
+            [7.935880, 2.054631, 6.053889], [7.986174, 5.996277, 1.901030], [0.073084, 5.950515, 5.952990],
+            [4.057353, 2.078078, 1.975213], [4.049787, 2.018112, 6.084813], [3.971569, 5.919147, 2.051521],
+            [3.945378, 6.072591, 6.041797], [1.964716, 0.069527, 2.062618], [1.928378, 7.984901, 6.068134],
+            [1.990663, 4.042357, 2.090104], [1.974315, 3.921490, 6.056360], [6.008068, 7.938413, 2.078371],
+            [5.953855, 0.062646, 6.062819], [5.900438, 4.009349, 1.999860], [6.040758, 3.924354, 6.051151],
+            [1.936480, 1.932966, 0.038363], [2.043398, 1.921099, 3.956512], [1.983471, 5.951049, 0.085619],
+            [2.010997, 6.095910, 4.026083], [5.955844, 1.984438, 7.911637], [6.075395, 1.996245, 4.065586],
+            [6.080717, 5.987091, 7.942396], [5.983861, 5.933218, 3.927338],
+        ]
+    )  # data of the reference fixture tests/conftest.py:45-86
+    return np.eye(3) * a, coords, np.array([22] * 8 + [8] * 24)
+
+
+def al_na():
+    r_nn = 3.0
+    al = (r_nn * math.sqrt(2) * np.eye(3), np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]]), np.full(4, 13))
+    na = (r_nn / math.sqrt(3) * 2 * np.eye(3), np.array([[0, 0, 0], [0.5, 0.5, 0.5]]), np.full(2, 11))
+    out = []
+    for lat, frac, z in (al, na):
+        out.append((lat, frac @ lat, z))
+    return out, r_nn + 1e-4
+
+
+def random_cell(n_atoms, box, seed, zmax=94, dmin=1.6):
+    rng = np.random.default_rng(seed)
+    pos = []
+    lat = np.eye(3) * box
+    while len(pos) < n_atoms:
+        p = rng.uniform(0, box, 3)
+        ok = True
+        for q in pos:
+            dv = p - q
+            dv -= box * np.round(dv / box)
+            if np.linalg.norm(dv) < dmin:
+                ok = False
+                break
+        if ok:
+            pos.append(p)
+    return lat, np.array(pos), rng.integers(1, zmax + 1, n_atoms)
+
+
+# ------------------------------------------------------------------ graph assembly
+def single_graph(lat, pos, z, cutoff, tb_cutoff, use_reference_threebody=True):
+    ei, shift, dist = nb.neighbor_list(lat, pos, cutoff)
+    n = len(pos)
+    if use_reference_threebody:
+        tei, nti, ntij = compute_threebody(n, torch.as_tensor(ei), torch.as_tensor(dist, dtype=torch.float), tb_cutoff)
+        tei = tei.numpy()
+    else:
+        tei, nti, ntij = nb.threebody_index(n, ei, dist.astype(np.float32), tb_cutoff)
+    # our vectorised enumeration must give the reference's list exactly
+    tei2, _, _ = nb.threebody_index(n, ei, dist.astype(np.float32), tb_cutoff)
+    assert np.array_equal(tei, tei2), "threebody_index disagrees with reference compute_threebody"
+    return dict(pos=pos.astype(np.float32), z=z, ei=ei, shift=shift, tei=tei, lat=lat.astype(np.float32))
+
+
+def collate(graphs):
+    """Concatenate with the index offsets of MaterialGraph.__inc__ (material_graph.py:122-130)."""
+    g = Batch()
+    n_off = e_off = 0
+    pos, types, ei, shift, tei, lat, batch = [], [], [], [], [], [], []
+    for s, gr in enumerate(graphs):
+        n, e = len(gr["pos"]), gr["ei"].shape[1]
+        pos.append(gr["pos"]); types.append(gr["z"] - 1)
+        ei.append(gr["ei"] + n_off); shift.append(gr["shift"]); tei.append(gr["tei"] + e_off)
+        lat.append(gr["lat"][None]); batch.append(np.full(n, s))
+        n_off += n; e_off += e
+    g[K.POS] = torch.tensor(np.concatenate(pos), dtype=torch.float)
+    g[K.ATOM_TYPES] = torch.tensor(np.concatenate(types), dtype=torch.long)
+    g[K.EDGE_INDEX] = torch.tensor(np.concatenate(ei, axis=1), dtype=torch.long)
+    g[K.EDGE_CELL_SHIFT] = torch.tensor(np.concatenate(shift), dtype=torch.int)
+    g[K.TRIPLET_EDGE_INDEX] = torch.tensor(np.concatenate(tei, axis=1), dtype=torch.long)
+    g[K.LATTICE] = torch.tensor(np.concatenate(lat), dtype=torch.float)
+    g[K.BATCH] = torch.tensor(np.concatenate(batch), dtype=torch.long)
+    g[K.NUM_NODES] = n_off
+    return g
+
+
+# ------------------------------------------------------------------ running the reference
+def documented_factors(cutoff, l_max, n_max):
+    z = torch.tensor(SPHERICAL_BESSEL_ZEROS, dtype=torch.float64)
+    rows = []
+    for order in range(l_max):
+        rows.append(math.sqrt(2 / cutoff**3) / torch.abs(spherical_bessel(z[order, :n_max], order + 1)))
+    # chi = j / factors  ->  factors := 1 / documented multiplier
+    return (1.0 / torch.stack(rows)).to(torch.float)
+
+
+def run_case(name, model, graph_np_list, mode, out):
+    g = collate(graph_np_list)
+    seq = model.model
+    tb_modules = [m for m in seq if type(m).__name__ == "ThreeBodyInteration"]
+    if mode == "doc":
+        for m in tb_modules:
+            m.nsb.factors = documented_factors(m.nsb.cutoff, m.nsb.l_max, m.nsb.n_max)
+    inter = {}
+    hooks = []
+    for b, m in enumerate(tb_modules):
+        hooks.append(m.gated_mlp.register_forward_hook(lambda mod, inp, outp, b=b: inter.__setitem__(f"mid_edge_features_{b}", inp[0].detach().clone())))
+    idx = 0
+    for i, m in enumerate(seq):
+        cls = type(m).__name__
+        hooks.append(m.register_forward_hook(lambda mod, inp, outp, cls=cls, i=i: _capture(inter, cls, i, outp)))
+    res = model(g)
+    for h in hooks:
+        h.remove()
+    d = {}
+    for key in (K.POS, K.ATOM_TYPES, K.EDGE_CELL_SHIFT, K.LATTICE, K.BATCH):
+        d["in_" + key] = g[key].detach().numpy()
+    d["in_edge_index"] = g[K.EDGE_INDEX].numpy().astype(np.int32)
+    d["in_triplet_edge_index"] = g[K.TRIPLET_EDGE_INDEX].numpy().astype(np.int32)
+    for key in (K.EDGE_DISTANCES, K.TRIPLET_ANGLES, K.EDGE_WEIGHTS, K.NODE_FEATURES, K.EDGE_ATTR,
+                K.SCALED_ATOMIC_ENERGIES, K.SCALED_TOTAL_ENERGY, K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+        d["out_" + key] = res[key].detach().numpy()
+    for k, v in inter.items():
+        d["mid_" + k] = v.numpy()
+    d["const_factors"] = tb_modules[0].nsb.factors.detach().numpy()
+    d["const_em"] = seq[4].em.numpy(); d["const_dm"] = seq[4].dm.numpy(); d["const_coeff"] = seq[4].coeff.numpy()
+    out[f"{name}_{mode}"] = d
+
+
+def _capture(inter, cls, i, graph):
+    if cls == "AtomFeaturizer":
+        inter["x0"] = graph[K.NODE_FEATURES].detach().clone()
+    elif cls == "EdgeAdjustor":
+        inter["edge_attr0"] = graph[K.EDGE_ATTR].detach().clone()
+    elif cls == "ThreeBodyInteration":
+        if i == 6:  # block 0 only (size)
+            inter["edge_attr_tb0"] = graph[K.EDGE_ATTR].detach().clone()
+    elif cls == "M3GNetConv":
+        b = (i - 7) // 2
+        inter[f"x_{b}"] = graph[K.NODE_FEATURES].detach().clone()
+        if b == 0:
+            inter["edge_attr_conv0"] = graph[K.EDGE_ATTR].detach().clone()
+
+
+def save_model(path, model, cfg):
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    sd["__elemental_energies"] = model.model[1].elemental_energies.detach().numpy()
+    for k, v in cfg.items():
+        sd["__cfg_" + k] = np.asarray(v)
+    np.savez_compressed(path, **sd)
+
+
+def main():
+    torch.set_num_threads(1)  # deterministic reduction order
+    out = {}
+
+    # default model, seed 0
+    cfg_default = dict(cutoff=5.0, threebody_cutoff=4.0, l_max=3, n_max=3, num_types=95, embedding_dim=64,
+                       num_blocks=3, energy_scale=1.0, length_scale=1.0)
+    def make(cfg, seed, elemental=None):
+        torch.manual_seed(seed)
+        return build_model(cfg["cutoff"], cfg["threebody_cutoff"], cfg["l_max"], cfg["n_max"], cfg["num_types"],
+                           cfg["embedding_dim"], cfg["num_blocks"], elemental_energies=elemental,
+                           energy_scale=cfg["energy_scale"], length_scale=cfg["length_scale"])
+
+    for mode in ("ref", "doc"):
+        m = make(cfg_default, 0)
+        if mode == "ref":
+            save_model(HERE / "model_default_seed0.npz", m, cfg_default)
+        lat, pos, z = fcc_cu(2, 2, 2)
+        run_case("cu32", m, [single_graph(lat, pos, z, 5.0, 4.0)], mode, out)
+        m = make(cfg_default, 0)
+        lat, pos, z = ti8o24()
+        run_case("tio", m, [single_graph(lat, pos, z, 5.0, 4.0)], mode, out)
+
+    # small test model of the reference's conftest
+    structs, rc = al_na()
+    cfg_small = dict(cutoff=rc, threebody_cutoff=rc, l_max=2, n_max=3, num_types=93, embedding_dim=17,
+                     num_blocks=2, energy_scale=1.0, length_scale=1.0)
+    rng = np.random.default_rng(1)
+    graphs = []
+    for lat, pos, z in structs:
+        # neighbour list on the ideal lattice (as the reference's fixture does), then perturb positions
+        gr = single_graph(lat, pos, z, rc, rc)
+        gr["pos"] = (pos + 1e-1 * (rng.random(pos.shape) - 0.5)).astype(np.float32)
+        graphs.append(gr)
+    for mode in ("ref", "doc"):
+        m = make(cfg_small, 0)
+        if mode == "ref":
+            save_model(HERE / "model_small_seed0.npz", m, cfg_small)
+        run_case("alna", m, graphs, mode, out)
+
+    # scales / elemental energies / mixed species batch
+    cfg_mix = dict(cutoff=5.0, threebody_cutoff=4.0, l_max=3, n_max=3, num_types=95, embedding_dim=64,
+                   num_blocks=3, energy_scale=2.5, length_scale=1.7)
+    elemental = torch.linspace(-3.0, 2.0, 95)
+    graphs = []
+    for seed, n_at in ((0, 24), (1, 17)):
+        lat, pos, z = random_cell(n_at, 7.3 if seed == 0 else 6.1, seed)
+        graphs.append(single_graph(lat, pos, z, 5.0, 4.0))
+    for mode in ("ref", "doc"):
+        m = make(cfg_mix, 3, elemental)
+        if mode == "ref":
+            save_model(HERE / "model_mix_seed3.npz", m, cfg_mix)
+        run_case("mix", m, graphs, mode, out)
+
+    for name, d in out.items():
+        np.savez_compressed(HERE / f"case_{name}.npz", **d)
+        e = d["out_total_energy"]
+        f = d["out_forces"]
+        print(f"{name:10s} N={len(d['in_pos']):4d} E={d['in_edge_index'].shape[1]:6d} T={d['in_triplet_edge_index'].shape[1]:7d} "
+              f"E_tot={e}  max|F|={np.abs(f).max():.3e}  |m0|max={np.abs(d['mid_mid_edge_features_0']).max():.3e}")
+
+
+if __name__ == "__main__":
+    main()
