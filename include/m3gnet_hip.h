@@ -1,0 +1,154 @@
+/*
+ * m3gnet_hip.h -- C ABI of libm3gnet_hip.so: MI355X (gfx950) M3GNet energy/force engine.
+ *
+ * The reference (lan496/torch-m3gnet) has no FFI: its operator boundary is the Python module
+ * protocol `forward(graph) -> graph` over keyed tensors.  This header is the
+ * plain-C boundary that protocol binds to in the MI355X build: every entry point names the
+ * reference interface it replaces (paths relative to /root/reference/src/torch_m3gnet).
+ *
+ * Conventions
+ *   - all `const float*` / `const int64_t*` / `void*` data arguments are DEVICE pointers unless
+ *     the parameter name starts with `host_`;
+ *   - buffers are caller-owned; the library never allocates inside a hot call -- scratch comes
+ *     from the caller (sizes from m3g_workspace_bytes / m3g_topology_bytes);
+ *   - every call takes the HIP stream to enqueue on (`hipStream_t` passed as void*); calls are
+ *     asynchronous with respect to the host unless stated otherwise;
+ *   - return value: 0 = M3G_OK, otherwise an m3g_status; m3g_last_error() gives a message
+ *     (thread-local).  The Python host turns M3G_ERR_VALUE into ValueError (the reference raises
+ *     ValueError for too-large l_max/n_max, nn/interaction.py:250-253) and the rest into RuntimeError;
+ *   - thread-compatible: no global mutable state; one plan may be used from one thread at a time.
+ *
+ * Tensor layouts are those of the reference's MaterialGraph (data/material_graph.py:14-107):
+ *   pos [N,3] f32, atom_types [N] i64 (Z-1), edge_index [2,E] i64 (row 0 centre i, row 1
+ *   neighbour j, SORTED BY CENTRE), edge_cell_shift [E,3] i32, triplet_edge_index [2,T] i64
+ *   (row 0 = edge ij, row 1 = edge ik, any order), lattice [S,3,3] f32 row-wise, batch [N] i64.
+ */
+#ifndef M3GNET_HIP_H
+#define M3GNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  M3G_OK = 0,
+  M3G_ERR_VALUE = 1,    /* bad hyper-parameter / malformed graph (Python: ValueError) */
+  M3G_ERR_STATE = 2,    /* call order violated (e.g. parameters not committed) */
+  M3G_ERR_SIZE = 3,     /* caller buffer too small */
+  M3G_ERR_HIP = 4,      /* a HIP runtime call failed */
+  M3G_ERR_UNSUPPORTED = 5
+} m3g_status;
+
+/* Hyper-parameters == arguments of build_model (model/build.py:16-28). */
+typedef struct {
+  double cutoff;            /* Angstrom, unscaled (Python float == double, as the reference holds it) */
+  double threebody_cutoff;  /* Angstrom, unscaled */
+  double energy_scale;
+  double length_scale;
+  int32_t l_max;
+  int32_t n_max;
+  int32_t num_types;
+  int32_t embedding_dim;
+  int32_t num_blocks;
+  int32_t reserved;
+} m3g_config;
+
+typedef struct m3g_plan m3g_plan; /* opaque: packed weights + constants + kernel selection */
+
+/* Library / device probe.  Returns M3G_OK and fills the fields when a gfx950 device is usable. */
+typedef struct {
+  int32_t abi_version;
+  int32_t device_count;
+  char arch[32]; /* gcnArchName of the current device, "" when none */
+} m3g_info;
+int m3g_get_info(m3g_info* out);
+const char* m3g_last_error(void);
+
+/* ---- plan: replaces module construction in build_model (model/build.py:37-81) -------------- */
+int m3g_plan_create(const m3g_config* cfg, m3g_plan** out);
+void m3g_plan_destroy(m3g_plan* plan);
+
+/* Set one parameter by its reference state_dict key ("model.7.concat_edge_update.dense.0.weight",
+ * ...).  HOST pointer, row-major as torch stores it, `numel` floats.  Unknown key
+ * or wrong size -> M3G_ERR_VALUE. */
+int m3g_plan_set_param(m3g_plan* plan, const char* key, const float* host_data, int64_t numel);
+
+/* Constants the reference keeps as plain module attributes (not in state_dict):
+ *   "elemental_energies" [num_types]   AtomRef            (nn/atom_ref.py:17-23)
+ *   "em" "dm" "coeff"     [n_max]      EdgeFeaturizer     (nn/featurizer.py:61-79)
+ *   "factors"             [l_max,n_max] NormalizedSphericalBessel (nn/interaction.py:256-266)
+ *   "bessel_zeros"        [l_max,n_max] rows 0..l_max-1 of SPHERICAL_BESSEL_ZEROS (interaction.py:14-135)
+ * HOST pointers. */
+int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data, int64_t numel);
+
+/* Pack and upload everything set so far (synchronous).  Must be called before any compute call
+ * and again after parameters/constants change.  Missing keys -> M3G_ERR_STATE. */
+int m3g_plan_commit(m3g_plan* plan);
+
+/* ---- topology: replaces nothing in the reference nn (which re-gathers by index on every call);
+ * it converts MaterialGraph index tensors into the receiver-sorted CSR form the kernels use.
+ * Depends on the index tensors only -- reusable across calls while they are unchanged. ---------- */
+int m3g_topology_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, size_t* bytes);
+/* On return (after stream sync) host_flags[0] != 0 means the graph is malformed:
+ *   bit 0: edge_index[0] not sorted; bit 1: index out of range; bit 2: triplet edges with different centres. */
+int m3g_topology_build(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
+                       const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
+                       void* topo, size_t topo_bytes, int32_t* host_flags, void* stream);
+
+/* ---- the hot call: replaces Gradient.forward over the whole Sequential (nn/gradient.py:25-64,
+ * model/build.py:37-81): energies, forces, virial stresses ------------------------------------- */
+int m3g_workspace_bytes(const m3g_plan* plan, int64_t n_atoms, int64_t n_edges, int64_t n_triplets,
+                        int64_t n_structs, size_t* bytes);
+
+typedef struct {
+  /* inputs (MaterialGraph) */
+  int64_t n_atoms, n_edges, n_triplets, n_structs;
+  const float* pos;               /* [N,3] */
+  const int64_t* atom_types;      /* [N] */
+  const int32_t* edge_cell_shift; /* [E,3] */
+  const float* lattice;           /* [S,3,3] */
+  const void* topo;               /* from m3g_topology_build for the same index tensors */
+  const int64_t* triplet_edge_index; /* [2,T] original order; only read when triplet_angles != NULL */
+  /* required outputs */
+  float* total_energy; /* [S]   MaterialGraphKey.TOTAL_ENERGY */
+  float* forces;       /* [N,3] MaterialGraphKey.FORCES (may be NULL: energy only, no reverse pass) */
+  /* optional outputs (NULL to skip) -- the other keys the reference writes */
+  float* stresses;               /* [S,6] Voigt xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62) */
+  float* scaled_total_energy;    /* [S] */
+  float* scaled_atomic_energies; /* [N] */
+  float* node_features;          /* [N,D]  "x" after the last block */
+  float* edge_attr;              /* [E,D]  after the last block */
+  float* edge_distances;         /* [E] (scaled length units) */
+  float* edge_weights;           /* [E,n_max] */
+  float* triplet_angles;         /* [T] cos(theta_jik), original triplet order */
+  float* mid_edge_features;      /* [num_blocks,E,l_max*n_max] three-body aggregate of every block */
+} m3g_io;
+
+int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- stage entry points: the reference modules a caller may run on their own ----------------- */
+/* ScaleLength + DistanceAndAngle (nn/scale.py:24-29, nn/invariant.py:20-59) */
+int m3g_distance_angle(double length_scale, int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
+                       const float* pos, const float* lattice, const int32_t* edge_cell_shift, const void* topo,
+                       const int64_t* triplet_edge_index, float* scratch_unit_vectors /* [E,3] */,
+                       float* edge_distances, float* triplet_angles, void* stream);
+/* EdgeFeaturizer.forward (nn/featurizer.py:81-100); host_em/dm/coeff are HOST arrays [n_max] */
+int m3g_edge_featurizer(int32_t n_max, double scaled_cutoff, const float* host_em, const float* host_dm,
+                        const float* host_coeff, int64_t n_edges, const float* edge_distances, float* edge_weights,
+                        void* stream);
+/* AtomFeaturizer.forward (nn/featurizer.py:33-38): x[a,:] = W[:, types[a]]; weight [D,num_types] DEVICE */
+int m3g_atom_featurizer(int32_t num_types, int32_t dim, const float* weight, int64_t n_atoms,
+                        const int64_t* atom_types, float* x, void* stream);
+/* AtomRef.forward (nn/atom_ref.py:25-29) */
+int m3g_atom_ref(int32_t num_types, const float* elemental_energies, int64_t n_atoms, const int64_t* atom_types,
+                 float* out, void* stream);
+
+#define M3G_ABI_VERSION 1
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3GNET_HIP_H */

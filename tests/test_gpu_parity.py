@@ -1,0 +1,66 @@
+"""GPU parity: the HIP engine (through the torch_m3gnet module API and the C ABI) against
+(1) golden vectors produced by the reference itself and (2) the CPU oracle on the same inputs.
+
+Tolerances (BASELINE.json north_star / SURVEY.md §8(d)): energies 1e-5 relative; forces 1e-4 relative to
+max|F|; three-body aggregate `mid_edge_features` 1e-4 relative in both `factors` modes.
+In `doc` mode with l_max = 3 the reference's own autograd forces are off by up to ~1.1e-4 because of its
+Legendre backward defect (SURVEY finding 2), so there the force check is against the oracle's exact
+derivative, and against the golden forces only at 5e-4.
+"""
+import pytest
+import torch
+
+from helpers import CASES, build_engine_model, engine_graph, load_oracle_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+E_TOL, F_TOL, M_TOL = 1e-5, 1e-4, 1e-4
+
+
+@pytest.mark.parametrize("case,mode", CASES)
+def test_engine_vs_golden_and_oracle(case, mode):
+    from oracle import m3gnet_oracle as orc
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    params, cfg, consts, graph, expect = load_oracle_case(case, mode)
+    model, _ = build_engine_model(case, mode)
+    g = model(engine_graph(graph))
+    torch.cuda.synchronize()
+
+    # ---- against the reference's own numbers
+    assert rel_err(g[K.EDGE_DISTANCES], expect["out_edge_distances"]) < 1e-6
+    assert float((g[K.TRIPLET_ANGLES].cpu() - expect["out_triplet_angles"]).abs().max()) < 2e-6
+    assert rel_err(g[K.EDGE_WEIGHTS], expect["out_edge_weights"]) < 1e-5
+    assert rel_err(g[K.NODE_FEATURES], expect["out_x"]) < 1e-5
+    assert rel_err(g[K.EDGE_ATTR], expect["out_edge_attr"]) < 1e-5
+    assert rel_err(g[K.SCALED_ATOMIC_ENERGIES], expect["out_scaled_atomic_energies"]) < E_TOL
+    e_ref = expect["out_total_energy"]
+    assert float(((g[K.TOTAL_ENERGY].cpu() - e_ref).abs() / e_ref.abs()).max()) < E_TOL
+    if case != "alna":  # alna's neighbours sit on the three-body cutoff: m is ~1e-17, pure rounding
+        for b in range(cfg.num_blocks):
+            key = f"mid_mid_edge_features_{b}"
+            if key in expect:
+                assert rel_err(g[K.MID_EDGE_FEATURES][b], expect[key]) < M_TOL, (b, "mid_edge_features")
+    f_tol_golden = F_TOL if mode == "ref" else 5e-4
+    assert rel_err(g[K.FORCES], expect["out_forces"]) < f_tol_golden
+    assert rel_err(g[K.STRESSES], expect["out_stresses"]) < 5e-4
+
+    # ---- against the oracle's exact derivative (fp64 restatement of the same math)
+    p64, cfg64, c64, graph64, _ = load_oracle_case(case, mode, dtype=torch.float64)
+    o = orc.energy_forces(p64, cfg64, c64, graph64, legendre_backward="exact")
+    assert rel_err(g[K.FORCES], o["forces"]) < F_TOL
+    assert float(((g[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < E_TOL
+    assert rel_err(g[K.STRESSES], o["stresses"]) < F_TOL
+    if case != "alna":
+        for b in range(cfg.num_blocks):
+            assert rel_err(g[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) < M_TOL
+
+
+def test_energy_only_call_matches():
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    _, _, _, graph, expect = load_oracle_case("cu32", "ref")
+    model, _ = build_engine_model("cu32", "ref")
+    g = model(engine_graph(graph), forces=False, extras=False)
+    assert K.FORCES not in g
+    assert rel_err(g[K.TOTAL_ENERGY], expect["out_total_energy"]) < E_TOL

@@ -1,0 +1,463 @@
+// C-ABI entry points of libm3gnet_hip.so: plan (weights + constants), workspace carving and the
+// orchestration of the energy/force pipeline.  See include/m3gnet_hip.h for the contract.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "m3g_internal.h"
+
+namespace m3g {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- weight layout ---------------------------------------------------------------------------------
+static void layout_mlp(MlpW& m, size_t& off) {
+  auto take = [&](size_t n) { size_t r = off; off += (n + 63) / 64 * 64; return r; };
+  m.w1a_t = take(kDP * 2 * kDP); m.w1b_t = take(kDP * 2 * kDP); m.w1c_t = take(kDP * 2 * kDP);
+  m.b1 = take(2 * kDP);
+  m.w2d_t = take(kDP * kDP); m.w2g_t = take(kDP * kDP);
+  m.b2d = take(kDP); m.b2g = take(kDP);
+  m.wl_t = take(kRP * kDP);
+  m.w1a = take(2 * kDP * kDP); m.w1b = take(2 * kDP * kDP); m.w1c = take(2 * kDP * kDP);
+  m.w2d = take(kDP * kDP); m.w2g = take(kDP * kDP);
+  m.wl = take(kDP * kRP);
+}
+
+static WeightLayout make_layout(const m3g_config& cfg) {
+  WeightLayout wl{};
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += (n + 63) / 64 * 64; return r; };
+  wl.emb = take((size_t)cfg.num_types * kDP);
+  wl.adj_t = take(kRP * kDP);
+  wl.adj = take(kDP * kRP);
+  wl.elemental = take(cfg.num_types);
+  for (int b = 0; b < cfg.num_blocks; ++b) {
+    BlockW& bw = wl.blk[b];
+    bw.tb_w1_t = take(kDP * kCP); bw.tb_b1 = take(kCP); bw.tb_w1 = take(kCP * kDP);
+    bw.tb_wd_t = take(kCP * kDP); bw.tb_wg_t = take(kCP * kDP);
+    bw.tb_wd = take(kDP * kCP); bw.tb_wg = take(kDP * kCP);
+    layout_mlp(bw.e, off);
+    layout_mlp(bw.n, off);
+  }
+  ReadoutW& r = wl.ro;
+  r.w1d_t = take(kDP * kDP); r.w1g_t = take(kDP * kDP); r.w2d_t = take(kDP * kDP); r.w2g_t = take(kDP * kDP);
+  r.w1d = take(kDP * kDP); r.w1g = take(kDP * kDP); r.w2d = take(kDP * kDP); r.w2g = take(kDP * kDP);
+  r.b1d = take(kDP); r.b1g = take(kDP); r.b2d = take(kDP); r.b2g = take(kDP);
+  r.w3d = take(kDP); r.w3g = take(kDP); r.b3 = take(2);
+  wl.total = off;
+  return wl;
+}
+
+// expected numel of every state_dict key
+static std::map<std::string, int64_t> expected_params(const m3g_config& c) {
+  std::map<std::string, int64_t> m;
+  const int64_t D = c.embedding_dim, C = (int64_t)c.l_max * c.n_max, R = c.n_max;
+  m["model.3.linear.weight"] = D * c.num_types;
+  m["model.5.linear.weight"] = D * R;
+  char buf[128];
+  for (int b = 0; b < c.num_blocks; ++b) {
+    int tb = 6 + 2 * b, cv = 7 + 2 * b;
+    snprintf(buf, sizeof buf, "model.%d.linear_sigmoid1.weight", tb); m[buf] = C * D;
+    snprintf(buf, sizeof buf, "model.%d.linear_sigmoid1.bias", tb); m[buf] = C;
+    snprintf(buf, sizeof buf, "model.%d.gated_mlp.dense.0.weight", tb); m[buf] = D * C;
+    snprintf(buf, sizeof buf, "model.%d.gated_mlp.gate.0.weight", tb); m[buf] = D * C;
+    for (const char* mlp : {"concat_edge_update", "concat_node_update"}) {
+      for (const char* br : {"dense", "gate"}) {
+        snprintf(buf, sizeof buf, "model.%d.%s.%s.0.weight", cv, mlp, br); m[buf] = D * 3 * D;
+        snprintf(buf, sizeof buf, "model.%d.%s.%s.0.bias", cv, mlp, br); m[buf] = D;
+        snprintf(buf, sizeof buf, "model.%d.%s.%s.2.weight", cv, mlp, br); m[buf] = D * D;
+        snprintf(buf, sizeof buf, "model.%d.%s.%s.2.bias", cv, mlp, br); m[buf] = D;
+      }
+    }
+    snprintf(buf, sizeof buf, "model.%d.edge_linear.weight", cv); m[buf] = D * R;
+    snprintf(buf, sizeof buf, "model.%d.node_linear.weight", cv); m[buf] = D * R;
+  }
+  int ro = 6 + 2 * c.num_blocks;
+  for (const char* br : {"dense", "gate"}) {
+    snprintf(buf, sizeof buf, "model.%d.gated.%s.0.weight", ro, br); m[buf] = D * D;
+    snprintf(buf, sizeof buf, "model.%d.gated.%s.0.bias", ro, br); m[buf] = D;
+    snprintf(buf, sizeof buf, "model.%d.gated.%s.2.weight", ro, br); m[buf] = D * D;
+    snprintf(buf, sizeof buf, "model.%d.gated.%s.2.bias", ro, br); m[buf] = D;
+    snprintf(buf, sizeof buf, "model.%d.gated.%s.4.weight", ro, br); m[buf] = D;
+    snprintf(buf, sizeof buf, "model.%d.gated.%s.4.bias", ro, br); m[buf] = 1;
+  }
+  return m;
+}
+
+static std::map<std::string, int64_t> expected_consts(const m3g_config& c) {
+  return {{"elemental_energies", c.num_types}, {"em", c.n_max}, {"dm", c.n_max}, {"coeff", c.n_max},
+          {"factors", (int64_t)c.l_max * c.n_max}, {"bessel_zeros", (int64_t)c.l_max * c.n_max}};
+}
+
+// out[k][o] (ld = ldo) = in[o][k0 + k] for o < rows, k < cols; `in` is [rows][ldi]
+static void put_t(std::vector<float>& blob, size_t off, int ldo, const float* in, int rows, int ldi, int k0, int cols,
+                  int col_off = 0) {
+  for (int o = 0; o < rows; ++o)
+    for (int k = 0; k < cols; ++k) blob[off + (size_t)k * ldo + col_off + o] = in[(size_t)o * ldi + k0 + k];
+}
+// out[o][k] (ld = ldo) = in[o][k0 + k]
+static void put_n(std::vector<float>& blob, size_t off, int ldo, const float* in, int rows, int ldi, int k0, int cols,
+                  int row_off = 0) {
+  for (int o = 0; o < rows; ++o)
+    for (int k = 0; k < cols; ++k) blob[off + (size_t)(row_off + o) * ldo + k] = in[(size_t)o * ldi + k0 + k];
+}
+
+static void pack_mlp(std::vector<float>& blob, const MlpW& m, const m3g_plan& p, const std::string& pre,
+                     const std::string& lin, int D, int R) {
+  const float* wd1 = p.params.at(pre + ".dense.0.weight").data();
+  const float* wg1 = p.params.at(pre + ".gate.0.weight").data();
+  const size_t parts_t[3] = {m.w1a_t, m.w1b_t, m.w1c_t};
+  const size_t parts_n[3] = {m.w1a, m.w1b, m.w1c};
+  for (int part = 0; part < 3; ++part) {
+    put_t(blob, parts_t[part], 2 * kDP, wd1, D, 3 * D, part * D, D, 0);
+    put_t(blob, parts_t[part], 2 * kDP, wg1, D, 3 * D, part * D, D, kDP);
+    put_n(blob, parts_n[part], kDP, wd1, D, 3 * D, part * D, D, 0);
+    put_n(blob, parts_n[part], kDP, wg1, D, 3 * D, part * D, D, kDP);
+  }
+  const float* bd1 = p.params.at(pre + ".dense.0.bias").data();
+  const float* bg1 = p.params.at(pre + ".gate.0.bias").data();
+  for (int o = 0; o < D; ++o) { blob[m.b1 + o] = bd1[o]; blob[m.b1 + kDP + o] = bg1[o]; }
+  const float* wd2 = p.params.at(pre + ".dense.2.weight").data();
+  const float* wg2 = p.params.at(pre + ".gate.2.weight").data();
+  put_t(blob, m.w2d_t, kDP, wd2, D, D, 0, D); put_t(blob, m.w2g_t, kDP, wg2, D, D, 0, D);
+  put_n(blob, m.w2d, kDP, wd2, D, D, 0, D); put_n(blob, m.w2g, kDP, wg2, D, D, 0, D);
+  const float* bd2 = p.params.at(pre + ".dense.2.bias").data();
+  const float* bg2 = p.params.at(pre + ".gate.2.bias").data();
+  for (int o = 0; o < D; ++o) { blob[m.b2d + o] = bd2[o]; blob[m.b2g + o] = bg2[o]; }
+  const float* wl = p.params.at(lin).data();  // [D,R]
+  put_t(blob, m.wl_t, kDP, wl, D, R, 0, R);
+  put_n(blob, m.wl, kRP, wl, D, R, 0, R);
+}
+
+Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
+  (void)T;
+  Work w{};
+  char* p = (char*)base;
+  size_t off = 0;
+  auto take = [&](size_t n_floats) { float* r = p ? (float*)(p + off) : nullptr; off += align_up(n_floats * sizeof(float)); return r; };
+  size_t e = (size_t)E, n = (size_t)N;
+  w.u = take(e * 3); w.d = take(e); w.h = take(e * kRP); w.hp = take(e * kRP);
+  w.q = take(e * kCP); w.qp = take(e * kCP); w.fc3 = take(e); w.fc3p = take(e);
+  for (int b = 0; b <= c.B; ++b) w.x[b] = take(n * kDP);
+  for (int b = 0; b < c.B; ++b) w.v[b] = take(n * kCP);
+  w.TA = take(n * 4 * kDP); w.TB = take(n * 4 * kDP);
+  w.e = take(e * kDP);
+  for (int b = 0; b < c.B; ++b) w.m[b] = take(e * kCP);
+  for (int b = 0; b < c.B; ++b) w.act[b] = take(e * 8 * kDP);
+  w.dx = take(n * kDP); w.dx2 = take(n * kDP);
+  w.de = take(e * kDP); w.dm = take(e * kCP); w.g = take(e * kCP); w.dg = take(e * kCP);
+  w.dh = take(e * kRP); w.dd = take(e); w.du = take(e * 3); w.dp1 = take(e * 4 * kDP); w.dr = take(e * 3);
+  // scratch for optional outputs the caller did not ask for
+  w.dr = w.dr;
+  off += align_up((n + (size_t)S * 2 + 64) * sizeof(float));
+  w.total_bytes = off;
+  return w;
+}
+
+}  // namespace m3g
+
+using namespace m3g;
+
+extern "C" const char* m3g_last_error(void) { return g_err; }
+
+extern "C" int m3g_get_info(m3g_info* out) {
+  if (!out) return M3G_ERR_VALUE;
+  memset(out, 0, sizeof(*out));
+  out->abi_version = M3G_ABI_VERSION;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  out->device_count = n;
+  if (n > 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      snprintf(out->arch, sizeof(out->arch), "%s", prop.gcnArchName);
+  }
+  return M3G_OK;
+}
+
+extern "C" int m3g_plan_create(const m3g_config* cfg, m3g_plan** out) {
+  if (!cfg || !out) { set_error("m3g_plan_create: null argument"); return M3G_ERR_VALUE; }
+  // the reference's Bessel-root table is 10x10 and needs row l_max (nn/interaction.py:250-253)
+  if (cfg->l_max + 1 > 10) { set_error("Too large l_max is specified."); return M3G_ERR_VALUE; }
+  if (cfg->n_max > 10) { set_error("Too large n_max is specified."); return M3G_ERR_VALUE; }
+  if (cfg->l_max < 1 || cfg->n_max < 1 || cfg->num_types < 1 || cfg->embedding_dim < 1 || cfg->num_blocks < 0) {
+    set_error("m3g_plan_create: non-positive hyper-parameter");
+    return M3G_ERR_VALUE;
+  }
+  if (cfg->threebody_cutoff > cfg->cutoff) {  // data/material_graph.py:149-150
+    set_error("Three body cutoff raidus should be smaller than two body.");
+    return M3G_ERR_VALUE;
+  }
+  if (cfg->l_max > kLCap || cfg->n_max > kRCap || cfg->embedding_dim > kDP || cfg->num_blocks > kMaxBlocks) {
+    set_error("unsupported size: this build handles l_max<=%d, n_max<=%d, embedding_dim<=%d, num_blocks<=%d", kLCap, kRCap,
+              kDP, kMaxBlocks);
+    return M3G_ERR_UNSUPPORTED;
+  }
+  m3g_plan* p = new m3g_plan();
+  p->cfg = *cfg;
+  p->wl = make_layout(*cfg);
+  *out = p;
+  return M3G_OK;
+}
+
+extern "C" void m3g_plan_destroy(m3g_plan* plan) {
+  if (!plan) return;
+  if (plan->d_weights) (void)hipFree(plan->d_weights);
+  delete plan;
+}
+
+extern "C" int m3g_plan_set_param(m3g_plan* plan, const char* key, const float* host_data, int64_t numel) {
+  if (!plan || !key || !host_data) { set_error("m3g_plan_set_param: null argument"); return M3G_ERR_VALUE; }
+  auto exp = expected_params(plan->cfg);
+  auto it = exp.find(key);
+  if (it == exp.end()) { set_error("unknown parameter key '%s'", key); return M3G_ERR_VALUE; }
+  if (it->second != numel) { set_error("parameter '%s': expected %lld values, got %lld", key, (long long)it->second, (long long)numel); return M3G_ERR_VALUE; }
+  plan->params[key].assign(host_data, host_data + numel);
+  plan->committed = false;
+  return M3G_OK;
+}
+
+extern "C" int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data, int64_t numel) {
+  if (!plan || !name || !host_data) { set_error("m3g_plan_set_const: null argument"); return M3G_ERR_VALUE; }
+  auto exp = expected_consts(plan->cfg);
+  auto it = exp.find(name);
+  if (it == exp.end()) { set_error("unknown constant '%s'", name); return M3G_ERR_VALUE; }
+  if (it->second != numel) { set_error("constant '%s': expected %lld values, got %lld", name, (long long)it->second, (long long)numel); return M3G_ERR_VALUE; }
+  plan->cvals[name].assign(host_data, host_data + numel);
+  plan->committed = false;
+  return M3G_OK;
+}
+
+extern "C" int m3g_plan_commit(m3g_plan* plan) {
+  if (!plan) { set_error("m3g_plan_commit: null plan"); return M3G_ERR_VALUE; }
+  const m3g_config& cfg = plan->cfg;
+  for (auto& kv : expected_params(cfg))
+    if (!plan->params.count(kv.first)) { set_error("parameter '%s' was never set", kv.first.c_str()); return M3G_ERR_STATE; }
+  for (auto& kv : expected_consts(cfg))
+    if (!plan->cvals.count(kv.first)) { set_error("constant '%s' was never set", kv.first.c_str()); return M3G_ERR_STATE; }
+  const int D = cfg.embedding_dim, R = cfg.n_max, L = cfg.l_max, C = L * R, B = cfg.num_blocks;
+
+  // ---- constants (fp32 arithmetic in the reference's order; see oracle make_constants/radial_basis) ----
+  Consts& c = plan->consts;
+  memset(&c, 0, sizeof(c));
+  c.L = L; c.R = R; c.C = C; c.D = D; c.B = B; c.num_types = cfg.num_types;
+  c.length_scale = (float)cfg.length_scale;
+  c.energy_scale = (float)cfg.energy_scale;
+  c.inv_len = 1.f / c.length_scale;
+  const double rc = cfg.cutoff / cfg.length_scale, rc3 = cfg.threebody_cutoff / cfg.length_scale;  // model/build.py:34-35
+  c.rc = (float)rc;
+  c.rc3 = (float)rc3;
+  const float pi_f = (float)M_PI;
+  const auto& em = plan->cvals.at("em");
+  const auto& dm = plan->cvals.at("dm");
+  for (int m = 0; m < R; ++m) {
+    c.a1[m] = ((float)(m + 1) * pi_f) / (float)rc;  // nn/featurizer.py:87-88
+    c.a2[m] = ((float)(m + 2) * pi_f) / (float)rc;
+    c.coeff[m] = plan->cvals.at("coeff")[m];
+    c.rec_mul[m] = m > 0 ? sqrtf(em[m] / dm[m - 1]) : 0.f;  // nn/featurizer.py:94-96
+    c.rec_div[m] = sqrtf(dm[m]);
+  }
+  for (int l = 0; l < L; ++l) {
+    c.ynorm[l] = (float)std::sqrt((2 * l + 1) / (4.0 * M_PI));  // nn/interaction.py:198
+    for (int n = 0; n < R; ++n) {
+      c.zeros[l][n] = plan->cvals.at("bessel_zeros")[l * R + n];
+      c.factors[l][n] = plan->cvals.at("factors")[l * R + n];
+    }
+  }
+
+  // ---- weights ------------------------------------------------------------------------------------
+  const WeightLayout& wl = plan->wl;
+  std::vector<float> blob(wl.total, 0.f);
+  put_t(blob, wl.emb, kDP, plan->params.at("model.3.linear.weight").data(), D, cfg.num_types, 0, cfg.num_types);
+  put_t(blob, wl.adj_t, kDP, plan->params.at("model.5.linear.weight").data(), D, R, 0, R);
+  put_n(blob, wl.adj, kRP, plan->params.at("model.5.linear.weight").data(), D, R, 0, R);
+  for (int t = 0; t < cfg.num_types; ++t) blob[wl.elemental + t] = plan->cvals.at("elemental_energies")[t];
+  char buf[128];
+  for (int b = 0; b < B; ++b) {
+    const BlockW& bw = wl.blk[b];
+    std::string tb = "model." + std::to_string(6 + 2 * b), cv = "model." + std::to_string(7 + 2 * b);
+    const float* w1 = plan->params.at(tb + ".linear_sigmoid1.weight").data();  // [C,D]
+    put_t(blob, bw.tb_w1_t, kCP, w1, C, D, 0, D);
+    put_n(blob, bw.tb_w1, kDP, w1, C, D, 0, D);
+    for (int cc = 0; cc < C; ++cc) blob[bw.tb_b1 + cc] = plan->params.at(tb + ".linear_sigmoid1.bias")[cc];
+    const float* wd = plan->params.at(tb + ".gated_mlp.dense.0.weight").data();  // [D,C]
+    const float* wg = plan->params.at(tb + ".gated_mlp.gate.0.weight").data();
+    put_t(blob, bw.tb_wd_t, kDP, wd, D, C, 0, C); put_t(blob, bw.tb_wg_t, kDP, wg, D, C, 0, C);
+    put_n(blob, bw.tb_wd, kCP, wd, D, C, 0, C); put_n(blob, bw.tb_wg, kCP, wg, D, C, 0, C);
+    pack_mlp(blob, bw.e, *plan, cv + ".concat_edge_update", cv + ".edge_linear.weight", D, R);
+    pack_mlp(blob, bw.n, *plan, cv + ".concat_node_update", cv + ".node_linear.weight", D, R);
+  }
+  {
+    const ReadoutW& r = wl.ro;
+    snprintf(buf, sizeof buf, "model.%d.gated", 6 + 2 * B);
+    std::string ro = buf;
+    const float* wd0 = plan->params.at(ro + ".dense.0.weight").data();
+    const float* wg0 = plan->params.at(ro + ".gate.0.weight").data();
+    const float* wd2 = plan->params.at(ro + ".dense.2.weight").data();
+    const float* wg2 = plan->params.at(ro + ".gate.2.weight").data();
+    put_t(blob, r.w1d_t, kDP, wd0, D, D, 0, D); put_t(blob, r.w1g_t, kDP, wg0, D, D, 0, D);
+    put_t(blob, r.w2d_t, kDP, wd2, D, D, 0, D); put_t(blob, r.w2g_t, kDP, wg2, D, D, 0, D);
+    put_n(blob, r.w1d, kDP, wd0, D, D, 0, D); put_n(blob, r.w1g, kDP, wg0, D, D, 0, D);
+    put_n(blob, r.w2d, kDP, wd2, D, D, 0, D); put_n(blob, r.w2g, kDP, wg2, D, D, 0, D);
+    for (int o = 0; o < D; ++o) {
+      blob[r.b1d + o] = plan->params.at(ro + ".dense.0.bias")[o];
+      blob[r.b1g + o] = plan->params.at(ro + ".gate.0.bias")[o];
+      blob[r.b2d + o] = plan->params.at(ro + ".dense.2.bias")[o];
+      blob[r.b2g + o] = plan->params.at(ro + ".gate.2.bias")[o];
+      blob[r.w3d + o] = plan->params.at(ro + ".dense.4.weight")[o];
+      blob[r.w3g + o] = plan->params.at(ro + ".gate.4.weight")[o];
+    }
+    blob[r.b3] = plan->params.at(ro + ".dense.4.bias")[0];
+    blob[r.b3 + 1] = plan->params.at(ro + ".gate.4.bias")[0];
+  }
+  if (!plan->d_weights) M3G_HIP_CHECK(hipMalloc((void**)&plan->d_weights, wl.total * sizeof(float)));
+  M3G_HIP_CHECK(hipMemcpy(plan->d_weights, blob.data(), wl.total * sizeof(float), hipMemcpyHostToDevice));
+  plan->committed = true;
+  return M3G_OK;
+}
+
+extern "C" int m3g_workspace_bytes(const m3g_plan* plan, int64_t N, int64_t E, int64_t T, int64_t S, size_t* bytes) {
+  if (!plan || !bytes || N < 0 || E < 0 || T < 0 || S < 0) { set_error("m3g_workspace_bytes: bad argument"); return M3G_ERR_VALUE; }
+  Consts c{};
+  c.B = plan->cfg.num_blocks;
+  *bytes = work_carve(c, N, E, T, S, nullptr).total_bytes;
+  return M3G_OK;
+}
+
+extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes,
+                                 void* stream_) {
+  if (!plan || !io) { set_error("m3g_energy_forces: null argument"); return M3G_ERR_VALUE; }
+  if (!plan->committed) { set_error("m3g_energy_forces: plan parameters not committed"); return M3G_ERR_STATE; }
+  const int64_t N = io->n_atoms, E = io->n_edges, T = io->n_triplets, S = io->n_structs;
+  if (N < 0 || E < 0 || T < 0 || S < 0) { set_error("negative size"); return M3G_ERR_VALUE; }
+  if (!io->total_energy || !io->topo || (N > 0 && (!io->pos || !io->atom_types)) || (S > 0 && !io->lattice) ||
+      (E > 0 && !io->edge_cell_shift)) {
+    set_error("m3g_energy_forces: missing required pointer");
+    return M3G_ERR_VALUE;
+  }
+  if (io->triplet_angles && T > 0 && !io->triplet_edge_index) { set_error("triplet_angles requires triplet_edge_index"); return M3G_ERR_VALUE; }
+  hipStream_t s = (hipStream_t)stream_;
+  const Consts& c = plan->consts;
+  const WeightLayout& wl = plan->wl;
+  const float* W = plan->d_weights;
+  Topo t = topo_carve(N, E, T, S, const_cast<void*>(io->topo));
+  Work w = work_carve(c, N, E, T, S, nullptr);
+  if (!workspace || workspace_bytes < w.total_bytes) { set_error("workspace too small: %zu < %zu", workspace_bytes, w.total_bytes); return M3G_ERR_SIZE; }
+  w = work_carve(c, N, E, T, S, workspace);
+  // tail scratch: per-atom energies + per-structure sums when the caller does not want them
+  float* tail = (float*)((char*)workspace + w.total_bytes - align_up(((size_t)N + (size_t)S * 2 + 64) * sizeof(float)));
+  float* ea = io->scaled_atomic_energies ? io->scaled_atomic_energies : tail;
+  float* st = io->scaled_total_energy ? io->scaled_total_energy : tail + N;
+
+  // ---------------- forward ----------------
+  launch_geometry(c, t, io->pos, io->lattice, io->edge_cell_shift, w, s);
+  launch_embed(c, W, wl, t, io->atom_types, w, s);
+  for (int b = 0; b < c.B; ++b) {
+    launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], w.TA, w.TB, s);
+    launch_threebody(c, t, w, w.v[b], w.m[b], s);
+    if (N > 0) M3G_HIP_CHECK(hipMemcpyAsync(w.x[b + 1], w.x[b], sizeof(float) * N * kDP, hipMemcpyDeviceToDevice, s));
+    launch_edge_block(c, W, wl.blk[b], t, w, b, w.x[b + 1], s);
+  }
+  const bool want_f = io->forces != nullptr;
+  launch_readout(c, W, wl, t, io->atom_types, w.x[c.B], w, ea, st, io->total_energy, want_f, s);
+
+  if (io->node_features) launch_copy_strided(w.x[c.B], kDP, io->node_features, c.D, c.D, N, s);
+  if (io->edge_attr) launch_copy_strided(w.e, kDP, io->edge_attr, c.D, c.D, E, s);
+  if (io->edge_distances && E > 0) M3G_HIP_CHECK(hipMemcpyAsync(io->edge_distances, w.d, sizeof(float) * E, hipMemcpyDeviceToDevice, s));
+  if (io->edge_weights) launch_copy_strided(w.h, kRP, io->edge_weights, c.R, c.R, E, s);
+  if (io->triplet_angles) launch_triplet_angles(t, io->triplet_edge_index, w.u, io->triplet_angles, s);
+  if (io->mid_edge_features)
+    for (int b = 0; b < c.B; ++b) launch_copy_strided(w.m[b], kCP, io->mid_edge_features + (size_t)b * E * c.C, c.C, c.C, E, s);
+
+  // ---------------- reverse ----------------
+  if (want_f) {
+    if (E > 0) {
+      M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
+      M3G_HIP_CHECK(hipMemsetAsync(w.dh, 0, sizeof(float) * E * kRP, s));
+      M3G_HIP_CHECK(hipMemsetAsync(w.dd, 0, sizeof(float) * E, s));
+      M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
+    }
+    float* dx_cur = w.dx;
+    float* dx_alt = w.dx2;
+    for (int b = c.B - 1; b >= 0; --b) {
+      launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
+      launch_threebody_reverse(c, t, w, w.v[b], s);
+      if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
+        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, s);
+        float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
+      }
+    }
+    launch_embed_reverse(c, W, wl, t, w, s);
+    launch_geometry_reverse(c, t, w, io->forces, s);
+    if (io->stresses) launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);
+  } else if (io->stresses) {
+    set_error("stresses require forces");
+    return M3G_ERR_VALUE;
+  }
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+
+// ---------------------------------------------------------------------------------- stage entry points
+extern "C" int m3g_distance_angle(double length_scale, int64_t N, int64_t E, int64_t T, int64_t S, const float* pos,
+                                  const float* lattice, const int32_t* shift, const void* topo,
+                                  const int64_t* triplet_edge_index, float* scratch_u, float* edge_distances,
+                                  float* triplet_angles, void* stream_) {
+  if (!topo || !edge_distances || (E > 0 && !scratch_u)) { set_error("m3g_distance_angle: null argument"); return M3G_ERR_VALUE; }
+  hipStream_t s = (hipStream_t)stream_;
+  Topo t = topo_carve(N, E, T, S, const_cast<void*>(topo));
+  launch_distance_only((float)length_scale, t, pos, lattice, shift, scratch_u, edge_distances, s);
+  if (triplet_angles) {
+    if (T > 0 && !triplet_edge_index) { set_error("triplet_angles requires triplet_edge_index"); return M3G_ERR_VALUE; }
+    launch_triplet_angles(t, triplet_edge_index, scratch_u, triplet_angles, s);
+  }
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+
+extern "C" int m3g_edge_featurizer(int32_t n_max, double scaled_cutoff, const float* host_em, const float* host_dm,
+                                   const float* host_coeff, int64_t E, const float* edge_distances, float* edge_weights,
+                                   void* stream_) {
+  if (n_max < 1 || n_max > kRCap) { set_error("m3g_edge_featurizer: n_max must be in 1..%d", kRCap); return M3G_ERR_UNSUPPORTED; }
+  if (!host_em || !host_dm || !host_coeff || (E > 0 && (!edge_distances || !edge_weights))) { set_error("null argument"); return M3G_ERR_VALUE; }
+  Consts c{};
+  c.R = n_max;
+  const float pi_f = (float)M_PI;
+  for (int m = 0; m < n_max; ++m) {
+    c.a1[m] = ((float)(m + 1) * pi_f) / (float)scaled_cutoff;
+    c.a2[m] = ((float)(m + 2) * pi_f) / (float)scaled_cutoff;
+    c.coeff[m] = host_coeff[m];
+    c.rec_mul[m] = m > 0 ? sqrtf(host_em[m] / host_dm[m - 1]) : 0.f;
+    c.rec_div[m] = sqrtf(host_dm[m]);
+  }
+  launch_edge_featurizer(c, E, edge_distances, edge_weights, n_max, (hipStream_t)stream_);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+
+extern "C" int m3g_atom_featurizer(int32_t num_types, int32_t dim, const float* weight, int64_t N, const int64_t* atom_types,
+                                   float* x, void* stream_) {
+  if (!weight || (N > 0 && (!atom_types || !x))) { set_error("m3g_atom_featurizer: null argument"); return M3G_ERR_VALUE; }
+  launch_gather_rows(weight, N, dim, num_types, num_types, true, atom_types, x, (hipStream_t)stream_);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+
+extern "C" int m3g_atom_ref(int32_t num_types, const float* elemental, int64_t N, const int64_t* atom_types, float* out,
+                            void* stream_) {
+  if (!elemental || (N > 0 && (!atom_types || !out))) { set_error("m3g_atom_ref: null argument"); return M3G_ERR_VALUE; }
+  launch_gather_rows(elemental, N, 1, 1, num_types, false, atom_types, out, (hipStream_t)stream_);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}

@@ -1,0 +1,252 @@
+// Per-edge geometry and bases (stage S0), its reverse (B0), force gather, virial stress.
+// Reference: nn/scale.py:24-29, nn/invariant.py:20-59, nn/featurizer.py:81-100,
+//            nn/interaction.py:268-350,389-400, nn/gradient.py:35-62.
+// All HBM-bound elementwise work: one thread per edge / atom, coalesced SoA-ish rows.
+#include "m3g_internal.h"
+
+namespace m3g {
+
+__device__ __forceinline__ float sinc_pi(float x) {  // torch.sinc: sin(pi x)/(pi x)
+  const float kPi = 3.14159265358979323846f;
+  float px = kPi * x;
+  return x == 0.f ? 1.f : sinf(px) / px;
+}
+
+// radial basis h_m(d) and dh_m/dd (nn/featurizer.py:84-96)
+__device__ __forceinline__ void radial_basis(const Consts& c, float d, float* h, float* hp) {
+  const float kPi = 3.14159265358979323846f;
+#pragma unroll
+  for (int m = 0; m < kRCap; ++m) {
+    if (m < c.R) {
+      float x1 = c.a1[m] * d, x2 = c.a2[m] * d;
+      float s1 = sinc_pi(x1), s2 = sinc_pi(x2);
+      float f = c.coeff[m] * (s1 + s2);
+      float df = c.coeff[m] * ((cosf(kPi * x1) - s1) + (cosf(kPi * x2) - s2)) / d;
+      if (m == 0) {
+        h[0] = f;
+        hp[0] = df;
+      } else {
+        h[m] = (f + c.rec_mul[m] * h[m - 1]) / c.rec_div[m];
+        hp[m] = (df + c.rec_mul[m] * hp[m - 1]) / c.rec_div[m];
+      }
+    } else {
+      h[m] = 0.f;
+      hp[m] = 0.f;
+    }
+  }
+}
+
+// j_l(x), j_l'(x) for l = 0..L-1, upward recurrence with the reference's x <= 1e-8 branch
+__device__ __forceinline__ void sph_bessel(int L, float x, float* j, float* dj) {
+  float seq[kLCap + 1];
+  if (x > 1e-8f) {
+    float sx = sinf(x) / x, cx = cosf(x);
+    seq[0] = sx;
+    seq[1] = (sx - cx) / x;
+#pragma unroll
+    for (int n = 1; n < kLCap; ++n) seq[n + 1] = (float)(2 * n + 1) / x * seq[n] - seq[n - 1];
+#pragma unroll
+    for (int l = 0; l < kLCap; ++l) {
+      j[l] = seq[l];
+      dj[l] = l == 0 ? -seq[1] : seq[l - 1] - (float)(l + 1) / x * seq[l];
+    }
+  } else {
+    float dfact = 1.f;
+#pragma unroll
+    for (int l = 0; l < kLCap; ++l) {
+      if (l > 0) dfact *= (float)(2 * l + 1);
+      j[l] = l == 0 ? 1.f : x / dfact;
+      dj[l] = l == 1 ? 1.f / 3.f : 0.f;
+    }
+  }
+  (void)L;
+}
+
+template <bool FULL>
+__global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int32_t* __restrict__ src,
+                                                  const int32_t* __restrict__ dst, const int32_t* __restrict__ batch,
+                                                  const float* __restrict__ pos, const float* __restrict__ lattice,
+                                                  const int32_t* __restrict__ shift, float* __restrict__ u,
+                                                  float* __restrict__ dist, float* __restrict__ h, float* __restrict__ hp,
+                                                  float* __restrict__ q, float* __restrict__ qp, float* __restrict__ fc3,
+                                                  float* __restrict__ fc3p) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int i = src[e], j = dst[e], s = batch[i];
+  float ls = c.length_scale;
+  float r[3];
+  float sh0 = (float)shift[e * 3 + 0], sh1 = (float)shift[e * 3 + 1], sh2 = (float)shift[e * 3 + 2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l0 = lattice[s * 9 + 0 + a] / ls, l1 = lattice[s * 9 + 3 + a] / ls, l2 = lattice[s * 9 + 6 + a] / ls;
+    float sv = (sh0 * l0 + sh1 * l1) + sh2 * l2;
+    r[a] = (pos[(int64_t)j * 3 + a] / ls + sv) - pos[(int64_t)i * 3 + a] / ls;
+  }
+  float d = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  dist[e] = d;
+  u[e * 3 + 0] = r[0] / d;
+  u[e * 3 + 1] = r[1] / d;
+  u[e * 3 + 2] = r[2] / d;
+  if (!FULL) return;
+  float hh[kRCap], hd[kRCap];
+  radial_basis(c, d, hh, hd);
+#pragma unroll
+  for (int m = 0; m < kRP; ++m) {
+    h[e * kRP + m] = hh[m];
+    hp[e * kRP + m] = hd[m];
+  }
+  // three-body cutoff envelope (nn/interaction.py:389-400) and its derivative
+  float rho = d / c.rc3;
+  float f = 0.f, fp = 0.f;
+  if (rho <= 1.f) {
+    float r2 = rho * rho, r3 = r2 * rho;
+    f = 1.f - 6.f * r3 * r2 + 15.f * r2 * r2 - 10.f * r3;
+    fp = (-30.f * r2 * r2 + 60.f * r3 - 30.f * r2) / c.rc3;
+  }
+  fc3[e] = f;
+  fc3p[e] = fp;
+  // q[e,c] = chi_ln(d) fc(d),  c = l*R + n  (nn/interaction.py:268-281)
+#pragma unroll
+  for (int cc = 0; cc < kCP; ++cc) { q[e * kCP + cc] = 0.f; qp[e * kCP + cc] = 0.f; }
+  for (int n = 0; n < c.R; ++n) {
+    float jl[kLCap], djl[kLCap];
+    for (int l = 0; l < c.L; ++l) {
+      // the argument differs per (l,n): z_ln * d / rc
+      float x = c.zeros[l][n] * d / c.rc;
+      sph_bessel(c.L, x, jl, djl);
+      float chi = jl[l] / c.factors[l][n];
+      float dchi = djl[l] * (c.zeros[l][n] / c.rc) / c.factors[l][n];
+      int cc = l * c.R + n;
+      q[e * kCP + cc] = chi * f;
+      qp[e * kCP + cc] = dchi * f + chi * fp;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_geometry_reverse(Consts c, int64_t E, const float* __restrict__ u,
+                                                          const float* __restrict__ dist, const float* __restrict__ hp,
+                                                          const float* __restrict__ dh, const float* __restrict__ dd,
+                                                          const float* __restrict__ du, float* __restrict__ dr) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float g = dd[e];
+#pragma unroll
+  for (int m = 0; m < kRP; ++m) g += dh[e * kRP + m] * hp[e * kRP + m];
+  float ux = u[e * 3], uy = u[e * 3 + 1], uz = u[e * 3 + 2];
+  float ax = du[e * 3], ay = du[e * 3 + 1], az = du[e * 3 + 2];
+  float proj = ax * ux + ay * uy + az * uz;
+  float inv = 1.f / dist[e];
+  dr[e * 3 + 0] = g * ux + (ax - proj * ux) * inv;
+  dr[e * 3 + 1] = g * uy + (ay - proj * uy) * inv;
+  dr[e * 3 + 2] = g * uz + (az - proj * uz) * inv;
+}
+
+// F_i = (sum_{e in row(i)} dr_e - sum_{e: dst(e)=i} dr_e) / length_scale   (no atomics: both CSR lists)
+__global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_t N, const int32_t* __restrict__ row_ptr,
+                                                      const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_edge,
+                                                      const float* __restrict__ dr, float* __restrict__ forces) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { fx += dr[e * 3]; fy += dr[e * 3 + 1]; fz += dr[e * 3 + 2]; }
+  for (int k = in_ptr[i]; k < in_ptr[i + 1]; ++k) {
+    int e = in_edge[k];
+    fx -= dr[e * 3]; fy -= dr[e * 3 + 1]; fz -= dr[e * 3 + 2];
+  }
+  forces[i * 3 + 0] = fx / length_scale;
+  forces[i * 3 + 1] = fy / length_scale;
+  forces[i * 3 + 2] = fz / length_scale;
+}
+
+// virial: sum_a pos_a (x) F_a / V in Voigt order xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62)
+__global__ void __launch_bounds__(256) k_stress(int64_t N, const int32_t* __restrict__ batch, const float* __restrict__ pos,
+                                                const float* __restrict__ lattice, const float* __restrict__ forces,
+                                                float* __restrict__ stresses) {
+  int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool live = a < N;
+  int s = live ? batch[a] : -1;
+  float val[6] = {0, 0, 0, 0, 0, 0};
+  if (live) {
+    const float* L = lattice + (int64_t)s * 9;
+    float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
+    float inv = 1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
+    float px = pos[a * 3], py = pos[a * 3 + 1], pz = pos[a * 3 + 2];
+    float fx = forces[a * 3], fy = forces[a * 3 + 1], fz = forces[a * 3 + 2];
+    val[0] = px * fx * inv; val[1] = py * fy * inv; val[2] = pz * fz * inv;
+    val[3] = py * fz * inv; val[4] = pz * fx * inv; val[5] = px * fy * inv;
+  }
+  int s0 = __shfl(s, 0);
+  bool uniform = __all(s == s0 || !live);
+  if (uniform && s0 >= 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float v = val[k];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&stresses[(int64_t)s0 * 6 + k], v);
+    }
+  } else if (live) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) atomicAdd(&stresses[(int64_t)s * 6 + k], val[k]);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_triplet_angles(int64_t T, const int64_t* __restrict__ tei, const float* __restrict__ u,
+                                                        float* __restrict__ out) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  int64_t e1 = tei[t], e2 = tei[T + t];
+  float c = u[e1 * 3] * u[e2 * 3] + u[e1 * 3 + 1] * u[e2 * 3 + 1] + u[e1 * 3 + 2] * u[e2 * 3 + 2];
+  out[t] = fminf(1.f, fmaxf(-1.f, c));
+}
+
+__global__ void __launch_bounds__(256) k_edge_featurizer(Consts c, int64_t E, const float* __restrict__ d, float* __restrict__ out,
+                                                         int out_stride) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float h[kRCap], hp[kRCap];
+  radial_basis(c, d[e], h, hp);
+  for (int m = 0; m < c.R; ++m) out[e * out_stride + m] = h[m];
+}
+
+static inline dim3 grid_for(int64_t n, int tpb = 256) { return dim3((unsigned)((n + tpb - 1) / tpb)); }
+
+void launch_geometry(const Consts& c, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
+                     const Work& w, hipStream_t s) {
+  if (t.E == 0) return;
+  hipLaunchKernelGGL(k_geometry<true>, grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos, lattice, shift,
+                     w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p);
+}
+
+void launch_distance_only(float length_scale, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
+                          float* u, float* d, hipStream_t s) {
+  if (t.E == 0) return;
+  Consts c{};
+  c.length_scale = length_scale;
+  hipLaunchKernelGGL(k_geometry<false>, grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos, lattice, shift,
+                     u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, float* forces, hipStream_t s) {
+  if (t.E > 0)
+    hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, c, t.E, w.u, w.d, w.hp, w.dh, w.dd, w.du, w.dr);
+  if (t.N > 0)
+    hipLaunchKernelGGL(k_force_gather, grid_for(t.N), dim3(256), 0, s, c.length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge,
+                       w.dr, forces);
+}
+
+void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
+                   float* stresses, hipStream_t s) {
+  (void)c;
+  (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
+  if (t.N > 0) hipLaunchKernelGGL(k_stress, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, pos, lattice, forces, stresses);
+}
+
+void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s) {
+  if (t.T > 0) hipLaunchKernelGGL(k_triplet_angles, grid_for(t.T), dim3(256), 0, s, t.T, tei, u, out);
+}
+
+void launch_edge_featurizer(const Consts& c, int64_t E, const float* d, float* out, int out_stride, hipStream_t s) {
+  if (E > 0) hipLaunchKernelGGL(k_edge_featurizer, grid_for(E), dim3(256), 0, s, c, E, d, out, out_stride);
+}
+
+}  // namespace m3g

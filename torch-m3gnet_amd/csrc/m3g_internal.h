@@ -1,0 +1,180 @@
+// Internal declarations shared by the translation units of libm3gnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/m3gnet_hip.h"
+
+namespace m3g {
+
+constexpr int kDP = 64;      // padded feature width (embedding_dim <= kDP; zero padding is exact)
+constexpr int kLCap = 4;     // l_max <= kLCap
+constexpr int kRCap = 4;     // n_max <= kRCap
+constexpr int kCP = 16;      // padded l_max*n_max
+constexpr int kRP = 4;       // padded n_max
+constexpr int kMaxBlocks = 8;
+
+void set_error(const char* fmt, ...);
+#define M3G_HIP_CHECK(expr)                                                               \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ::m3g::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return M3G_ERR_HIP;                                                                 \
+    }                                                                                     \
+  } while (0)
+
+// ---- small constants passed to kernels by value -------------------------------------------------
+struct Consts {
+  int L, R, C, D, B, num_types;
+  float inv_len;        // 1 / length_scale is NOT used for pos (reference divides); kept for forces
+  float length_scale, energy_scale;
+  float rc, rc3;        // scaled cutoffs
+  float a1[kRCap], a2[kRCap];          // (m+1)*pi/rc, (m+2)*pi/rc formed in fp32 like the reference
+  float coeff[kRCap];
+  float rec_mul[kRCap], rec_div[kRCap]; // sqrt(em[m]/dm[m-1]), sqrt(dm[m])
+  float zeros[kLCap][kRCap];
+  float factors[kLCap][kRCap];
+  float ynorm[kLCap];   // sqrt((2l+1)/(4 pi))
+};
+
+// ---- packed weight blob: offsets in floats from the blob base -------------------------------------
+struct MlpW {
+  // forward orientation, k-major ("_t" = transposed w.r.t. torch's [out,in])
+  size_t w1a_t, w1b_t, w1c_t;  // [kDP][2*kDP]  columns: dense | gate
+  size_t b1;                   // [2*kDP]
+  size_t w2d_t, w2g_t;         // [kDP][kDP]
+  size_t b2d, b2g;             // [kDP]
+  size_t wl_t;                 // [kRP][kDP]
+  // reverse orientation, out-major (torch layout, padded)
+  size_t w1a, w1b, w1c;        // [2*kDP][kDP]
+  size_t w2d, w2g;             // [kDP][kDP]
+  size_t wl;                   // [kDP][kRP]
+};
+struct BlockW {
+  size_t tb_w1_t;   // [kDP][kCP]   v = sigmoid(x W1^T + b1)
+  size_t tb_b1;     // [kCP]
+  size_t tb_w1;     // [kCP][kDP]
+  size_t tb_wd_t, tb_wg_t;  // [kCP][kDP]
+  size_t tb_wd, tb_wg;      // [kDP][kCP]
+  MlpW e, n;
+};
+struct ReadoutW {
+  size_t w1d_t, w1g_t, w2d_t, w2g_t;  // [kDP][kDP] k-major
+  size_t w1d, w1g, w2d, w2g;          // [kDP][kDP] out-major
+  size_t b1d, b1g, b2d, b2g;          // [kDP]
+  size_t w3d, w3g;                    // [kDP]
+  size_t b3;                          // [2]  (dense, gate)
+};
+struct WeightLayout {
+  size_t emb;      // [num_types][kDP]
+  size_t adj_t;    // [kRP][kDP]
+  size_t adj;      // [kDP][kRP]
+  size_t elemental;  // [num_types]
+  BlockW blk[kMaxBlocks];
+  ReadoutW ro;
+  size_t total;
+};
+
+}  // namespace m3g
+
+struct m3g_plan {
+  m3g_config cfg;
+  m3g::Consts consts;
+  m3g::WeightLayout wl;
+  std::map<std::string, std::vector<float>> params;  // raw state_dict tensors (host)
+  std::map<std::string, std::vector<float>> cvals;   // raw constants (host)
+  float* d_weights = nullptr;
+  bool committed = false;
+};
+
+namespace m3g {
+
+// ---- topology view (device arrays carved from the caller's topo buffer) -----------------------------
+struct Topo {
+  int64_t N, E, T, S;
+  int32_t* src;      // [E] centre of each edge
+  int32_t* dst;      // [E] neighbour of each edge
+  int32_t* row_ptr;  // [N+1] edges of centre i: row_ptr[i] .. row_ptr[i+1]
+  int32_t* in_ptr;   // [N+1] incoming edges of atom j (dst == j)
+  int32_t* in_edge;  // [E]
+  int32_t* t1_ptr;   // [E+1] triplets grouped by first edge e1
+  int32_t* t1_e2;    // [T]
+  int32_t* t2_ptr;   // [E+1] triplets grouped by second edge e2
+  int32_t* t2_e1;    // [T]
+  int32_t* batch;    // [N]
+  int32_t* flags;    // [4] malformed-graph flags
+  void* sort_tmp;    // scratch for the radix sorts
+  size_t sort_tmp_bytes;
+  size_t total_bytes;
+};
+Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base);
+size_t topo_sort_tmp_bytes(int64_t E, int64_t T);
+
+// ---- workspace view ---------------------------------------------------------------------------------
+struct Work {
+  // per-edge geometry / bases
+  float *u, *d, *h, *hp, *q, *qp, *fc3, *fc3p;  // [E,3] [E] [E,kRP] [E,kRP] [E,kCP] [E,kCP] [E] [E]
+  float* x[kMaxBlocks + 1];   // [N,kDP] node features before block b (x[B] = final)
+  float* v[kMaxBlocks];       // [N,kCP]
+  float *TA, *TB;             // [N,4*kDP]
+  float* e;                   // [E,kDP] edge features (updated in place)
+  float* m[kMaxBlocks];       // [E,kCP]
+  float* act[kMaxBlocks];     // [E,8*kDP] saved pre-activations: e:{p1[2DP],p2d,p2g} n:{p1[2DP],p2d,p2g}
+  // reverse pass
+  float *dx, *dx2;            // [N,kDP]
+  float* de;                  // [E,kDP]
+  float* dm;                  // [E,kCP]
+  float* g;                   // [E,kCP] q * v[dst] of the current block
+  float* dg;                  // [E,kCP]
+  float* dh;                  // [E,kRP]
+  float* dd;                  // [E]
+  float* du;                  // [E,3]
+  float* dp1;                 // [E,4*kDP]
+  float* dr;                  // [E,3]
+  size_t total_bytes;
+};
+Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
+
+// ---- kernel launchers (each in its own .hip) -----------------------------------------------------------
+// geometry.hip
+void launch_geometry(const Consts& c, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
+                     const Work& w, hipStream_t s);
+void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, float* forces, hipStream_t s);
+void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
+                   float* stresses, hipStream_t s);
+void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s);
+void launch_distance_only(float length_scale, const Topo& t, const float* pos, const float* lattice,
+                          const int32_t* shift, float* u, float* d, hipStream_t s);
+void launch_edge_featurizer(const Consts& c, int64_t E, const float* d, float* out, int out_stride, hipStream_t s);
+// node.hip
+void launch_embed(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
+                  const Work& w, hipStream_t s);
+void launch_embed_reverse(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const Work& w,
+                          hipStream_t s);
+void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const float* x, float* v,
+                     float* TA, float* TB, hipStream_t s);
+void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
+                         const float* v, const float* dx_new, float* dx_out, hipStream_t s);
+void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
+                    const float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
+                    bool want_grad, hipStream_t s);
+void launch_gather_rows(const float* table, int64_t n, int width, int table_stride, int table_rows, bool transposed,
+                        const int64_t* idx, float* out, hipStream_t s);
+void launch_copy_strided(const float* in, int in_stride, float* out, int out_stride, int width, int64_t rows,
+                         hipStream_t s);
+// threebody.hip
+void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s);
+void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s);
+// edge_simple.hip
+void launch_edge_block(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, int b,
+                       float* x_new, hipStream_t s);
+void launch_edge_block_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, int b,
+                               const float* dx_new, hipStream_t s);
+
+}  // namespace m3g

@@ -1,0 +1,172 @@
+// Topology build: MaterialGraph index tensors (int64, reference layout data/material_graph.py:14-107)
+// -> int32 receiver-sorted CSR lists used by every kernel.
+//   * edges by centre (row_ptr)            -- input must already be centre-sorted, as the reference's
+//                                             builder produces it (material_graph.py:182-187)
+//   * edges by neighbour (in_ptr/in_edge)  -- reverse-pass gathers without atomics
+//   * triplets by first edge (t1) and by second edge (t2), each list in canonical (sorted) order so
+//     results do not depend on the order of triplet_edge_index (reference property test
+//     tests/test_model.py:21-38).
+// Index-only integer work: HBM-bound radix sorts (hipCUB) + binary searches; not on the per-step path
+// while the neighbour list is unchanged.
+#include <hipcub/hipcub.hpp>
+
+#include "m3g_internal.h"
+
+namespace m3g {
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+size_t topo_sort_tmp_bytes(int64_t E, int64_t T) {
+  size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
+  size_t cub = 0;
+  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)m, 0, 64, 0);
+  return align_up(cub) + 2 * align_up(m * sizeof(uint64_t));
+}
+
+Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
+  Topo t{};
+  t.N = N; t.E = E; t.T = T; t.S = S;
+  char* p = (char*)base;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { void* r = p ? (void*)(p + off) : nullptr; off += align_up(bytes); return r; };
+  t.src = (int32_t*)take(sizeof(int32_t) * (E + 1));
+  t.dst = (int32_t*)take(sizeof(int32_t) * (E + 1));
+  t.row_ptr = (int32_t*)take(sizeof(int32_t) * (N + 1));
+  t.in_ptr = (int32_t*)take(sizeof(int32_t) * (N + 1));
+  t.in_edge = (int32_t*)take(sizeof(int32_t) * (E + 1));
+  t.t1_ptr = (int32_t*)take(sizeof(int32_t) * (E + 1));
+  t.t1_e2 = (int32_t*)take(sizeof(int32_t) * (T + 1));
+  t.t2_ptr = (int32_t*)take(sizeof(int32_t) * (E + 1));
+  t.t2_e1 = (int32_t*)take(sizeof(int32_t) * (T + 1));
+  t.batch = (int32_t*)take(sizeof(int32_t) * (N + 1));
+  t.flags = (int32_t*)take(sizeof(int32_t) * 4);
+  t.sort_tmp_bytes = topo_sort_tmp_bytes(E, T);
+  t.sort_tmp = take(t.sort_tmp_bytes);
+  t.total_bytes = off;
+  return t;
+}
+
+__global__ void k_convert_edges(int64_t N, int64_t E, const int64_t* __restrict__ ei, int32_t* src, int32_t* dst,
+                                uint64_t* in_keys, int32_t* flags) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t i = ei[e], j = ei[E + e];
+  int bad = 0;
+  if (i < 0 || i >= N || j < 0 || j >= N) { bad |= 2; i = 0; j = 0; }
+  if (e > 0 && ei[e - 1] > i) bad |= 1;
+  src[e] = (int32_t)i;
+  dst[e] = (int32_t)j;
+  in_keys[e] = ((uint64_t)j << 32) | (uint64_t)e;
+  if (bad) atomicOr(flags, bad);
+}
+
+__global__ void k_convert_batch(int64_t N, int64_t S, const int64_t* __restrict__ batch, int32_t* out, int32_t* flags) {
+  int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  int64_t b = batch[a];
+  if (b < 0 || b >= S) { atomicOr(flags, 2); b = 0; }
+  out[a] = (int32_t)b;
+}
+
+__global__ void k_convert_triplets(int64_t E, int64_t T, const int64_t* __restrict__ tei, const int32_t* __restrict__ src,
+                                   uint64_t* keys, int which, int32_t* flags) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  int64_t e1 = tei[t], e2 = tei[T + t];
+  int bad = 0;
+  if (e1 < 0 || e1 >= E || e2 < 0 || e2 >= E) { bad |= 2; e1 = 0; e2 = 0; }
+  else if (src[e1] != src[e2]) bad |= 4;
+  keys[t] = which == 0 ? (((uint64_t)e1 << 32) | (uint64_t)e2) : (((uint64_t)e2 << 32) | (uint64_t)e1);
+  if (bad) atomicOr(flags, bad);
+}
+
+// ptr[r] = first position whose key (high word of keys64, or keys32[pos]) >= r, for r = 0..rows
+__global__ void k_lower_bound64(int64_t rows, int64_t n, const uint64_t* __restrict__ keys, int32_t* ptr) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r > rows) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(keys[mid] >> 32) < r) lo = mid + 1; else hi = mid;
+  }
+  ptr[r] = (int32_t)lo;
+}
+__global__ void k_lower_bound32(int64_t rows, int64_t n, const int32_t* __restrict__ keys, int32_t* ptr) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r > rows) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)keys[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  ptr[r] = (int32_t)lo;
+}
+__global__ void k_low_word(int64_t n, const uint64_t* __restrict__ keys, int32_t* out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)(keys[i] & 0xffffffffu);
+}
+
+static inline int bits_for(int64_t n) {
+  int b = 1;
+  while ((int64_t(1) << b) < n) ++b;
+  return b;
+}
+
+}  // namespace m3g
+
+using namespace m3g;
+
+extern "C" int m3g_topology_bytes(int64_t N, int64_t E, int64_t T, int64_t S, size_t* bytes) {
+  if (!bytes || N < 0 || E < 0 || T < 0 || S < 0) { set_error("m3g_topology_bytes: bad argument"); return M3G_ERR_VALUE; }
+  if (N >= (int64_t(1) << 31) || E >= (int64_t(1) << 31) || T >= (int64_t(1) << 31)) {
+    set_error("graph too large for int32 indices");
+    return M3G_ERR_UNSUPPORTED;
+  }
+  *bytes = topo_carve(N, E, T, S, nullptr).total_bytes;
+  return M3G_OK;
+}
+
+extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
+                                  const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
+                                  size_t topo_bytes, int32_t* host_flags, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  size_t need = 0;
+  int rc = m3g_topology_bytes(N, E, T, S, &need);
+  if (rc) return rc;
+  if (!topo_buf || topo_bytes < need) { set_error("topology buffer too small: %zu < %zu", topo_bytes, need); return M3G_ERR_SIZE; }
+  Topo t = topo_carve(N, E, T, S, topo_buf);
+  const int TPB = 256;
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + TPB - 1) / TPB)); };
+  M3G_HIP_CHECK(hipMemsetAsync(t.flags, 0, 4 * sizeof(int32_t), s));
+
+  size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
+  char* tmp = (char*)t.sort_tmp;
+  uint64_t* keysA = (uint64_t*)tmp;
+  uint64_t* keysB = (uint64_t*)(tmp + align_up(m * sizeof(uint64_t)));
+  void* cub_tmp = tmp + 2 * align_up(m * sizeof(uint64_t));
+  size_t cub_bytes = t.sort_tmp_bytes - 2 * align_up(m * sizeof(uint64_t));
+
+  if (N > 0) hipLaunchKernelGGL(k_convert_batch, grid(N), dim3(TPB), 0, s, N, S, batch, t.batch, t.flags);
+  if (E > 0) {
+    hipLaunchKernelGGL(k_convert_edges, grid(E), dim3(TPB), 0, s, N, E, edge_index, t.src, t.dst, keysA, t.flags);
+    M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)E, 0, 32 + bits_for(N + 1), s));
+    hipLaunchKernelGGL(k_low_word, grid(E), dim3(TPB), 0, s, E, keysB, t.in_edge);
+  }
+  hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, t.src, t.row_ptr);
+  hipLaunchKernelGGL(k_lower_bound64, grid(N + 1), dim3(TPB), 0, s, N, E, keysB, t.in_ptr);
+  for (int which = 0; which < 2; ++which) {
+    int32_t* ptr = which == 0 ? t.t1_ptr : t.t2_ptr;
+    int32_t* lst = which == 0 ? t.t1_e2 : t.t2_e1;
+    if (T > 0) {
+      hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, which, t.flags);
+      M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)T, 0, 32 + bits_for(E + 1), s));
+      hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, keysB, lst);
+    }
+    hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, keysB, ptr);
+  }
+  M3G_HIP_CHECK(hipGetLastError());
+  if (host_flags) {
+    M3G_HIP_CHECK(hipMemcpyAsync(host_flags, t.flags, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  }
+  return M3G_OK;
+}

@@ -1,0 +1,148 @@
+"""Host side of the fused path: turns the module tree built by `build_model` into an m3g_plan and
+drives `m3g_energy_forces` (C ABI, include/m3gnet_hip.h).  PyTorch supplies device memory and the
+stream only."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data import MaterialGraphKey as K
+from .nn import modules as M
+
+
+def _host_f32(t: torch.Tensor) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().to(device="cpu", dtype=torch.float32).numpy())
+
+
+class Engine:
+    """One plan per model; re-commits automatically when parameters or captured constants change."""
+
+    def __init__(self, seq: torch.nn.Module):
+        mods = list(seq)
+        kinds = [type(m).__name__ for m in mods]
+        head = ["ScaleLength", "AtomRef", "DistanceAndAngle", "AtomFeaturizer", "EdgeFeaturizer", "EdgeAdjustor"]
+        n_blocks = (len(mods) - len(head) - 1) // 2
+        expect = head + ["ThreeBodyInteration", "M3GNetConv"] * n_blocks + ["AtomWiseReadout"]
+        if kinds != expect:
+            raise RuntimeError(
+                "Gradient(model): the fused MI355X path needs the module order of build_model "
+                f"({' -> '.join(head)} -> [ThreeBodyInteration -> M3GNetConv]* -> AtomWiseReadout); got {kinds}"
+            )
+        self.seq = seq
+        self.mods = mods
+        self.num_blocks = n_blocks
+        self.scale, self.atom_ref, _, self.atom_feat, self.edge_feat, self.edge_adj = mods[:6]
+        self.tb = [mods[6 + 2 * b] for b in range(n_blocks)]
+        self.readout = mods[-1]
+        tb0 = self.tb[0] if n_blocks else None
+        ls = float(self.scale.length_scale)
+        self.cfg = _lib.M3GConfig(
+            cutoff=float(self.edge_feat.cutoff) * ls,
+            threebody_cutoff=(float(tb0.threebody_cutoff) * ls) if tb0 is not None else float(self.edge_feat.cutoff) * ls,
+            energy_scale=float(self.readout.scale), length_scale=ls,
+            l_max=int(tb0.l_max) if tb0 is not None else 1, n_max=int(self.edge_feat.degree),
+            num_types=int(self.atom_feat.num_types), embedding_dim=int(self.atom_feat.linear.out_features),
+            num_blocks=n_blocks, reserved=0,
+        )
+        # build.py divides the cutoffs by length_scale before handing them to the modules; the plan takes
+        # the unscaled values and repeats that division in double, so recover them exactly when possible
+        self._scaled_cutoff = float(self.edge_feat.cutoff)
+        self._scaled_tb_cutoff = float(tb0.threebody_cutoff) if tb0 is not None else self._scaled_cutoff
+        self.lib = _lib.load_library()
+        self.plan = C.c_void_p()
+        _lib.check(self.lib.m3g_plan_create(C.byref(self.cfg), C.byref(self.plan)))
+        self._sig = None
+        self._workspace = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None) and self.plan.value:
+                self.lib.m3g_plan_destroy(self.plan)
+                self.plan = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- parameters
+    def _signature(self):
+        sig = [(p.data_ptr(), p._version) for p in self.seq.parameters()]
+        for m in self.tb[:1]:
+            sig.append((m.nsb.factors.data_ptr(), m.nsb.factors._version))
+        e = self.atom_ref.elemental_energies
+        sig.append((e.data_ptr(), e._version))
+        return tuple(sig)
+
+    def commit(self) -> None:
+        lib, plan = self.lib, self.plan
+        for key, val in self.seq.state_dict().items():
+            arr = _host_f32(val)
+            _lib.check(lib.m3g_plan_set_param(plan, f"model.{key}".encode(), arr.ctypes.data, arr.size))
+        em, dm, coeff = self.edge_feat.host_constants()
+        consts = {"em": em, "dm": dm, "coeff": coeff, "elemental_energies": _host_f32(self.atom_ref.elemental_energies)}
+        if self.tb:
+            nsb = self.tb[0].nsb
+            for other in self.tb[1:]:
+                if not torch.equal(other.nsb.factors.cpu(), nsb.factors.cpu()):
+                    raise RuntimeError("all ThreeBodyInteration blocks must share the same `nsb.factors`")
+            consts["factors"] = _host_f32(nsb.factors)
+            consts["bessel_zeros"] = _host_f32(nsb.spherical_bessel_zeros[: nsb.l_max, : nsb.n_max])
+        else:
+            consts["factors"] = np.ones(self.cfg.n_max, dtype=np.float32)
+            consts["bessel_zeros"] = np.ones(self.cfg.n_max, dtype=np.float32)
+        for name, arr in consts.items():
+            _lib.check(lib.m3g_plan_set_const(plan, name.encode(), arr.ctypes.data, arr.size))
+        _lib.check(lib.m3g_plan_commit(plan))
+
+    # ---------------------------------------------------------------- the hot call
+    def run(self, graph, want_forces: bool = True, extras: bool = True):
+        pos = graph[K.POS]
+        M._require_cuda(pos, K.POS)
+        dev = pos.device
+        sig = self._signature()
+        if sig != self._sig:
+            with torch.cuda.device(dev):
+                self.commit()
+            self._sig = sig
+        with torch.cuda.device(dev):
+            topo = M._Topology.of(graph)
+            N, E, T, S = topo.N, topo.E, topo.T, topo.S
+            D, R, Cc, B = self.cfg.embedding_dim, self.cfg.n_max, self.cfg.l_max * self.cfg.n_max, self.num_blocks
+            pos_c = pos.detach().contiguous().float()
+            types = graph[K.ATOM_TYPES].contiguous().long()
+            shift = graph[K.EDGE_CELL_SHIFT].contiguous().to(torch.int32)
+            lat = graph[K.LATTICE].contiguous().float()
+            nbytes = C.c_size_t()
+            _lib.check(self.lib.m3g_workspace_bytes(self.plan, N, E, T, S, C.byref(nbytes)))
+            if self._workspace is None or self._workspace.numel() < nbytes.value or self._workspace.device != dev:
+                self._workspace = None
+                self._workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            f32 = dict(dtype=torch.float, device=dev)
+            out = {K.TOTAL_ENERGY: torch.empty(S, **f32)}
+            if want_forces:
+                out[K.FORCES] = torch.empty(N, 3, **f32)
+                out[K.STRESSES] = torch.empty(S, 6, **f32)
+            out[K.SCALED_TOTAL_ENERGY] = torch.empty(S, **f32)
+            out[K.SCALED_ATOMIC_ENERGIES] = torch.empty(N, **f32)
+            if extras:
+                out[K.NODE_FEATURES] = torch.empty(N, D, **f32)
+                out[K.EDGE_ATTR] = torch.empty(E, D, **f32)
+                out[K.EDGE_DISTANCES] = torch.empty(E, **f32)
+                out[K.EDGE_WEIGHTS] = torch.empty(E, R, **f32)
+                out[K.TRIPLET_ANGLES] = torch.empty(T, **f32)
+                out[K.MID_EDGE_FEATURES] = torch.empty(B, E, Cc, **f32)
+            p = M._ptr
+            io = _lib.M3GIO(
+                n_atoms=N, n_edges=E, n_triplets=T, n_structs=S, pos=p(pos_c), atom_types=p(types), edge_cell_shift=p(shift),
+                lattice=p(lat), topo=p(topo.buf), triplet_edge_index=p(topo.tei),
+                total_energy=p(out[K.TOTAL_ENERGY]), forces=p(out.get(K.FORCES)), stresses=p(out.get(K.STRESSES)),
+                scaled_total_energy=p(out[K.SCALED_TOTAL_ENERGY]), scaled_atomic_energies=p(out[K.SCALED_ATOMIC_ENERGIES]),
+                node_features=p(out.get(K.NODE_FEATURES)), edge_attr=p(out.get(K.EDGE_ATTR)),
+                edge_distances=p(out.get(K.EDGE_DISTANCES)), edge_weights=p(out.get(K.EDGE_WEIGHTS)),
+                triplet_angles=p(out.get(K.TRIPLET_ANGLES)), mid_edge_features=p(out.get(K.MID_EDGE_FEATURES)),
+            )
+            _lib.check(self.lib.m3g_energy_forces(self.plan, C.byref(io), p(self._workspace), self._workspace.numel(), M._stream()))
+        for key, val in out.items():
+            graph[key] = val
+        return graph

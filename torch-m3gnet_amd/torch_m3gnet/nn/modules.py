@@ -1,0 +1,387 @@
+"""`torch_m3gnet.nn` modules: same class names, constructor signatures, attribute names and
+`state_dict` keys as the reference -- the compute is libm3gnet_hip.so.
+
+Every module keeps the reference protocol `forward(graph) -> graph` (mutates and returns the keyed
+container).  `Gradient(Sequential(...))` as assembled by `build_model` runs the whole path as ONE
+fused engine call (m3g_energy_forces).  The cheap leading modules (ScaleLength, AtomRef,
+DistanceAndAngle, AtomFeaturizer, EdgeFeaturizer) can also run on their own through the C-ABI
+stage entry points, as the reference's unit tests use them.  The block modules (EdgeAdjustor,
+ThreeBodyInteration, M3GNetConv, AtomWiseReadout, GatedMLP) only run fused.
+
+Parameter creation order follows the reference so that a given `torch.manual_seed` yields the same
+initial weights; constants (`em`, `dm`, `coeff`, `factors`) are built with the same fp32 torch
+arithmetic because the reference treats them as captured, platform-dependent values
+(SURVEY finding 1).  Outputs are plain tensors: this is an inference engine, nothing is attached
+to an autograd graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..data import MaterialGraphKey as K
+from ._bessel_zeros import SPHERICAL_BESSEL_ZEROS
+
+
+# ----------------------------------------------------------------------------------------------
+# host-side special functions (constant set-up and API parity only; never on the per-step path)
+def spherical_bessel(x: torch.Tensor, order: int) -> torch.Tensor:
+    """j_order(x): upward recurrence with the small-argument branch (reference nn/interaction.py:284-318)."""
+    if order < 0:
+        raise AssertionError("order must be non-negative")
+    tiny = 1e-8
+    safe = x > tiny
+    ratio = torch.sin(x) / x
+    cur = torch.where(safe, ratio, torch.ones_like(x))
+    if order == 0:
+        return cur
+    prev, cur = cur, torch.where(safe, (ratio - torch.cos(x)) / x, x / 3)
+    denom = 3
+    for n in range(1, order):
+        denom *= 2 * n + 3
+        prev, cur = cur, torch.where(safe, (2 * n + 1) / x * cur - prev, x / denom)
+    return cur
+
+
+def legendre_cos(x: torch.Tensor, order: int) -> torch.Tensor:
+    """Legendre polynomial P_order(x) (reference nn/interaction.py:353-365); plain autograd, exact derivative."""
+    if order < 0:
+        raise AssertionError("order must be non-negative")
+    prev, cur = torch.ones_like(x), x
+    if order == 0:
+        return prev
+    for n in range(1, order):
+        prev, cur = cur, ((2 * n + 1) * x * cur - n * prev) / (n + 1)
+    return cur
+
+
+def cutoff_function(r: torch.Tensor, cutoff: float) -> torch.Tensor:
+    """Polynomial envelope 1 - 6 t^5 + 15 t^4 - 10 t^3, t = r / cutoff, zero beyond (nn/interaction.py:389-400)."""
+    t = r / cutoff
+    return torch.where(t <= 1, 1 - 6 * t**5 + 15 * t**4 - 10 * t**3, torch.zeros_like(r))
+
+
+# ----------------------------------------------------------------------------------------------
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(
+            f"torch_m3gnet (MI355X build): '{what}' must be a GPU tensor -- this package has no CPU path "
+            "(move the graph with graph.to('cuda'))"
+        )
+
+
+def _ptr(t: torch.Tensor | None):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Topology:
+    """Device-side CSR form of a graph's index tensors (m3g_topology_build), cached on the graph."""
+
+    def __init__(self, graph) -> None:
+        lib = _lib.load_library()
+        ei, tei, batch = graph[K.EDGE_INDEX], graph[K.TRIPLET_EDGE_INDEX], graph[K.BATCH]
+        for t, name in ((ei, K.EDGE_INDEX), (tei, K.TRIPLET_EDGE_INDEX), (batch, K.BATCH)):
+            _require_cuda(t, name)
+        self.ei = ei.contiguous().long()
+        self.tei = tei.contiguous().long()
+        self.batch = batch.contiguous().long()
+        self.N, self.E, self.T = int(self.batch.numel()), int(self.ei.size(1)), int(self.tei.size(1))
+        self.S = int(graph[K.LATTICE].size(0))
+        nbytes = C.c_size_t()
+        _lib.check(lib.m3g_topology_bytes(self.N, self.E, self.T, self.S, C.byref(nbytes)))
+        self.buf = torch.empty(nbytes.value, dtype=torch.uint8, device=self.ei.device)
+        flags = (C.c_int32 * 1)(0)
+        _lib.check(lib.m3g_topology_build(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
+                                          _ptr(self.buf), nbytes.value, flags, _stream()))
+        torch.cuda.current_stream().synchronize()
+        if flags[0] & 1:
+            raise ValueError("edge_index must be sorted by centre atom (row 0), as MaterialGraph builds it")
+        if flags[0] & 2:
+            raise ValueError("graph index out of range (edge_index / triplet_edge_index / batch)")
+        if flags[0] & 4:
+            raise ValueError("triplet_edge_index pairs edges that do not share a centre atom")
+
+    @staticmethod
+    def signature(graph):
+        sig = []
+        for key in (K.EDGE_INDEX, K.TRIPLET_EDGE_INDEX, K.BATCH):
+            t = graph[key]
+            sig.append((t.data_ptr(), t._version, tuple(t.shape)))
+        sig.append(int(graph[K.LATTICE].size(0)))
+        return tuple(sig)
+
+    @classmethod
+    def of(cls, graph) -> "_Topology":
+        sig = cls.signature(graph)
+        cached = graph.get("_m3g_topology") if isinstance(graph, dict) else None
+        if cached is not None and cached[0] == sig:
+            return cached[1]
+        topo = cls(graph)
+        if isinstance(graph, dict):
+            dict.__setitem__(graph, "_m3g_topology", (sig, topo))
+        return topo
+
+
+# ----------------------------------------------------------------------------------------------
+class ScaleLength(torch.nn.Module):
+    """pos, lattice -> scaled_pos, scaled_lattice (reference nn/scale.py:8-29).  In the fused path the
+    division happens inside the geometry kernel; standalone it is a device-side elementwise op."""
+
+    def __init__(self, length_scale: float):
+        super().__init__()
+        self.length_scale = length_scale
+
+    def forward(self, graph):
+        _require_cuda(graph[K.POS], K.POS)
+        graph[K.SCALED_POS] = graph[K.POS] / self.length_scale
+        graph[K.SCALED_LATTICE] = graph[K.LATTICE] / self.length_scale
+        return graph
+
+
+class AtomRef(torch.nn.Module):
+    """elemental_energies[atom_types] (reference nn/atom_ref.py:10-29)."""
+
+    def __init__(self, elemental_energies: torch.Tensor, device: torch.device | None = None):
+        super().__init__()
+        self.elemental_energies = elemental_energies.to(device)
+
+    def forward(self, graph):
+        types = graph[K.ATOM_TYPES]
+        _require_cuda(types, K.ATOM_TYPES)
+        table = self.elemental_energies.to(device=types.device, dtype=torch.float).contiguous()
+        out = torch.empty(types.numel(), dtype=torch.float, device=types.device)
+        lib = _lib.load_library()
+        types = types.contiguous().long()
+        _lib.check(lib.m3g_atom_ref(table.numel(), _ptr(table), types.numel(), _ptr(types), _ptr(out), _stream()))
+        graph[K.ELEMENTAL_ENERGIES] = out
+        return graph
+
+
+class DistanceAndAngle(torch.nn.Module):
+    """edge_distances and clamped cos(theta_jik) from scaled positions (reference nn/invariant.py:8-59)."""
+
+    def forward(self, graph):
+        pos, lat = graph[K.SCALED_POS], graph[K.SCALED_LATTICE]
+        _require_cuda(pos, K.SCALED_POS)
+        topo = _Topology.of(graph)
+        pos = pos.contiguous().float()
+        lat = lat.contiguous().float()
+        shift = graph[K.EDGE_CELL_SHIFT].contiguous().to(torch.int32)
+        dist = torch.empty(topo.E, dtype=torch.float, device=pos.device)
+        ang = torch.empty(topo.T, dtype=torch.float, device=pos.device)
+        scratch = torch.empty(max(topo.E, 1) * 3, dtype=torch.float, device=pos.device)
+        lib = _lib.load_library()
+        _lib.check(lib.m3g_distance_angle(1.0, topo.N, topo.E, topo.T, topo.S, _ptr(pos), _ptr(lat), _ptr(shift), _ptr(topo.buf),
+                                          _ptr(topo.tei), _ptr(scratch), _ptr(dist), _ptr(ang), _stream()))
+        graph[K.EDGE_DISTANCES] = dist
+        graph[K.TRIPLET_ANGLES] = ang
+        return graph
+
+
+class AtomFeaturizer(torch.nn.Module):
+    """One-hot(species) @ W^T, i.e. a row gather of W^T (reference nn/featurizer.py:11-38)."""
+
+    def __init__(self, num_types: int, embedding_dim: int, device: torch.device | None = None):
+        super().__init__()
+        self._num_types = num_types
+        self.linear = torch.nn.Linear(num_types, embedding_dim, bias=False, device=device)
+
+    @property
+    def num_types(self) -> int:
+        return self._num_types
+
+    def forward(self, graph):
+        types = graph[K.ATOM_TYPES]
+        _require_cuda(types, K.ATOM_TYPES)
+        w = self.linear.weight.detach().to(device=types.device, dtype=torch.float).contiguous()
+        types = types.contiguous().long()
+        x = torch.empty(types.numel(), w.size(0), dtype=torch.float, device=types.device)
+        lib = _lib.load_library()
+        _lib.check(lib.m3g_atom_featurizer(self._num_types, w.size(0), _ptr(w), types.numel(), _ptr(types), _ptr(x), _stream()))
+        graph[K.NODE_FEATURES] = x
+        return graph
+
+
+class EdgeFeaturizer(torch.nn.Module):
+    """Orthogonalised sinc-pair radial basis (reference nn/featurizer.py:41-100)."""
+
+    def __init__(self, degree: int, cutoff: float, device: torch.device | None = None):
+        super().__init__()
+        self.degree, self.cutoff, self.device = degree, cutoff, device
+        idx = torch.arange(degree, device=device)
+        # e_m = m^2 (m+2)^2 / (4 (m+1)^4 + 1);  d_0 = 1, d_m = 1 - e_m / d_{m-1}
+        self.em = (idx**2) * ((idx + 2) ** 2) / (4 * ((idx + 1) ** 4) + 1)
+        dm = torch.ones(degree, device=device)
+        for m in range(1, degree):
+            dm[m] = 1 - self.em[m] / dm[m - 1]
+        self.dm = dm
+        coeff = torch.empty(degree)
+        for m in range(degree):
+            sign = -1 if m % 2 else 1
+            coeff[m] = sign * np.sqrt(2) * np.pi / (cutoff**1.5) * (m + 1) * (m + 2) / np.sqrt((m + 1) ** 2 + (m + 2) ** 2)
+        self.coeff = coeff.to(device)
+
+    def host_constants(self):
+        f = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)  # noqa: E731
+        return f(self.em), f(self.dm), f(self.coeff)
+
+    def forward(self, graph):
+        dist = graph[K.EDGE_DISTANCES]
+        _require_cuda(dist, K.EDGE_DISTANCES)
+        dist = dist.contiguous().float()
+        out = torch.empty(dist.numel(), self.degree, dtype=torch.float, device=dist.device)
+        em, dm, coeff = self.host_constants()
+        lib = _lib.load_library()
+        _lib.check(lib.m3g_edge_featurizer(self.degree, float(self.cutoff), em.ctypes.data, dm.ctypes.data, coeff.ctypes.data,
+                                           dist.numel(), _ptr(dist), _ptr(out), _stream()))
+        graph[K.EDGE_WEIGHTS] = out
+        return graph
+
+
+def _fused_only(name: str):
+    raise RuntimeError(
+        f"torch_m3gnet (MI355X build): {name} runs only inside the fused model returned by build_model(...) "
+        "(Gradient(Sequential(...))); it has no standalone kernel entry point yet"
+    )
+
+
+class EdgeAdjustor(torch.nn.Module):
+    """edge_attr = SiLU(W edge_weights) (reference nn/featurizer.py:103-132)."""
+
+    def __init__(self, degree: int, num_edge_features: int, device: torch.device | None = None):
+        super().__init__()
+        self.degree, self.num_edge_features = degree, num_edge_features
+        self.linear = torch.nn.Linear(degree, num_edge_features, bias=False, device=device)
+        self.swish = torch.nn.SiLU()
+
+    def forward(self, graph):
+        _fused_only("EdgeAdjustor")
+
+
+class GatedMLP(torch.nn.Module):
+    """dense(x) * gate(x) (reference nn/core.py:6-62).  Holds the parameters with the reference's
+    Sequential numbering (Linear at even indices, activation at odd)."""
+
+    def __init__(self, in_features: int, dimensions: list[int], is_output: bool = False, use_bias: bool = True,
+                 device: torch.device | None = None):
+        super().__init__()
+        self.in_features, self.dimensions, self.is_output, self.use_bias = in_features, dimensions, is_output, use_bias
+        self.dense, self.gate = torch.nn.Sequential(), torch.nn.Sequential()
+        widths = [in_features] + list(dimensions)
+        last = len(dimensions) - 1
+        for i in range(len(dimensions)):
+            self.dense.append(torch.nn.Linear(widths[i], widths[i + 1], bias=use_bias, device=device))
+            if not (is_output and i == last):
+                self.dense.append(torch.nn.SiLU())
+            self.gate.append(torch.nn.Linear(widths[i], widths[i + 1], bias=use_bias, device=device))
+            self.gate.append(torch.nn.Sigmoid() if i == last else torch.nn.SiLU())
+
+    def forward(self, x):
+        _fused_only("GatedMLP")
+
+
+class NormalizedSphericalBessel(torch.nn.Module):
+    """chi_ln(r) = j_l(z_ln r / rc) / factors[l, n] (reference nn/interaction.py:226-281).
+
+    `factors` reproduces the reference construction, INCLUDING its evaluation of j_{l+1} at the roots
+    of j_{l+1} itself (SURVEY finding 1): it is a captured constant of rounding-noise size, not the
+    documented normalisation.  It is a plain attribute; assign another tensor to change it (see
+    `documented_factors`)."""
+
+    def __init__(self, cutoff: float, l_max: int, n_max: int, device: torch.device | None = None):
+        super().__init__()
+        self.cutoff, self.l_max, self.n_max, self.device = cutoff, l_max, n_max, device
+        self.spherical_bessel_zeros = torch.tensor(SPHERICAL_BESSEL_ZEROS, device=device)
+        if self.spherical_bessel_zeros.size(0) < l_max + 1:
+            raise ValueError("Too large l_max is specified.")
+        if self.spherical_bessel_zeros.size(1) < n_max:
+            raise ValueError("Too large n_max is specified.")
+        scale = math.sqrt(2 / (cutoff**3))
+        rows = [scale / torch.abs(spherical_bessel(self.spherical_bessel_zeros[l + 1, :n_max], l + 1)) for l in range(l_max)]
+        self.factors = torch.stack(rows)
+
+    def documented_factors(self) -> torch.Tensor:
+        """`factors` realising sqrt(2/rc^3) j_l(z_ln r/rc) / |j_{l+1}(z_ln)| (reference docs/architecture.md:127-132)."""
+        z = torch.tensor(SPHERICAL_BESSEL_ZEROS, dtype=torch.float64)
+        scale = math.sqrt(2 / (self.cutoff**3))
+        rows = [scale / torch.abs(spherical_bessel(z[l, : self.n_max], l + 1)) for l in range(self.l_max)]
+        return (1.0 / torch.stack(rows)).to(torch.float)
+
+    def forward(self, rs):
+        _fused_only("NormalizedSphericalBessel")
+
+
+class ThreeBodyInteration(torch.nn.Module):
+    """Three-body edge update (reference nn/interaction.py:138-223; class name spelled as there)."""
+
+    def __init__(self, cutoff: float, threebody_cutoff: float, l_max: int, n_max: int, num_node_features: int,
+                 num_edge_features: int, device: torch.device | None = None):
+        super().__init__()
+        self.cutoff, self.threebody_cutoff = cutoff, threebody_cutoff
+        self.l_max, self.n_max, self.degree = l_max, n_max, l_max * n_max
+        self.num_node_features, self.num_edge_features, self.device = num_node_features, num_edge_features, device
+        self.nsb = NormalizedSphericalBessel(cutoff=cutoff, l_max=l_max, n_max=n_max, device=device)
+        self.linear_sigmoid1 = torch.nn.Linear(num_node_features, self.degree, device=device)
+        self.gated_mlp = GatedMLP(self.degree, [num_edge_features], use_bias=False, device=device)
+
+    def forward(self, graph):
+        _fused_only("ThreeBodyInteration")
+
+
+class M3GNetConv(torch.nn.Module):
+    """Gated edge update then gated node update with centre-atom aggregation (reference nn/conv.py:12-97)."""
+
+    def __init__(self, degree: int, num_node_features: int, num_edge_features: int, device: torch.device | None = None):
+        super().__init__()
+        self.degree, self.num_node_features, self.num_edge_features = degree, num_node_features, num_edge_features
+        self.num_concat_features = 2 * num_node_features + num_edge_features
+        self.concat_edge_update = GatedMLP(self.num_concat_features, [num_edge_features, num_edge_features], device=device)
+        self.edge_linear = torch.nn.Linear(degree, num_edge_features, bias=False, device=device)
+        self.concat_node_update = GatedMLP(self.num_concat_features, [num_edge_features, num_node_features], device=device)
+        self.node_linear = torch.nn.Linear(degree, num_node_features, bias=False, device=device)
+
+    def forward(self, graph):
+        _fused_only("M3GNetConv")
+
+
+class AtomWiseReadout(torch.nn.Module):
+    """Per-atom gated MLP to a scalar, summed per structure (reference nn/readout.py:12-58)."""
+
+    def __init__(self, in_features: int, num_layers: int, scale: float, device: torch.device | None = None):
+        super().__init__()
+        self.in_features, self.num_layers, self.scale = in_features, num_layers, scale
+        self.gated = GatedMLP(in_features, [in_features] * (num_layers - 1) + [1], is_output=True, device=device)
+
+    def forward(self, graph):
+        _fused_only("AtomWiseReadout")
+
+
+class Gradient(torch.nn.Module):
+    """Energies + forces + virial stresses (reference nn/gradient.py:10-64) as one fused engine call.
+
+    The wrapped `model` must be the Sequential laid out by `build_model` (model/build.py:37-76);
+    forces come from the engine's analytic reverse pass, not from autograd."""
+
+    def __init__(self, model: torch.nn.Module):
+        super().__init__()
+        self.model = model
+        self._engine = None
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            from ..engine import Engine
+
+            self._engine = Engine(self.model)
+        return self._engine
+
+    def forward(self, graph, forces: bool = True, extras: bool = True):
+        return self.engine.run(graph, want_forces=forces, extras=extras)
