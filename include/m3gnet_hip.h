@@ -146,6 +146,15 @@ int m3g_atom_featurizer(int32_t num_types, int32_t dim, const float* weight, int
 int m3g_atom_ref(int32_t num_types, const float* elemental_energies, int64_t n_atoms, const int64_t* atom_types,
                  float* out, void* stream);
 
+/* ---- measurement: per-stage device time from HIP events recorded on the call's own stream ---------
+ * m3g_profile_enable(plan, 1) makes every following m3g_energy_forces record an event pair around each
+ * stage launch; m3g_profile_read synchronises those events, returns per-stage totals since the last
+ * read and resets.  `names[i]` points to static strings.  Off by default (no events, no overhead). */
+#define M3G_MAX_STAGES 16
+int m3g_profile_enable(m3g_plan* plan, int32_t enable);
+int m3g_profile_read(m3g_plan* plan, int32_t* n_stages, const char** names /* [M3G_MAX_STAGES] */,
+                     float* total_ms /* [M3G_MAX_STAGES] */, int32_t* launches /* [M3G_MAX_STAGES] */);
+
 #define M3G_ABI_VERSION 1
 
 #ifdef __cplusplus

@@ -1,0 +1,305 @@
+"""GPU: the reference's own property tests re-expressed against the HIP engine (tests/test_model.py,
+tests/test_invariance.py, tests/test_nn.py of the reference), edge cases, and BASELINE.json's full-size
+configurations checked through size-independent properties and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_engine_model, engine_graph, fcc_cu_graph, load_oracle_case, random_cell_graph, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _K():
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    return K
+
+
+def _small_model(seed=0):
+    from torch_m3gnet.model.build import build_model
+
+    torch.manual_seed(seed)
+    return build_model(3.0001, 3.0001, 2, 3, 93, 17, 2)  # reference tests/conftest.py:150-178
+
+
+def _default_model(seed=0, **kw):
+    from torch_m3gnet.model.build import build_model
+
+    torch.manual_seed(seed)
+    args = dict(cutoff=5.0, threebody_cutoff=4.0, l_max=3, n_max=3, num_types=95, embedding_dim=64, num_blocks=3)
+    args.update(kw)
+    model = build_model(**args)
+    for m in model.model:  # documented chi so the three-body path carries weight
+        if type(m).__name__ == "ThreeBodyInteration":
+            m.nsb.factors = m.nsb.documented_factors()
+    return model
+
+
+def _al_na(perturb=True):
+    from torch_m3gnet.data.material_graph import MaterialGraph
+
+    r = 3.0
+    la, ln = r * np.sqrt(2) * np.eye(3), r / np.sqrt(3) * 2 * np.eye(3)
+    al = MaterialGraph.from_arrays(la, np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0]]) @ la, [13] * 4, r + 1e-4, r + 1e-4)
+    na = MaterialGraph.from_arrays(ln, np.array([[0, 0, 0], [.5, .5, .5]]) @ ln, [11] * 2, r + 1e-4, r + 1e-4)
+    if perturb:
+        torch.manual_seed(0)
+        for g in (al, na):
+            g["pos"] = g["pos"] + 1e-1 * (torch.rand(g["pos"].shape) - 0.5)
+    return [al, na]
+
+
+def _oracle_inputs(model, graph):
+    """(params, cfg, consts, graph dict) of the CPU oracle for a torch_m3gnet model (checker only)."""
+    from oracle import m3gnet_oracle as orc
+
+    seq = model.model
+    n_blocks = (len(seq) - 7) // 2
+    tb = seq[6]
+    ls = float(seq[0].length_scale)
+    cfg = orc.OracleConfig(cutoff=float(seq[4].cutoff) * ls, threebody_cutoff=float(tb.threebody_cutoff) * ls, l_max=tb.l_max,
+                           n_max=tb.n_max, num_types=seq[3].num_types, embedding_dim=seq[3].linear.out_features,
+                           num_blocks=n_blocks, energy_scale=float(seq[-1].scale), length_scale=ls)
+    consts = orc.make_constants(cfg, seq[1].elemental_energies.cpu())
+    consts.factors = tb.nsb.factors.clone().cpu()
+    params = {f"model.{k}": v.detach().cpu().clone() for k, v in seq.state_dict().items()}
+    g = {k: graph[k].cpu() for k in ("pos", "atom_types", "edge_index", "edge_cell_shift", "triplet_edge_index", "lattice", "batch")}
+    return params, cfg, consts, g
+
+
+# ------------------------------------------------------------------ reference tests/test_model.py
+def test_model_outputs_finite():
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    g = _small_model()(Batch.from_data_list(_al_na(False)).to(DEV))
+    for key in (K.NODE_FEATURES, K.EDGE_ATTR, K.SCALED_ATOMIC_ENERGIES, K.FORCES, K.STRESSES):
+        assert torch.isfinite(g[key]).all(), key
+
+
+def test_three_body_interaction_invariant_to_triplet_order():
+    """reference tests/test_model.py:21-38.  The topology build canonicalises the triplet order, so the
+    three-body aggregate itself is bitwise identical; later blocks see float-atomic node sums whose order is
+    not fixed, hence assert_close (as the reference does) for the rest."""
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _default_model()
+    g = Batch.from_data_list([random_cell_graph(20, 6.5, 3)]).to(DEV)
+    first = model(g)
+    out1 = {k: first[k].clone() for k in (K.EDGE_ATTR, K.FORCES, K.TOTAL_ENERGY, K.MID_EDGE_FEATURES)}
+    perm = torch.randperm(g[K.TRIPLET_EDGE_INDEX].size(1), device=DEV)
+    g[K.TRIPLET_EDGE_INDEX][0] = g[K.TRIPLET_EDGE_INDEX][0][perm]
+    g[K.TRIPLET_EDGE_INDEX][1] = g[K.TRIPLET_EDGE_INDEX][1][perm]
+    out2 = model(g)
+    assert torch.equal(out1[K.MID_EDGE_FEATURES][0], out2[K.MID_EDGE_FEATURES][0])
+    for k, v in out1.items():
+        torch.testing.assert_close(v, out2[k], rtol=1e-5, atol=1e-7)
+    assert not torch.isnan(out1[K.EDGE_ATTR]).any()
+
+
+def test_rotation_invariance_of_node_features():
+    """reference tests/test_model.py:41-56 (Ti8O24 cell, fixed rotation)."""
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+
+    K = _K()
+    _, _, _, graph, _ = load_oracle_case("tio", "ref")
+    lat = graph["lattice"][0].double().numpy()
+    pos = graph["pos"].double().numpy()
+    z = graph["atom_types"].numpy() + 1
+    rot = np.dot(np.array([[.5, np.sqrt(3) / 2, 0], [-np.sqrt(3) / 2, .5, 0], [0, 0, 1]]),
+                 np.array([[0, 0, 1], [1 / np.sqrt(2), -1 / np.sqrt(2), 0], [1 / np.sqrt(2), 1 / np.sqrt(2), 0]]))
+    model = _default_model()
+    g1 = model(Batch.from_data_list([MaterialGraph.from_arrays(lat, pos, z, 5.0, 4.0)]).to(DEV))
+    g2 = model(Batch.from_data_list([MaterialGraph.from_arrays(lat @ rot.T, pos @ rot.T, z, 5.0, 4.0)]).to(DEV))
+    torch.testing.assert_close(g1[K.NODE_FEATURES], g2[K.NODE_FEATURES], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(g1[K.TOTAL_ENERGY], g2[K.TOTAL_ENERGY], rtol=1e-5, atol=1e-6)
+    f1 = g1[K.FORCES].double().cpu().numpy() @ rot.T
+    assert np.abs(f1 - g2[K.FORCES].double().cpu().numpy()).max() < 1e-4 * np.abs(f1).max() + 1e-7
+
+
+def test_batched_equals_per_graph():
+    """reference tests/test_model.py:59-78 and tests/test_invariance.py:15-38."""
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _small_model()
+    graphs = _al_na()
+    gb = model(Batch.from_data_list([g.clone() for g in graphs]).to(DEV))
+    singles = [model(Batch.from_data_list([g.clone()]).to(DEV)) for g in graphs]
+    torch.testing.assert_close(gb[K.TOTAL_ENERGY], torch.cat([s[K.TOTAL_ENERGY] for s in singles]))
+    torch.testing.assert_close(gb[K.FORCES], torch.cat([s[K.FORCES] for s in singles]))
+    torch.testing.assert_close(gb[K.EDGE_DISTANCES], torch.cat([s[K.EDGE_DISTANCES] for s in singles]))
+    torch.testing.assert_close(gb[K.TRIPLET_ANGLES], torch.cat([s[K.TRIPLET_ANGLES] for s in singles]))
+
+
+def test_forces_against_finite_differences_of_engine_energy():
+    """reference tests/test_model.py:90-120: central differences, delta 1e-2, atol 1e-3 / rtol 1e-2."""
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _small_model()
+    g0 = Batch.from_data_list(_al_na()).to(DEV)
+    forces = model(g0.clone())[K.FORCES].cpu()
+    delta = 1e-2
+    for node in range(6):
+        s = int(g0[K.BATCH][node])
+        for axis in range(3):
+            e = []
+            for sign in (+1, -1):
+                g = g0.clone()
+                g[K.POS][node, axis] += sign * delta
+                e.append(float(model(g, forces=False, extras=False)[K.TOTAL_ENERGY][s]))
+            torch.testing.assert_close(forces[node, axis], torch.tensor(-(e[0] - e[1]) / (2 * delta)), atol=1e-3, rtol=1e-2)
+
+
+# ------------------------------------------------------------------ reference tests/test_invariance.py / test_nn.py
+def test_standalone_distance_angle_and_featurizers():
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+    from torch_m3gnet.nn.atom_ref import AtomRef
+    from torch_m3gnet.nn.featurizer import AtomFeaturizer, EdgeFeaturizer
+    from torch_m3gnet.nn.invariant import DistanceAndAngle
+    from torch_m3gnet.nn.scale import ScaleLength
+
+    K = _K()
+    g = Batch.from_data_list(_al_na(False)).to(DEV)
+    seq = torch.nn.Sequential(ScaleLength(1.0), DistanceAndAngle(), EdgeFeaturizer(degree=3, cutoff=5.0))
+    g = seq(g)
+    ang = g[K.TRIPLET_ANGLES]
+    assert (ang <= 1).all() and (ang >= -1).all()
+    theta_sum = float(torch.arccos(ang.double()).sum()) / np.pi
+    assert abs(theta_sum - round(theta_sum)) < 1e-3  # reference tests/test_invariance.py:69-82
+    torch.testing.assert_close(g[K.EDGE_DISTANCES], torch.full_like(g[K.EDGE_DISTANCES], 3.0), rtol=1e-5, atol=1e-5)
+    assert g[K.EDGE_WEIGHTS].shape[1] == 3 and torch.isfinite(g[K.EDGE_WEIGHTS]).all()
+    # oracle cross-check of the standalone stage outputs
+    from oracle import m3gnet_oracle as orc
+
+    cfg = orc.OracleConfig(cutoff=5.0, n_max=3)
+    ew = orc.radial_basis(g[K.EDGE_DISTANCES].cpu(), cfg, orc.make_constants(cfg))
+    assert rel_err(g[K.EDGE_WEIGHTS], ew) < 1e-5
+    g = AtomFeaturizer(num_types=15, embedding_dim=64)(g)
+    assert g[K.NODE_FEATURES].shape == (6, 64) and torch.isfinite(g[K.NODE_FEATURES]).all()
+    # AtomRef known answer (reference tests/test_nn.py:16-30): Li Li H H with energies [2,0,3] -> 10
+    lih = MaterialGraph.from_arrays(np.eye(3), np.array([[0, 0, 0], [.5, .5, .5], [.5, 0, 0], [0, .5, .5]]), [3, 3, 1, 1], 1, 1)
+    out = AtomRef(torch.tensor([2, 0, 3]))(Batch.from_data_list([lih]).to(DEV))
+    assert abs(float(out[K.ELEMENTAL_ENERGIES].sum()) - 10.0) < 1e-6
+
+
+# ------------------------------------------------------------------ edge cases
+def test_malformed_graphs_raise_value_error():
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _small_model()
+    g = Batch.from_data_list(_al_na()).to(DEV)
+    bad = g.clone()
+    bad[K.EDGE_INDEX] = bad[K.EDGE_INDEX].flip(1)
+    with pytest.raises(ValueError, match="sorted by centre"):
+        model(bad)
+    bad = g.clone()
+    bad[K.TRIPLET_EDGE_INDEX][1, 0] = 10_000
+    with pytest.raises(ValueError, match="out of range"):
+        model(bad)
+
+
+def test_empty_and_ragged_inputs():
+    """No triplets at all, no edges at all, and a batch mixing an isolated atom with a dense cell."""
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+
+    K = _K()
+    model = _default_model()
+    lone = MaterialGraph.from_arrays(np.eye(3) * 20.0, np.array([[1.0, 2.0, 3.0]]), [8], 5.0, 4.0)  # no edges
+    pair = MaterialGraph.from_arrays(np.eye(3) * 20.0, np.array([[0, 0, 0], [0, 0, 4.5]]), [8, 1], 5.0, 4.0)  # edges, no triplets
+    dense = random_cell_graph(12, 5.2, 9)
+    assert lone[K.NUM_EDGES] == 0 and pair[K.NUM_EDGES] == 2 and pair[K.NUM_TRIPLETS] == 0
+    for graphs in ([lone], [pair], [lone, dense, pair]):
+        g = model(Batch.from_data_list([x.clone() for x in graphs]).to(DEV))
+        assert torch.isfinite(g[K.TOTAL_ENERGY]).all() and torch.isfinite(g[K.FORCES]).all()
+        p, cfg, c, og = _oracle_inputs(model, g)
+        from oracle import m3gnet_oracle as orc
+
+        o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+        assert rel_err(g[K.TOTAL_ENERGY], o["total_energy"]) < 1e-5
+        assert float((g[K.FORCES].cpu() - o["forces"]).abs().max()) < 1e-4 * float(o["forces"].abs().max()) + 1e-9
+    assert float(model(Batch.from_data_list([lone]).to(DEV))[K.FORCES].abs().max()) == 0.0
+
+
+def test_scales_and_elemental_energies():
+    from torch_m3gnet.data.material_graph import Batch
+    from oracle import m3gnet_oracle as orc
+
+    K = _K()
+    model = _default_model(seed=4, energy_scale=3.5, length_scale=1.3, elemental_energies=torch.linspace(-2, 1, 95))
+    g = model(Batch.from_data_list([random_cell_graph(16, 6.0, s) for s in (1, 2)]).to(DEV))
+    p, cfg, c, og = _oracle_inputs(model, g)
+    o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+    assert rel_err(g[K.TOTAL_ENERGY], o["total_energy"]) < 1e-5
+    assert rel_err(g[K.FORCES], o["forces"]) < 1e-4
+    assert rel_err(g[K.STRESSES], o["stresses"]) < 1e-4
+
+
+# ------------------------------------------------------------------ BASELINE.json configurations
+def test_config3_10k_atom_cu_supercell_vs_oracle():
+    """10,000-atom Cu supercell (BASELINE config 3): full-size parity against the fp32 CPU oracle plus
+    size-independent properties (net force ~ 0, translation invariance)."""
+    from oracle import m3gnet_oracle as orc
+
+    K = _K()
+    model = _default_model()
+    g = fcc_cu_graph(10, 10, 25).to(DEV)
+    assert g[K.NUM_NODES] == 10_000 and g[K.NUM_EDGES] == 420_000 and g[K.NUM_TRIPLETS] == 3_060_000
+    out = model(g)
+    torch.set_num_threads(8)
+    p, cfg, c, og = _oracle_inputs(model, out)
+    o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+    assert rel_err(out[K.TOTAL_ENERGY], o["total_energy"]) < 1e-5
+    assert rel_err(out[K.FORCES], o["forces"]) < 1e-4
+    assert rel_err(out[K.MID_EDGE_FEATURES][0], o["mid_edge_features_0"]) < 1e-4
+    f = out[K.FORCES].double()
+    assert float(f.sum(0).abs().max()) < 1e-3 * float(f.abs().max())
+    shifted = g.clone()
+    shifted[K.POS] = shifted[K.POS] + torch.tensor([0.37, -1.1, 2.3], device=DEV)
+    out2 = model(shifted)
+    assert rel_err(out2[K.TOTAL_ENERGY], out[K.TOTAL_ENERGY]) < 1e-5
+    assert rel_err(out2[K.FORCES], out[K.FORCES]) < 1e-3
+
+
+def test_config2_batched_random_species_cells():
+    """Batched 64-atom random-species cells (BASELINE config 2; 32 of the 256 cells against the oracle,
+    then all 256 batched == the same cells evaluated in two halves)."""
+    from oracle import m3gnet_oracle as orc
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _default_model()
+    cells = [random_cell_graph(64, 9.1, s) for s in range(32)]
+    out = model(Batch.from_data_list(cells).to(DEV))
+    torch.set_num_threads(8)
+    p, cfg, c, og = _oracle_inputs(model, out)
+    o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+    assert float(((out[K.TOTAL_ENERGY].cpu() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < 1e-5
+    assert rel_err(out[K.FORCES], o["forces"]) < 1e-4
+    halves = [model(Batch.from_data_list(cells[a:b]).to(DEV)) for a, b in ((0, 16), (16, 32))]
+    torch.testing.assert_close(out[K.TOTAL_ENERGY], torch.cat([h[K.TOTAL_ENERGY] for h in halves]), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out[K.FORCES], torch.cat([h[K.FORCES] for h in halves]), rtol=1e-5, atol=1e-7)
+
+
+def test_config5_high_triplet_density():
+    """r_cut = 6 A with 3-body cutoff 6 A (~60 neighbours, thousands of triplets per atom), reduced to 250
+    atoms for the oracle comparison."""
+    from oracle import m3gnet_oracle as orc
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _default_model(cutoff=6.0, threebody_cutoff=6.0)
+    cell = random_cell_graph(250, 15.55, 0, cutoff=6.0, tb_cutoff=6.0)
+    out = model(Batch.from_data_list([cell]).to(DEV))
+    assert out[K.NUM_TRIPLETS] / out[K.NUM_NODES] > 2000
+    torch.set_num_threads(8)
+    p, cfg, c, og = _oracle_inputs(model, out)
+    o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+    assert rel_err(out[K.TOTAL_ENERGY], o["total_energy"]) < 1e-5
+    assert rel_err(out[K.FORCES], o["forces"]) < 1e-4
+    assert rel_err(out[K.MID_EDGE_FEATURES][2], o["mid_edge_features_2"]) < 1e-4

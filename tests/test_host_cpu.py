@@ -1,0 +1,230 @@
+"""CPU-only checks of the host side: C-ABI export surface, drop-in API/state_dict parity, graph
+construction, error behaviour, and the no-fallback rule.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from torch_m3gnet import _lib
+
+    header = (ROOT / "include" / "m3gnet_hip.h").read_text()
+    declared = set(re.findall(r"\b(m3g_[a-z_]+)\s*\(", header))
+    declared -= {"m3g_plan"}  # type name
+    lib = _lib.load_library()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/m3gnet_hip.h but not exported"
+        assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype"
+    info = _lib.M3GInfo()
+    assert lib.m3g_get_info(C.byref(info)) == 0
+    assert info.abi_version == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header_sizes():
+    from torch_m3gnet import _lib
+
+    assert C.sizeof(_lib.M3GConfig) == 4 * 8 + 6 * 4
+    assert C.sizeof(_lib.M3GIO) == 4 * 8 + 17 * 8
+
+
+def test_seeded_build_model_reproduces_reference_weights_and_keys():
+    """Same construction order as the reference => same RNG stream => identical initial weights."""
+    from torch_m3gnet.model.build import build_model
+
+    torch.manual_seed(0)
+    model = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
+    z = np.load(GOLDEN / "model_default_seed0.npz")
+    keys = [k for k in z.files if not k.startswith("__")]
+    sd = model.state_dict()
+    assert set(sd) == set(keys) and len(sd) == 80
+    for k in keys:
+        assert np.array_equal(sd[k].numpy(), z[k]), k
+    assert sum(p.numel() for p in model.parameters()) == 227_549  # reference docs/architecture.md:50
+    g = np.load(GOLDEN / "case_cu32_ref.npz")
+    assert np.array_equal(model.model[4].em.numpy(), g["const_em"])
+    assert np.array_equal(model.model[4].dm.numpy(), g["const_dm"])
+    assert np.array_equal(model.model[4].coeff.numpy(), g["const_coeff"])
+    gd = np.load(GOLDEN / "case_cu32_doc.npz")
+    np.testing.assert_allclose(model.model[6].nsb.documented_factors().numpy(), gd["const_factors"], rtol=1e-6)
+
+
+def test_small_model_keys_match_reference():
+    from torch_m3gnet.model.build import build_model
+
+    z = np.load(GOLDEN / "model_small_seed0.npz")
+    torch.manual_seed(0)
+    model = build_model(float(z["__cfg_cutoff"]), float(z["__cfg_threebody_cutoff"]), 2, 3, 93, 17, 2)
+    for k in (k for k in z.files if not k.startswith("__")):
+        assert np.array_equal(model.state_dict()[k].numpy(), z[k]), k
+
+
+def test_reference_import_paths_exist():
+    from torch_m3gnet.data import MaterialGraphKey  # noqa: F401
+    from torch_m3gnet.data.material_graph import BatchMaterialGraph, MaterialGraph  # noqa: F401
+    from torch_m3gnet.nn.atom_ref import AtomRef  # noqa: F401
+    from torch_m3gnet.nn.conv import M3GNetConv  # noqa: F401
+    from torch_m3gnet.nn.core import GatedMLP  # noqa: F401
+    from torch_m3gnet.nn.featurizer import AtomFeaturizer, EdgeAdjustor, EdgeFeaturizer  # noqa: F401
+    from torch_m3gnet.nn.gradient import Gradient  # noqa: F401
+    from torch_m3gnet.nn.interaction import (SPHERICAL_BESSEL_ZEROS, ThreeBodyInteration, cutoff_function,  # noqa: F401
+                                             legendre_cos, spherical_bessel)
+    from torch_m3gnet.nn.invariant import DistanceAndAngle  # noqa: F401
+    from torch_m3gnet.nn.readout import AtomWiseReadout  # noqa: F401
+    from torch_m3gnet.nn.scale import ScaleLength  # noqa: F401
+
+    assert len(SPHERICAL_BESSEL_ZEROS) == 10 and len(SPHERICAL_BESSEL_ZEROS[0]) == 10
+
+
+def test_basis_functions_known_answers():
+    """reference tests/test_basis.py: zeros, gradcheck, cutoff values -- on the package's host functions."""
+    from torch_m3gnet.nn.interaction import SPHERICAL_BESSEL_ZEROS, cutoff_function, legendre_cos, spherical_bessel
+
+    for order in range(10):
+        for root in SPHERICAL_BESSEL_ZEROS[order]:
+            torch.testing.assert_close(spherical_bessel(torch.tensor([root]), order), torch.tensor([0.0]))
+    for order in range(4):
+        x = torch.linspace(1e-1, 10, steps=16, dtype=torch.float64, requires_grad=True)
+        assert torch.autograd.gradcheck(spherical_bessel, (x, order), eps=1e-4)
+        c = torch.linspace(-1, 1, steps=16, dtype=torch.float64, requires_grad=True)
+        assert torch.autograd.gradcheck(legendre_cos, (c, order), eps=1e-4)
+    torch.testing.assert_close(cutoff_function(torch.tensor([0.0, 2.0, 4.0]), 2.0), torch.tensor([1.0, 0.0, 0.0]))
+
+
+def _al_na():
+    from torch_m3gnet.data.material_graph import MaterialGraph
+
+    r = 3.0
+    la, ln = r * np.sqrt(2) * np.eye(3), r / np.sqrt(3) * 2 * np.eye(3)
+    al = MaterialGraph.from_arrays(la, np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0]]) @ la, [13] * 4, r + 1e-4, r + 1e-4)
+    na = MaterialGraph.from_arrays(ln, np.array([[0, 0, 0], [.5, .5, .5]]) @ ln, [11] * 2, r + 1e-4, r + 1e-4)
+    return al, na
+
+
+def test_batch_collation_known_answers():
+    """reference tests/test_data.py:10-23: batch vector, fcc 12*11 and bcc 8*7 triplets per atom."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.material_graph import Batch
+
+    g = Batch.from_data_list(list(_al_na()))
+    torch.testing.assert_close(g.batch, torch.tensor([0, 0, 0, 0, 1, 1]))
+    assert g.num_nodes == 6 and g.pos.shape == (6, 3) and g.lattice.shape == (2, 3, 3)
+    torch.testing.assert_close(g[K.NUM_TRIPLET_I], torch.tensor([132, 132, 132, 132, 56, 56]))
+    # offsets of __inc__: second graph's edges point at atoms 4,5 and its triplets at edges >= 48
+    assert int(g.edge_index[:, 48:].min()) == 4 and int(g.triplet_edge_index[:, 4 * 132:].min()) == 48
+
+
+def test_threebody_index_matches_loop_restatement():
+    """Vectorised enumeration == the plain triple loop of the reference's compute_threebody
+    (data/material_graph.py:229-248), on a cell where some edges exceed the three-body cutoff."""
+    from torch_m3gnet.data.neighbors import neighbor_list, threebody_index
+
+    rng = np.random.default_rng(5)
+    lat = np.eye(3) * 6.0
+    pos = rng.uniform(0, 6.0, (12, 3))
+    ei, shift, dist = neighbor_list(lat, pos, 4.5)
+    tei, nti, ntij = threebody_index(12, ei, dist, 3.2)
+    valid = np.nonzero(dist <= 3.2)[0]
+    deg = np.bincount(ei[0][valid], minlength=12)
+    loop = []
+    off = 0
+    for i in range(12):
+        for j in range(deg[i]):
+            for k in range(deg[i]):
+                if j != k:
+                    loop.append((valid[off + j], valid[off + k]))
+        off += deg[i]
+    assert np.array_equal(tei.T, np.array(loop).reshape(-1, 2))
+    assert np.array_equal(nti, deg * (deg - 1))
+    # geometry of the list itself
+    r = pos[ei[1]] + shift @ lat - pos[ei[0]]
+    np.testing.assert_allclose(np.linalg.norm(r, axis=1), dist, atol=1e-12)
+    assert np.all(np.diff(ei[0]) >= 0) and dist.max() <= 4.5 + 1e-8
+
+
+def test_neighbor_list_rotation_invariance_and_self_images():
+    """Sorted distances are invariant under rotation of a strained cell (reference
+    tests/test_invariance.py:41-66); tiny cells produce self-image edges i -> i."""
+    from torch_m3gnet.data.neighbors import neighbor_list
+
+    rng = np.random.default_rng(2)
+    lat = np.eye(3) * 8.01 + 0.1 * rng.uniform(-1, 1, (3, 3))
+    pos = rng.uniform(0, 8, (20, 3))
+    rot = np.dot(np.array([[.5, np.sqrt(3) / 2, 0], [-np.sqrt(3) / 2, .5, 0], [0, 0, 1]]),
+                 np.array([[0, 0, 1], [1 / np.sqrt(2), -1 / np.sqrt(2), 0], [1 / np.sqrt(2), 1 / np.sqrt(2), 0]]))
+    _, _, d1 = neighbor_list(lat, pos, 5.0)
+    _, _, d2 = neighbor_list(lat @ rot.T, pos @ rot.T, 5.0)
+    np.testing.assert_allclose(np.sort(d1), np.sort(d2), atol=1e-9)
+    ei, shift, _ = neighbor_list(np.eye(3) * 2.5, np.zeros((1, 3)), 3.6)
+    assert ei.shape[1] == 18 and np.all(ei[0] == 0) and np.all(ei[1] == 0) and np.all(np.abs(shift).sum(1) > 0)
+
+
+def test_error_behaviour_matches_reference():
+    from torch_m3gnet.data.material_graph import MaterialGraph
+    from torch_m3gnet.nn.interaction import NormalizedSphericalBessel
+
+    with pytest.raises(ValueError, match="Too large l_max"):
+        NormalizedSphericalBessel(5.0, 10, 3)  # nn/interaction.py:250-251
+    with pytest.raises(ValueError, match="Too large n_max"):
+        NormalizedSphericalBessel(5.0, 3, 11)  # nn/interaction.py:252-253
+    with pytest.raises(ValueError, match="Three body cutoff"):
+        MaterialGraph.from_arrays(np.eye(3) * 4, np.zeros((1, 3)), [1], 3.0, 3.5)  # material_graph.py:149-150
+
+
+def test_c_abi_plan_error_codes():
+    from torch_m3gnet import _lib
+
+    lib = _lib.load_library()
+    cfg = _lib.M3GConfig(5.0, 4.0, 1.0, 1.0, 3, 3, 95, 64, 3, 0)
+    plan = C.c_void_p()
+    assert lib.m3g_plan_create(C.byref(cfg), C.byref(plan)) == _lib.M3G_OK
+    buf = np.zeros(64 * 95, dtype=np.float32)
+    assert lib.m3g_plan_set_param(plan, b"model.3.linear.weight", buf.ctypes.data, buf.size) == _lib.M3G_OK
+    assert lib.m3g_plan_set_param(plan, b"model.3.linear.weight", buf.ctypes.data, 7) == _lib.M3G_ERR_VALUE
+    assert lib.m3g_plan_set_param(plan, b"model.99.nope", buf.ctypes.data, 7) == _lib.M3G_ERR_VALUE
+    assert b"unknown parameter" in lib.m3g_last_error()
+    assert lib.m3g_plan_commit(plan) == _lib.M3G_ERR_STATE  # parameters missing
+    lib.m3g_plan_destroy(plan)
+    bad = _lib.M3GConfig(5.0, 4.0, 1.0, 1.0, 10, 3, 95, 64, 3, 0)
+    assert lib.m3g_plan_create(C.byref(bad), C.byref(plan)) == _lib.M3G_ERR_VALUE
+    with pytest.raises(ValueError, match="Too large l_max"):
+        _lib.check(_lib.M3G_ERR_VALUE)
+    big = _lib.M3GConfig(5.0, 4.0, 1.0, 1.0, 3, 3, 95, 256, 3, 0)
+    assert lib.m3g_plan_create(C.byref(big), C.byref(plan)) == _lib.M3G_ERR_UNSUPPORTED
+    tb = _lib.M3GConfig(4.0, 5.0, 1.0, 1.0, 3, 3, 95, 64, 3, 0)
+    assert lib.m3g_plan_create(C.byref(tb), C.byref(plan)) == _lib.M3G_ERR_VALUE
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly on CPU tensors / without a GPU -- never compute on the host."""
+    from torch_m3gnet.data.material_graph import Batch
+    from torch_m3gnet.model.build import build_model
+    from torch_m3gnet.nn.featurizer import AtomFeaturizer
+    from torch_m3gnet.nn.invariant import DistanceAndAngle
+    from torch_m3gnet.nn.scale import ScaleLength
+
+    g = Batch.from_data_list(list(_al_na()))
+    model = build_model(3.0001, 3.0001, 2, 3, 93, 17, 2)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        model(g)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        torch.nn.Sequential(ScaleLength(1.0), DistanceAndAngle())(g)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        AtomFeaturizer(15, 8)(g)
+    with pytest.raises(RuntimeError, match="fused"):
+        model.model[7](g)
+
+
+def test_unfused_layout_is_rejected():
+    from torch_m3gnet.nn import modules as nn
+
+    with pytest.raises(RuntimeError, match="module order of build_model"):
+        nn.Gradient(torch.nn.Sequential(nn.ScaleLength(1.0), nn.DistanceAndAngle())).engine

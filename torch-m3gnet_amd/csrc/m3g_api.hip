@@ -168,6 +168,58 @@ Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, voi
 
 using namespace m3g;
 
+// ---- stage profiler ---------------------------------------------------------------------------------
+enum StageId { ST_GEOM = 0, ST_EMBED, ST_NODE_PRE, ST_THREEBODY, ST_EDGE_FWD, ST_READOUT, ST_OUTPUTS, ST_EDGE_REV,
+               ST_THREEBODY_REV, ST_NODE_REV, ST_EMBED_REV, ST_GEOM_REV, ST_COUNT };
+static const char* kStageNames[ST_COUNT] = {"geometry_basis", "embed", "node_pre", "threebody_fwd", "edge_block_fwd", "readout",
+                                            "optional_outputs", "edge_block_rev", "threebody_rev", "node_rev", "embed_rev",
+                                            "geometry_rev_forces"};
+struct StageTimer {
+  const m3g_plan* p;
+  hipStream_t s;
+  size_t pair = (size_t)-1;
+  StageTimer(const m3g_plan* plan, int stage, hipStream_t stream) : p(plan), s(stream) {
+    if (!p->profile) return;
+    if (p->ev_used * 2 + 2 > p->ev_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      p->ev_pool.push_back(a);
+      p->ev_pool.push_back(b);
+      p->ev_stage.push_back(stage);
+    }
+    pair = p->ev_used++;
+    p->ev_stage[pair] = stage;
+    (void)hipEventRecord(p->ev_pool[2 * pair], s);
+  }
+  ~StageTimer() {
+    if (pair != (size_t)-1) (void)hipEventRecord(p->ev_pool[2 * pair + 1], s);
+  }
+};
+#define M3G_STAGE(id) StageTimer _st_##id(plan, id, s)
+
+extern "C" int m3g_profile_enable(m3g_plan* plan, int32_t enable) {
+  if (!plan) { set_error("m3g_profile_enable: null plan"); return M3G_ERR_VALUE; }
+  plan->profile = enable != 0;
+  plan->ev_used = 0;
+  return M3G_OK;
+}
+
+extern "C" int m3g_profile_read(m3g_plan* plan, int32_t* n_stages, const char** names, float* total_ms, int32_t* launches) {
+  if (!plan || !n_stages || !names || !total_ms || !launches) { set_error("m3g_profile_read: null argument"); return M3G_ERR_VALUE; }
+  static_assert(ST_COUNT <= M3G_MAX_STAGES, "stage table too large");
+  *n_stages = ST_COUNT;
+  for (int i = 0; i < ST_COUNT; ++i) { names[i] = kStageNames[i]; total_ms[i] = 0.f; launches[i] = 0; }
+  for (size_t k = 0; k < plan->ev_used; ++k) {
+    M3G_HIP_CHECK(hipEventSynchronize(plan->ev_pool[2 * k + 1]));
+    float ms = 0.f;
+    M3G_HIP_CHECK(hipEventElapsedTime(&ms, plan->ev_pool[2 * k], plan->ev_pool[2 * k + 1]));
+    total_ms[plan->ev_stage[k]] += ms;
+    launches[plan->ev_stage[k]] += 1;
+  }
+  plan->ev_used = 0;
+  return M3G_OK;
+}
+
 extern "C" const char* m3g_last_error(void) { return g_err; }
 
 extern "C" int m3g_get_info(m3g_info* out) {
@@ -214,6 +266,7 @@ extern "C" int m3g_plan_create(const m3g_config* cfg, m3g_plan** out) {
 extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (!plan) return;
   if (plan->d_weights) (void)hipFree(plan->d_weights);
+  for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
   delete plan;
 }
 
@@ -361,16 +414,18 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   float* st = io->scaled_total_energy ? io->scaled_total_energy : tail + N;
 
   // ---------------- forward ----------------
-  launch_geometry(c, t, io->pos, io->lattice, io->edge_cell_shift, w, s);
-  launch_embed(c, W, wl, t, io->atom_types, w, s);
+  { M3G_STAGE(ST_GEOM); launch_geometry(c, t, io->pos, io->lattice, io->edge_cell_shift, w, s); }
+  { M3G_STAGE(ST_EMBED); launch_embed(c, W, wl, t, io->atom_types, w, s); }
   for (int b = 0; b < c.B; ++b) {
-    launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], w.TA, w.TB, s);
-    launch_threebody(c, t, w, w.v[b], w.m[b], s);
+    { M3G_STAGE(ST_NODE_PRE); launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], w.TA, w.TB, s); }
+    { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }
+    M3G_STAGE(ST_EDGE_FWD);
     if (N > 0) M3G_HIP_CHECK(hipMemcpyAsync(w.x[b + 1], w.x[b], sizeof(float) * N * kDP, hipMemcpyDeviceToDevice, s));
     launch_edge_block(c, W, wl.blk[b], t, w, b, w.x[b + 1], s);
   }
   const bool want_f = io->forces != nullptr;
-  launch_readout(c, W, wl, t, io->atom_types, w.x[c.B], w, ea, st, io->total_energy, want_f, s);
+  { M3G_STAGE(ST_READOUT); launch_readout(c, W, wl, t, io->atom_types, w.x[c.B], w, ea, st, io->total_energy, want_f, s); }
+  StageTimer* st_out = new StageTimer(plan, ST_OUTPUTS, s);
 
   if (io->node_features) launch_copy_strided(w.x[c.B], kDP, io->node_features, c.D, c.D, N, s);
   if (io->edge_attr) launch_copy_strided(w.e, kDP, io->edge_attr, c.D, c.D, E, s);
@@ -379,26 +434,32 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   if (io->triplet_angles) launch_triplet_angles(t, io->triplet_edge_index, w.u, io->triplet_angles, s);
   if (io->mid_edge_features)
     for (int b = 0; b < c.B; ++b) launch_copy_strided(w.m[b], kCP, io->mid_edge_features + (size_t)b * E * c.C, c.C, c.C, E, s);
+  delete st_out;
 
   // ---------------- reverse ----------------
   if (want_f) {
-    if (E > 0) {
-      M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
-      M3G_HIP_CHECK(hipMemsetAsync(w.dh, 0, sizeof(float) * E * kRP, s));
-      M3G_HIP_CHECK(hipMemsetAsync(w.dd, 0, sizeof(float) * E, s));
-      M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
-    }
     float* dx_cur = w.dx;
     float* dx_alt = w.dx2;
     for (int b = c.B - 1; b >= 0; --b) {
-      launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
-      launch_threebody_reverse(c, t, w, w.v[b], s);
+      {
+        M3G_STAGE(ST_EDGE_REV);
+        if (b == c.B - 1 && E > 0) {
+          M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
+          M3G_HIP_CHECK(hipMemsetAsync(w.dh, 0, sizeof(float) * E * kRP, s));
+          M3G_HIP_CHECK(hipMemsetAsync(w.dd, 0, sizeof(float) * E, s));
+          M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
+        }
+        launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
+      }
+      { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], s); }
       if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
+        M3G_STAGE(ST_NODE_REV);
         launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
       }
     }
-    launch_embed_reverse(c, W, wl, t, w, s);
+    { M3G_STAGE(ST_EMBED_REV); launch_embed_reverse(c, W, wl, t, w, s); }
+    M3G_STAGE(ST_GEOM_REV);
     launch_geometry_reverse(c, t, w, io->forces, s);
     if (io->stresses) launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);
   } else if (io->stresses) {

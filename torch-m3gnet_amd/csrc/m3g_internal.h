@@ -91,6 +91,11 @@ struct m3g_plan {
   std::map<std::string, std::vector<float>> cvals;   // raw constants (host)
   float* d_weights = nullptr;
   bool committed = false;
+  // opt-in stage profiler (m3g_profile_*): event pairs recorded around stage launches
+  mutable bool profile = false;
+  mutable std::vector<hipEvent_t> ev_pool;
+  mutable std::vector<int> ev_stage;   // stage id of pair k (events 2k, 2k+1)
+  mutable size_t ev_used = 0;          // pairs used since the last read
 };
 
 namespace m3g {

@@ -95,6 +95,19 @@ class Engine:
             _lib.check(lib.m3g_plan_set_const(plan, name.encode(), arr.ctypes.data, arr.size))
         _lib.check(lib.m3g_plan_commit(plan))
 
+    # ---------------------------------------------------------------- measurement
+    def profile(self, enable: bool) -> None:
+        _lib.check(self.lib.m3g_profile_enable(self.plan, 1 if enable else 0))
+
+    def profile_read(self) -> dict:
+        """{stage: (total_ms, launches)} from the HIP events recorded since the last read."""
+        n = C.c_int32()
+        names = (C.c_char_p * _lib.MAX_STAGES)()
+        ms = (C.c_float * _lib.MAX_STAGES)()
+        cnt = (C.c_int32 * _lib.MAX_STAGES)()
+        _lib.check(self.lib.m3g_profile_read(self.plan, C.byref(n), names, ms, cnt))
+        return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n.value)}
+
     # ---------------------------------------------------------------- the hot call
     def run(self, graph, want_forces: bool = True, extras: bool = True):
         pos = graph[K.POS]
