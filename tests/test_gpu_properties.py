@@ -170,7 +170,10 @@ def test_standalone_distance_angle_and_featurizers():
     ang = g[K.TRIPLET_ANGLES]
     assert (ang <= 1).all() and (ang >= -1).all()
     theta_sum = float(torch.arccos(ang.double()).sum()) / np.pi
-    assert abs(theta_sum - round(theta_sum)) < 1e-3  # reference tests/test_invariance.py:69-82
+    # reference tests/test_invariance.py:69-82.  arccos is ill-conditioned at +-1 (perfectly collinear lattice
+    # triplets): a 1e-7 difference in cos moves one angle by ~4e-4 rad, so the bound is 5e-3 (the cosines
+    # themselves are checked against the reference to 2e-6 in test_gpu_parity.py).
+    assert abs(theta_sum - round(theta_sum)) < 5e-3
     torch.testing.assert_close(g[K.EDGE_DISTANCES], torch.full_like(g[K.EDGE_DISTANCES], 3.0), rtol=1e-5, atol=1e-5)
     assert g[K.EDGE_WEIGHTS].shape[1] == 3 and torch.isfinite(g[K.EDGE_WEIGHTS]).all()
     # oracle cross-check of the standalone stage outputs
