@@ -84,6 +84,10 @@ int m3g_plan_set_param(m3g_plan* plan, const char* key, const float* host_data, 
  * HOST pointers. */
 int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data, int64_t numel);
 
+/* Engine options (not part of the reference): "edge_kernel" = 1 fused fp32-MFMA edge blocks (default),
+ * 0 = vector-ALU baseline kernels (also selectable with the environment variable M3G_EDGE_KERNEL). */
+int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value);
+
 /* Pack and upload everything set so far (synchronous).  Must be called before any compute call
  * and again after parameters/constants change.  Missing keys -> M3G_ERR_STATE. */
 int m3g_plan_commit(m3g_plan* plan);

@@ -64,3 +64,22 @@ def test_energy_only_call_matches():
     g = model(engine_graph(graph), forces=False, extras=False)
     assert K.FORCES not in g
     assert rel_err(g[K.TOTAL_ENERGY], expect["out_total_energy"]) < E_TOL
+
+
+@pytest.mark.parametrize("edge_kernel", [0, 1])
+@pytest.mark.parametrize("case,mode", [("cu32", "doc"), ("alna", "ref"), ("mix", "doc")])
+def test_both_edge_kernels_against_oracle(case, mode, edge_kernel):
+    """edge_kernel = 1: fused fp32-MFMA edge blocks (default); 0: vector-ALU baseline kernels (fallback)."""
+    from oracle import m3gnet_oracle as orc
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    model, _ = build_engine_model(case, mode)
+    model.engine.set_option("edge_kernel", edge_kernel)
+    _, _, _, graph, _ = load_oracle_case(case, mode)
+    g = model(engine_graph(graph))
+    p64, cfg64, c64, graph64, _ = load_oracle_case(case, mode, dtype=torch.float64)
+    o = orc.energy_forces(p64, cfg64, c64, graph64, legendre_backward="exact")
+    assert float(((g[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < E_TOL
+    assert rel_err(g[K.FORCES], o["forces"]) < F_TOL
+    assert rel_err(g[K.EDGE_ATTR], o["edge_attr"]) < 1e-5
+    assert rel_err(g[K.NODE_FEATURES], o["x"]) < 1e-5

@@ -257,7 +257,13 @@ def test_config3_10k_atom_cu_supercell_vs_oracle():
     torch.set_num_threads(8)
     p, cfg, c, og = _oracle_inputs(model, out)
     o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
-    assert rel_err(out[K.TOTAL_ENERGY], o["total_energy"]) < 1e-5
+    # Per-atom energies are compared with the reference arithmetic (fp32 torch on the CPU).  The TOTAL is
+    # compared with the fp64 sum of those: the reference path adds 10,000 near-identical fp32 numbers
+    # sequentially (scatter_sum), which is itself 3.8e-5 away from the exact sum (fp64 oracle: -317.028015,
+    # fp32 CPU path: -317.0400, engine: -317.02808).
+    assert rel_err(out[K.SCALED_ATOMIC_ENERGIES], o["scaled_atomic_energies"]) < 1e-5
+    e_exact = float(o["scaled_atomic_energies"].double().sum()) * cfg.energy_scale
+    assert abs(float(out[K.TOTAL_ENERGY][0]) - e_exact) < 1e-5 * abs(e_exact)
     assert rel_err(out[K.FORCES], o["forces"]) < 1e-4
     assert rel_err(out[K.MID_EDGE_FEATURES][0], o["mid_edge_features_0"]) < 1e-4
     f = out[K.FORCES].double()

@@ -153,10 +153,12 @@ Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, voi
   w.TA = take(n * 4 * kDP); w.TB = take(n * 4 * kDP);
   w.e = take(e * kDP);
   for (int b = 0; b < c.B; ++b) w.m[b] = take(e * kCP);
-  for (int b = 0; b < c.B; ++b) w.act[b] = take(e * 8 * kDP);
+  const size_t tiles = (e + 31) / 32;
+  for (int b = 0; b < c.B; ++b) w.act[b] = take(tiles * 32 * 8 * kDP);  // also the MFMA path's [tiles][2][128][64] image
   w.dx = take(n * kDP); w.dx2 = take(n * kDP);
   w.de = take(e * kDP); w.dm = take(e * kCP); w.g = take(e * kCP); w.dg = take(e * kCP);
   w.dh = take(e * kRP); w.dd = take(e); w.du = take(e * 3); w.dp1 = take(e * 4 * kDP); w.dr = take(e * 3);
+  w.e_soa = take(tiles * 2048); w.de_soa = take(tiles * 2048); w.msg = take(e * kDP);
   // scratch for optional outputs the caller did not ask for
   w.dr = w.dr;
   off += align_up((n + (size_t)S * 2 + 64) * sizeof(float));
@@ -258,6 +260,7 @@ extern "C" int m3g_plan_create(const m3g_config* cfg, m3g_plan** out) {
   }
   m3g_plan* p = new m3g_plan();
   p->cfg = *cfg;
+  if (const char* env = getenv("M3G_EDGE_KERNEL")) p->edge_kernel = atoi(env) != 0 ? 1 : 0;
   p->wl = make_layout(*cfg);
   *out = p;
   return M3G_OK;
@@ -266,6 +269,8 @@ extern "C" int m3g_plan_create(const m3g_config* cfg, m3g_plan** out) {
 extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (!plan) return;
   if (plan->d_weights) (void)hipFree(plan->d_weights);
+  if (plan->d_mfma_fwd) (void)hipFree(plan->d_mfma_fwd);
+  if (plan->d_mfma_rev) (void)hipFree(plan->d_mfma_rev);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
   delete plan;
 }
@@ -290,6 +295,17 @@ extern "C" int m3g_plan_set_const(m3g_plan* plan, const char* name, const float*
   plan->cvals[name].assign(host_data, host_data + numel);
   plan->committed = false;
   return M3G_OK;
+}
+
+extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value) {
+  if (!plan || !name) { set_error("m3g_plan_set_option: null argument"); return M3G_ERR_VALUE; }
+  if (strcmp(name, "edge_kernel") == 0) {
+    if (value != 0 && value != 1) { set_error("edge_kernel must be 0 (VALU baseline) or 1 (MFMA)"); return M3G_ERR_VALUE; }
+    plan->edge_kernel = value;
+    return M3G_OK;
+  }
+  set_error("unknown option '%s'", name);
+  return M3G_ERR_VALUE;
 }
 
 extern "C" int m3g_plan_commit(m3g_plan* plan) {
@@ -376,6 +392,7 @@ extern "C" int m3g_plan_commit(m3g_plan* plan) {
   }
   if (!plan->d_weights) M3G_HIP_CHECK(hipMalloc((void**)&plan->d_weights, wl.total * sizeof(float)));
   M3G_HIP_CHECK(hipMemcpy(plan->d_weights, blob.data(), wl.total * sizeof(float), hipMemcpyHostToDevice));
+  { int rc = pack_mfma_images(plan); if (rc) return rc; }
   plan->committed = true;
   return M3G_OK;
 }
@@ -415,20 +432,32 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
 
   // ---------------- forward ----------------
   { M3G_STAGE(ST_GEOM); launch_geometry(c, t, io->pos, io->lattice, io->edge_cell_shift, w, s); }
-  { M3G_STAGE(ST_EMBED); launch_embed(c, W, wl, t, io->atom_types, w, s); }
+  const bool mfma = plan->edge_kernel == 1;
+  {
+    M3G_STAGE(ST_EMBED);
+    launch_embed(c, W, wl, t, io->atom_types, w, s);
+    if (mfma) launch_rows_to_soa(w.e, w.e_soa, E, s);
+  }
   for (int b = 0; b < c.B; ++b) {
     { M3G_STAGE(ST_NODE_PRE); launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], w.TA, w.TB, s); }
     { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }
     M3G_STAGE(ST_EDGE_FWD);
-    if (N > 0) M3G_HIP_CHECK(hipMemcpyAsync(w.x[b + 1], w.x[b], sizeof(float) * N * kDP, hipMemcpyDeviceToDevice, s));
-    launch_edge_block(c, W, wl.blk[b], t, w, b, w.x[b + 1], s);
+    if (mfma) {
+      launch_edge_block_mfma(plan, c, t, w, b, w.x[b], w.x[b + 1], s);
+    } else {
+      if (N > 0) M3G_HIP_CHECK(hipMemcpyAsync(w.x[b + 1], w.x[b], sizeof(float) * N * kDP, hipMemcpyDeviceToDevice, s));
+      launch_edge_block(c, W, wl.blk[b], t, w, b, w.x[b + 1], s);
+    }
   }
   const bool want_f = io->forces != nullptr;
   { M3G_STAGE(ST_READOUT); launch_readout(c, W, wl, t, io->atom_types, w.x[c.B], w, ea, st, io->total_energy, want_f, s); }
   StageTimer* st_out = new StageTimer(plan, ST_OUTPUTS, s);
 
   if (io->node_features) launch_copy_strided(w.x[c.B], kDP, io->node_features, c.D, c.D, N, s);
-  if (io->edge_attr) launch_copy_strided(w.e, kDP, io->edge_attr, c.D, c.D, E, s);
+  if (io->edge_attr) {
+    if (mfma) launch_soa_to_rows(w.e_soa, io->edge_attr, c.D, c.D, E, s);
+    else launch_copy_strided(w.e, kDP, io->edge_attr, c.D, c.D, E, s);
+  }
   if (io->edge_distances && E > 0) M3G_HIP_CHECK(hipMemcpyAsync(io->edge_distances, w.d, sizeof(float) * E, hipMemcpyDeviceToDevice, s));
   if (io->edge_weights) launch_copy_strided(w.h, kRP, io->edge_weights, c.R, c.R, E, s);
   if (io->triplet_angles) launch_triplet_angles(t, io->triplet_edge_index, w.u, io->triplet_angles, s);
@@ -444,12 +473,14 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
       {
         M3G_STAGE(ST_EDGE_REV);
         if (b == c.B - 1 && E > 0) {
-          M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
+          if (mfma) M3G_HIP_CHECK(hipMemsetAsync(w.de_soa, 0, sizeof(float) * ((E + 31) / 32) * 2048, s));
+          else M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
           M3G_HIP_CHECK(hipMemsetAsync(w.dh, 0, sizeof(float) * E * kRP, s));
           M3G_HIP_CHECK(hipMemsetAsync(w.dd, 0, sizeof(float) * E, s));
           M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
         }
-        launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
+        if (mfma) launch_edge_block_reverse_mfma(plan, c, t, w, b, dx_cur, s);
+        else launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
       }
       { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], s); }
       if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
@@ -458,7 +489,11 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
       }
     }
-    { M3G_STAGE(ST_EMBED_REV); launch_embed_reverse(c, W, wl, t, w, s); }
+    {
+      M3G_STAGE(ST_EMBED_REV);
+      if (mfma) launch_soa_to_rows(w.de_soa, w.de, kDP, kDP, E, s);
+      launch_embed_reverse(c, W, wl, t, w, s);
+    }
     M3G_STAGE(ST_GEOM_REV);
     launch_geometry_reverse(c, t, w, io->forces, s);
     if (io->stresses) launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);

@@ -81,6 +81,30 @@ struct WeightLayout {
   size_t total;
 };
 
+// ---- MFMA edge-block weight images (one per block), copied verbatim into LDS by the kernels -----------
+// A-operand image of a layer with OB 32-row output blocks and KB 32-wide k blocks for v_mfma_f32_32x32x2_f32
+// in the "accumulator feeds the next layer" chain:  img[((ob*KB + kb)*16 + s)*64 + lane] =
+//   W[ob*32 + (lane&31)][kb*32 + feat_of(s, lane>>5)],  feat_of(r,h) = (r&3) + 8*(r>>2) + 4*h
+// "direct" images (k taken straight from memory): img[(ob*S + s)*64 + lane] = W[ob*32 + (lane&31)][2*s + (lane>>5)]
+constexpr int kTbSteps = 8;            // three-body MLP: k = l_max*n_max padded to 16 -> 8 k-steps of 2
+struct MfmaMlpFwd {                     // offsets in floats inside the forward image
+  int w1c;   // [4][2][16][64]  rows: dense 0-63 | gate 64-127, k: edge features
+  int w2d;   // [2][2][16][64]
+  int w2g;   // [2][2][16][64]
+  int b2;    // [2 (dense,gate)][2 ob][64]   bias as a k-step: lanes < 32 hold b[ob*32+lane], others 0
+  int wl;    // [2 ob][2 s][64]              direct image of W_l [64][R<=4]
+};
+struct MfmaFwdLayout { int tb; /* [4][kTbSteps][64] dense ob0,ob1, gate ob0,ob1 */ MfmaMlpFwd mlp[2]; int total; };
+struct MfmaMlpRev {
+  int w2dT;  // [2][2][16][64]   rows: hidden k, cols: out o
+  int w2gT;
+  int w1cT;  // [2][4][16][64]   rows: edge feature k, cols: layer-1 outputs (dense 0-63 | gate 64-127)
+  int wl;    // [64][4] plain
+};
+struct MfmaRevLayout { int tb; /* forward three-body image */ int tbT; /* [1][4][16][64] rows: c */ MfmaMlpRev mlp[2]; int total; };
+MfmaFwdLayout mfma_fwd_layout();
+MfmaRevLayout mfma_rev_layout();
+
 }  // namespace m3g
 
 struct m3g_plan {
@@ -90,6 +114,9 @@ struct m3g_plan {
   std::map<std::string, std::vector<float>> params;  // raw state_dict tensors (host)
   std::map<std::string, std::vector<float>> cvals;   // raw constants (host)
   float* d_weights = nullptr;
+  float* d_mfma_fwd = nullptr;   // [num_blocks][MfmaFwdLayout.total]
+  float* d_mfma_rev = nullptr;   // [num_blocks][MfmaRevLayout.total]
+  int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
   bool committed = false;
   // opt-in stage profiler (m3g_profile_*): event pairs recorded around stage launches
   mutable bool profile = false;
@@ -142,6 +169,10 @@ struct Work {
   float* du;                  // [E,3]
   float* dp1;                 // [E,4*kDP]
   float* dr;                  // [E,3]
+  // MFMA path: tile-SoA images ([tile][slot][64 lanes], 32 edges per tile) of e / de, row-major messages
+  float* e_soa;               // [tiles,32,64]
+  float* de_soa;              // [tiles,32,64]
+  float* msg;                 // [E,kDP]
   size_t total_bytes;
 };
 Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
@@ -176,6 +207,14 @@ void launch_copy_strided(const float* in, int in_stride, float* out, int out_str
 // threebody.hip
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s);
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s);
+// pack_mfma.hip / edge_mfma.hip
+int pack_mfma_images(m3g_plan* plan);
+void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_old,
+                            float* x_new, hipStream_t s);
+void launch_edge_block_reverse_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b,
+                                    const float* dx_new, hipStream_t s);
+void launch_rows_to_soa(const float* rows, float* soa, int64_t E, hipStream_t s);
+void launch_soa_to_rows(const float* soa, float* rows, int row_stride, int width, int64_t E, hipStream_t s);
 // edge_simple.hip
 void launch_edge_block(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, int b,
                        float* x_new, hipStream_t s);

@@ -45,6 +45,7 @@ SYMBOLS = {
     "m3g_plan_destroy": (None, [C.c_void_p]),
     "m3g_plan_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "m3g_plan_set_const": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "m3g_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "m3g_plan_commit": (C.c_int, [C.c_void_p]),
     "m3g_topology_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_topology_build": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -95,6 +95,10 @@ class Engine:
             _lib.check(lib.m3g_plan_set_const(plan, name.encode(), arr.ctypes.data, arr.size))
         _lib.check(lib.m3g_plan_commit(plan))
 
+    def set_option(self, name: str, value: int) -> None:
+        """Engine options, e.g. set_option("edge_kernel", 0) selects the vector-ALU baseline kernels."""
+        _lib.check(self.lib.m3g_plan_set_option(self.plan, name.encode(), int(value)))
+
     # ---------------------------------------------------------------- measurement
     def profile(self, enable: bool) -> None:
         _lib.check(self.lib.m3g_profile_enable(self.plan, 1 if enable else 0))
