@@ -159,6 +159,10 @@ int m3g_profile_enable(m3g_plan* plan, int32_t enable);
 int m3g_profile_read(m3g_plan* plan, int32_t* n_stages, const char** names /* [M3G_MAX_STAGES] */,
                      float* total_ms /* [M3G_MAX_STAGES] */, int32_t* launches /* [M3G_MAX_STAGES] */);
 
+/* Diagnostic only: with option "stamps" = 1 the forward edge kernel runs a stamped variant (s_memtime per
+ * phase); this copies the per-wave phase cycle sums [256][16][12] of the LAST launch to the host. */
+int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
+
 #define M3G_ABI_VERSION 1
 
 #ifdef __cplusplus

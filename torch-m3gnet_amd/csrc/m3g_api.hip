@@ -154,7 +154,7 @@ Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, voi
   w.e = take(e * kDP);
   for (int b = 0; b < c.B; ++b) w.m[b] = take(e * kCP);
   const size_t tiles = (e + 31) / 32;
-  for (int b = 0; b < c.B; ++b) w.act[b] = take(tiles * 32 * 8 * kDP);  // also the MFMA path's [tiles][2][128][64] image
+  for (int b = 0; b < c.B; ++b) w.act[b] = take(tiles * 32 * 8 * kDP);  // VALU path [E][512]; MFMA path uses the first [tiles][2][64][64]
   w.dx = take(n * kDP); w.dx2 = take(n * kDP);
   w.de = take(e * kDP); w.dm = take(e * kCP); w.g = take(e * kCP); w.dg = take(e * kCP);
   w.dh = take(e * kRP); w.dd = take(e); w.du = take(e * 3); w.dp1 = take(e * 4 * kDP); w.dr = take(e * 3);
@@ -271,6 +271,7 @@ extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (plan->d_weights) (void)hipFree(plan->d_weights);
   if (plan->d_mfma_fwd) (void)hipFree(plan->d_mfma_fwd);
   if (plan->d_mfma_rev) (void)hipFree(plan->d_mfma_rev);
+  if (plan->d_stamps) (void)hipFree(plan->d_stamps);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
   delete plan;
 }
@@ -304,8 +305,24 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->edge_kernel = value;
     return M3G_OK;
   }
+  if (strcmp(name, "stamps") == 0) {  // diagnostic: forward edge kernel with s_memtime phase stamps
+    if (value && !plan->d_stamps) {
+      M3G_HIP_CHECK(hipMalloc((void**)&plan->d_stamps, 256 * 16 * 12 * sizeof(unsigned long long)));
+      M3G_HIP_CHECK(hipMemset(plan->d_stamps, 0, 256 * 16 * 12 * sizeof(unsigned long long)));
+    } else if (!value && plan->d_stamps) {
+      (void)hipFree(plan->d_stamps);
+      plan->d_stamps = nullptr;
+    }
+    return M3G_OK;
+  }
   set_error("unknown option '%s'", name);
   return M3G_ERR_VALUE;
+}
+
+extern "C" int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out /* [256*16*12] */) {
+  if (!plan || !host_out || !plan->d_stamps) { set_error("stamps not enabled"); return M3G_ERR_STATE; }
+  M3G_HIP_CHECK(hipMemcpy(host_out, plan->d_stamps, 256 * 16 * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return M3G_OK;
 }
 
 extern "C" int m3g_plan_commit(m3g_plan* plan) {
@@ -435,8 +452,12 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   const bool mfma = plan->edge_kernel == 1;
   {
     M3G_STAGE(ST_EMBED);
-    launch_embed(c, W, wl, t, io->atom_types, w, s);
-    if (mfma) launch_rows_to_soa(w.e, w.e_soa, E, s);
+    if (mfma) {
+      launch_embed_nodes_only(c, W, wl, t, io->atom_types, w, s);
+      launch_embed_edges_soa(c, W + wl.adj_t, w.h, w.e_soa, E, s);
+    } else {
+      launch_embed(c, W, wl, t, io->atom_types, w, s);
+    }
   }
   for (int b = 0; b < c.B; ++b) {
     { M3G_STAGE(ST_NODE_PRE); launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], w.TA, w.TB, s); }
@@ -491,8 +512,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     }
     {
       M3G_STAGE(ST_EMBED_REV);
-      if (mfma) launch_soa_to_rows(w.de_soa, w.de, kDP, kDP, E, s);
-      launch_embed_reverse(c, W, wl, t, w, s);
+      if (mfma) launch_embed_edges_reverse_soa(W + wl.adj, w.h, w.de_soa, w.dh, E, s);
+      else launch_embed_reverse(c, W, wl, t, w, s);
     }
     M3G_STAGE(ST_GEOM_REV);
     launch_geometry_reverse(c, t, w, io->forces, s);

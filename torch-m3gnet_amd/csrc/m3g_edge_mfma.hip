@@ -1,20 +1,24 @@
 // Edge block on the matrix cores: stage S4 (three-body gated update + M3GNetConv edge and node MLPs) and its
-// reverse B4, fused per 32-edge tile, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32; gfx950 has no xf32).
+// reverse B4, fused per 16-edge tile, fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32; gfx950 has no xf32).
 // Reference: nn/interaction.py:220-221, nn/conv.py:63-97, nn/core.py:61-62; algebra: oracle/staged.py.
 //
 // Formulation: every dense layer is computed TRANSPOSED, Y^T[feature, edge] = W[feature, k] . X^T[k, edge]:
-//   * the 32 edges of a tile sit on the MFMA column index (lane & 31), output features in the 16 accumulator
-//     registers (row = (r&3) + 8*(r>>2) + 4*(lane>>5)), so all per-edge elementwise work is lane-local;
-//   * an accumulator tile is directly the B operand of the next layer (register r of lane-half h carries
-//     k = feat_of(r,h)); the matching k permutation is folded into the weight images (m3g_pack_mfma.hip),
-//     which one workgroup copies into LDS once and every wave re-reads as the A operand (ds_read_b32,
-//     conflict-free: 64 consecutive floats per k-step);
+//   * the 16 edges of a tile sit on the MFMA column index (lane & 15); lane quarter qd = lane >> 4 holds, in the
+//     4 accumulator registers of 16-feature block blk, features blk*16 + 4*qd + {0..3}; all per-edge elementwise
+//     work (SiLU / sigmoid gating, residuals, W_l h) is therefore lane-local;
+//   * an accumulator block is directly the B operand of the next layer (k-step (blk, reg) consumes the four
+//     features blk*16 + 4*qd + reg); the matching k permutation is folded into the weight images
+//     (m3g_pack_mfma.hip), which a workgroup copies into LDS once and every wave re-reads as the A operand
+//     (ds_read_b32 of 64 consecutive floats per k-step: conflict-free);
 //   * layer-1 accumulators start from the gathered per-node tables TA[i] + TB[j] (x_i / x_j parts, bias folded);
 //     layer-2 biases enter as one extra k-step against a constant-one operand.
-// Edge features travel between blocks in a tile-SoA image ([tile][slot = kb*16 + r][64 lanes]) so every register
-// load/store is one contiguous 256-B wave access; saved pre-activations use the same shape.
-// One persistent workgroup (8 waves, 2 per SIMD) per CU; tiles are dealt so that workgroups sharing an XCD
-// (blockIdx % 8) walk a contiguous edge range, keeping their TA/TB rows in that XCD's L2.
+// Why 16x16x4 and not 32x32x2 (same FLOP rate): every per-tile array is half the size (~100 live VGPRs instead of
+// 232), so 4 waves per SIMD are resident instead of 2 and cover each other's store bursts and gather latency; a
+// lane's 4 accumulator registers are 4 consecutive features, so every tile load/store is a 16-byte access
+// (1 KiB per wave instruction) and row-major rows get 64-byte segments.
+// Tile-SoA images ([tile][blk][64 lanes][4]) carry edge features between blocks and the saved layer-1
+// pre-activations.  One persistent workgroup (16 waves, 4 per SIMD) per CU; workgroups sharing an XCD
+// (blockIdx % 8) walk a contiguous edge range so their TA/TB rows stay in that XCD's L2.
 #include <utility>
 
 #include "m3g_device.h"
@@ -22,13 +26,15 @@
 
 namespace m3g {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kFwdLdsFloats = 4 * kTbSteps * 64 + 2 * (4 * 2 * 16 * 64 + 2 * (2 * 2 * 16 * 64) + 2 * 2 * 64 + 2 * 2 * 64);
-constexpr int kRevLdsFloats = 4 * kTbSteps * 64 + 4 * 16 * 64 + 2 * (2 * (2 * 2 * 16 * 64) + 2 * 4 * 16 * 64 + 64 * 4);
-constexpr int kWaves = 8;
-constexpr int kActPerTile = 2 * 128 * 64;  // floats of saved pre-activations per tile per block (both MLPs)
+constexpr int kFwdLdsFloats = 8 * kTbSteps * 64 + 2 * (8 * 4 * 4 * 64 + 2 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 64);
+constexpr int kRevMlpFloats = 4 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 8 * 4 * 64 + 64 * 4;   // node-MLP reverse image
+constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;                // + three-body images
+constexpr int kWaves = 16;
+constexpr int kTileEdges = 16;
+constexpr int kTileFloats = 4 * 64 * 4;     // one 64-feature tile image: [4 blk][64 lanes][4]
+constexpr int kActPerTile = 2 * 8 * 64 * 4;  // saved layer-1 pre-activations per tile per block: [2 MLPs][8 ob][64][4]
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -39,7 +45,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ float fsigmoid(float p) { return __builtin_amdgcn_rcpf(1.f + __expf(-p)); }
 __device__ __forceinline__ float fsilu(float p) { return p * fsigmoid(p); }
@@ -48,49 +54,89 @@ __device__ __forceinline__ float fdsilu(float p) {
   return s * (1.f + p * (1.f - s));
 }
 
-// acc[ob] += Wimg(ob, :) . x   with x[kb] accumulator-layout tiles (chain image, see m3g_internal.h)
+// acc[AOFF + ob] += Wimg(ob, :) . x[XOFF ..]   (chain image, see m3g_internal.h)
 template <int OB, int KB, int XOFF = 0, int AOFF = 0, int NX, int NA>
-__device__ __forceinline__ void chain(const float* img, const f32x16 (&x)[NX], f32x16 (&acc)[NA], int lane) {
+__device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
   static_assert(XOFF + KB <= NX && AOFF + OB <= NA, "chain operand out of range");
   static_for<KB>([&]<int kb>() {
-    static_for<16>([&]<int s>() {
-      const float b = x[XOFF + kb][s];
+    static_for<4>([&]<int reg>() {
+      const float b = x[XOFF + kb][reg];
       static_for<OB>([&]<int ob>() {
-        const float a = img[((ob * KB + kb) * 16 + s) * 64 + lane];
-        acc[AOFF + ob] = mfma32(a, b, acc[AOFF + ob]);
+        const float a = img[((ob * KB + kb) * 4 + reg) * 64 + lane];
+        acc[AOFF + ob] = mfma16(a, b, acc[AOFF + ob]);
       });
     });
   });
 }
 
-__device__ __forceinline__ void zero(f32x16& v) {
-  static_for<16>([&]<int r>() { v[r] = 0.f; });
+template <int N>
+__device__ __forceinline__ void zero(f32x4 (&v)[N]) {
+  static_for<N>([&]<int i>() { v[i] = f32x4{0.f, 0.f, 0.f, 0.f}; });
 }
 
-// persistent tile walk: workgroup g of G (G % 8 == 0) -> XCD label g % 8 owns a contiguous chunk of tiles
-struct TileWalk {
-  int64_t tiles, per_xcd;
-  int xcd, q, wgs_per_xcd, wave;
-  __device__ TileWalk(int64_t n_tiles, int wave_id) {
-    tiles = n_tiles;
-    per_xcd = (n_tiles + 7) / 8;
-    xcd = blockIdx.x & 7;
-    q = blockIdx.x >> 3;
-    wgs_per_xcd = gridDim.x >> 3;
-    wave = wave_id;
+// bias as one k-step: A = bias image (lanes < 16 carry b[ob*16 + lane]), B = 1 on lane quarter 0
+template <int OB, int AOFF, int NA>
+__device__ __forceinline__ void bias_step(const float* img, f32x4 (&acc)[NA], int lane) {
+  const float one = lane < 16 ? 1.f : 0.f;
+  static_for<OB>([&]<int ob>() { acc[AOFF + ob] = mfma16(img[ob * 64 + lane], one, f32x4{0.f, 0.f, 0.f, 0.f}); });
+}
+
+// Persistent tile queue.  Static over workgroups, dynamic inside one:
+//   * workgroups with the same blockIdx % 8 share an XCD (speed only, never correctness); that label owns one
+//     contiguous eighth of the tiles, cut into equal contiguous chunks, one per workgroup -> the TA/TB rows a
+//     workgroup gathers stay in its L1/L2;
+//   * the 16 waves of a workgroup pull tiles of its chunk from an LDS counter.  A SIMD arbitrates its resident
+//     waves oldest-first, so with equal static shares the old waves finish early and the matrix pipe runs
+//     under-occupied in the tail (measured: waves 0-3 done at 320 k cycles, waves 12-15 at 680 k).
+//     A global atomic head was tried and rejected: its microsecond return sits in front of every tile load on the
+//     in-order vmcnt queue.
+struct TileQueue {
+  int* head;       // LDS counter of this workgroup
+  int64_t base;
+  int count;
+  __device__ TileQueue(int64_t n_tiles, int* lds_head) {
+    const int64_t per_xcd = (n_tiles + 7) / 8;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, wgs = gridDim.x >> 3;
+    const int64_t chunk = (per_xcd + wgs - 1) / wgs;
+    const int64_t lo = (int64_t)xcd * per_xcd + (int64_t)q * chunk;
+    int64_t hi = lo + chunk;
+    const int64_t xcd_end = (int64_t)(xcd + 1) * per_xcd < n_tiles ? (int64_t)(xcd + 1) * per_xcd : n_tiles;
+    if (hi > xcd_end) hi = xcd_end;
+    base = lo;
+    count = hi > lo ? (int)(hi - lo) : 0;
+    head = lds_head;
   }
-  __device__ int64_t tile(int it) const {
-    int64_t local = ((int64_t)it * wgs_per_xcd + q) * kWaves + wave;
-    if (local >= per_xcd) return -1;
-    int64_t t = (int64_t)xcd * per_xcd + local;
-    return t < tiles ? t : -1;
+  __device__ __forceinline__ int fetch(int lane) const {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(head, 1);
+    return __builtin_amdgcn_readfirstlane(v);
   }
 };
 
-__device__ __forceinline__ void load_image(float* lds, const float* __restrict__ src, int n_floats) {
+__device__ __forceinline__ void load_image(float* lds, const float* __restrict__ src, int n_floats, int* lds_head) {
   for (int i = threadIdx.x * 4; i < n_floats; i += blockDim.x * 4) *(f32x4*)(lds + i) = *(const f32x4*)(src + i);
+  if (threadIdx.x == 0) *lds_head = 0;
   __syncthreads();
 }
+
+// In-kernel phase stamps (diagnostic build only, never in the shipped kernel): s_memtime deltas summed per
+// wave into a debug buffer that no other code reads (cdna_hip_programming.md section 7, "In-kernel stamps").
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+template <bool ON>
+struct Stamps {
+  unsigned long long last = 0, sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  __device__ __forceinline__ void start() { if (ON) last = stamp_now(); }
+  template <int I>
+  __device__ __forceinline__ void mark() {
+    if (ON) { unsigned long long t = stamp_now(); sum[I] += t - last; last = t; }
+  }
+};
 
 // ---------------------------------------------------------------------------------------------- forward
 struct FwdArgs {
@@ -98,285 +144,337 @@ struct FwdArgs {
   const float* img;        // forward weight image of this block
   const int32_t *src, *dst;
   const float *h, *m, *TA, *TB;
-  float* e_soa;            // in/out
-  float* act;              // [tiles][2][128][64]
+  float* e_soa;            // in/out  [tiles][4][64][4]
+  float* act;              // [tiles][2][8][64][4]
   float* msg;              // [E][64] row-major
+  unsigned long long* stamps;  // diagnostic build: [gridDim.x][kWaves][12] phase cycle sums
 };
 
+// three-body MLP pre-activations: p[0..3] dense, p[4..7] gate
 template <int TBS>
-__device__ __forceinline__ void tb_preact(const float* tbimg, const float (&mb)[TBS], f32x16 (&pd)[2], f32x16 (&pg)[2], int lane) {
-  zero(pd[0]); zero(pd[1]); zero(pg[0]); zero(pg[1]);
+__device__ __forceinline__ void tb_preact(const float* tbimg, const float (&mb)[TBS], f32x4 (&p)[8], int lane) {
+  zero(p);
   static_for<TBS>([&]<int s>() {
     const float b = mb[s];
-    pd[0] = mfma32(tbimg[(0 * kTbSteps + s) * 64 + lane], b, pd[0]);
-    pd[1] = mfma32(tbimg[(1 * kTbSteps + s) * 64 + lane], b, pd[1]);
-    pg[0] = mfma32(tbimg[(2 * kTbSteps + s) * 64 + lane], b, pg[0]);
-    pg[1] = mfma32(tbimg[(3 * kTbSteps + s) * 64 + lane], b, pg[1]);
+    static_for<8>([&]<int ob>() { p[ob] = mfma16(tbimg[(ob * kTbSteps + s) * 64 + lane], b, p[ob]); });
   });
 }
 
 // one conv GatedMLP, forward.  x = edge-feature input tile; out = MLP(x) * (W_l h)
+template <bool ST, int S0>
 __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlpFwd& L, int mlp, const FwdArgs& a, int64_t ci,
-                                                 int64_t cj, const float (&hb)[2], const f32x16 (&x)[2], float* act_tile,
-                                                 f32x16 (&out)[2], int lane) {
-  const int h = lane >> 5;
-  f32x16 p1[4];
+                                                 int64_t cj, float hb, const f32x4 (&x)[4], float* act_tile, f32x4 (&out)[4],
+                                                 int lane, Stamps<ST>& st) {
+  const int qd = lane >> 4;
+  f32x4 p1[8];
   {
-    const float* ta = a.TA + ci * (4 * kDP) + mlp * (2 * kDP) + 4 * h;
-    const float* tb = a.TB + cj * (4 * kDP) + mlp * (2 * kDP) + 4 * h;
-    static_for<4>([&]<int ob>() {
-      static_for<4>([&]<int g>() {
-        const f32x4 va = *(const f32x4*)(ta + ob * 32 + 8 * g);
-        const f32x4 vb = *(const f32x4*)(tb + ob * 32 + 8 * g);
-        static_for<4>([&]<int qq>() { p1[ob][4 * g + qq] = va[qq] + vb[qq]; });
-      });
-    });
+    const float* ta = a.TA + ci * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
+    const float* tb = a.TB + cj * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
+    static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(ta + ob * 16) + *(const f32x4*)(tb + ob * 16); });
   }
-  chain<4, 2>(lds + L.w1c, x, p1, lane);
-  float* act_m = act_tile + mlp * (128 * 64) + lane;
+  st.template mark<S0>();      // table gather
+  chain<8, 4>(lds + L.w1c, x, p1, lane);
+  st.template mark<S0 + 1>();  // layer-1 chain
+  // only the layer-1 pre-activations are saved; the reverse pass recomputes layer 2 from them
+  float* act_m = act_tile + mlp * (8 * 256) + lane * 4;
+  static_for<8>([&]<int ob>() {
+    *(f32x4*)(act_m + ob * 256) = p1[ob];
+    static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); });
+  });
+  st.template mark<S0 + 2>();  // P1 stores + SiLU
+  f32x4 p2[8];  // dense 0..3, gate 4..7
+  bias_step<4, 0>(lds + L.b2, p2, lane);
+  bias_step<4, 4>(lds + L.b2 + 4 * 64, p2, lane);
+  chain<4, 4, 0, 0>(lds + L.w2d, p1, p2, lane);  // hidden dense = p1[0..3]
+  chain<4, 4, 4, 4>(lds + L.w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
   static_for<4>([&]<int ob>() {
-    static_for<16>([&]<int r>() {
-      act_m[(ob * 16 + r) * 64] = p1[ob][r];
-      p1[ob][r] = fsilu(p1[ob][r]);
-    });
+    out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
+    static_for<4>([&]<int r>() { out[ob][r] = fsilu(p2[ob][r]) * fsigmoid(p2[4 + ob][r]) * out[ob][r]; });
   });
-  f32x16 p2d[2], p2g[2];
-  const float one = lane < 32 ? 1.f : 0.f;
-  static_for<2>([&]<int ob>() {
-    zero(p2d[ob]);
-    zero(p2g[ob]);
-    p2d[ob] = mfma32(lds[L.b2 + (0 * 2 + ob) * 64 + lane], one, p2d[ob]);
-    p2g[ob] = mfma32(lds[L.b2 + (1 * 2 + ob) * 64 + lane], one, p2g[ob]);
-  });
-  chain<2, 2, 0, 0>(lds + L.w2d, p1, p2d, lane);  // hidden dense = p1[0..1]
-  chain<2, 2, 2, 0>(lds + L.w2g, p1, p2g, lane);  // hidden gate  = p1[2..3]
-  static_for<2>([&]<int ob>() {
-    zero(out[ob]);
-    static_for<2>([&]<int s>() { out[ob] = mfma32(lds[L.wl + (ob * 2 + s) * 64 + lane], hb[s], out[ob]); });
-    static_for<16>([&]<int r>() {
-      act_m[(64 + ob * 16 + r) * 64] = p2d[ob][r];
-      act_m[(96 + ob * 16 + r) * 64] = p2g[ob][r];
-      out[ob][r] = fsilu(p2d[ob][r]) * fsigmoid(p2g[ob][r]) * out[ob][r];
-    });
-  });
+  st.template mark<S0 + 3>();  // layer-2 chains + gating
 }
 
-template <int TBS>
-__global__ void __launch_bounds__(512, 2) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
-  __shared__ __attribute__((aligned(16))) float lds[kFwdLdsFloats];
-  load_image(lds, a.img, kFwdLdsFloats);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-  TileWalk walk(a.tiles, wave);
-  for (int it = 0;; ++it) {
-    const int64_t tile = walk.tile(it);
-    if (tile < 0) break;
-    const int64_t edge = tile * 32 + (lane & 31);
+template <int TBS, bool ST = false>
+__global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
+  __shared__ __attribute__((aligned(16))) float lds[kFwdLdsFloats + 4];  // + tile-queue head
+  int* q_head = reinterpret_cast<int*>(lds + kFwdLdsFloats);
+  load_image(lds, a.img, kFwdLdsFloats, q_head);
+  const int lane = threadIdx.x & 63, qd = lane >> 4;
+  TileQueue queue(a.tiles, q_head);
+  Stamps<ST> st;
+  for (int ticket = queue.fetch(lane); ticket < queue.count;) {
+    const int64_t tile = queue.base + ticket;
+    ticket = queue.fetch(lane);  // next tile's ticket, consumed at the top of the next iteration
+    // the weight-image reads are loop-invariant: without this the compiler hoists hundreds of LDS loads out of
+    // the tile loop and spills them; `lv` is the lane id made opaque once per tile
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    st.start();
+    const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
     const int64_t ci = a.src[ec], cj = a.dst[ec];
-    float* e_tile = a.e_soa + tile * 2048 + lane;
+    float* e_tile = a.e_soa + tile * kTileFloats + lane * 4;
     float* act_tile = a.act + tile * kActPerTile;
-    f32x16 x[2];
-    static_for<2>([&]<int kb>() { static_for<16>([&]<int r>() { x[kb][r] = e_tile[(kb * 16 + r) * 64]; }); });
-    float mb[TBS], hb[2];
-    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 2 * s + h]; });
-    hb[0] = a.h[ec * kRP + h];
-    hb[1] = a.h[ec * kRP + 2 + h];
+    f32x4 x[4];
+    static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+    float mb[TBS];
+    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
+    const float hb = a.h[ec * kRP + qd];
+    st.template mark<0>();  // tile loads issued
     {  // three-body gated update (nn/interaction.py:220-221)
-      f32x16 pd[2], pg[2];
-      tb_preact<TBS>(lds + L.tb, mb, pd, pg, lane);
-      static_for<2>([&]<int kb>() { static_for<16>([&]<int r>() { x[kb][r] += fsilu(pd[kb][r]) * fsigmoid(pg[kb][r]); }); });
+      f32x4 p[8];
+      tb_preact<TBS>(lds + L.tb, mb, p, lv);
+      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
     }
-    f32x16 out[2];
-    mlp_forward_mfma(lds, L.mlp[0], 0, a, ci, cj, hb, x, act_tile, out, lane);  // edge update (nn/conv.py:68-75)
-    static_for<2>([&]<int kb>() {
-      static_for<16>([&]<int r>() {
-        x[kb][r] += out[kb][r];
-        e_tile[(kb * 16 + r) * 64] = x[kb][r];
-      });
+    st.template mark<1>();  // three-body MLP
+    f32x4 out[4];
+    mlp_forward_mfma<ST, 2>(lds, L.mlp[0], 0, a, ci, cj, hb, x, act_tile, out, lv, st);  // edge update (nn/conv.py:68-75)
+    static_for<4>([&]<int blk>() {
+      x[blk] += out[blk];
+      *(f32x4*)(e_tile + blk * 256) = x[blk];
     });
-    mlp_forward_mfma(lds, L.mlp[1], 1, a, ci, cj, hb, x, act_tile, out, lane);  // node message (nn/conv.py:77-89)
+    st.template mark<6>();  // e2 residual + store
+    mlp_forward_mfma<ST, 7>(lds, L.mlp[1], 1, a, ci, cj, hb, x, act_tile, out, lv, st);  // node message (nn/conv.py:77-89)
     if (edge < a.E) {
-      float* mrow = a.msg + edge * kDP + 4 * h;
-      static_for<2>([&]<int ob>() {
-        static_for<4>([&]<int g>() {
-          f32x4 v;
-          static_for<4>([&]<int qq>() { v[qq] = out[ob][4 * g + qq]; });
-          *(f32x4*)(mrow + ob * 32 + 8 * g) = v;
-        });
-      });
+      float* mrow = a.msg + edge * kDP + 4 * qd;
+      static_for<4>([&]<int blk>() { *(f32x4*)(mrow + blk * 16) = out[blk]; });
     }
+    st.template mark<11>();  // message store
+  }
+  if (ST && lane == 0) {
+    const int wave = threadIdx.x >> 6;
+    unsigned long long* dst = a.stamps + ((size_t)blockIdx.x * kWaves + wave) * 12;
+    for (int i = 0; i < 12; ++i) dst[i] = st.sum[i];
   }
 }
 
 // ---------------------------------------------------------------------------------------------- reverse
+// Two kernels per block (each with its own LDS image): node-MLP reverse, then edge-MLP + three-body reverse.
 struct RevArgs {
   int64_t E, tiles;
-  const float* img;
+  const float* img;     // reverse image of this kernel's MLP (edge image also carries the three-body images)
   const int32_t* src;
   const float *h, *m, *act, *dx_new;
-  float* de_soa;   // in: dL/d e (after this block), out: dL/d e (before this block)
-  float* dm;       // [E][16]
-  float* dh;       // [E][4]  (+=)
-  float* dp1;      // [E][256]
+  float* de_soa;   // dL/d e: node kernel adds its contribution; edge kernel turns dL/d e2 into dL/d e_in
+  float* dm;       // [E][16]   (edge kernel)
+  float* dh;       // [E][4]    (+=)
+  float* dp1;      // [E][256]  each kernel writes its MLP's 128 columns
 };
 
-// reverse of one conv GatedMLP: d_upd = dL/d(output); returns contrib = W1c^T d_p1, accumulates dL/dh into dhv
+// reverse of one conv GatedMLP: d_upd = dL/d(output); returns contrib = W1c^T d_p1, accumulates dL/dh into dhv.
+// Layer 2 is recomputed from the saved layer-1 pre-activations.
 __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlpRev& L, int mlp, const RevArgs& a, int64_t edge,
-                                                 const f32x4& hv, const float* act_tile, const f32x16 (&d_upd)[2],
-                                                 f32x16 (&contrib)[2], f32x4& dhv, int lane) {
-  const int h = lane >> 5;
-  const float* act_m = act_tile + mlp * (128 * 64) + lane;
-  f32x16 d2[4];  // d_p2d[0..1], d_p2g[0..1]
-  // processed four registers at a time with scheduling fences: letting the compiler hoist all 64 loads and
-  // 32 LDS reads of this phase costs > 256 VGPRs (spills)
-  static_for<2>([&]<int ob>() {
-    static_for<4>([&]<int g>() {
-      static_for<4>([&]<int qq>() {
-        constexpr int r = 4 * g + qq;
-        const float p2d = act_m[(64 + ob * 16 + r) * 64], p2g = act_m[(96 + ob * 16 + r) * 64];
-        const f32x4 w = *(const f32x4*)(lds + L.wl + (ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4);
-        const float s_lin = w[0] * hv[0] + w[1] * hv[1] + w[2] * hv[2] + w[3] * hv[3];
-        const float sg = fsigmoid(p2g), sgd = fsigmoid(p2d), sd = p2d * sgd;
-        const float du = d_upd[ob][r];
-        const float d_out = du * s_lin, d_s = du * sd * sg;
-        dhv[0] += d_s * w[0]; dhv[1] += d_s * w[1]; dhv[2] += d_s * w[2]; dhv[3] += d_s * w[3];
-        d2[ob][r] = d_out * sg * (sgd * (1.f + p2d * (1.f - sgd)));
-        d2[2 + ob][r] = d_out * sd * sg * (1.f - sg);
-      });
-      // pin the running dL/dh sums here: otherwise LLVM sinks the whole accumulation chain to its only use at
-      // the end of the kernel and keeps every w / sd / sg temporary alive (1.3 KB of scratch per lane)
-      asm volatile("" : "+v"(dhv[0]), "+v"(dhv[1]), "+v"(dhv[2]), "+v"(dhv[3]));
-      __builtin_amdgcn_sched_barrier(0);
+                                                 const f32x4& hv, const float* act_tile, const f32x4 (&d_upd)[4],
+                                                 f32x4 (&contrib)[4], f32x4& dhv, int lane) {
+  const int qd = lane >> 4;
+  const float* act_m = act_tile + mlp * (8 * 256) + lane * 4;
+  f32x4 d2[8];  // first p2 dense 0..3 / gate 4..7; then d_p2 in place
+  {
+    f32x4 hid[8];
+    static_for<8>([&]<int ob>() {
+      const f32x4 p = *(const f32x4*)(act_m + ob * 256);
+      static_for<4>([&]<int r>() { hid[ob][r] = fsilu(p[r]); });
     });
-  });
-  __builtin_amdgcn_sched_barrier(0);
-  f32x16 dp1[4];
-  static_for<4>([&]<int ob>() { zero(dp1[ob]); });
-  chain<2, 2, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..1]
-  chain<2, 2, 2, 2>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[2..3]
-  __builtin_amdgcn_sched_barrier(0);
+    bias_step<4, 0>(lds + L.b2, d2, lane);
+    bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
+    chain<4, 4, 0, 0>(lds + L.w2d, hid, d2, lane);
+    chain<4, 4, 4, 4>(lds + L.w2g, hid, d2, lane);
+  }
   static_for<4>([&]<int ob>() {
-    static_for<2>([&]<int g>() {
-      static_for<8>([&]<int qq>() { dp1[ob][8 * g + qq] *= fdsilu(act_m[(ob * 16 + 8 * g + qq) * 64]); });
-      __builtin_amdgcn_sched_barrier(0);
+    static_for<4>([&]<int r>() {
+      const float p2d = d2[ob][r], p2g = d2[4 + ob][r];
+      const f32x4 w = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + r) * 4);
+      const float s_lin = w[0] * hv[0] + w[1] * hv[1] + w[2] * hv[2] + w[3] * hv[3];
+      const float sg = fsigmoid(p2g), sgd = fsigmoid(p2d), sd = p2d * sgd;
+      const float du = d_upd[ob][r];
+      const float d_out = du * s_lin, d_s = du * sd * sg;
+      dhv[0] += d_s * w[0]; dhv[1] += d_s * w[1]; dhv[2] += d_s * w[2]; dhv[3] += d_s * w[3];
+      d2[ob][r] = d_out * sg * (sgd * (1.f + p2d * (1.f - sgd)));
+      d2[4 + ob][r] = d_out * sd * sg * (1.f - sg);
     });
+    // pin the running dL/dh sums: otherwise LLVM sinks the accumulation chain to its only use at the end of the
+    // kernel and keeps every w / sd / sg temporary alive
+    asm volatile("" : "+v"(dhv[0]), "+v"(dhv[1]), "+v"(dhv[2]), "+v"(dhv[3]));
+  });
+  f32x4 dp1[8];
+  zero(dp1);
+  chain<4, 4, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..3]
+  chain<4, 4, 4, 4>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[4..7]
+  static_for<8>([&]<int ob>() {
+    const f32x4 p = *(const f32x4*)(act_m + ob * 256);
+    static_for<4>([&]<int r>() { dp1[ob][r] *= fdsilu(p[r]); });
   });
   if (edge < a.E) {
-    float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + 4 * h;
-    static_for<4>([&]<int ob>() {
-      static_for<4>([&]<int g>() {
-        f32x4 v;
-        static_for<4>([&]<int qq>() { v[qq] = dp1[ob][4 * g + qq]; });
-        *(f32x4*)(row + ob * 32 + 8 * g) = v;
-      });
-    });
+    float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
+    static_for<8>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
   }
-  __builtin_amdgcn_sched_barrier(0);
-  zero(contrib[0]);
-  zero(contrib[1]);
-  chain<2, 4>(lds + L.w1cT, dp1, contrib, lane);
-  __builtin_amdgcn_sched_barrier(0);
+  zero(contrib);
+  chain<4, 8>(lds + L.w1cT, dp1, contrib, lane);
 }
 
-template <int TBS>
-__global__ void __launch_bounds__(512, 2) k_edge_block_reverse_mfma(RevArgs a, MfmaRevLayout L) {
-  __shared__ __attribute__((aligned(16))) float lds[kRevLdsFloats];
-  load_image(lds, a.img, kRevLdsFloats);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-  TileWalk walk(a.tiles, wave);
-  for (int it = 0;; ++it) {
-    const int64_t tile = walk.tile(it);
-    if (tile < 0) break;
-    const int64_t edge = tile * 32 + (lane & 31);
+__device__ __forceinline__ void add_dh(float* dh, int64_t edge, int64_t E, f32x4 dhv, int qd) {
+  // the four lane quarters hold disjoint feature sets of the same edge: combine, then quarter 0 owns the edge
+  static_for<4>([&]<int rr>() {
+    dhv[rr] += __shfl_xor(dhv[rr], 16);
+    dhv[rr] += __shfl_xor(dhv[rr], 32);
+  });
+  if (qd == 0 && edge < E) {
+    f32x4 old = *(f32x4*)(dh + edge * kRP);
+    *(f32x4*)(dh + edge * kRP) = old + dhv;
+  }
+}
+
+// node-message MLP (nn/conv.py:77-89), reverse: d msg[e] = dx_new[centre(e)]
+__global__ void __launch_bounds__(1024, 4) k_edge_rev_node_mlp(RevArgs a, MfmaRevLayout L) {
+  __shared__ __attribute__((aligned(16))) float lds[kRevMlpFloats + 4];  // + tile-queue head
+  int* q_head = reinterpret_cast<int*>(lds + kRevMlpFloats);
+  load_image(lds, a.img, kRevMlpFloats, q_head);
+  const int lane = threadIdx.x & 63, qd = lane >> 4;
+  TileQueue queue(a.tiles, q_head);
+  for (int ticket = queue.fetch(lane); ticket < queue.count;) {
+    const int64_t tile = queue.base + ticket;
+    ticket = queue.fetch(lane);  // next tile's ticket, consumed at the top of the next iteration
+    int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
+    asm volatile("" : "+v"(lv));
+    const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
     const int64_t ci = a.src[ec];
-    float* de_tile = a.de_soa + tile * 2048 + lane;
+    float* de_tile = a.de_soa + tile * kTileFloats + lane * 4;
     const float* act_tile = a.act + tile * kActPerTile;
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
-    f32x16 de[2], contrib[2];
+    f32x4 contrib[4];
     {
-      f32x16 dmsg[2];
-      const float* xrow = a.dx_new + ci * kDP + 4 * h;
-      static_for<2>([&]<int ob>() {
-        static_for<4>([&]<int g>() {
-          const f32x4 v = *(const f32x4*)(xrow + ob * 32 + 8 * g);
-          static_for<4>([&]<int qq>() { dmsg[ob][4 * g + qq] = v[qq]; });
-        });
-      });
-      mlp_reverse_mfma(lds, L.mlp[1], 1, a, edge, hv, act_tile, dmsg, contrib, dhv, lane);
+      f32x4 dmsg[4];
+      const float* xrow = a.dx_new + ci * kDP + 4 * qd;
+      static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
+      mlp_reverse_mfma(lds, L.mlp, 1, a, edge, hv, act_tile, dmsg, contrib, dhv, lv);
     }
-    // dL/d e2 = incoming + node-MLP contribution; parked in its tile image while the edge MLP is reversed
-    static_for<2>([&]<int kb>() {
-      static_for<16>([&]<int r>() {
-        de[kb][r] = de_tile[(kb * 16 + r) * 64] + contrib[kb][r];
-        de_tile[(kb * 16 + r) * 64] = de[kb][r];
-      });
+    static_for<4>([&]<int blk>() { *(f32x4*)(de_tile + blk * 256) += contrib[blk]; });  // -> dL/d e2
+    add_dh(a.dh, edge, a.E, dhv, qd);
+  }
+}
+
+// edge-update MLP (nn/conv.py:68-75) + three-body gated update (nn/interaction.py:220-221), reverse
+template <int TBS>
+__global__ void __launch_bounds__(1024, 4) k_edge_rev_edge_mlp(RevArgs a, MfmaRevLayout L) {
+  __shared__ __attribute__((aligned(16))) float lds[kRevEdgeFloats + 4];  // + tile-queue head
+  int* q_head = reinterpret_cast<int*>(lds + kRevEdgeFloats);
+  load_image(lds, a.img, kRevEdgeFloats, q_head);
+  const int lane = threadIdx.x & 63, qd = lane >> 4;
+  TileQueue queue(a.tiles, q_head);
+  for (int ticket = queue.fetch(lane); ticket < queue.count;) {
+    const int64_t tile = queue.base + ticket;
+    ticket = queue.fetch(lane);  // next tile's ticket, consumed at the top of the next iteration
+    int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
+    asm volatile("" : "+v"(lv));
+    const int64_t edge = tile * kTileEdges + (lane & 15);
+    const int64_t ec = edge < a.E ? edge : a.E - 1;
+    float* de_tile = a.de_soa + tile * kTileFloats + lane * 4;
+    const float* act_tile = a.act + tile * kActPerTile;
+    const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
+    f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 de[4], contrib[4];
+    static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256); });
+    mlp_reverse_mfma(lds, L.mlp, 0, a, edge, hv, act_tile, de, contrib, dhv, lv);
+    static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
+      de[blk] += contrib[blk];
+      *(f32x4*)(de_tile + blk * 256) = de[blk];
     });
-    mlp_reverse_mfma(lds, L.mlp[0], 0, a, edge, hv, act_tile, de, contrib, dhv, lane);
-    asm volatile("" ::: "memory");
-    static_for<2>([&]<int kb>() {
-      static_for<16>([&]<int r>() {
-        de[kb][r] = de_tile[(kb * 16 + r) * 64] + contrib[kb][r];
-        de_tile[(kb * 16 + r) * 64] = de[kb][r];
-      });
-    });
-    // three-body gated update, reverse: recompute pd, pg from m
+    // three-body gated update, reverse: recompute the pre-activations from m
     float mb[TBS];
-    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 2 * s + h]; });
-    f32x16 d4[4];
-    {
-      f32x16 pd[2], pg[2];
-      tb_preact<TBS>(lds + L.tb, mb, pd, pg, lane);
-      static_for<2>([&]<int kb>() {
-        static_for<16>([&]<int r>() {
-          const float p = pd[kb][r], sgd = fsigmoid(p), sg = fsigmoid(pg[kb][r]);
-          d4[kb][r] = de[kb][r] * sg * (sgd * (1.f + p * (1.f - sgd)));
-          d4[2 + kb][r] = de[kb][r] * (p * sgd) * sg * (1.f - sg);
-        });
+    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
+    f32x4 d8[8];
+    tb_preact<TBS>(lds + L.tb, mb, d8, lv);
+    static_for<4>([&]<int blk>() {
+      static_for<4>([&]<int r>() {
+        const float p = d8[blk][r], sgd = fsigmoid(p), sg = fsigmoid(d8[4 + blk][r]);
+        d8[blk][r] = de[blk][r] * sg * (sgd * (1.f + p * (1.f - sgd)));
+        d8[4 + blk][r] = de[blk][r] * (p * sgd) * sg * (1.f - sg);
       });
-    }
-    f32x16 dmv[1];
-    zero(dmv[0]);
-    chain<1, 4>(lds + L.tbT, d4, dmv, lane);
-    // lane-half dhv halves hold disjoint feature sets of the same edge: combine, then lanes < 32 own the edge
-    static_for<4>([&]<int rr>() { dhv[rr] += __shfl_xor(dhv[rr], 32); });
-    if (edge < a.E) {
-      // rows c = feat_of(r, h): registers 0-3 -> c = 4h..4h+3, registers 4-7 -> c = 8+4h..
-      f32x4 lo, hi;
-      static_for<4>([&]<int qq>() { lo[qq] = dmv[0][qq]; hi[qq] = dmv[0][4 + qq]; });
-      *(f32x4*)(a.dm + edge * kCP + 4 * h) = lo;
-      *(f32x4*)(a.dm + edge * kCP + 8 + 4 * h) = hi;
-      if (h == 0) {
-        f32x4 old = *(f32x4*)(a.dh + edge * kRP);
-        *(f32x4*)(a.dh + edge * kRP) = old + dhv;
-      }
-    }
+    });
+    f32x4 dmv[1];
+    zero(dmv);
+    chain<1, 8>(lds + L.tbT, d8, dmv, lv);
+    add_dh(a.dh, edge, a.E, dhv, qd);
+    if (edge < a.E) *(f32x4*)(a.dm + edge * kCP + 4 * qd) = dmv[0];  // rows c = 4*qd + reg
   }
 }
 
 // ---------------------------------------------------------------------------------------------- helpers
-__device__ __forceinline__ int feat_of_dev(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// rows [E][64] -> tile-SoA [tiles][32 slots][64]; padding edges get zeros
-__global__ void __launch_bounds__(256) k_rows_to_soa(int64_t E, int64_t tiles, const float* __restrict__ rows, float* __restrict__ soa) {
-  int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (idx >= tiles * 2048) return;
-  int64_t tile = idx >> 11;
-  int slot = (int)((idx >> 6) & 31), p = (int)(idx & 63);
-  int64_t edge = tile * 32 + (p & 31);
-  int o = (slot >> 4) * 32 + feat_of_dev(slot & 15, p >> 5);
-  soa[idx] = edge < E ? rows[edge * kDP + o] : 0.f;
+// tile-SoA element index of (edge, feature)
+__device__ __forceinline__ int64_t soa_index(int64_t edge, int o) {
+  return (edge >> 4) * kTileFloats + (o >> 4) * 256 + (((o >> 2) & 3) * 16 + (int)(edge & 15)) * 4 + (o & 3);
 }
+
 __global__ void __launch_bounds__(256) k_soa_to_rows(int64_t E, int width, int row_stride, const float* __restrict__ soa,
                                                      float* __restrict__ rows) {
   int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (idx >= E * kDP) return;
   int64_t edge = idx >> 6;
   int o = (int)(idx & 63);
-  if (o >= width) return;
-  int kb = o >> 5, w = o & 31, hh = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);
-  rows[edge * row_stride + o] = soa[(edge >> 5) * 2048 + (kb * 16 + r) * 64 + hh * 32 + (edge & 31)];
+  if (o < width) rows[edge * row_stride + o] = soa[soa_index(edge, o)];
+}
+__global__ void __launch_bounds__(256) k_rows_to_soa(int64_t E, int64_t tiles, const float* __restrict__ rows, float* __restrict__ soa) {
+  int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= tiles * kTileFloats) return;
+  int64_t tile = idx / kTileFloats;
+  int rem = (int)(idx % kTileFloats), blk = rem >> 8, lane = (rem >> 2) & 63, reg = rem & 3;
+  int64_t edge = tile * kTileEdges + (lane & 15);
+  int o = blk * 16 + 4 * (lane >> 4) + reg;
+  soa[idx] = edge < E ? rows[edge * kDP + o] : 0.f;
+}
+
+// e0 = SiLU(W_adj h) written straight into the tile-SoA image (nn/featurizer.py:128-132)
+__global__ void __launch_bounds__(256) k_embed_edges_soa(int R, int64_t E, int64_t tiles, const float* __restrict__ adj_t,
+                                                         const float* __restrict__ h, float* __restrict__ soa) {
+  int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= tiles * kTileFloats) return;
+  int64_t tile = idx / kTileFloats;
+  int rem = (int)(idx % kTileFloats), blk = rem >> 8, lane = (rem >> 2) & 63, reg = rem & 3;
+  int64_t edge = tile * kTileEdges + (lane & 15);
+  int o = blk * 16 + 4 * (lane >> 4) + reg;
+  float v = 0.f;
+  if (edge < E) {
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) acc += adj_t[r * kDP + o] * h[edge * kRP + r];
+    v = silu_f(acc);
+  }
+  soa[idx] = v;
+}
+
+// dh[e,:] += sum_o de[e,o] SiLU'(pe0[e,o]) W_adj[o,:] reading de from its tile-SoA image: one lane per (edge, quarter)
+__global__ void __launch_bounds__(256) k_embed_edges_reverse_soa(int64_t E, int64_t tiles, const float* __restrict__ adj /*[64][4]*/,
+                                                                 const float* __restrict__ h, const float* __restrict__ de_soa,
+                                                                 float* __restrict__ dh) {
+  int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t tile = gid >> 6;
+  if (tile >= tiles) return;  // whole waves exit together (64 lanes per tile)
+  int lane = (int)(gid & 63), qd = lane >> 4;
+  int64_t edge = tile * kTileEdges + (lane & 15);
+  int64_t ec = edge < E ? edge : E - 1;
+  const f32x4 hv = *(const f32x4*)(h + ec * kRP);
+  const float* src = de_soa + tile * kTileFloats + lane * 4;
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const f32x4 dv = *(const f32x4*)(src + blk * 256);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      int o = blk * 16 + 4 * qd + reg;
+      const f32x4 w = *(const f32x4*)(adj + o * kRP);
+      float pe = w[0] * hv[0] + w[1] * hv[1] + w[2] * hv[2] + w[3] * hv[3];
+      float t = dv[reg] * dsilu_f(pe);
+      d0 += t * w[0]; d1 += t * w[1]; d2 += t * w[2]; d3 += t * w[3];
+    }
+  }
+  d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16); d2 += __shfl_xor(d2, 16); d3 += __shfl_xor(d3, 16);
+  d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32); d3 += __shfl_xor(d3, 32);
+  if (qd == 0 && edge < E) {
+    f32x4 old = *(f32x4*)(dh + edge * kRP);
+    old[0] += d0; old[1] += d1; old[2] += d2; old[3] += d3;
+    *(f32x4*)(dh + edge * kRP) = old;
+  }
 }
 
 // x_new[i,:] = x[i,:] + sum_{e in row(i)} msg[e,:]   (nn/conv.py:82-88): one wave per atom, no atomics
@@ -385,9 +483,17 @@ __global__ void __launch_bounds__(256) k_node_sum(int64_t N, const int32_t* __re
   int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   int o = threadIdx.x & 63;
   if (i >= N) return;
-  float acc = x[i * kDP + o];
-  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) acc += msg[(int64_t)e * kDP + o];
-  x_new[i * kDP + o] = acc;
+  float a0 = x[i * kDP + o], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int e1 = row_ptr[i + 1];
+  int e = row_ptr[i];
+  for (; e + 4 <= e1; e += 4) {
+    a0 += msg[(int64_t)e * kDP + o];
+    a1 += msg[(int64_t)(e + 1) * kDP + o];
+    a2 += msg[(int64_t)(e + 2) * kDP + o];
+    a3 += msg[(int64_t)(e + 3) * kDP + o];
+  }
+  for (; e < e1; ++e) a0 += msg[(int64_t)e * kDP + o];
+  x_new[i * kDP + o] = (a0 + a1) + (a2 + a3);
 }
 
 static inline int grid_for_tiles(int64_t tiles) {
@@ -398,27 +504,48 @@ static inline int grid_for_tiles(int64_t tiles) {
   return (int)wgs;
 }
 
-static inline int tb_steps_for(int C) { return C <= 6 ? 3 : (C <= 10 ? 5 : 8); }
+static inline int tb_steps_for(int C) { return (C + 3) / 4; }
+static inline int64_t tiles_for(int64_t E) { return (E + kTileEdges - 1) / kTileEdges; }
 
 void launch_rows_to_soa(const float* rows, float* soa, int64_t E, hipStream_t s) {
-  int64_t tiles = (E + 31) / 32;
-  if (tiles > 0) hipLaunchKernelGGL(k_rows_to_soa, dim3((unsigned)((tiles * 2048 + 255) / 256)), dim3(256), 0, s, E, tiles, rows, soa);
+  int64_t tiles = tiles_for(E);
+  if (tiles > 0)
+    hipLaunchKernelGGL(k_rows_to_soa, dim3((unsigned)((tiles * kTileFloats + 255) / 256)), dim3(256), 0, s, E, tiles, rows, soa);
 }
 void launch_soa_to_rows(const float* soa, float* rows, int row_stride, int width, int64_t E, hipStream_t s) {
   if (E > 0) hipLaunchKernelGGL(k_soa_to_rows, dim3((unsigned)((E * kDP + 255) / 256)), dim3(256), 0, s, E, width, row_stride, soa, rows);
 }
+void launch_embed_edges_soa(const Consts& c, const float* adj_t, const float* h, float* soa, int64_t E, hipStream_t s) {
+  int64_t tiles = tiles_for(E);
+  if (tiles > 0)
+    hipLaunchKernelGGL(k_embed_edges_soa, dim3((unsigned)((tiles * kTileFloats + 255) / 256)), dim3(256), 0, s, c.R, E, tiles, adj_t, h, soa);
+}
+void launch_embed_edges_reverse_soa(const float* adj, const float* h, const float* de_soa, float* dh, int64_t E, hipStream_t s) {
+  int64_t tiles = tiles_for(E);
+  if (tiles > 0)
+    hipLaunchKernelGGL(k_embed_edges_reverse_soa, dim3((unsigned)((tiles * 64 + 255) / 256)), dim3(256), 0, s, E, tiles, adj, h, de_soa, dh);
+}
+
+#define M3G_TBS_SWITCH(C_, CALL)                     \
+  switch (tb_steps_for(C_)) {                        \
+    case 1: { constexpr int TBS = 1; CALL; } break;  \
+    case 2: { constexpr int TBS = 2; CALL; } break;  \
+    case 3: { constexpr int TBS = 3; CALL; } break;  \
+    default: { constexpr int TBS = 4; CALL; } break; \
+  }
 
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_old,
                             float* x_new, hipStream_t s) {
-  const int64_t tiles = (t.E + 31) / 32;
+  const int64_t tiles = tiles_for(t.E);
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
-    FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TA, w.TB, w.e_soa, w.act[b], w.msg};
+    FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TA, w.TB, w.e_soa, w.act[b], w.msg,
+              plan->d_stamps};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
-    switch (tb_steps_for(c.C)) {
-      case 3: hipLaunchKernelGGL((k_edge_block_mfma<3>), grid, block, 0, s, a, L); break;
-      case 5: hipLaunchKernelGGL((k_edge_block_mfma<5>), grid, block, 0, s, a, L); break;
-      default: hipLaunchKernelGGL((k_edge_block_mfma<8>), grid, block, 0, s, a, L); break;
+    if (plan->d_stamps && tb_steps_for(c.C) == 3) {  // diagnostic build of the default configuration
+      hipLaunchKernelGGL((k_edge_block_mfma<3, true>), grid, block, 0, s, a, L);
+    } else {
+      M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS>), grid, block, 0, s, a, L));
     }
   }
   if (t.N > 0) hipLaunchKernelGGL(k_node_sum, dim3((unsigned)((t.N + 3) / 4)), dim3(256), 0, s, t.N, t.row_ptr, x_old, w.msg, x_new);
@@ -426,16 +553,17 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
 
 void launch_edge_block_reverse_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b,
                                     const float* dx_new, hipStream_t s) {
-  const int64_t tiles = (t.E + 31) / 32;
+  const int64_t tiles = tiles_for(t.E);
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
-  RevArgs a{t.E, tiles, plan->d_mfma_rev + (size_t)b * L.total, t.src, w.h, w.m[b], w.act[b], dx_new, w.de_soa, w.dm, w.dh, w.dp1};
+  const float* img_e = plan->d_mfma_rev + (size_t)b * L.per_block;
+  const float* img_n = img_e + L.total_e;
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
-  switch (tb_steps_for(c.C)) {
-    case 3: hipLaunchKernelGGL((k_edge_block_reverse_mfma<3>), grid, block, 0, s, a, L); break;
-    case 5: hipLaunchKernelGGL((k_edge_block_reverse_mfma<5>), grid, block, 0, s, a, L); break;
-    default: hipLaunchKernelGGL((k_edge_block_reverse_mfma<8>), grid, block, 0, s, a, L); break;
-  }
+  RevArgs an{t.E, tiles, img_n, t.src, w.h, w.m[b], w.act[b], dx_new, w.de_soa, w.dm, w.dh, w.dp1};
+  hipLaunchKernelGGL(k_edge_rev_node_mlp, grid, block, 0, s, an, L);
+  RevArgs ae = an;
+  ae.img = img_e;
+  M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS>), grid, block, 0, s, ae, L));
 }
 
 }  // namespace m3g

@@ -82,26 +82,39 @@ struct WeightLayout {
 };
 
 // ---- MFMA edge-block weight images (one per block), copied verbatim into LDS by the kernels -----------
-// A-operand image of a layer with OB 32-row output blocks and KB 32-wide k blocks for v_mfma_f32_32x32x2_f32
-// in the "accumulator feeds the next layer" chain:  img[((ob*KB + kb)*16 + s)*64 + lane] =
-//   W[ob*32 + (lane&31)][kb*32 + feat_of(s, lane>>5)],  feat_of(r,h) = (r&3) + 8*(r>>2) + 4*h
-// "direct" images (k taken straight from memory): img[(ob*S + s)*64 + lane] = W[ob*32 + (lane&31)][2*s + (lane>>5)]
-constexpr int kTbSteps = 8;            // three-body MLP: k = l_max*n_max padded to 16 -> 8 k-steps of 2
+// v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D col = lane&15,
+// row = 4*(lane>>4) + reg.  A tile is 16 edges (lane & 15); lane quarter qd = lane>>4 holds, in register `reg`
+// of 16-feature block `blk`, feature blk*16 + 4*qd + reg.
+// "chain" image of a layer with OB 16-row output blocks and KB 16-wide k blocks (accumulator feeds next layer):
+//   img[((ob*KB + kb)*4 + reg)*64 + lane] = W[ob*16 + (lane&15)][kb*16 + 4*(lane>>4) + reg]
+// "direct" image (k straight from memory, S steps of 4):
+//   img[(ob*S + s)*64 + lane] = W[ob*16 + (lane&15)][4*s + (lane>>4)]
+constexpr int kTbSteps = 4;             // three-body MLP: k = l_max*n_max padded to 16 -> 4 k-steps of 4
 struct MfmaMlpFwd {                     // offsets in floats inside the forward image
-  int w1c;   // [4][2][16][64]  rows: dense 0-63 | gate 64-127, k: edge features
-  int w2d;   // [2][2][16][64]
-  int w2g;   // [2][2][16][64]
-  int b2;    // [2 (dense,gate)][2 ob][64]   bias as a k-step: lanes < 32 hold b[ob*32+lane], others 0
-  int wl;    // [2 ob][2 s][64]              direct image of W_l [64][R<=4]
+  int w1c;   // chain [8][4]   rows: dense 0-63 | gate 64-127, k: edge features      (8192 floats)
+  int w2d;   // chain [4][4]                                                         (4096)
+  int w2g;   // chain [4][4]
+  int b2;    // [2 (dense,gate)][4 ob][64]  bias as a k-step: lanes < 16 hold b[ob*16+lane], others 0
+  int wl;    // direct [4 ob][1 step][64]   W_l [64][R<=4]
 };
-struct MfmaFwdLayout { int tb; /* [4][kTbSteps][64] dense ob0,ob1, gate ob0,ob1 */ MfmaMlpFwd mlp[2]; int total; };
+struct MfmaFwdLayout { int tb; /* direct [8 ob][kTbSteps][64]: dense ob0-3, gate ob4-7 */ MfmaMlpFwd mlp[2]; int total; };
+// reverse images: one per conv MLP (two kernels per block: node MLP first, then edge MLP + three-body update)
 struct MfmaMlpRev {
-  int w2dT;  // [2][2][16][64]   rows: hidden k, cols: out o
+  int w2d, w2g, b2;  // forward layer-2 images (layer-2 pre-activations are recomputed, not saved)
+  int w2dT;  // chain [4][4]   rows: hidden k, cols: out o
   int w2gT;
-  int w1cT;  // [2][4][16][64]   rows: edge feature k, cols: layer-1 outputs (dense 0-63 | gate 64-127)
+  int w1cT;  // chain [4][8]   rows: edge feature k, cols: layer-1 outputs (dense 0-63 | gate 64-127)
   int wl;    // [64][4] plain
+  int total; // floats of the MLP part (the node-MLP kernel's whole image)
 };
-struct MfmaRevLayout { int tb; /* forward three-body image */ int tbT; /* [1][4][16][64] rows: c */ MfmaMlpRev mlp[2]; int total; };
+struct MfmaRevLayout {
+  MfmaMlpRev mlp;   // offsets inside either image
+  int tb;           // edge-MLP image only: forward three-body image
+  int tbT;          // edge-MLP image only: chain [1][8] rows: c
+  int total_n;      // node-MLP image size
+  int total_e;      // edge-MLP image size (MLP part + tb + tbT)
+  int per_block;    // total_e + total_n; block b: [edge image | node image]
+};
 MfmaFwdLayout mfma_fwd_layout();
 MfmaRevLayout mfma_rev_layout();
 
@@ -117,6 +130,7 @@ struct m3g_plan {
   float* d_mfma_fwd = nullptr;   // [num_blocks][MfmaFwdLayout.total]
   float* d_mfma_rev = nullptr;   // [num_blocks][MfmaRevLayout.total]
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
+  unsigned long long* d_stamps = nullptr;  // option "stamps": diagnostic phase-cycle sums [256][16][12] of the fwd edge kernel
   bool committed = false;
   // opt-in stage profiler (m3g_profile_*): event pairs recorded around stage launches
   mutable bool profile = false;
@@ -213,6 +227,10 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
                             float* x_new, hipStream_t s);
 void launch_edge_block_reverse_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b,
                                     const float* dx_new, hipStream_t s);
+void launch_embed_edges_soa(const Consts& c, const float* adj_t, const float* h, float* soa, int64_t E, hipStream_t s);
+void launch_embed_edges_reverse_soa(const float* adj, const float* h, const float* de_soa, float* dh, int64_t E, hipStream_t s);
+void launch_embed_nodes_only(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
+                             const Work& w, hipStream_t s);
 void launch_rows_to_soa(const float* rows, float* soa, int64_t E, hipStream_t s);
 void launch_soa_to_rows(const float* soa, float* rows, int row_stride, int width, int64_t E, hipStream_t s);
 // edge_simple.hip

@@ -5,19 +5,17 @@
 
 namespace m3g {
 
-static inline int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
 MfmaFwdLayout mfma_fwd_layout() {
   MfmaFwdLayout L{};
   int off = 0;
   auto take = [&](int n) { int r = off; off += n; return r; };
-  L.tb = take(4 * kTbSteps * 64);
+  L.tb = take(8 * kTbSteps * 64);
   for (int m = 0; m < 2; ++m) {
-    L.mlp[m].w1c = take(4 * 2 * 16 * 64);
-    L.mlp[m].w2d = take(2 * 2 * 16 * 64);
-    L.mlp[m].w2g = take(2 * 2 * 16 * 64);
-    L.mlp[m].b2 = take(2 * 2 * 64);
-    L.mlp[m].wl = take(2 * 2 * 64);
+    L.mlp[m].w1c = take(8 * 4 * 4 * 64);
+    L.mlp[m].w2d = take(4 * 4 * 4 * 64);
+    L.mlp[m].w2g = take(4 * 4 * 4 * 64);
+    L.mlp[m].b2 = take(2 * 4 * 64);
+    L.mlp[m].wl = take(4 * 1 * 64);
   }
   L.total = off;
   return L;
@@ -27,33 +25,37 @@ MfmaRevLayout mfma_rev_layout() {
   MfmaRevLayout L{};
   int off = 0;
   auto take = [&](int n) { int r = off; off += n; return r; };
-  L.tb = take(4 * kTbSteps * 64);
-  L.tbT = take(1 * 4 * 16 * 64);
-  for (int m = 0; m < 2; ++m) {
-    L.mlp[m].w2dT = take(2 * 2 * 16 * 64);
-    L.mlp[m].w2gT = take(2 * 2 * 16 * 64);
-    L.mlp[m].w1cT = take(2 * 4 * 16 * 64);
-    L.mlp[m].wl = take(64 * 4);
-  }
-  L.total = off;
+  L.mlp.w2d = take(4 * 4 * 4 * 64);
+  L.mlp.w2g = take(4 * 4 * 4 * 64);
+  L.mlp.b2 = take(2 * 4 * 64);
+  L.mlp.w2dT = take(4 * 4 * 4 * 64);
+  L.mlp.w2gT = take(4 * 4 * 4 * 64);
+  L.mlp.w1cT = take(4 * 8 * 4 * 64);
+  L.mlp.wl = take(64 * 4);
+  L.mlp.total = off;
+  L.total_n = off;
+  L.tb = take(8 * kTbSteps * 64);
+  L.tbT = take(1 * 8 * 4 * 64);
+  L.total_e = off;
+  L.per_block = L.total_e + L.total_n;
   return L;
 }
 
-// chain image: img[((ob*KB + kb)*16 + s)*64 + lane] = get(row = ob*32 + (lane&31), k = kb*32 + feat_of(s, lane>>5))
+// chain image: img[((ob*KB + kb)*4 + reg)*64 + lane] = get(row = ob*16 + (lane&15), k = kb*16 + 4*(lane>>4) + reg)
 template <class F>
 static void chain_image(float* img, int OB, int KB, F get) {
   for (int ob = 0; ob < OB; ++ob)
     for (int kb = 0; kb < KB; ++kb)
-      for (int s = 0; s < 16; ++s)
+      for (int reg = 0; reg < 4; ++reg)
         for (int lane = 0; lane < 64; ++lane)
-          img[((ob * KB + kb) * 16 + s) * 64 + lane] = get(ob * 32 + (lane & 31), kb * 32 + feat_of(s, lane >> 5));
+          img[((ob * KB + kb) * 4 + reg) * 64 + lane] = get(ob * 16 + (lane & 15), kb * 16 + 4 * (lane >> 4) + reg);
 }
-// direct image: img[(ob*S + s)*64 + lane] = get(row = ob*32 + (lane&31), k = 2*s + (lane>>5))
+// direct image: img[(ob*S + s)*64 + lane] = get(row = ob*16 + (lane&15), k = 4*s + (lane>>4))
 template <class F>
 static void direct_image(float* img, int OB, int S, F get) {
   for (int ob = 0; ob < OB; ++ob)
     for (int s = 0; s < S; ++s)
-      for (int lane = 0; lane < 64; ++lane) img[(ob * S + s) * 64 + lane] = get(ob * 32 + (lane & 31), 2 * s + (lane >> 5));
+      for (int lane = 0; lane < 64; ++lane) img[(ob * S + s) * 64 + lane] = get(ob * 16 + (lane & 15), 4 * s + (lane >> 4));
 }
 
 int pack_mfma_images(m3g_plan* plan) {
@@ -61,10 +63,10 @@ int pack_mfma_images(m3g_plan* plan) {
   const int D = cfg.embedding_dim, R = cfg.n_max, C = cfg.l_max * cfg.n_max, B = cfg.num_blocks;
   const MfmaFwdLayout F = mfma_fwd_layout();
   const MfmaRevLayout Rv = mfma_rev_layout();
-  std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.total, 0.f);
+  std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.per_block, 0.f);
   for (int b = 0; b < B; ++b) {
     float* f = fwd.data() + (size_t)b * F.total;
-    float* r = rev.data() + (size_t)b * Rv.total;
+    float* r = rev.data() + (size_t)b * Rv.per_block;  // [edge-MLP image | node-MLP image]
     const std::string tb = "model." + std::to_string(6 + 2 * b), cv = "model." + std::to_string(7 + 2 * b);
     const float* wd = plan->params.at(tb + ".gated_mlp.dense.0.weight").data();  // [D,C]
     const float* wg = plan->params.at(tb + ".gated_mlp.gate.0.weight").data();
@@ -74,10 +76,10 @@ int pack_mfma_images(m3g_plan* plan) {
       int o = row & 63;
       return (o < D && k < C) ? w[(size_t)o * C + k] : 0.f;
     };
-    direct_image(f + F.tb, 4, kTbSteps, tbw);
-    direct_image(r + Rv.tb, 4, kTbSteps, tbw);
-    // reverse three-body: rows = c (padded to 32), k = 0..127 over (dense f | gate f)
-    chain_image(r + Rv.tbT, 1, 4, [&](int row, int k) -> float {
+    direct_image(f + F.tb, 8, kTbSteps, tbw);
+    direct_image(r + Rv.tb, 8, kTbSteps, tbw);
+    // reverse three-body: rows = c (16), k = 0..127 over (dense f | gate f)
+    chain_image(r + Rv.tbT, 1, 8, [&](int row, int k) -> float {
       const float* w = k < 64 ? wd : wg;
       int o = k & 63;
       return (row < C && o < D) ? w[(size_t)o * C + row] : 0.f;
@@ -101,22 +103,29 @@ int pack_mfma_images(m3g_plan* plan) {
       };
       auto sq = [&](const float* w) { return [=](int row, int k) -> float { return (row < D && k < D) ? w[(size_t)row * D + k] : 0.f; }; };
       auto sqT = [&](const float* w) { return [=](int row, int k) -> float { return (row < D && k < D) ? w[(size_t)k * D + row] : 0.f; }; };
-      chain_image(f + F.mlp[m].w1c, 4, 2, w1c);
-      chain_image(f + F.mlp[m].w2d, 2, 2, sq(w2d));
-      chain_image(f + F.mlp[m].w2g, 2, 2, sq(w2g));
-      for (int g = 0; g < 2; ++g)
-        for (int ob = 0; ob < 2; ++ob)
-          for (int lane = 0; lane < 64; ++lane) {
-            int o = ob * 32 + lane;
-            f[F.mlp[m].b2 + (g * 2 + ob) * 64 + lane] = (lane < 32 && o < D) ? (g == 0 ? b2d[o] : b2g[o]) : 0.f;
-          }
-      direct_image(f + F.mlp[m].wl, 2, 2, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
-      // reverse images
-      chain_image(r + Rv.mlp[m].w2dT, 2, 2, sqT(w2d));
-      chain_image(r + Rv.mlp[m].w2gT, 2, 2, sqT(w2g));
-      chain_image(r + Rv.mlp[m].w1cT, 2, 4, [&](int row, int k) -> float { return w1c(k, row); });
+      auto bias_image = [&](float* img) {
+        for (int g = 0; g < 2; ++g)
+          for (int ob = 0; ob < 4; ++ob)
+            for (int lane = 0; lane < 64; ++lane) {
+              int o = ob * 16 + lane;
+              img[(g * 4 + ob) * 64 + lane] = (lane < 16 && o < D) ? (g == 0 ? b2d[o] : b2g[o]) : 0.f;
+            }
+      };
+      chain_image(f + F.mlp[m].w1c, 8, 4, w1c);
+      chain_image(f + F.mlp[m].w2d, 4, 4, sq(w2d));
+      chain_image(f + F.mlp[m].w2g, 4, 4, sq(w2g));
+      bias_image(f + F.mlp[m].b2);
+      direct_image(f + F.mlp[m].wl, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
+      // reverse images: m == 0 (edge MLP) at offset 0, m == 1 (node MLP) after the edge image
+      float* rm = r + (m == 0 ? 0 : Rv.total_e);
+      chain_image(rm + Rv.mlp.w2d, 4, 4, sq(w2d));
+      chain_image(rm + Rv.mlp.w2g, 4, 4, sq(w2g));
+      bias_image(rm + Rv.mlp.b2);
+      chain_image(rm + Rv.mlp.w2dT, 4, 4, sqT(w2d));
+      chain_image(rm + Rv.mlp.w2gT, 4, 4, sqT(w2g));
+      chain_image(rm + Rv.mlp.w1cT, 4, 8, [&](int row, int k) -> float { return w1c(k, row); });
       for (int o = 0; o < 64; ++o)
-        for (int rr = 0; rr < 4; ++rr) r[Rv.mlp[m].wl + o * 4 + rr] = (o < D && rr < R) ? wl[(size_t)o * R + rr] : 0.f;
+        for (int rr = 0; rr < 4; ++rr) rm[Rv.mlp.wl + o * 4 + rr] = (o < D && rr < R) ? wl[(size_t)o * R + rr] : 0.f;
     }
   }
   if (plan->d_mfma_fwd) { (void)hipFree(plan->d_mfma_fwd); plan->d_mfma_fwd = nullptr; }
