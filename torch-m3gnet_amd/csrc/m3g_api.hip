@@ -171,11 +171,12 @@ Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, voi
 using namespace m3g;
 
 // ---- stage profiler ---------------------------------------------------------------------------------
-enum StageId { ST_GEOM = 0, ST_EMBED, ST_NODE_PRE, ST_THREEBODY, ST_EDGE_FWD, ST_READOUT, ST_OUTPUTS, ST_EDGE_REV,
-               ST_THREEBODY_REV, ST_NODE_REV, ST_EMBED_REV, ST_GEOM_REV, ST_COUNT };
-static const char* kStageNames[ST_COUNT] = {"geometry_basis", "embed", "node_pre", "threebody_fwd", "edge_block_fwd", "readout",
-                                            "optional_outputs", "edge_block_rev", "threebody_rev", "node_rev", "embed_rev",
-                                            "geometry_rev_forces"};
+enum StageId { ST_GEOM = 0, ST_EMBED, ST_NODE_PRE, ST_THREEBODY, ST_EDGE_FWD, ST_NODE_SUM, ST_READOUT, ST_OUTPUTS, ST_EDGE_REV_NODE,
+               ST_EDGE_REV, ST_THREEBODY_REV, ST_NODE_REV, ST_EMBED_REV, ST_GEOM_REV, ST_COUNT };
+// edge_block_fwd / edge_rev_node_mlp / edge_rev_edge_mlp each time exactly ONE kernel launch (the MFMA kernels)
+static const char* kStageNames[ST_COUNT] = {"geometry_basis", "embed", "node_pre", "threebody_fwd", "edge_block_fwd", "node_sum",
+                                            "readout", "optional_outputs", "edge_rev_node_mlp", "edge_rev_edge_mlp", "threebody_rev",
+                                            "node_rev", "embed_rev", "geometry_rev_forces"};
 struct StageTimer {
   const m3g_plan* p;
   hipStream_t s;
@@ -462,10 +463,12 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   for (int b = 0; b < c.B; ++b) {
     { M3G_STAGE(ST_NODE_PRE); launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], w.TA, w.TB, s); }
     { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }
-    M3G_STAGE(ST_EDGE_FWD);
     if (mfma) {
-      launch_edge_block_mfma(plan, c, t, w, b, w.x[b], w.x[b + 1], s);
+      { M3G_STAGE(ST_EDGE_FWD); launch_edge_block_mfma(plan, c, t, w, b, s); }
+      M3G_STAGE(ST_NODE_SUM);
+      launch_node_sum(t, w.x[b], w.msg, w.x[b + 1], s);
     } else {
+      M3G_STAGE(ST_EDGE_FWD);
       if (N > 0) M3G_HIP_CHECK(hipMemcpyAsync(w.x[b + 1], w.x[b], sizeof(float) * N * kDP, hipMemcpyDeviceToDevice, s));
       launch_edge_block(c, W, wl.blk[b], t, w, b, w.x[b + 1], s);
     }
@@ -491,17 +494,20 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     float* dx_cur = w.dx;
     float* dx_alt = w.dx2;
     for (int b = c.B - 1; b >= 0; --b) {
-      {
-        M3G_STAGE(ST_EDGE_REV);
-        if (b == c.B - 1 && E > 0) {
+      if (b == c.B - 1 && E > 0) {
           if (mfma) M3G_HIP_CHECK(hipMemsetAsync(w.de_soa, 0, sizeof(float) * ((E + 31) / 32) * 2048, s));
           else M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
           M3G_HIP_CHECK(hipMemsetAsync(w.dh, 0, sizeof(float) * E * kRP, s));
           M3G_HIP_CHECK(hipMemsetAsync(w.dd, 0, sizeof(float) * E, s));
           M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
-        }
-        if (mfma) launch_edge_block_reverse_mfma(plan, c, t, w, b, dx_cur, s);
-        else launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
+      }
+      if (mfma) {
+        { M3G_STAGE(ST_EDGE_REV_NODE); launch_edge_rev_node_mlp(plan, c, t, w, b, dx_cur, s); }
+        M3G_STAGE(ST_EDGE_REV);
+        launch_edge_rev_edge_mlp(plan, c, t, w, b, dx_cur, s);
+      } else {
+        M3G_STAGE(ST_EDGE_REV);
+        launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
       }
       { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], s); }
       if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed

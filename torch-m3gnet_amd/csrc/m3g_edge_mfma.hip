@@ -34,7 +34,16 @@ constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;  
 constexpr int kWaves = 16;
 constexpr int kTileEdges = 16;
 constexpr int kTileFloats = 4 * 64 * 4;     // one 64-feature tile image: [4 blk][64 lanes][4]
-constexpr int kActPerTile = 2 * 8 * 64 * 4;  // saved layer-1 pre-activations per tile per block: [2 MLPs][8 ob][64][4]
+// Saved pre-activations per tile per block: [2 MLPs][kActSlots][64 lanes][4].  kSaveP2 = true keeps both layers
+// (16 slots); false keeps only layer 1 (8 slots) and recomputes layer 2 in the reverse pass (+136 MFMAs per MLP and
+// tile, half the activation traffic and workspace).  Measured on the 10k-atom workload: saving both is faster
+// (3.95 vs 4.21 ms/step) because the reverse kernels become HBM-bound instead of matrix-pipe-bound.
+#ifndef M3G_SAVE_P2
+#define M3G_SAVE_P2 1
+#endif
+constexpr bool kSaveP2 = M3G_SAVE_P2 != 0;
+constexpr int kActSlots = kSaveP2 ? 16 : 8;
+constexpr int kActPerTile = 2 * kActSlots * 64 * 4;
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -176,7 +185,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
   chain<8, 4>(lds + L.w1c, x, p1, lane);
   st.template mark<S0 + 1>();  // layer-1 chain
   // only the layer-1 pre-activations are saved; the reverse pass recomputes layer 2 from them
-  float* act_m = act_tile + mlp * (8 * 256) + lane * 4;
+  float* act_m = act_tile + mlp * (kActSlots * 256) + lane * 4;
   static_for<8>([&]<int ob>() {
     *(f32x4*)(act_m + ob * 256) = p1[ob];
     static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); });
@@ -187,6 +196,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
   bias_step<4, 4>(lds + L.b2 + 4 * 64, p2, lane);
   chain<4, 4, 0, 0>(lds + L.w2d, p1, p2, lane);  // hidden dense = p1[0..3]
   chain<4, 4, 4, 4>(lds + L.w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
+  if (kSaveP2) static_for<8>([&]<int ob>() { *(f32x4*)(act_m + (8 + ob) * 256) = p2[ob]; });
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
     static_for<4>([&]<int r>() { out[ob][r] = fsilu(p2[ob][r]) * fsigmoid(p2[4 + ob][r]) * out[ob][r]; });
@@ -267,9 +277,11 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
                                                  const f32x4& hv, const float* act_tile, const f32x4 (&d_upd)[4],
                                                  f32x4 (&contrib)[4], f32x4& dhv, int lane) {
   const int qd = lane >> 4;
-  const float* act_m = act_tile + mlp * (8 * 256) + lane * 4;
+  const float* act_m = act_tile + mlp * (kActSlots * 256) + lane * 4;
   f32x4 d2[8];  // first p2 dense 0..3 / gate 4..7; then d_p2 in place
-  {
+  if (kSaveP2) {
+    static_for<8>([&]<int ob>() { d2[ob] = *(const f32x4*)(act_m + (8 + ob) * 256); });
+  } else {
     f32x4 hid[8];
     static_for<8>([&]<int ob>() {
       const f32x4 p = *(const f32x4*)(act_m + ob * 256);
@@ -534,8 +546,7 @@ void launch_embed_edges_reverse_soa(const float* adj, const float* h, const floa
     default: { constexpr int TBS = 4; CALL; } break; \
   }
 
-void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_old,
-                            float* x_new, hipStream_t s) {
+void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s) {
   const int64_t tiles = tiles_for(t.E);
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
@@ -548,21 +559,31 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
       M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS>), grid, block, 0, s, a, L));
     }
   }
-  if (t.N > 0) hipLaunchKernelGGL(k_node_sum, dim3((unsigned)((t.N + 3) / 4)), dim3(256), 0, s, t.N, t.row_ptr, x_old, w.msg, x_new);
 }
 
-void launch_edge_block_reverse_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b,
-                                    const float* dx_new, hipStream_t s) {
+void launch_node_sum(const Topo& t, const float* x_old, const float* msg, float* x_new, hipStream_t s) {
+  if (t.N > 0) hipLaunchKernelGGL(k_node_sum, dim3((unsigned)((t.N + 3) / 4)), dim3(256), 0, s, t.N, t.row_ptr, x_old, msg, x_new);
+}
+
+void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
+                              hipStream_t s) {
+  (void)c;
+  const int64_t tiles = tiles_for(t.E);
+  if (tiles == 0) return;
+  const MfmaRevLayout L = mfma_rev_layout();
+  const float* img_n = plan->d_mfma_rev + (size_t)b * L.per_block + L.total_e;
+  RevArgs an{t.E, tiles, img_n, t.src, w.h, w.m[b], w.act[b], dx_new, w.de_soa, w.dm, w.dh, w.dp1};
+  hipLaunchKernelGGL(k_edge_rev_node_mlp, dim3(grid_for_tiles(tiles)), dim3(64 * kWaves), 0, s, an, L);
+}
+
+void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
+                              hipStream_t s) {
   const int64_t tiles = tiles_for(t.E);
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_e = plan->d_mfma_rev + (size_t)b * L.per_block;
-  const float* img_n = img_e + L.total_e;
+  RevArgs ae{t.E, tiles, img_e, t.src, w.h, w.m[b], w.act[b], dx_new, w.de_soa, w.dm, w.dh, w.dp1};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
-  RevArgs an{t.E, tiles, img_n, t.src, w.h, w.m[b], w.act[b], dx_new, w.de_soa, w.dm, w.dh, w.dp1};
-  hipLaunchKernelGGL(k_edge_rev_node_mlp, grid, block, 0, s, an, L);
-  RevArgs ae = an;
-  ae.img = img_e;
   M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS>), grid, block, 0, s, ae, L));
 }
 

@@ -223,10 +223,12 @@ void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s);
 // pack_mfma.hip / edge_mfma.hip
 int pack_mfma_images(m3g_plan* plan);
-void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_old,
-                            float* x_new, hipStream_t s);
-void launch_edge_block_reverse_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b,
-                                    const float* dx_new, hipStream_t s);
+void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s);
+void launch_node_sum(const Topo& t, const float* x_old, const float* msg, float* x_new, hipStream_t s);
+void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
+                              hipStream_t s);
+void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
+                              hipStream_t s);
 void launch_embed_edges_soa(const Consts& c, const float* adj_t, const float* h, float* soa, int64_t E, hipStream_t s);
 void launch_embed_edges_reverse_soa(const float* adj, const float* h, const float* de_soa, float* dh, int64_t E, hipStream_t s);
 void launch_embed_nodes_only(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,

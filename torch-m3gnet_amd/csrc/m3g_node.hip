@@ -51,15 +51,15 @@ __global__ void __launch_bounds__(256) k_embed_edges_reverse(int R, int64_t E, c
 }
 
 // ---- S2: v = sigmoid(W1 x + b1);  TA = [W1a_e x + b1_e | W1a_n x + b1_n];  TB = [W1b_e x | W1b_n x] ----
-constexpr int kNodesPerBlock = 4;
+constexpr int kNodesPerBlock = 16;  // weights (128 KB per block of W1a/W1b) are read once per 16 atoms
 __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float* __restrict__ W, BlockW bw,
                                                   const float* __restrict__ x, float* __restrict__ v, float* __restrict__ TA,
                                                   float* __restrict__ TB) {
   __shared__ float xs[kNodesPerBlock][kDP];
   int64_t n0 = (int64_t)blockIdx.x * kNodesPerBlock;
   int tid = threadIdx.x;
-  {
-    int nb = tid >> 6, k = tid & 63;
+  for (int idx = tid; idx < kNodesPerBlock * kDP; idx += 256) {
+    int nb = idx >> 6, k = idx & 63;
     int64_t a = n0 + nb;
     xs[nb][k] = a < N ? x[a * kDP + k] : 0.f;
   }
@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
     int64_t a = n0 + nb;
     if (a < N) { TA[a * 4 * kDP + o] = accA[nb]; TB[a * 4 * kDP + o] = accB[nb]; }
   }
+  static_assert(kNodesPerBlock * kCP <= 256, "one thread per (atom, c)");
   if (tid < kNodesPerBlock * kCP) {
     int nb = tid / kCP, c = tid % kCP;
     int64_t a = n0 + nb;
@@ -100,61 +101,94 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
 }
 
 // ---- B2: dx_in[i] = dx_new[i] + (sum_{row(i)} dp1) W1a + (sum_{in(i)} dp1) W1b + (dv v(1-v)) W1 ----
+// kNodesRev atoms per workgroup: phase 1 streams the dp1 rows (HBM-bound gather: a wave reads a whole 1-KB row per
+// instruction, 16 B per lane), phase 2 applies the transposed first-layer weights once for all atoms of the group
+// (the 128 KB of W1a/W1b would otherwise be re-read from L2 for every atom).
+constexpr int kNodesRev = 8;
 __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const float* __restrict__ W, BlockW bw,
                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ in_ptr,
                                                       const int32_t* __restrict__ in_edge, const float* __restrict__ dp1,
                                                       const float* __restrict__ dgq, const float* __restrict__ v,
                                                       const float* __restrict__ dx_new, float* __restrict__ dx_out) {
-  __shared__ float sA[4 * kDP], sB[4 * kDP], tv[kCP], part[4][kDP];
-  int64_t i = blockIdx.x;
-  int tid = threadIdx.x;
-  {
-    // 4 independent accumulators per list: keeps 8 row loads in flight per thread (HBM-bound gather of dp1)
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    const int e0 = row_ptr[i], e1 = row_ptr[i + 1];
-    int e = e0;
-    for (; e + 4 <= e1; e += 4) {
-      a0 += dp1[(int64_t)e * 4 * kDP + tid];
-      a1 += dp1[(int64_t)(e + 1) * 4 * kDP + tid];
-      a2 += dp1[(int64_t)(e + 2) * 4 * kDP + tid];
-      a3 += dp1[(int64_t)(e + 3) * 4 * kDP + tid];
+  __shared__ float4 sA[kNodesRev][64], sB[kNodesRev][64];   // row / in-edge sums of dp1, 256 columns as 64 float4
+  __shared__ float tv[kNodesRev][kCP];
+  __shared__ float part[4][kNodesRev][kDP];
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int64_t n0 = (int64_t)blockIdx.x * kNodesRev;
+  const float4* rows = reinterpret_cast<const float4*>(dp1) + ln;
+  // phase 1: wave wv gathers for atoms wv, wv+4 of the group
+  for (int nb = wv; nb < kNodesRev; nb += 4) {
+    const int64_t i = n0 + nb;
+    float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    if (i < N) {
+      const int e1 = row_ptr[i + 1];
+      int e = row_ptr[i];
+      for (; e + 1 < e1; e += 2) {
+        const float4 u = rows[(int64_t)e * 64], w2 = rows[(int64_t)(e + 1) * 64];
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        a1.x += w2.x; a1.y += w2.y; a1.z += w2.z; a1.w += w2.w;
+      }
+      if (e < e1) {
+        const float4 u = rows[(int64_t)e * 64];
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+      }
+      const int k1 = in_ptr[i + 1];
+      int k = in_ptr[i];
+      for (; k + 1 < k1; k += 2) {
+        const int f0 = in_edge[k], f1 = in_edge[k + 1];
+        const float4 u = rows[(int64_t)f0 * 64], w2 = rows[(int64_t)f1 * 64];
+        b0.x += u.x; b0.y += u.y; b0.z += u.z; b0.w += u.w;
+        b1.x += w2.x; b1.y += w2.y; b1.z += w2.z; b1.w += w2.w;
+      }
+      if (k < k1) {
+        const float4 u = rows[(int64_t)in_edge[k] * 64];
+        b0.x += u.x; b0.y += u.y; b0.z += u.z; b0.w += u.w;
+      }
     }
-    for (; e < e1; ++e) a0 += dp1[(int64_t)e * 4 * kDP + tid];
-    const int k0 = in_ptr[i], k1 = in_ptr[i + 1];
-    int k = k0;
-    for (; k + 4 <= k1; k += 4) {
-      const int f0 = in_edge[k], f1 = in_edge[k + 1], f2 = in_edge[k + 2], f3 = in_edge[k + 3];
-      b0 += dp1[(int64_t)f0 * 4 * kDP + tid];
-      b1 += dp1[(int64_t)f1 * 4 * kDP + tid];
-      b2 += dp1[(int64_t)f2 * 4 * kDP + tid];
-      b3 += dp1[(int64_t)f3 * 4 * kDP + tid];
-    }
-    for (; k < k1; ++k) b0 += dp1[(int64_t)in_edge[k] * 4 * kDP + tid];
-    sA[tid] = (a0 + a1) + (a2 + a3);
-    sB[tid] = (b0 + b1) + (b2 + b3);
+    sA[nb][ln] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    sB[nb][ln] = make_float4(b0.x + b1.x, b0.y + b1.y, b0.z + b1.z, b0.w + b1.w);
   }
-  if (tid < kCP) {
-    float dv = 0.f;
-    for (int k = in_ptr[i]; k < in_ptr[i + 1]; ++k) dv += dgq[(int64_t)in_edge[k] * kCP + tid];
-    float vv = v[i * kCP + tid];
-    tv[tid] = tid < C ? dv * vv * (1.f - vv) : 0.f;
+  if (tid < kNodesRev * kCP) {
+    const int nb = tid / kCP, c = tid % kCP;
+    const int64_t i = n0 + nb;
+    float val = 0.f;
+    if (i < N && c < C) {
+      float dv = 0.f;
+      for (int k = in_ptr[i]; k < in_ptr[i + 1]; ++k) dv += dgq[(int64_t)in_edge[k] * kCP + c];
+      const float vv = v[i * kCP + c];
+      val = dv * vv * (1.f - vv);
+    }
+    tv[nb][c] = val;
   }
   __syncthreads();
-  int k = tid & 63, pq = tid >> 6;  // quarter pq handles table columns [pq*kDP, (pq+1)*kDP)
+  // phase 2: quarter pq of the threads handles table columns [pq*64, pq*64+64) for output feature k
   {
+    const int k = tid & 63, pq = tid >> 6;
     const MlpW& mw = pq < 2 ? bw.e : bw.n;
-    int row0 = (pq & 1) * kDP;  // row inside the MLP's [2*kDP][kDP] matrices
+    const int row0 = (pq & 1) * kDP;  // row inside the MLP's [2*kDP][kDP] matrices
     const float* wa = W + mw.w1a + (size_t)row0 * kDP + k;
     const float* wb = W + mw.w1b + (size_t)row0 * kDP + k;
-    float acc = 0.f;
-    for (int o = 0; o < kDP; ++o) acc += sA[pq * kDP + o] * wa[o * kDP] + sB[pq * kDP + o] * wb[o * kDP];
-    part[pq][k] = acc;
+    float acc[kNodesRev];
+#pragma unroll
+    for (int nb = 0; nb < kNodesRev; ++nb) acc[nb] = 0.f;
+    const float* fa = reinterpret_cast<const float*>(&sA[0][0]) + pq * kDP;
+    const float* fb = reinterpret_cast<const float*>(&sB[0][0]) + pq * kDP;
+    for (int o = 0; o < kDP; ++o) {
+      const float a = wa[o * kDP], b = wb[o * kDP];
+#pragma unroll
+      for (int nb = 0; nb < kNodesRev; ++nb) acc[nb] += fa[nb * 256 + o] * a + fb[nb * 256 + o] * b;
+    }
+#pragma unroll
+    for (int nb = 0; nb < kNodesRev; ++nb) part[pq][nb][k] = acc[nb];
   }
   __syncthreads();
-  if (tid < kDP) {
-    float acc = dx_new[i * kDP + tid] + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
-    for (int c = 0; c < C; ++c) acc += tv[c] * W[bw.tb_w1 + c * kDP + tid];
-    dx_out[i * kDP + tid] = acc;
+  for (int idx = tid; idx < kNodesRev * kDP; idx += 256) {
+    const int nb = idx >> 6, k = idx & 63;
+    const int64_t i = n0 + nb;
+    if (i >= N) continue;
+    float acc = dx_new[i * kDP + k] + ((part[0][nb][k] + part[1][nb][k]) + (part[2][nb][k] + part[3][nb][k]));
+    for (int c = 0; c < C; ++c) acc += tv[nb][c] * W[bw.tb_w1 + c * kDP + k];
+    dx_out[i * kDP + k] = acc;
   }
 }
 
@@ -288,7 +322,7 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
                          const float* v, const float* dx_new, float* dx_out, hipStream_t s) {
   if (t.N > 0)
-    hipLaunchKernelGGL(k_node_reverse, dim3((unsigned)t.N), dim3(256), 0, s, c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge,
+    hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge,
                        w.dp1, w.dg, v, dx_new, dx_out);
 }
 

@@ -4,13 +4,20 @@
 //
 //   m[e1,c] = fc(d_e1) * sum_{t in T1(e1)} Y_l(cos_t) g[e2(t),c],   g[e,c] = q[e,c] v[dst(e),c],  c = l*R+n
 //
-// Triplets are CSR-grouped by e1 (forward, and the e1 half of the reverse) and by e2 (the e2 half of
-// the reverse), so every sum is a private register accumulation -- no atomics, run-to-run reproducible.
-// One thread per edge row: consecutive rows share a centre atom, hence the same partner window of
-// g/u rows, which stays in L1/L2.  (An LDS-staged per-atom tile version is the planned upgrade.)
+// Triplets are CSR-grouped by e1 (forward, and the e1 half of the reverse) and by e2 (the e2 half of the
+// reverse), so every sum is a private register accumulation -- no atomics, run-to-run reproducible.
+// One thread per edge row, 256 consecutive rows per workgroup.  The partners of those rows are edges of the
+// same centre atoms, i.e. one contiguous window of the centre-sorted edge list: the workgroup stages that
+// window's unit vectors and per-edge payload rows (g = q*v[dst] for the forward / e1 half, dS = fc*dm for the e2
+// half) in LDS once -- the per-atom triplet tile -- and the triplet loops read LDS instead of gathering from
+// L2.  Partners outside the staged window (only possible for degrees beyond the LDS budget) fall back to global
+// memory, so correctness does not depend on the window size.
 #include "m3g_internal.h"
 
 namespace m3g {
+
+constexpr int kTbRows = 256;   // edge rows per workgroup
+constexpr int kTbCap = 384;    // staged window capacity in edges: 256 rows + boundary rows (overflow -> global reads); 18 KB -> 8 WGs per CU
 
 template <int L>
 __device__ __forceinline__ void legendre(float x, float* P, float* dP) {
@@ -23,153 +30,142 @@ __device__ __forceinline__ void legendre(float x, float* P, float* dP) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_make_g(int64_t E, const int32_t* __restrict__ dst, const float* __restrict__ q,
-                                                const float* __restrict__ v, float* __restrict__ g) {
-  int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (idx >= E * kCP) return;
-  int64_t e = idx / kCP;
-  int c = (int)(idx % kCP);
-  g[idx] = q[idx] * v[(int64_t)dst[e] * kCP + c];
+struct TbArgs {
+  int64_t E;
+  const int32_t *src, *dst, *row_ptr;
+  const int32_t *t_ptr, *t_other;     // triplet CSR of this pass (by e1: partner = e2; by e2: partner = e1)
+  const float *u, *fc3, *fc3p, *q, *qp, *v;
+  const float* dm;                    // reverse: dL/dm [E][kCP]
+  float* m;                           // forward out [E][kCP]
+  float *dd, *du, *dgq;               // reverse in/out
+};
+
+// payload of edge e for this pass: MODE 0/1 -> g[e,:] = q*v[dst];  MODE 2 -> dS[e,:] = fc3*dm
+template <int C, int MODE>
+__device__ __forceinline__ void payload(const TbArgs& a, int64_t e, float* out) {
+  if (MODE == 2) {
+    const float f = a.fc3[e];
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = f * a.dm[e * kCP + c];
+  } else {
+    const int64_t k = a.dst[e];
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = a.q[e * kCP + c] * a.v[k * kCP + c];
+  }
 }
 
-template <int L, int R>
-__global__ void __launch_bounds__(256) k_threebody(Consts c, int64_t E, const int32_t* __restrict__ t1_ptr,
-                                                   const int32_t* __restrict__ t1_e2, const float* __restrict__ u,
-                                                   const float* __restrict__ fc3, const float* __restrict__ g,
-                                                   float* __restrict__ m) {
-  int64_t e1 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e1 >= E) return;
+// MODE 0: forward (rows = e1);  MODE 1: reverse e1 half (d fc(d_e1), d u_e1);  MODE 2: reverse e2 half
+template <int L, int R, int MODE>
+__global__ void __launch_bounds__(kTbRows) k_threebody_tile(Consts c, TbArgs a) {
   constexpr int C = L * R;
-  float acc[C];
+  __shared__ float su[kTbCap * 3];
+  __shared__ float sp[kTbCap * C];
+  const int64_t eb = (int64_t)blockIdx.x * kTbRows;
+  const int64_t elast = (eb + kTbRows - 1 < a.E ? eb + kTbRows - 1 : a.E - 1);
+  const int lo = a.row_ptr[a.src[eb]];
+  const int hi_full = a.row_ptr[a.src[elast] + 1];
+  const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
+  for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
+    const int64_t e = lo + idx;
+    su[idx * 3 + 0] = a.u[e * 3];
+    su[idx * 3 + 1] = a.u[e * 3 + 1];
+    su[idx * 3 + 2] = a.u[e * 3 + 2];
+    float row[C];
+    payload<C, MODE>(a, e, row);
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) sp[idx * C + cc] = row[cc];
+  }
+  __syncthreads();
+  const int64_t e = eb + threadIdx.x;
+  if (e >= a.E) return;
+  const int t0 = a.t_ptr[e], t1 = a.t_ptr[e + 1];
+  const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
+  float acc[C], own[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) acc[k] = 0.f;
-  float ux = u[e1 * 3], uy = u[e1 * 3 + 1], uz = u[e1 * 3 + 2];
-  int t0 = t1_ptr[e1], t1 = t1_ptr[e1 + 1];
-  for (int t = t0; t < t1; ++t) {
-    int e2 = t1_e2[t];
-    float cs = ux * u[e2 * 3] + uy * u[e2 * 3 + 1] + uz * u[e2 * 3 + 2];
-    cs = fminf(1.f, fmaxf(-1.f, cs));
-    float P[L], dP[L];
-    legendre<L>(cs, P, dP);
-    const float* ge = g + (int64_t)e2 * kCP;
+  if (MODE == 1) {
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-      float y = c.ynorm[l] * P[l];
-#pragma unroll
-      for (int n = 0; n < R; ++n) acc[l * R + n] += y * ge[l * R + n];
-    }
+    for (int k = 0; k < C; ++k) own[k] = a.dm[e * kCP + k];           // dm of this e1
+  } else if (MODE == 2) {
+    payload<C, 0>(a, e, own);                                         // g of this e2
   }
-  float f = fc3[e1];
-#pragma unroll
-  for (int k = 0; k < kCP; ++k) m[e1 * kCP + k] = k < C ? f * acc[k < C ? k : 0] : 0.f;
-}
-
-// reverse, e1 half: d fc(d_e1), d u_e1
-template <int L, int R>
-__global__ void __launch_bounds__(256) k_threebody_rev1(Consts c, int64_t E, const int32_t* __restrict__ t1_ptr,
-                                                        const int32_t* __restrict__ t1_e2, const float* __restrict__ u,
-                                                        const float* __restrict__ fc3, const float* __restrict__ fc3p,
-                                                        const float* __restrict__ g, const float* __restrict__ dm,
-                                                        float* __restrict__ dd, float* __restrict__ du) {
-  int64_t e1 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e1 >= E) return;
-  int t0 = t1_ptr[e1], t1 = t1_ptr[e1 + 1];
-  if (t0 == t1) return;
-  constexpr int C = L * R;
-  float S[C], dm1[C];
-  float f = fc3[e1];
-#pragma unroll
-  for (int k = 0; k < C; ++k) { S[k] = 0.f; dm1[k] = dm[e1 * kCP + k]; }
-  float ux = u[e1 * 3], uy = u[e1 * 3 + 1], uz = u[e1 * 3 + 2];
   float ax = 0.f, ay = 0.f, az = 0.f;
   for (int t = t0; t < t1; ++t) {
-    int e2 = t1_e2[t];
-    float vx = u[e2 * 3], vy = u[e2 * 3 + 1], vz = u[e2 * 3 + 2];
-    float raw = ux * vx + uy * vy + uz * vz;
-    bool inside = raw >= -1.f && raw <= 1.f;
-    float cs = fminf(1.f, fmaxf(-1.f, raw));
+    const int eo = a.t_other[t];
+    const int idx = eo - lo;
+    float vx, vy, vz, pr[C];
+    if (idx >= 0 && idx < n) {
+      vx = su[idx * 3]; vy = su[idx * 3 + 1]; vz = su[idx * 3 + 2];
+#pragma unroll
+      for (int k = 0; k < C; ++k) pr[k] = sp[idx * C + k];
+    } else {
+      vx = a.u[(int64_t)eo * 3]; vy = a.u[(int64_t)eo * 3 + 1]; vz = a.u[(int64_t)eo * 3 + 2];
+      payload<C, MODE>(a, eo, pr);
+    }
+    const float raw = ux * vx + uy * vy + uz * vz;
+    const float cs = fminf(1.f, fmaxf(-1.f, raw));
     float P[L], dP[L];
     legendre<L>(cs, P, dP);
-    const float* ge = g + (int64_t)e2 * kCP;
-    float dcos = 0.f;
+    if (MODE == 0) {
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-      float y = c.ynorm[l] * P[l], dy = c.ynorm[l] * dP[l];
+      for (int l = 0; l < L; ++l) {
+        const float y = c.ynorm[l] * P[l];
 #pragma unroll
-      for (int n = 0; n < R; ++n) {
-        float gv = ge[l * R + n];
-        S[l * R + n] += y * gv;
-        dcos += dm1[l * R + n] * dy * gv;
+        for (int nn = 0; nn < R; ++nn) acc[l * R + nn] += y * pr[l * R + nn];
       }
-    }
-    dcos = inside ? dcos * f : 0.f;
-    ax += dcos * vx; ay += dcos * vy; az += dcos * vz;
-  }
-  float dfc = 0.f;
+    } else {
+      const bool inside = raw >= -1.f && raw <= 1.f;   // torch.clamp passes the gradient only inside [-1, 1]
+      float dcos = 0.f;
 #pragma unroll
-  for (int k = 0; k < C; ++k) dfc += dm1[k] * S[k];
-  dd[e1] += fc3p[e1] * dfc;
-  du[e1 * 3] += ax; du[e1 * 3 + 1] += ay; du[e1 * 3 + 2] += az;
+      for (int l = 0; l < L; ++l) {
+        const float y = c.ynorm[l] * P[l], dy = c.ynorm[l] * dP[l];
+#pragma unroll
+        for (int nn = 0; nn < R; ++nn) {
+          const int k = l * R + nn;
+          if (MODE == 1) {            // pr = g[e2]: S += Y g;  dcos += dm1 dY g
+            acc[k] += y * pr[k];
+            dcos += own[k] * dy * pr[k];
+          } else {                    // pr = dS[e1]: dg += dS Y;  dcos += dS dY g_own
+            acc[k] += pr[k] * y;
+            dcos += pr[k] * dy * own[k];
+          }
+        }
+      }
+      dcos = inside ? dcos : 0.f;
+      ax += dcos * vx; ay += dcos * vy; az += dcos * vz;
+    }
+  }
+  if (MODE == 0) {
+    const float f = a.fc3[e];
+#pragma unroll
+    for (int k = 0; k < kCP; ++k) a.m[e * kCP + k] = k < C ? f * acc[k < C ? k : 0] : 0.f;
+  } else if (MODE == 1) {
+    if (t0 == t1) return;
+    const float f = a.fc3[e];
+    float dfc = 0.f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) dfc += own[k] * acc[k];               // acc = S[e1,:]
+    a.dd[e] += a.fc3p[e] * dfc;
+    a.du[e * 3] += f * ax; a.du[e * 3 + 1] += f * ay; a.du[e * 3 + 2] += f * az;   // dS = fc * dm
+  } else {
+    if (t0 != t1) { a.du[e * 3] += ax; a.du[e * 3 + 1] += ay; a.du[e * 3 + 2] += az; }
+    const int64_t k = a.dst[e];
+    float ddv = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < kCP; ++cc) {
+      float val = 0.f;
+      if (cc < C) {
+        const float dg = acc[cc < C ? cc : 0];                         // acc = dg[e2,:]
+        ddv += dg * a.v[k * kCP + cc] * a.qp[e * kCP + cc];
+        val = dg * a.q[e * kCP + cc];
+      }
+      a.dgq[e * kCP + cc] = val;
+    }
+    if (t0 != t1) a.dd[e] += ddv;
+  }
 }
 
-// reverse, e2 half: d g[e2,:] (-> d d_e2 through q', and dgq = dg*q for the node gather), d u_e2
-template <int L, int R>
-__global__ void __launch_bounds__(256) k_threebody_rev2(Consts c, int64_t E, const int32_t* __restrict__ t2_ptr,
-                                                        const int32_t* __restrict__ t2_e1, const int32_t* __restrict__ dst,
-                                                        const float* __restrict__ u, const float* __restrict__ fc3,
-                                                        const float* __restrict__ g, const float* __restrict__ q,
-                                                        const float* __restrict__ qp, const float* __restrict__ v,
-                                                        const float* __restrict__ dm, float* __restrict__ dd,
-                                                        float* __restrict__ du, float* __restrict__ dgq) {
-  int64_t e2 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e2 >= E) return;
-  constexpr int C = L * R;
-  int t0 = t2_ptr[e2], t1 = t2_ptr[e2 + 1];
-  float dg[C], gs[C];
-#pragma unroll
-  for (int k = 0; k < C; ++k) { dg[k] = 0.f; gs[k] = g[e2 * kCP + k]; }
-  float ux = u[e2 * 3], uy = u[e2 * 3 + 1], uz = u[e2 * 3 + 2];
-  float ax = 0.f, ay = 0.f, az = 0.f;
-  for (int t = t0; t < t1; ++t) {
-    int e1 = t2_e1[t];
-    float f = fc3[e1];
-    float vx = u[e1 * 3], vy = u[e1 * 3 + 1], vz = u[e1 * 3 + 2];
-    float raw = ux * vx + uy * vy + uz * vz;
-    bool inside = raw >= -1.f && raw <= 1.f;
-    float cs = fminf(1.f, fmaxf(-1.f, raw));
-    float P[L], dP[L];
-    legendre<L>(cs, P, dP);
-    const float* dme = dm + (int64_t)e1 * kCP;
-    float dcos = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      float y = c.ynorm[l] * P[l], dy = c.ynorm[l] * dP[l];
-#pragma unroll
-      for (int n = 0; n < R; ++n) {
-        float ds = f * dme[l * R + n];
-        dg[l * R + n] += ds * y;
-        dcos += ds * dy * gs[l * R + n];
-      }
-    }
-    dcos = inside ? dcos : 0.f;
-    ax += dcos * vx; ay += dcos * vy; az += dcos * vz;
-  }
-  if (t0 != t1) { du[e2 * 3] += ax; du[e2 * 3 + 1] += ay; du[e2 * 3 + 2] += az; }
-  int k = dst[e2];
-  float ddv = 0.f;
-#pragma unroll
-  for (int cc = 0; cc < kCP; ++cc) {
-    float val = 0.f;
-    if (cc < C) {
-      ddv += dg[cc < C ? cc : 0] * v[(int64_t)k * kCP + cc] * qp[e2 * kCP + cc];
-      val = dg[cc < C ? cc : 0] * q[e2 * kCP + cc];
-    }
-    dgq[e2 * kCP + cc] = val;
-  }
-  if (t0 != t1) dd[e2] += ddv;
-}
-
-static inline dim3 grid_for(int64_t n, int tpb = 256) { return dim3((unsigned)((n + tpb - 1) / tpb)); }
+static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 1) / kTbRows)); }
 
 #define M3G_DISPATCH_LR(L_, R_, BODY)                         \
   switch ((L_) * 8 + (R_)) {                                  \
@@ -194,21 +190,19 @@ static inline dim3 grid_for(int64_t n, int tpb = 256) { return dim3((unsigned)((
 
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s) {
   if (t.E == 0) return;
-  hipLaunchKernelGGL(k_make_g, grid_for(t.E * kCP), dim3(256), 0, s, t.E, t.dst, w.q, v, w.g);
-  M3G_DISPATCH_LR(c.L, c.R,
-                  hipLaunchKernelGGL((k_threebody<L, R>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.t1_ptr, t.t1_e2, w.u,
-                                     w.fc3, w.g, m));
+  TbArgs a{t.E, t.src, t.dst, t.row_ptr, t.t1_ptr, t.t1_e2, w.u, w.fc3, w.fc3p, w.q, w.qp, v, nullptr, m, nullptr, nullptr, nullptr};
+  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_tile<L, R, 0>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }
 
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s) {
   if (t.E == 0) return;
-  // g of this block is recomputed (cheap) so blocks do not each keep a copy
-  hipLaunchKernelGGL(k_make_g, grid_for(t.E * kCP), dim3(256), 0, s, t.E, t.dst, w.q, v, w.g);
+  TbArgs a1{t.E, t.src, t.dst, t.row_ptr, t.t1_ptr, t.t1_e2, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd, w.du, w.dg};
+  TbArgs a2 = a1;
+  a2.t_ptr = t.t2_ptr;
+  a2.t_other = t.t2_e1;
   M3G_DISPATCH_LR(c.L, c.R, {
-    hipLaunchKernelGGL((k_threebody_rev1<L, R>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.t1_ptr, t.t1_e2, w.u, w.fc3,
-                       w.fc3p, w.g, w.dm, w.dd, w.du);
-    hipLaunchKernelGGL((k_threebody_rev2<L, R>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.t2_ptr, t.t2_e1, t.dst, w.u,
-                       w.fc3, w.g, w.q, w.qp, v, w.dm, w.dd, w.du, w.dg);
+    hipLaunchKernelGGL((k_threebody_tile<L, R, 1>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a1);
+    hipLaunchKernelGGL((k_threebody_tile<L, R, 2>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a2);
   });
 }
 
