@@ -24,6 +24,12 @@ import torch
 from .m3gnet_oracle import OracleConfig, OracleConstants, cutoff_function, radial_basis
 
 
+# Matrix-product hook for the edge-block products (the ones the MFMA kernels execute); tools/split_precision_study.py
+# swaps it for an emulation of split-precision MFMA arithmetic.  Default: plain matmul.
+def MM(a, b):
+    return a @ b
+
+
 def _silu(p):
     return p * torch.sigmoid(p)
 
@@ -85,10 +91,10 @@ def split_conv_weights(p, prefix, D):
 def _mlp2_forward(table_sum, e_in, w, h):
     """One conv GatedMLP given the gathered layer-1 table contribution.  Returns output and saved pre-acts."""
     D = e_in.size(1)
-    p1 = table_sum + e_in @ w["w1c"].T  # [E, 2D] (bias already in TA)
+    p1 = table_sum + MM(e_in, w["w1c"].T)  # [E, 2D] (bias already in TA)
     hd, hg = _silu(p1[:, :D]), _silu(p1[:, D:])
-    p2d = hd @ w["w2d"].T + w["b2d"]
-    p2g = hg @ w["w2g"].T + w["b2g"]
+    p2d = MM(hd, w["w2d"].T) + w["b2d"]
+    p2g = MM(hg, w["w2g"].T) + w["b2g"]
     out = _silu(p2d) * torch.sigmoid(p2g)
     s = h @ w["wl"].T
     return out * s, dict(p1=p1, p2d=p2d, p2g=p2g, out=out, s=s)
@@ -102,10 +108,10 @@ def _mlp2_backward(d_upd, sv, w, D):
     sg = torch.sigmoid(sv["p2g"])
     d_p2d = d_out * sg * _dsilu(sv["p2d"])
     d_p2g = d_out * _silu(sv["p2d"]) * sg * (1 - sg)
-    d_hd, d_hg = d_p2d @ w["w2d"], d_p2g @ w["w2g"]
+    d_hd, d_hg = MM(d_p2d, w["w2d"]), MM(d_p2g, w["w2g"])
     p1 = sv["p1"]
     d_p1 = torch.cat([d_hd * _dsilu(p1[:, :D]), d_hg * _dsilu(p1[:, D:])], dim=1)
-    return d_p1 @ w["w1c"], d_p1, d_h
+    return MM(d_p1, w["w1c"]), d_p1, d_h
 
 
 def forward_backward(p: dict, cfg: OracleConfig, c: OracleConstants, graph: dict) -> dict:
@@ -182,7 +188,7 @@ def forward_backward(p: dict, cfg: OracleConfig, c: OracleConstants, graph: dict
         m = fc3[:, None] * Ssum
         # ---- S4 edge block -----------------------------------------------------------------
         wd, wg = p[f"{tb}.gated_mlp.dense.0.weight"], p[f"{tb}.gated_mlp.gate.0.weight"]  # [D,C]
-        pd, pg = m @ wd.T, m @ wg.T
+        pd, pg = MM(m, wd.T), MM(m, wg.T)
         e1 = e + _silu(pd) * torch.sigmoid(pg)
         tab = TA[src] + TB[dst]
         upd_e, sv_e = _mlp2_forward(tab[:, : 2 * D], e1, w["e"], h)
@@ -238,7 +244,7 @@ def forward_backward(p: dict, cfg: OracleConfig, c: OracleConstants, graph: dict
         sgg = torch.sigmoid(sv["pg"])
         d_pd = d_e1 * sgg * _dsilu(sv["pd"])
         d_pg = d_e1 * _silu(sv["pd"]) * sgg * (1 - sgg)
-        d_m = d_pd @ sv["wd"] + d_pg @ sv["wg"]  # [E,C]
+        d_m = MM(d_pd, sv["wd"]) + MM(d_pg, sv["wg"])  # [E,C]
         d_e = d_e1
         dp1 = torch.cat([dp1_e, dp1_n], dim=1)  # [E,4D]
         d_TA = torch.zeros(N, 4 * D, dtype=dt).index_add(0, src, dp1)

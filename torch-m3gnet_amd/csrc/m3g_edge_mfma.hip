@@ -63,17 +63,43 @@ __device__ __forceinline__ float fdsilu(float p) {
   return s * (1.f + p * (1.f - s));
 }
 
-// acc[AOFF + ob] += Wimg(ob, :) . x[XOFF ..]   (chain image, see m3g_internal.h)
-template <int OB, int KB, int XOFF = 0, int AOFF = 0, int NX, int NA>
+// ---- the dense chains run on v_mfma_f32_16x16x32_bf16 with split operands ("bf16x3") ----------------------------
+// a = a_hi + a_lo (both bf16; the residual a - a_hi is formed exactly in fp32), a.b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi,
+// accumulated in fp32: 3 MFMAs at 16x the fp32-MFMA rate.  bf16 keeps the fp32 exponent range, which the tiny gradient
+// operands of the reverse pass need (f16 would flush them).  Parity effect (tools/split_precision_study.py, same
+// arithmetic emulated in the oracle): force error 1.1e-5 of max|F| vs 7e-6 for plain fp32 -- budget 1e-4.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// B operand of one k-step (32 features = accumulator blocks a, b): element j < 4 from a, j >= 4 from b
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+  static_for<4>([&]<int j>() {
+    hi[j] = (__bf16)a[j];
+    hi[4 + j] = (__bf16)b[j];
+  });
+  static_for<4>([&]<int j>() {
+    lo[j] = (__bf16)(a[j] - (float)hi[j]);
+    lo[4 + j] = (__bf16)(b[j] - (float)hi[4 + j]);
+  });
+}
+
+// acc[AOFF + ob] += W(ob-th 16-row block, :) . x[XOFF .. XOFF + 2*KS)   (chain image: m3g_pack_mfma.hip)
+template <int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
 __device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
-  static_assert(XOFF + KB <= NX && AOFF + OB <= NA, "chain operand out of range");
-  static_for<KB>([&]<int kb>() {
-    static_for<4>([&]<int reg>() {
-      const float b = x[XOFF + kb][reg];
-      static_for<OB>([&]<int ob>() {
-        const float a = img[((ob * KB + kb) * 4 + reg) * 64 + lane];
-        acc[AOFF + ob] = mfma16(a, b, acc[AOFF + ob]);
-      });
+  static_assert(XOFF + 2 * KS <= NX && AOFF + OB <= NA, "chain operand out of range");
+  const bf16x8* hi_img = reinterpret_cast<const bf16x8*>(img) + lane;
+  const bf16x8* lo_img = hi_img + OB * KS * 64;
+  static_for<KS>([&]<int s>() {
+    bf16x8 bh, bl;
+    split8(x[XOFF + 2 * s], x[XOFF + 2 * s + 1], bh, bl);
+    static_for<OB>([&]<int ob>() {
+      const bf16x8 ah = hi_img[(ob * KS + s) * 64], al = lo_img[(ob * KS + s) * 64];
+      acc[AOFF + ob] = mfma_bf16(ah, bh, acc[AOFF + ob]);
+      acc[AOFF + ob] = mfma_bf16(ah, bl, acc[AOFF + ob]);
+      acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
     });
   });
 }
@@ -182,7 +208,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
     static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(ta + ob * 16) + *(const f32x4*)(tb + ob * 16); });
   }
   st.template mark<S0>();      // table gather
-  chain<8, 4>(lds + L.w1c, x, p1, lane);
+  chain<8, 2>(lds + L.w1c, x, p1, lane);
   st.template mark<S0 + 1>();  // layer-1 chain
   // only the layer-1 pre-activations are saved; the reverse pass recomputes layer 2 from them
   float* act_m = act_tile + mlp * (kActSlots * 256) + lane * 4;
@@ -194,8 +220,8 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
   f32x4 p2[8];  // dense 0..3, gate 4..7
   bias_step<4, 0>(lds + L.b2, p2, lane);
   bias_step<4, 4>(lds + L.b2 + 4 * 64, p2, lane);
-  chain<4, 4, 0, 0>(lds + L.w2d, p1, p2, lane);  // hidden dense = p1[0..3]
-  chain<4, 4, 4, 4>(lds + L.w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
+  chain<4, 2, 0, 0>(lds + L.w2d, p1, p2, lane);  // hidden dense = p1[0..3]
+  chain<4, 2, 4, 4>(lds + L.w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
   if (kSaveP2) static_for<8>([&]<int ob>() { *(f32x4*)(act_m + (8 + ob) * 256) = p2[ob]; });
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -289,8 +315,8 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
     });
     bias_step<4, 0>(lds + L.b2, d2, lane);
     bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
-    chain<4, 4, 0, 0>(lds + L.w2d, hid, d2, lane);
-    chain<4, 4, 4, 4>(lds + L.w2g, hid, d2, lane);
+    chain<4, 2, 0, 0>(lds + L.w2d, hid, d2, lane);
+    chain<4, 2, 4, 4>(lds + L.w2g, hid, d2, lane);
   }
   static_for<4>([&]<int ob>() {
     static_for<4>([&]<int r>() {
@@ -310,8 +336,8 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
   });
   f32x4 dp1[8];
   zero(dp1);
-  chain<4, 4, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..3]
-  chain<4, 4, 4, 4>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[4..7]
+  chain<4, 2, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..3]
+  chain<4, 2, 4, 4>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[4..7]
   static_for<8>([&]<int ob>() {
     const f32x4 p = *(const f32x4*)(act_m + ob * 256);
     static_for<4>([&]<int r>() { dp1[ob][r] *= fdsilu(p[r]); });
@@ -321,7 +347,7 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
     static_for<8>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
   }
   zero(contrib);
-  chain<4, 8>(lds + L.w1cT, dp1, contrib, lane);
+  chain<4, 4>(lds + L.w1cT, dp1, contrib, lane);
 }
 
 __device__ __forceinline__ void add_dh(float* dh, int64_t edge, int64_t E, f32x4 dhv, int qd) {
@@ -407,7 +433,7 @@ __global__ void __launch_bounds__(1024, 4) k_edge_rev_edge_mlp(RevArgs a, MfmaRe
     });
     f32x4 dmv[1];
     zero(dmv);
-    chain<1, 8>(lds + L.tbT, d8, dmv, lv);
+    chain<1, 4>(lds + L.tbT, d8, dmv, lv);
     add_dh(a.dh, edge, a.E, dhv, qd);
     if (edge < a.E) *(f32x4*)(a.dm + edge * kCP + 4 * qd) = dmv[0];  // rows c = 4*qd + reg
   }

@@ -1,6 +1,8 @@
 // Host-side packing of the per-block weight images the MFMA edge kernels copy into LDS.
 // Layout rules: m3g_internal.h (MfmaFwdLayout / MfmaRevLayout).  Source tensors: the reference's state_dict
 // entries of ThreeBodyInteration.gated_mlp (nn/interaction.py:180-185) and of M3GNetConv (nn/conv.py:39-61).
+#include <cstring>
+
 #include "m3g_internal.h"
 
 namespace m3g {
@@ -41,14 +43,40 @@ MfmaRevLayout mfma_rev_layout() {
   return L;
 }
 
-// chain image: img[((ob*KB + kb)*4 + reg)*64 + lane] = get(row = ob*16 + (lane&15), k = kb*16 + 4*(lane>>4) + reg)
+// bf16 helpers (round to nearest even; weights are finite)
+static inline uint16_t bf16_rne(float w) {
+  uint32_t u;
+  memcpy(&u, &w, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_float(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// chain image for v_mfma_f32_16x16x32_bf16 with the split W = W_hi + W_lo (both bf16; residual exact in fp32):
+//   part[((ob*KS + s)*64 + lane)*8 + j] = W[ob*16 + (lane&15)][feat(s, lane>>4, j)],
+//   feat(s, qd, j) = (2*s + (j>>2))*16 + 4*qd + (j&3)        (k-step s consumes accumulator blocks 2s and 2s+1)
+// The image holds the hi part followed by the lo part; OB*KS*256 floats each, i.e. OB*K*16 floats in total --
+// the same size as an fp32 image of the layer.
 template <class F>
-static void chain_image(float* img, int OB, int KB, F get) {
+static void chain_image(float* img, int OB, int KS, F get) {
+  uint16_t* hi = reinterpret_cast<uint16_t*>(img);
+  uint16_t* lo = hi + (size_t)OB * KS * 512;
   for (int ob = 0; ob < OB; ++ob)
-    for (int kb = 0; kb < KB; ++kb)
-      for (int reg = 0; reg < 4; ++reg)
-        for (int lane = 0; lane < 64; ++lane)
-          img[((ob * KB + kb) * 4 + reg) * 64 + lane] = get(ob * 16 + (lane & 15), kb * 16 + 4 * (lane >> 4) + reg);
+    for (int s = 0; s < KS; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int feat = (2 * s + (j >> 2)) * 16 + 4 * (lane >> 4) + (j & 3);
+          const float w = get(ob * 16 + (lane & 15), feat);
+          const uint16_t h = bf16_rne(w);
+          const size_t idx = (((size_t)ob * KS + s) * 64 + lane) * 8 + j;
+          hi[idx] = h;
+          lo[idx] = bf16_rne(w - bf16_to_float(h));
+        }
 }
 // direct image: img[(ob*S + s)*64 + lane] = get(row = ob*16 + (lane&15), k = 4*s + (lane>>4))
 template <class F>
@@ -79,7 +107,7 @@ int pack_mfma_images(m3g_plan* plan) {
     direct_image(f + F.tb, 8, kTbSteps, tbw);
     direct_image(r + Rv.tb, 8, kTbSteps, tbw);
     // reverse three-body: rows = c (16), k = 0..127 over (dense f | gate f)
-    chain_image(r + Rv.tbT, 1, 8, [&](int row, int k) -> float {
+    chain_image(r + Rv.tbT, 1, 4, [&](int row, int k) -> float {
       const float* w = k < 64 ? wd : wg;
       int o = k & 63;
       return (row < C && o < D) ? w[(size_t)o * C + row] : 0.f;
@@ -111,19 +139,19 @@ int pack_mfma_images(m3g_plan* plan) {
               img[(g * 4 + ob) * 64 + lane] = (lane < 16 && o < D) ? (g == 0 ? b2d[o] : b2g[o]) : 0.f;
             }
       };
-      chain_image(f + F.mlp[m].w1c, 8, 4, w1c);
-      chain_image(f + F.mlp[m].w2d, 4, 4, sq(w2d));
-      chain_image(f + F.mlp[m].w2g, 4, 4, sq(w2g));
+      chain_image(f + F.mlp[m].w1c, 8, 2, w1c);
+      chain_image(f + F.mlp[m].w2d, 4, 2, sq(w2d));
+      chain_image(f + F.mlp[m].w2g, 4, 2, sq(w2g));
       bias_image(f + F.mlp[m].b2);
       direct_image(f + F.mlp[m].wl, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
       // reverse images: m == 0 (edge MLP) at offset 0, m == 1 (node MLP) after the edge image
       float* rm = r + (m == 0 ? 0 : Rv.total_e);
-      chain_image(rm + Rv.mlp.w2d, 4, 4, sq(w2d));
-      chain_image(rm + Rv.mlp.w2g, 4, 4, sq(w2g));
+      chain_image(rm + Rv.mlp.w2d, 4, 2, sq(w2d));
+      chain_image(rm + Rv.mlp.w2g, 4, 2, sq(w2g));
       bias_image(rm + Rv.mlp.b2);
-      chain_image(rm + Rv.mlp.w2dT, 4, 4, sqT(w2d));
-      chain_image(rm + Rv.mlp.w2gT, 4, 4, sqT(w2g));
-      chain_image(rm + Rv.mlp.w1cT, 4, 8, [&](int row, int k) -> float { return w1c(k, row); });
+      chain_image(rm + Rv.mlp.w2dT, 4, 2, sqT(w2d));
+      chain_image(rm + Rv.mlp.w2gT, 4, 2, sqT(w2g));
+      chain_image(rm + Rv.mlp.w1cT, 4, 4, [&](int row, int k) -> float { return w1c(k, row); });
       for (int o = 0; o < 64; ++o)
         for (int rr = 0; rr < 4; ++rr) rm[Rv.mlp.wl + o * 4 + rr] = (o < D && rr < R) ? wl[(size_t)o * R + rr] : 0.f;
     }
