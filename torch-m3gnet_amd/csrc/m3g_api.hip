@@ -139,7 +139,7 @@ static void pack_mlp(std::vector<float>& blob, const MlpW& m, const m3g_plan& p,
   put_n(blob, m.wl, kRP, wl, D, R, 0, R);
 }
 
-Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
+Work work_carve(const Consts& c, bool mfma, int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   (void)T;
   Work w{};
   char* p = (char*)base;
@@ -150,17 +150,27 @@ Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, voi
   w.q = take(e * kCP); w.qp = take(e * kCP); w.fc3 = take(e); w.fc3p = take(e);
   for (int b = 0; b <= c.B; ++b) w.x[b] = take(n * kDP);
   for (int b = 0; b < c.B; ++b) w.v[b] = take(n * kCP);
-  w.TA = take(n * 4 * kDP); w.TB = take(n * 4 * kDP);
-  w.e = take(e * kDP);
   for (int b = 0; b < c.B; ++b) w.m[b] = take(e * kCP);
-  const size_t tiles = (e + 31) / 32;
-  for (int b = 0; b < c.B; ++b) w.act[b] = take(tiles * 32 * 8 * kDP);  // VALU path [E][512]; MFMA path uses the first [tiles][2][64][64]
   w.dx = take(n * kDP); w.dx2 = take(n * kDP);
-  w.de = take(e * kDP); w.dm = take(e * kCP); w.g = take(e * kCP); w.dg = take(e * kCP);
+  w.dm = take(e * kCP); w.g = take(e * kCP); w.dg = take(e * kCP);
   w.dh = take(e * kRP); w.dd = take(e); w.du = take(e * 3); w.dp1 = take(e * 4 * kDP); w.dr = take(e * 3);
-  w.e_soa = take(tiles * 2048); w.de_soa = take(tiles * 2048); w.msg = take(e * kDP);
-  // scratch for optional outputs the caller did not ask for
-  w.dr = w.dr;
+  const size_t tiles16 = (e + 15) / 16;
+  if (mfma) {
+    // fused MFMA path: per-block edge-feature images and node tables; the reverse pass recomputes every activation
+    for (int b = 0; b <= c.B; ++b) w.e_blk[b] = take(tiles16 * 1024);
+    for (int b = 0; b < c.B; ++b) { w.TAb[b] = take(n * 4 * kDP); w.TBb[b] = take(n * 4 * kDP); }
+    w.de_soa = take(tiles16 * 1024);
+    w.dcn = take(tiles16 * 1024);
+    w.dh_parts = take((size_t)(2 * c.B + 1) * e * kRP);
+    w.msg = take(e * kDP);
+  } else {
+    // vector-ALU baseline path: in-place row-major edge features and saved pre-activations [E,512] per block
+    w.TA = take(n * 4 * kDP); w.TB = take(n * 4 * kDP);
+    w.e = take(e * kDP);
+    w.de = take(e * kDP);
+    for (int b = 0; b < c.B; ++b) w.act[b] = take(e * 8 * kDP);
+  }
+  // tail scratch for optional outputs the caller did not ask for
   off += align_up((n + (size_t)S * 2 + 64) * sizeof(float));
   w.total_bytes = off;
   return w;
@@ -419,7 +429,7 @@ extern "C" int m3g_workspace_bytes(const m3g_plan* plan, int64_t N, int64_t E, i
   if (!plan || !bytes || N < 0 || E < 0 || T < 0 || S < 0) { set_error("m3g_workspace_bytes: bad argument"); return M3G_ERR_VALUE; }
   Consts c{};
   c.B = plan->cfg.num_blocks;
-  *bytes = work_carve(c, N, E, T, S, nullptr).total_bytes;
+  *bytes = work_carve(c, plan->edge_kernel == 1, N, E, T, S, nullptr).total_bytes;
   return M3G_OK;
 }
 
@@ -440,9 +450,10 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   const WeightLayout& wl = plan->wl;
   const float* W = plan->d_weights;
   Topo t = topo_carve(N, E, T, S, const_cast<void*>(io->topo));
-  Work w = work_carve(c, N, E, T, S, nullptr);
+  const bool mfma = plan->edge_kernel == 1;
+  Work w = work_carve(c, mfma, N, E, T, S, nullptr);
   if (!workspace || workspace_bytes < w.total_bytes) { set_error("workspace too small: %zu < %zu", workspace_bytes, w.total_bytes); return M3G_ERR_SIZE; }
-  w = work_carve(c, N, E, T, S, workspace);
+  w = work_carve(c, mfma, N, E, T, S, workspace);
   // tail scratch: per-atom energies + per-structure sums when the caller does not want them
   float* tail = (float*)((char*)workspace + w.total_bytes - align_up(((size_t)N + (size_t)S * 2 + 64) * sizeof(float)));
   float* ea = io->scaled_atomic_energies ? io->scaled_atomic_energies : tail;
@@ -450,18 +461,20 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
 
   // ---------------- forward ----------------
   { M3G_STAGE(ST_GEOM); launch_geometry(c, t, io->pos, io->lattice, io->edge_cell_shift, w, s); }
-  const bool mfma = plan->edge_kernel == 1;
   {
     M3G_STAGE(ST_EMBED);
     if (mfma) {
       launch_embed_nodes_only(c, W, wl, t, io->atom_types, w, s);
-      launch_embed_edges_soa(c, W + wl.adj_t, w.h, w.e_soa, E, s);
+      launch_embed_edges_soa(c, W + wl.adj_t, w.h, w.e_blk[0], E, s);
     } else {
       launch_embed(c, W, wl, t, io->atom_types, w, s);
     }
   }
   for (int b = 0; b < c.B; ++b) {
-    { M3G_STAGE(ST_NODE_PRE); launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], w.TA, w.TB, s); }
+    {
+      M3G_STAGE(ST_NODE_PRE);
+      launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], mfma ? w.TAb[b] : w.TA, mfma ? w.TBb[b] : w.TB, s);
+    }
     { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }
     if (mfma) {
       { M3G_STAGE(ST_EDGE_FWD); launch_edge_block_mfma(plan, c, t, w, b, s); }
@@ -479,7 +492,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
 
   if (io->node_features) launch_copy_strided(w.x[c.B], kDP, io->node_features, c.D, c.D, N, s);
   if (io->edge_attr) {
-    if (mfma) launch_soa_to_rows(w.e_soa, io->edge_attr, c.D, c.D, E, s);
+    if (mfma) launch_soa_to_rows(w.e_blk[c.B], io->edge_attr, c.D, c.D, E, s);
     else launch_copy_strided(w.e, kDP, io->edge_attr, c.D, c.D, E, s);
   }
   if (io->edge_distances && E > 0) M3G_HIP_CHECK(hipMemcpyAsync(io->edge_distances, w.d, sizeof(float) * E, hipMemcpyDeviceToDevice, s));
@@ -495,16 +508,17 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     float* dx_alt = w.dx2;
     for (int b = c.B - 1; b >= 0; --b) {
       if (b == c.B - 1 && E > 0) {
-          if (mfma) M3G_HIP_CHECK(hipMemsetAsync(w.de_soa, 0, sizeof(float) * ((E + 31) / 32) * 2048, s));
-          else M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
-          M3G_HIP_CHECK(hipMemsetAsync(w.dh, 0, sizeof(float) * E * kRP, s));
+          if (!mfma) {
+            M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
+            M3G_HIP_CHECK(hipMemsetAsync(w.dh, 0, sizeof(float) * E * kRP, s));
+          }
           M3G_HIP_CHECK(hipMemsetAsync(w.dd, 0, sizeof(float) * E, s));
           M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
       }
       if (mfma) {
         { M3G_STAGE(ST_EDGE_REV_NODE); launch_edge_rev_node_mlp(plan, c, t, w, b, dx_cur, s); }
         M3G_STAGE(ST_EDGE_REV);
-        launch_edge_rev_edge_mlp(plan, c, t, w, b, dx_cur, s);
+        launch_edge_rev_edge_mlp(plan, c, t, w, b, dx_cur, /*de_is_zero=*/b == c.B - 1, s);
       } else {
         M3G_STAGE(ST_EDGE_REV);
         launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
@@ -518,11 +532,12 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     }
     {
       M3G_STAGE(ST_EMBED_REV);
-      if (mfma) launch_embed_edges_reverse_soa(W + wl.adj, w.h, w.de_soa, w.dh, E, s);
+      if (mfma) launch_embed_edges_reverse_soa(W + wl.adj, w.h, w.de_soa, w.dh_parts + (size_t)2 * c.B * E * kRP, E, s);
       else launch_embed_reverse(c, W, wl, t, w, s);
     }
     M3G_STAGE(ST_GEOM_REV);
-    launch_geometry_reverse(c, t, w, io->forces, s);
+    if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, 2 * c.B + 1, io->forces, s);
+    else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, s);
     if (io->stresses) launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);
   } else if (io->stresses) {
     set_error("stresses require forces");

@@ -29,21 +29,15 @@ namespace m3g {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kFwdLdsFloats = 8 * kTbSteps * 64 + 2 * (8 * 4 * 4 * 64 + 2 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 64);
-constexpr int kRevMlpFloats = 4 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 8 * 4 * 64 + 64 * 4;   // node-MLP reverse image
+constexpr int kRevMlpFloats = 8 * 4 * 4 * 64 + 4 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 8 * 4 * 64 + 64 * 4;   // node-MLP reverse image
 constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;                // + three-body images
-constexpr int kWaves = 16;
+constexpr int kWaves = 16;      // forward kernel: 16 waves = 4 per SIMD (<= 128 VGPRs)
+constexpr int kWavesRev = 12;   // reverse kernels hold layer-1 pre-activations across the recompute: 3 per SIMD (<= 168 VGPRs)
 constexpr int kTileEdges = 16;
 constexpr int kTileFloats = 4 * 64 * 4;     // one 64-feature tile image: [4 blk][64 lanes][4]
-// Saved pre-activations per tile per block: [2 MLPs][kActSlots][64 lanes][4].  kSaveP2 = true keeps both layers
-// (16 slots); false keeps only layer 1 (8 slots) and recomputes layer 2 in the reverse pass (+136 MFMAs per MLP and
-// tile, half the activation traffic and workspace).  Measured on the 10k-atom workload: saving both is faster
-// (3.95 vs 4.21 ms/step) because the reverse kernels become HBM-bound instead of matrix-pipe-bound.
-#ifndef M3G_SAVE_P2
-#define M3G_SAVE_P2 1
-#endif
-constexpr bool kSaveP2 = M3G_SAVE_P2 != 0;
-constexpr int kActSlots = kSaveP2 ? 16 : 8;
-constexpr int kActPerTile = 2 * kActSlots * 64 * 4;
+// Nothing is saved for the reverse pass except the per-block edge-feature images and node tables: with the dense
+// chains on bf16x3 the matrix work is cheap, and recomputing both layers of both MLPs in the reverse kernels costs less
+// than streaming 2 KB of pre-activations per edge and block through HBM (measured history: DESIGN.md section 4).
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -148,6 +142,15 @@ struct TileQueue {
   }
 };
 
+// centre / neighbour atom of this lane's edge in `tile` (clamped for the padding lanes of the last tile)
+__device__ __forceinline__ void load_ends(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t tile, int64_t E,
+                                          int lane, int& ci, int& cj) {
+  const int64_t edge = tile * kTileEdges + (lane & 15);
+  const int64_t ec = edge < E ? edge : E - 1;
+  ci = src[ec];
+  cj = dst ? dst[ec] : 0;
+}
+
 __device__ __forceinline__ void load_image(float* lds, const float* __restrict__ src, int n_floats, int* lds_head) {
   for (int i = threadIdx.x * 4; i < n_floats; i += blockDim.x * 4) *(f32x4*)(lds + i) = *(const f32x4*)(src + i);
   if (threadIdx.x == 0) *lds_head = 0;
@@ -179,8 +182,8 @@ struct FwdArgs {
   const float* img;        // forward weight image of this block
   const int32_t *src, *dst;
   const float *h, *m, *TA, *TB;
-  float* e_soa;            // in/out  [tiles][4][64][4]
-  float* act;              // [tiles][2][8][64][4]
+  const float* e_in;       // [tiles][4][64][4] edge features before this block
+  float* e_out;            // same shape, after this block
   float* msg;              // [E][64] row-major
   unsigned long long* stamps;  // diagnostic build: [gridDim.x][kWaves][12] phase cycle sums
 };
@@ -195,39 +198,49 @@ __device__ __forceinline__ void tb_preact(const float* tbimg, const float (&mb)[
   });
 }
 
+// layer-1 accumulators start from the gathered per-node tables TA[i] + TB[j] (x_i / x_j parts, bias folded)
+__device__ __forceinline__ void gather_tables(const float* __restrict__ TA, const float* __restrict__ TB, int mlp, int64_t ci,
+                                              int64_t cj, int qd, f32x4 (&p1)[8]) {
+  const float* ta = TA + ci * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
+  const float* tb = TB + cj * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
+  static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(ta + ob * 16) + *(const f32x4*)(tb + ob * 16); });
+}
+
+// both layers of one conv GatedMLP from the edge-feature tile x: p1 = layer-1 pre-activations (dense 0..3, gate 4..7),
+// p2 = layer-2 pre-activations.  `w1c/w2d/w2g/b2` are offsets of the forward images inside `lds`.
+template <bool KEEP_P1>
+__device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, int w2g, int b2, const f32x4 (&x)[4], f32x4 (&p1)[8],
+                                            f32x4 (&p2)[8], int lane) {
+  chain<8, 2>(lds + w1c, x, p1, lane);
+  bias_step<4, 0>(lds + b2, p2, lane);
+  bias_step<4, 4>(lds + b2 + 4 * 64, p2, lane);
+  if (KEEP_P1) {
+    f32x4 hid[8];
+    static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { hid[ob][r] = fsilu(p1[ob][r]); }); });
+    chain<4, 2, 0, 0>(lds + w2d, hid, p2, lane);
+    chain<4, 2, 4, 4>(lds + w2g, hid, p2, lane);
+  } else {
+    static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); }); });
+    chain<4, 2, 0, 0>(lds + w2d, p1, p2, lane);  // hidden dense = p1[0..3]
+    chain<4, 2, 4, 4>(lds + w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
+  }
+}
+
 // one conv GatedMLP, forward.  x = edge-feature input tile; out = MLP(x) * (W_l h)
 template <bool ST, int S0>
 __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlpFwd& L, int mlp, const FwdArgs& a, int64_t ci,
-                                                 int64_t cj, float hb, const f32x4 (&x)[4], float* act_tile, f32x4 (&out)[4],
-                                                 int lane, Stamps<ST>& st) {
-  const int qd = lane >> 4;
-  f32x4 p1[8];
-  {
-    const float* ta = a.TA + ci * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
-    const float* tb = a.TB + cj * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
-    static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(ta + ob * 16) + *(const f32x4*)(tb + ob * 16); });
-  }
+                                                 int64_t cj, float hb, const f32x4 (&x)[4], f32x4 (&out)[4], int lane,
+                                                 Stamps<ST>& st) {
+  f32x4 p1[8], p2[8];
+  gather_tables(a.TA, a.TB, mlp, ci, cj, lane >> 4, p1);
   st.template mark<S0>();      // table gather
-  chain<8, 2>(lds + L.w1c, x, p1, lane);
-  st.template mark<S0 + 1>();  // layer-1 chain
-  // only the layer-1 pre-activations are saved; the reverse pass recomputes layer 2 from them
-  float* act_m = act_tile + mlp * (kActSlots * 256) + lane * 4;
-  static_for<8>([&]<int ob>() {
-    *(f32x4*)(act_m + ob * 256) = p1[ob];
-    static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); });
-  });
-  st.template mark<S0 + 2>();  // P1 stores + SiLU
-  f32x4 p2[8];  // dense 0..3, gate 4..7
-  bias_step<4, 0>(lds + L.b2, p2, lane);
-  bias_step<4, 4>(lds + L.b2 + 4 * 64, p2, lane);
-  chain<4, 2, 0, 0>(lds + L.w2d, p1, p2, lane);  // hidden dense = p1[0..3]
-  chain<4, 2, 4, 4>(lds + L.w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
-  if (kSaveP2) static_for<8>([&]<int ob>() { *(f32x4*)(act_m + (8 + ob) * 256) = p2[ob]; });
+  mlp_preacts<false>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane);
+  st.template mark<S0 + 1>();  // both layers
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
     static_for<4>([&]<int r>() { out[ob][r] = fsilu(p2[ob][r]) * fsigmoid(p2[4 + ob][r]) * out[ob][r]; });
   });
-  st.template mark<S0 + 3>();  // layer-2 chains + gating
+  st.template mark<S0 + 3>();  // gating
 }
 
 template <int TBS, bool ST = false>
@@ -238,9 +251,18 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
   const int lane = threadIdx.x & 63, qd = lane >> 4;
   TileQueue queue(a.tiles, q_head);
   Stamps<ST> st;
-  for (int ticket = queue.fetch(lane); ticket < queue.count;) {
+  int ticket = queue.fetch(lane);
+  if (ticket >= queue.count) return;
+  int ci_i, cj_i;
+  load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, ci_i, cj_i);
+  for (;;) {
     const int64_t tile = queue.base + ticket;
-    ticket = queue.fetch(lane);  // next tile's ticket, consumed at the top of the next iteration
+    // next tile's ticket and end atoms one tile ahead: the table gathers depend on them, and a dependent round trip
+    // per tile is what these latency-bound kernels cannot afford
+    ticket = queue.fetch(lane);
+    const bool has_next = ticket < queue.count;   // wave-uniform
+    int nci = 0, ncj = 0;
+    if (has_next) load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
     // the weight-image reads are loop-invariant: without this the compiler hoists hundreds of LDS loads out of
     // the tile loop and spills them; `lv` is the lane id made opaque once per tile
     int lv = lane;
@@ -248,9 +270,9 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
     st.start();
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
-    const int64_t ci = a.src[ec], cj = a.dst[ec];
-    float* e_tile = a.e_soa + tile * kTileFloats + lane * 4;
-    float* act_tile = a.act + tile * kActPerTile;
+    const int64_t ci = ci_i, cj = cj_i;
+    const float* e_tile = a.e_in + tile * kTileFloats + lane * 4;
+    float* e_otile = a.e_out + tile * kTileFloats + lane * 4;
     f32x4 x[4];
     static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
     float mb[TBS];
@@ -264,18 +286,21 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
     }
     st.template mark<1>();  // three-body MLP
     f32x4 out[4];
-    mlp_forward_mfma<ST, 2>(lds, L.mlp[0], 0, a, ci, cj, hb, x, act_tile, out, lv, st);  // edge update (nn/conv.py:68-75)
+    mlp_forward_mfma<ST, 2>(lds, L.mlp[0], 0, a, ci, cj, hb, x, out, lv, st);  // edge update (nn/conv.py:68-75)
     static_for<4>([&]<int blk>() {
       x[blk] += out[blk];
-      *(f32x4*)(e_tile + blk * 256) = x[blk];
+      *(f32x4*)(e_otile + blk * 256) = x[blk];
     });
     st.template mark<6>();  // e2 residual + store
-    mlp_forward_mfma<ST, 7>(lds, L.mlp[1], 1, a, ci, cj, hb, x, act_tile, out, lv, st);  // node message (nn/conv.py:77-89)
+    mlp_forward_mfma<ST, 7>(lds, L.mlp[1], 1, a, ci, cj, hb, x, out, lv, st);  // node message (nn/conv.py:77-89)
     if (edge < a.E) {
       float* mrow = a.msg + edge * kDP + 4 * qd;
       static_for<4>([&]<int blk>() { *(f32x4*)(mrow + blk * 16) = out[blk]; });
     }
     st.template mark<11>();  // message store
+    if (!has_next) break;
+    ci_i = nci;
+    cj_i = ncj;
   }
   if (ST && lane == 0) {
     const int wave = threadIdx.x >> 6;
@@ -289,35 +314,28 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
 struct RevArgs {
   int64_t E, tiles;
   const float* img;     // reverse image of this kernel's MLP (edge image also carries the three-body images)
-  const int32_t* src;
-  const float *h, *m, *act, *dx_new;
-  float* de_soa;   // dL/d e: node kernel adds its contribution; edge kernel turns dL/d e2 into dL/d e_in
+  const int32_t *src, *dst;
+  const float *h, *m, *dx_new;
+  const float *TA, *TB;   // node tables of this block
+  const float* e_tile;    // node kernel: edge features AFTER the block (input of the node MLP);
+                          // edge kernel: edge features BEFORE the block (three-body update + edge MLP are recomputed)
+  float* de_soa;   // edge kernel: in dL/d e after this block (unless de_is_zero), out dL/d e before this block
+  float* dcn;      // node kernel -> edge kernel: the node MLP's contribution to dL/d e2 (tile-SoA)
+  int de_is_zero;  // last block: nothing flows in from later blocks
   float* dm;       // [E][16]   (edge kernel)
-  float* dh;       // [E][4]    (+=)
+  float* dh;       // [E][4] slice of this kernel (store only)
   float* dp1;      // [E][256]  each kernel writes its MLP's 128 columns
 };
 
-// reverse of one conv GatedMLP: d_upd = dL/d(output); returns contrib = W1c^T d_p1, accumulates dL/dh into dhv.
-// Layer 2 is recomputed from the saved layer-1 pre-activations.
+// reverse of one conv GatedMLP whose edge-feature input tile is x: both layers are recomputed, then
+// d_upd = dL/d(output) is pulled back; returns contrib = W1c^T d_p1 and accumulates dL/dh into dhv.
 __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlpRev& L, int mlp, const RevArgs& a, int64_t edge,
-                                                 const f32x4& hv, const float* act_tile, const f32x4 (&d_upd)[4],
-                                                 f32x4 (&contrib)[4], f32x4& dhv, int lane) {
+                                                 int64_t ci, int64_t cj, const f32x4& hv, const f32x4 (&x)[4],
+                                                 const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane) {
   const int qd = lane >> 4;
-  const float* act_m = act_tile + mlp * (kActSlots * 256) + lane * 4;
-  f32x4 d2[8];  // first p2 dense 0..3 / gate 4..7; then d_p2 in place
-  if (kSaveP2) {
-    static_for<8>([&]<int ob>() { d2[ob] = *(const f32x4*)(act_m + (8 + ob) * 256); });
-  } else {
-    f32x4 hid[8];
-    static_for<8>([&]<int ob>() {
-      const f32x4 p = *(const f32x4*)(act_m + ob * 256);
-      static_for<4>([&]<int r>() { hid[ob][r] = fsilu(p[r]); });
-    });
-    bias_step<4, 0>(lds + L.b2, d2, lane);
-    bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
-    chain<4, 2, 0, 0>(lds + L.w2d, hid, d2, lane);
-    chain<4, 2, 4, 4>(lds + L.w2g, hid, d2, lane);
-  }
+  f32x4 p1[8], d2[8];  // d2: first p2 dense 0..3 / gate 4..7, then d_p2 in place
+  gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
+  mlp_preacts<true>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, d2, lane);
   static_for<4>([&]<int ob>() {
     static_for<4>([&]<int r>() {
       const float p2d = d2[ob][r], p2g = d2[4 + ob][r];
@@ -338,10 +356,7 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
   zero(dp1);
   chain<4, 2, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..3]
   chain<4, 2, 4, 4>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[4..7]
-  static_for<8>([&]<int ob>() {
-    const f32x4 p = *(const f32x4*)(act_m + ob * 256);
-    static_for<4>([&]<int r>() { dp1[ob][r] *= fdsilu(p[r]); });
-  });
+  static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { dp1[ob][r] *= fdsilu(p1[ob][r]); }); });
   if (edge < a.E) {
     float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
     static_for<8>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
@@ -350,78 +365,110 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
   chain<4, 4>(lds + L.w1cT, dp1, contrib, lane);
 }
 
-__device__ __forceinline__ void add_dh(float* dh, int64_t edge, int64_t E, f32x4 dhv, int qd) {
-  // the four lane quarters hold disjoint feature sets of the same edge: combine, then quarter 0 owns the edge
+__device__ __forceinline__ void store_dh(float* dh, int64_t edge, int64_t E, f32x4 dhv, int qd) {
+  // the four lane quarters hold disjoint feature sets of the same edge: combine, then quarter 0 owns the edge.
+  // Store-only into this kernel's slice: a read-modify-write here would queue its load behind the dp1 stores.
   static_for<4>([&]<int rr>() {
     dhv[rr] += __shfl_xor(dhv[rr], 16);
     dhv[rr] += __shfl_xor(dhv[rr], 32);
   });
-  if (qd == 0 && edge < E) {
-    f32x4 old = *(f32x4*)(dh + edge * kRP);
-    *(f32x4*)(dh + edge * kRP) = old + dhv;
-  }
+  if (qd == 0 && edge < E) *(f32x4*)(dh + edge * kRP) = dhv;
 }
 
 // node-message MLP (nn/conv.py:77-89), reverse: d msg[e] = dx_new[centre(e)]
-__global__ void __launch_bounds__(1024, 4) k_edge_rev_node_mlp(RevArgs a, MfmaRevLayout L) {
+__global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs a, MfmaRevLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kRevMlpFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevMlpFloats);
   load_image(lds, a.img, kRevMlpFloats, q_head);
   const int lane = threadIdx.x & 63, qd = lane >> 4;
   TileQueue queue(a.tiles, q_head);
-  for (int ticket = queue.fetch(lane); ticket < queue.count;) {
+  int ticket = queue.fetch(lane);
+  if (ticket >= queue.count) return;
+  int ci_i, cj_i;
+  load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, ci_i, cj_i);
+  for (;;) {
     const int64_t tile = queue.base + ticket;
-    ticket = queue.fetch(lane);  // next tile's ticket, consumed at the top of the next iteration
+    ticket = queue.fetch(lane);  // next tile's ticket and end atoms one tile ahead (see the forward kernel)
+    const bool has_next = ticket < queue.count;
+    int nci = 0, ncj = 0;
+    if (has_next) load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
     int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
     asm volatile("" : "+v"(lv));
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
-    const int64_t ci = a.src[ec];
-    float* de_tile = a.de_soa + tile * kTileFloats + lane * 4;
-    const float* act_tile = a.act + tile * kActPerTile;
+    const int64_t ci = ci_i, cj = cj_i;
+    float* dcn_tile = a.dcn + tile * kTileFloats + lane * 4;
+    const float* e_tile = a.e_tile + tile * kTileFloats + lane * 4;
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
     f32x4 contrib[4];
     {
-      f32x4 dmsg[4];
+      f32x4 dmsg[4], x[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
-      static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
-      mlp_reverse_mfma(lds, L.mlp, 1, a, edge, hv, act_tile, dmsg, contrib, dhv, lv);
+      static_for<4>([&]<int blk>() {
+        dmsg[blk] = *(const f32x4*)(xrow + blk * 16);
+        x[blk] = *(const f32x4*)(e_tile + blk * 256);     // e2: the node MLP's input
+      });
+      mlp_reverse_mfma(lds, L.mlp, 1, a, edge, ci, cj, hv, x, dmsg, contrib, dhv, lv);
     }
-    static_for<4>([&]<int blk>() { *(f32x4*)(de_tile + blk * 256) += contrib[blk]; });  // -> dL/d e2
-    add_dh(a.dh, edge, a.E, dhv, qd);
+    static_for<4>([&]<int blk>() { *(f32x4*)(dcn_tile + blk * 256) = contrib[blk]; });
+    store_dh(a.dh, edge, a.E, dhv, qd);
+    if (!has_next) break;
+    ci_i = nci;
+    cj_i = ncj;
   }
 }
 
 // edge-update MLP (nn/conv.py:68-75) + three-body gated update (nn/interaction.py:220-221), reverse
 template <int TBS>
-__global__ void __launch_bounds__(1024, 4) k_edge_rev_edge_mlp(RevArgs a, MfmaRevLayout L) {
+__global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs a, MfmaRevLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kRevEdgeFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevEdgeFloats);
   load_image(lds, a.img, kRevEdgeFloats, q_head);
   const int lane = threadIdx.x & 63, qd = lane >> 4;
   TileQueue queue(a.tiles, q_head);
-  for (int ticket = queue.fetch(lane); ticket < queue.count;) {
+  int ticket = queue.fetch(lane);
+  if (ticket >= queue.count) return;
+  int ci_i, cj_i;
+  load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, ci_i, cj_i);
+  for (;;) {
     const int64_t tile = queue.base + ticket;
-    ticket = queue.fetch(lane);  // next tile's ticket, consumed at the top of the next iteration
+    ticket = queue.fetch(lane);  // next tile's ticket and end atoms one tile ahead (see the forward kernel)
+    const bool has_next = ticket < queue.count;
+    int nci = 0, ncj = 0;
+    if (has_next) load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
     int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
     asm volatile("" : "+v"(lv));
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
+    const int64_t ci = ci_i, cj = cj_i;
     float* de_tile = a.de_soa + tile * kTileFloats + lane * 4;
-    const float* act_tile = a.act + tile * kActPerTile;
+    const float* e_tile = a.e_tile + tile * kTileFloats + lane * 4;
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
+    float mb[TBS];
+    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
     f32x4 de[4], contrib[4];
-    static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256); });
-    mlp_reverse_mfma(lds, L.mlp, 0, a, edge, hv, act_tile, de, contrib, dhv, lv);
+    {
+      // recompute e1 = e_in + three-body gated update: the edge MLP's input
+      f32x4 x[4], p[8];
+      static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+      tb_preact<TBS>(lds + L.tb, mb, p, lv);
+      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
+      // dL/d e2 = what flows in from later blocks + the node MLP's contribution (both loaded here, at the tile start)
+      const float* dcn_tile = a.dcn + tile * kTileFloats + lane * 4;
+      if (a.de_is_zero) {
+        static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(dcn_tile + blk * 256); });
+      } else {
+        static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + *(const f32x4*)(dcn_tile + blk * 256); });
+      }
+      mlp_reverse_mfma(lds, L.mlp, 0, a, edge, ci, cj, hv, x, de, contrib, dhv, lv);
+    }
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
       *(f32x4*)(de_tile + blk * 256) = de[blk];
     });
-    // three-body gated update, reverse: recompute the pre-activations from m
-    float mb[TBS];
-    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
+    // three-body gated update, reverse: pre-activations once more from m (24 small MFMAs; cheaper than 32 live VGPRs)
     f32x4 d8[8];
     tb_preact<TBS>(lds + L.tb, mb, d8, lv);
     static_for<4>([&]<int blk>() {
@@ -434,8 +481,11 @@ __global__ void __launch_bounds__(1024, 4) k_edge_rev_edge_mlp(RevArgs a, MfmaRe
     f32x4 dmv[1];
     zero(dmv);
     chain<1, 4>(lds + L.tbT, d8, dmv, lv);
-    add_dh(a.dh, edge, a.E, dhv, qd);
+    store_dh(a.dh, edge, a.E, dhv, qd);
     if (edge < a.E) *(f32x4*)(a.dm + edge * kCP + 4 * qd) = dmv[0];  // rows c = 4*qd + reg
+    if (!has_next) break;
+    ci_i = nci;
+    cj_i = ncj;
   }
 }
 
@@ -508,11 +558,7 @@ __global__ void __launch_bounds__(256) k_embed_edges_reverse_soa(int64_t E, int6
   }
   d0 += __shfl_xor(d0, 16); d1 += __shfl_xor(d1, 16); d2 += __shfl_xor(d2, 16); d3 += __shfl_xor(d3, 16);
   d0 += __shfl_xor(d0, 32); d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32); d3 += __shfl_xor(d3, 32);
-  if (qd == 0 && edge < E) {
-    f32x4 old = *(f32x4*)(dh + edge * kRP);
-    old[0] += d0; old[1] += d1; old[2] += d2; old[3] += d3;
-    *(f32x4*)(dh + edge * kRP) = old;
-  }
+  if (qd == 0 && edge < E) *(f32x4*)(dh + edge * kRP) = f32x4{d0, d1, d2, d3};   // this kernel's own slice
 }
 
 // x_new[i,:] = x[i,:] + sum_{e in row(i)} msg[e,:]   (nn/conv.py:82-88): one wave per atom, no atomics
@@ -576,8 +622,8 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
   const int64_t tiles = tiles_for(t.E);
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
-    FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TA, w.TB, w.e_soa, w.act[b], w.msg,
-              plan->d_stamps};
+    FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], w.e_blk[b],
+              w.e_blk[b + 1], w.msg, plan->d_stamps};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
     if (plan->d_stamps && tb_steps_for(c.C) == 3) {  // diagnostic build of the default configuration
       hipLaunchKernelGGL((k_edge_block_mfma<3, true>), grid, block, 0, s, a, L);
@@ -598,18 +644,20 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_n = plan->d_mfma_rev + (size_t)b * L.per_block + L.total_e;
-  RevArgs an{t.E, tiles, img_n, t.src, w.h, w.m[b], w.act[b], dx_new, w.de_soa, w.dm, w.dh, w.dp1};
-  hipLaunchKernelGGL(k_edge_rev_node_mlp, dim3(grid_for_tiles(tiles)), dim3(64 * kWaves), 0, s, an, L);
+  RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b + 1], w.de_soa, w.dcn, 0, w.dm,
+             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1};
+  hipLaunchKernelGGL(k_edge_rev_node_mlp, dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L);
 }
 
 void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
-                              hipStream_t s) {
+                              bool de_is_zero, hipStream_t s) {
   const int64_t tiles = tiles_for(t.E);
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_e = plan->d_mfma_rev + (size_t)b * L.per_block;
-  RevArgs ae{t.E, tiles, img_e, t.src, w.h, w.m[b], w.act[b], dx_new, w.de_soa, w.dm, w.dh, w.dp1};
-  dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
+  RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], w.de_soa, w.dcn,
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1};
+  dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
   M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS>), grid, block, 0, s, ae, L));
 }
 

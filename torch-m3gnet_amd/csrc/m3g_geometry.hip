@@ -125,13 +125,19 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int
 
 __global__ void __launch_bounds__(256) k_geometry_reverse(Consts c, int64_t E, const float* __restrict__ u,
                                                           const float* __restrict__ dist, const float* __restrict__ hp,
-                                                          const float* __restrict__ dh, const float* __restrict__ dd,
+                                                          const float* __restrict__ dh, int dh_parts, const float* __restrict__ dd,
                                                           const float* __restrict__ du, float* __restrict__ dr) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= E) return;
   float g = dd[e];
+  // dL/dh arrives in `dh_parts` slices (one per reverse kernel that produced a share); summed here, in a fixed order
+  float dhs[kRP] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < dh_parts; ++p) {
 #pragma unroll
-  for (int m = 0; m < kRP; ++m) g += dh[e * kRP + m] * hp[e * kRP + m];
+    for (int m = 0; m < kRP; ++m) dhs[m] += dh[((int64_t)p * E + e) * kRP + m];
+  }
+#pragma unroll
+  for (int m = 0; m < kRP; ++m) g += dhs[m] * hp[e * kRP + m];
   float ux = u[e * 3], uy = u[e * 3 + 1], uz = u[e * 3 + 2];
   float ax = du[e * 3], ay = du[e * 3 + 1], az = du[e * 3 + 2];
   float proj = ax * ux + ay * uy + az * uz;
@@ -226,9 +232,10 @@ void launch_distance_only(float length_scale, const Topo& t, const float* pos, c
                      u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, float* forces, hipStream_t s) {
+void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
+                             hipStream_t s) {
   if (t.E > 0)
-    hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, c, t.E, w.u, w.d, w.hp, w.dh, w.dd, w.du, w.dr);
+    hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, c, t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, w.dr);
   if (t.N > 0)
     hipLaunchKernelGGL(k_force_gather, grid_for(t.N), dim3(256), 0, s, c.length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge,
                        w.dr, forces);

@@ -100,7 +100,8 @@ struct MfmaMlpFwd {                     // offsets in floats inside the forward 
 struct MfmaFwdLayout { int tb; /* direct [8 ob][kTbSteps][64]: dense ob0-3, gate ob4-7 */ MfmaMlpFwd mlp[2]; int total; };
 // reverse images: one per conv MLP (two kernels per block: node MLP first, then edge MLP + three-body update)
 struct MfmaMlpRev {
-  int w2d, w2g, b2;  // forward layer-2 images (layer-2 pre-activations are recomputed, not saved)
+  int w1c;           // forward layer-1 image: nothing is saved by the forward pass, both layers are recomputed
+  int w2d, w2g, b2;  // forward layer-2 images
   int w2dT;  // chain [4][4]   rows: hidden k, cols: out o
   int w2gT;
   int w1cT;  // chain [4][8]   rows: edge feature k, cols: layer-1 outputs (dense 0-63 | gate 64-127)
@@ -183,19 +184,25 @@ struct Work {
   float* du;                  // [E,3]
   float* dp1;                 // [E,4*kDP]
   float* dr;                  // [E,3]
-  // MFMA path: tile-SoA images ([tile][slot][64 lanes], 32 edges per tile) of e / de, row-major messages
-  float* e_soa;               // [tiles,32,64]
-  float* de_soa;              // [tiles,32,64]
+  // MFMA path: tile-SoA images ([tile of 16 edges][4 blk][64 lanes][4]) of the edge features BEFORE each block
+  // (e_blk[b]; e_blk[B] = final) and of dL/de, per-block node tables, row-major messages.  No activations saved.
+  float* e_blk[kMaxBlocks + 1];
+  float* TAb[kMaxBlocks];     // [N,4*kDP] per block (the reverse pass recomputes layer 1 from them)
+  float* TBb[kMaxBlocks];
+  float* de_soa;
+  float* dcn;                 // tile-SoA: node-MLP kernel's contribution to dL/de2 (store-only there, loaded by the edge-MLP kernel)
+  float* dh_parts;            // [2B+1][E,kRP]: every reverse kernel stores its dL/dh share in its own slice (no read-modify-write)
   float* msg;                 // [E,kDP]
   size_t total_bytes;
 };
-Work work_carve(const Consts& c, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
+Work work_carve(const Consts& c, bool mfma, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
 
 // ---- kernel launchers (each in its own .hip) -----------------------------------------------------------
 // geometry.hip
 void launch_geometry(const Consts& c, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
                      const Work& w, hipStream_t s);
-void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, float* forces, hipStream_t s);
+void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
+                             hipStream_t s);
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s);
 void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s);
@@ -228,9 +235,9 @@ void launch_node_sum(const Topo& t, const float* x_old, const float* msg, float*
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
                               hipStream_t s);
 void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
-                              hipStream_t s);
+                              bool de_is_zero, hipStream_t s);
 void launch_embed_edges_soa(const Consts& c, const float* adj_t, const float* h, float* soa, int64_t E, hipStream_t s);
-void launch_embed_edges_reverse_soa(const float* adj, const float* h, const float* de_soa, float* dh, int64_t E, hipStream_t s);
+void launch_embed_edges_reverse_soa(const float* adj, const float* h, const float* de_soa, float* dh_slice, int64_t E, hipStream_t s);
 void launch_embed_nodes_only(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
                              const Work& w, hipStream_t s);
 void launch_rows_to_soa(const float* rows, float* soa, int64_t E, hipStream_t s);

@@ -27,6 +27,7 @@ MfmaRevLayout mfma_rev_layout() {
   MfmaRevLayout L{};
   int off = 0;
   auto take = [&](int n) { int r = off; off += n; return r; };
+  L.mlp.w1c = take(8 * 4 * 4 * 64);
   L.mlp.w2d = take(4 * 4 * 4 * 64);
   L.mlp.w2g = take(4 * 4 * 4 * 64);
   L.mlp.b2 = take(2 * 4 * 64);
@@ -146,6 +147,7 @@ int pack_mfma_images(m3g_plan* plan) {
       direct_image(f + F.mlp[m].wl, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
       // reverse images: m == 0 (edge MLP) at offset 0, m == 1 (node MLP) after the edge image
       float* rm = r + (m == 0 ? 0 : Rv.total_e);
+      chain_image(rm + Rv.mlp.w1c, 8, 2, w1c);
       chain_image(rm + Rv.mlp.w2d, 4, 2, sq(w2d));
       chain_image(rm + Rv.mlp.w2g, 4, 2, sq(w2g));
       bias_image(rm + Rv.mlp.b2);
