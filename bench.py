@@ -35,7 +35,19 @@ import torch  # noqa: E402
 
 FLOPS_PER_EDGE_BLOCK = 134_144      # a14 65,536+384, a15 65,536+384, a8 MLP 2,304 (forward)
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 matrix peak (no xf32/TF32 on gfx950)
-EXECUTED_MFMA_PER_TILE_FWD = 560    # v_mfma_f32_16x16x4_f32 per 16-edge tile in k_edge_block_mfma (2 x 268 + 24), 2048 FLOP each
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA peak
+PEAK_HBM_GBS = 8000.0               # HBM3E spec (about 6.3 TB/s achievable)
+# The three fused edge kernels (m3g_edge_mfma.hip).  Algorithmic figures per edge and launch:
+#   bytes = edge-feature images the kernel must read/write (64 fp32 = 256 B each); FLOPs from SURVEY.md 8(d).
+#   MFMA counts per 16-edge tile: v_mfma_f32_16x16x32_bf16 (16,384 FLOP) / v_mfma_f32_16x16x4_f32 (2,048 FLOP).
+EDGE_KERNELS = {
+    "edge_block_fwd": dict(kernel="k_edge_block_mfma", alg_bytes_per_edge=2 * 256, alg_flops_per_edge=134_144,
+                           bf16_mfma_per_tile=192, f32_mfma_per_tile=48),
+    "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", alg_bytes_per_edge=2 * 256, alg_flops_per_edge=65_920,
+                              bf16_mfma_per_tile=192, f32_mfma_per_tile=8),
+    "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", alg_bytes_per_edge=4 * 256, alg_flops_per_edge=68_224,
+                              bf16_mfma_per_tile=204, f32_mfma_per_tile=56),
+}
 
 
 def log(msg):
@@ -197,30 +209,42 @@ def main():
 
     if rank == 0:
         per_launch = {k: (ms / max(cnt, 1), cnt) for k, (ms, cnt) in stages.items() if cnt}
-        # dominant kernel = the forward fused edge block (one k_edge_block_mfma launch per block); its stage timer
-        # brackets exactly that launch, so avg_launch_ms is comparable with rocprofv3's average for the kernel
-        dom = "edge_block_fwd"
-        dom_ms = per_launch[dom][0]
-        flops = n_edges * FLOPS_PER_EDGE_BLOCK      # ALGORITHMIC FLOPs of one launch
         tiles = (n_edges + 15) // 16
-        executed = tiles * EXECUTED_MFMA_PER_TILE_FWD * 2048   # FLOPs the matrix pipe actually executes per launch
-        achieved = flops / (dom_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = ROOT / "profiles" / "r01_mfma_pmc_hbm_traffic.json"
-        if pmc.exists() and tuple(args.cells) == (10, 10, 25):
-            rec = json.loads(pmc.read_text()).get("k_edge_block_mfma")
-            if rec:  # bytes per launch: 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, KB -> B
-                traffic = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0
-        roofline = {"bound": "mfma", "kernel": "k_edge_block_mfma (stage edge_block_fwd)", "achieved": achieved,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                    "avg_launch_ms": dom_ms, "algorithmic_flops_per_launch": flops,
-                    "executed_flops_per_launch": executed, "executed_tflops": executed / (dom_ms * 1e-3) / 1e12,
-                    "note": "achieved = algorithmic FLOPs / time (contract); the per-node table restructuring executes "
-                            "about half the algorithmic FLOPs, so executed_tflops is the matrix-pipe figure to compare with peak"}
+        pmc_path = ROOT / "profiles" / "r01_final_pmc_hbm_traffic.json"
+        pmc = json.loads(pmc_path.read_text()) if (pmc_path.exists() and tuple(args.cells) == (10, 10, 25)) else {}
+
+        def kernel_roofline(stage):
+            """Roofline views of one fused edge kernel (each stage timer brackets exactly one launch of it)."""
+            spec = EDGE_KERNELS[stage]
+            ms = per_launch[stage][0]
+            alg_bytes = n_edges * spec["alg_bytes_per_edge"]
+            alg_flops = n_edges * spec["alg_flops_per_edge"]
+            exe_flops = tiles * (spec["bf16_mfma_per_tile"] * 16384 + spec["f32_mfma_per_tile"] * 2048)
+            rec = pmc.get(spec["kernel"])
+            traffic = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 if rec else None  # gfx950: FETCH_SIZE x 2
+            achieved = alg_bytes / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": f"{spec['kernel']} (stage {stage})", "achieved": achieved, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_ms": ms,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "measured_traffic_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
+                    "mfma_view": {"algorithmic_flops_per_launch": alg_flops,
+                                  "algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12,
+                                  "executed_flops_per_launch": exe_flops,
+                                  "executed_tflops": exe_flops / (ms * 1e-3) / 1e12,
+                                  "peak_bf16_dense_tflops": PEAK_BF16_MFMA_TFLOPS, "peak_f32_tflops": PEAK_F32_MFMA_TFLOPS,
+                                  "executed_frac_of_bf16_peak": exe_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}}
+
+        views = {st: kernel_roofline(st) for st in EDGE_KERNELS if st in per_launch}
+        dom = max(views, key=lambda k: views[k]["avg_launch_ms"])   # dominant kernel = longest average launch
+        roofline = views[dom]
+        roofline["note"] = ("dense chains run as 3x bf16 split MFMAs (fp32 accumulate) and nothing is saved for the reverse "
+                            "pass, so the fused edge kernels are bandwidth/latency-bound, not matrix-bound; `achieved` uses "
+                            "the algorithmic bytes of DESIGN.md section 4, `traffic` is PMC-measured HBM bytes per launch")
         out = {
             "metric": "atom-steps/sec (energy+forces) on 10k-atom PBC batch", "value": value, "unit": "atom-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (dense chains: 3x bf16 split MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"single {n_atoms}-atom fcc Cu PBC supercell per GPU ({'x'.join(map(str, args.cells))} cells, "
                                    "a=3.61 A, jitter 0.025 A), r_cut 5 A / 3-body 4 A, default M3GNet (l_max=n_max=3, D=64, "
                                    "3 blocks), energy+forces+stress",
@@ -228,6 +252,7 @@ def main():
                        "first_call_s_incl_topology_build": first_call_s, "topology_build_ms": topo_ms,
                        "stage_ms_per_step": {k: round(ms / args.steps, 4) for k, (ms, cnt) in stages.items() if cnt}},
             "roofline": roofline,
+            "roofline_other_kernels": [v for k, v in views.items() if k != dom],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -215,8 +215,15 @@ __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, 
   bias_step<4, 0>(lds + b2, p2, lane);
   bias_step<4, 4>(lds + b2 + 4 * 64, p2, lane);
   if (KEEP_P1) {
+    // reverse pass: p1 is only needed again as SiLU'(p1) -- leave that in p1 (one sigmoid evaluation for both)
     f32x4 hid[8];
-    static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { hid[ob][r] = fsilu(p1[ob][r]); }); });
+    static_for<8>([&]<int ob>() {
+      static_for<4>([&]<int r>() {
+        const float p = p1[ob][r], sg = fsigmoid(p);
+        hid[ob][r] = p * sg;
+        p1[ob][r] = sg * (1.f + p * (1.f - sg));
+      });
+    });
     chain<4, 2, 0, 0>(lds + w2d, hid, p2, lane);
     chain<4, 2, 4, 4>(lds + w2g, hid, p2, lane);
   } else {
@@ -325,17 +332,22 @@ struct RevArgs {
   float* dm;       // [E][16]   (edge kernel)
   float* dh;       // [E][4] slice of this kernel (store only)
   float* dp1;      // [E][256]  each kernel writes its MLP's 128 columns
+  unsigned long long* stamps;  // diagnostic build only
 };
 
 // reverse of one conv GatedMLP whose edge-feature input tile is x: both layers are recomputed, then
 // d_upd = dL/d(output) is pulled back; returns contrib = W1c^T d_p1 and accumulates dL/dh into dhv.
+template <bool ST>
 __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlpRev& L, int mlp, const RevArgs& a, int64_t edge,
                                                  int64_t ci, int64_t cj, const f32x4& hv, const f32x4 (&x)[4],
-                                                 const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane) {
+                                                 const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane,
+                                                 Stamps<ST>& st) {
   const int qd = lane >> 4;
   f32x4 p1[8], d2[8];  // d2: first p2 dense 0..3 / gate 4..7, then d_p2 in place
   gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
+  st.template mark<2>();   // table gather (+ wait for the tile loads)
   mlp_preacts<true>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, d2, lane);
+  st.template mark<3>();   // recompute both layers
   static_for<4>([&]<int ob>() {
     static_for<4>([&]<int r>() {
       const float p2d = d2[ob][r], p2g = d2[4 + ob][r];
@@ -352,26 +364,37 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
     // kernel and keeps every w / sd / sg temporary alive
     asm volatile("" : "+v"(dhv[0]), "+v"(dhv[1]), "+v"(dhv[2]), "+v"(dhv[3]));
   });
+  st.template mark<4>();   // gating derivatives (VALU)
   f32x4 dp1[8];
   zero(dp1);
   chain<4, 2, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..3]
   chain<4, 2, 4, 4>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[4..7]
-  static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { dp1[ob][r] *= fdsilu(p1[ob][r]); }); });
+  static_for<8>([&]<int ob>() { dp1[ob] *= p1[ob]; });   // p1 holds SiLU'(p1) here (mlp_preacts<true>)
+  st.template mark<5>();   // layer-2 transposed chains + SiLU'
   if (edge < a.E) {
     float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
     static_for<8>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
   }
   zero(contrib);
   chain<4, 4>(lds + L.w1cT, dp1, contrib, lane);
+  st.template mark<6>();   // dp1 stores + layer-1 transposed chain
+}
+
+// x summed over the four lane quarters (lanes l, l^16, l^32, l^48), result in every lane.  v_permlane16/32_swap
+// are VALU moves (gfx950); the ds_bpermute behind __shfl_xor costs an LDS round trip per call.
+__device__ __forceinline__ float sum_lane_quarters(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows {1,3} of vdst <-> rows {0,2} of src
+  const float y = __builtin_bit_cast(float, (unsigned)r16[0]) + __builtin_bit_cast(float, (unsigned)r16[1]);
+  const unsigned v = __builtin_bit_cast(unsigned, y);
+  auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // lanes 32-63 of vdst <-> lanes 0-31 of src
+  return __builtin_bit_cast(float, (unsigned)r32[0]) + __builtin_bit_cast(float, (unsigned)r32[1]);
 }
 
 __device__ __forceinline__ void store_dh(float* dh, int64_t edge, int64_t E, f32x4 dhv, int qd) {
   // the four lane quarters hold disjoint feature sets of the same edge: combine, then quarter 0 owns the edge.
   // Store-only into this kernel's slice: a read-modify-write here would queue its load behind the dp1 stores.
-  static_for<4>([&]<int rr>() {
-    dhv[rr] += __shfl_xor(dhv[rr], 16);
-    dhv[rr] += __shfl_xor(dhv[rr], 32);
-  });
+  static_for<4>([&]<int rr>() { dhv[rr] = sum_lane_quarters(dhv[rr]); });
   if (qd == 0 && edge < E) *(f32x4*)(dh + edge * kRP) = dhv;
 }
 
@@ -409,7 +432,8 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs
         dmsg[blk] = *(const f32x4*)(xrow + blk * 16);
         x[blk] = *(const f32x4*)(e_tile + blk * 256);     // e2: the node MLP's input
       });
-      mlp_reverse_mfma(lds, L.mlp, 1, a, edge, ci, cj, hv, x, dmsg, contrib, dhv, lv);
+      Stamps<false> st0;
+      mlp_reverse_mfma<false>(lds, L.mlp, 1, a, edge, ci, cj, hv, x, dmsg, contrib, dhv, lv, st0);
     }
     static_for<4>([&]<int blk>() { *(f32x4*)(dcn_tile + blk * 256) = contrib[blk]; });
     store_dh(a.dh, edge, a.E, dhv, qd);
@@ -420,8 +444,9 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs
 }
 
 // edge-update MLP (nn/conv.py:68-75) + three-body gated update (nn/interaction.py:220-221), reverse
-template <int TBS>
+template <int TBS, bool ST = false>
 __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs a, MfmaRevLayout L) {
+  Stamps<ST> st;
   __shared__ __attribute__((aligned(16))) float lds[kRevEdgeFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevEdgeFloats);
   load_image(lds, a.img, kRevEdgeFloats, q_head);
@@ -439,6 +464,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
     if (has_next) load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
     int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
     asm volatile("" : "+v"(lv));
+    st.start();
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
     const int64_t ci = ci_i, cj = cj_i;
@@ -455,6 +481,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
       static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
       tb_preact<TBS>(lds + L.tb, mb, p, lv);
       static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
+      st.template mark<1>();   // tile loads + three-body recompute
       // dL/d e2 = what flows in from later blocks + the node MLP's contribution (both loaded here, at the tile start)
       const float* dcn_tile = a.dcn + tile * kTileFloats + lane * 4;
       if (a.de_is_zero) {
@@ -462,7 +489,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
       } else {
         static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + *(const f32x4*)(dcn_tile + blk * 256); });
       }
-      mlp_reverse_mfma(lds, L.mlp, 0, a, edge, ci, cj, hv, x, de, contrib, dhv, lv);
+      mlp_reverse_mfma<ST>(lds, L.mlp, 0, a, edge, ci, cj, hv, x, de, contrib, dhv, lv, st);
     }
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
@@ -483,9 +510,15 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
     chain<1, 4>(lds + L.tbT, d8, dmv, lv);
     store_dh(a.dh, edge, a.E, dhv, qd);
     if (edge < a.E) *(f32x4*)(a.dm + edge * kCP + 4 * qd) = dmv[0];  // rows c = 4*qd + reg
+    st.template mark<7>();   // de store + three-body reverse + dm/dh stores
     if (!has_next) break;
     ci_i = nci;
     cj_i = ncj;
+  }
+  if (ST && lane == 0) {
+    const int wave = threadIdx.x >> 6;
+    unsigned long long* dst = a.stamps + ((size_t)blockIdx.x * 16 + wave) * 12;
+    for (int i = 0; i < 12; ++i) dst[i] = st.sum[i];
   }
 }
 
@@ -625,7 +658,7 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
     FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], w.e_blk[b],
               w.e_blk[b + 1], w.msg, plan->d_stamps};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
-    if (plan->d_stamps && tb_steps_for(c.C) == 3) {  // diagnostic build of the default configuration
+    if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3) {  // diagnostic build of the default configuration
       hipLaunchKernelGGL((k_edge_block_mfma<3, true>), grid, block, 0, s, a, L);
     } else {
       M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS>), grid, block, 0, s, a, L));
@@ -645,7 +678,7 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_n = plan->d_mfma_rev + (size_t)b * L.per_block + L.total_e;
   RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b + 1], w.de_soa, w.dcn, 0, w.dm,
-             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1};
+             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr};
   hipLaunchKernelGGL(k_edge_rev_node_mlp, dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L);
 }
 
@@ -656,8 +689,12 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_e = plan->d_mfma_rev + (size_t)b * L.per_block;
   RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], w.de_soa, w.dcn,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1};
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
+  if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3) {  // diagnostic build
+    hipLaunchKernelGGL((k_edge_rev_edge_mlp<3, true>), grid, block, 0, s, ae, L);
+    return;
+  }
   M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS>), grid, block, 0, s, ae, L));
 }
 

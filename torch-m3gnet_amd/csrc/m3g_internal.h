@@ -131,6 +131,7 @@ struct m3g_plan {
   float* d_mfma_fwd = nullptr;   // [num_blocks][MfmaFwdLayout.total]
   float* d_mfma_rev = nullptr;   // [num_blocks][MfmaRevLayout.total]
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
+  int stamp_target = 0;          // which kernel runs its stamped variant: 0 forward edge block, 1 reverse edge-MLP kernel
   unsigned long long* d_stamps = nullptr;  // option "stamps": diagnostic phase-cycle sums [256][16][12] of the fwd edge kernel
   bool committed = false;
   // opt-in stage profiler (m3g_profile_*): event pairs recorded around stage launches
