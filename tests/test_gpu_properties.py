@@ -312,3 +312,39 @@ def test_config5_high_triplet_density():
     assert rel_err(out[K.TOTAL_ENERGY], o["total_energy"]) < 1e-5
     assert rel_err(out[K.FORCES], o["forces"]) < 1e-4
     assert rel_err(out[K.MID_EDGE_FEATURES][2], o["mid_edge_features_2"]) < 1e-4
+
+
+# ------------------------------------------------------------------ hyper-parameter sweep (padding paths, template variants)
+@pytest.mark.parametrize("l_max,n_max,dim,blocks,cut,tb_cut", [
+    (1, 1, 8, 1, 4.0, 3.0),     # smallest everything: C = 1, one three-body k-step
+    (2, 2, 33, 4, 4.5, 4.5),    # odd width (zero-padded to 64), 4 blocks, 3-body cutoff == cutoff
+    (4, 4, 64, 2, 5.0, 3.5),    # largest supported bases: C = 16
+    (3, 4, 48, 1, 4.2, 4.0),    # n_max = 4, C = 12
+    (4, 1, 16, 3, 5.0, 4.0),    # C = 4
+])
+def test_hyperparameter_sweep_against_oracle(l_max, n_max, dim, blocks, cut, tb_cut):
+    from oracle import m3gnet_oracle as orc
+    from torch_m3gnet.data.material_graph import Batch
+    from torch_m3gnet.model.build import build_model
+
+    K = _K()
+    torch.manual_seed(11)
+    model = build_model(cut, tb_cut, l_max, n_max, 60, dim, blocks, elemental_energies=torch.linspace(-1, 1, 60), energy_scale=1.7)
+    for m in model.model:
+        if type(m).__name__ == "ThreeBodyInteration":
+            m.nsb.factors = m.nsb.documented_factors()
+    cells = [random_cell_graph(14 + 3 * s, 6.0 + 0.3 * s, 20 + s, cutoff=cut, tb_cutoff=tb_cut, zmax=59) for s in range(3)]
+    for kern in (1, 0):
+        model.engine.set_option("edge_kernel", kern)
+        out = model(Batch.from_data_list([c.clone() for c in cells]).to(DEV))
+        p, cfg, c, og = _oracle_inputs(model, out)
+        p = {k: v.double() for k, v in p.items()}
+        c = orc.make_constants(cfg, model.model[1].elemental_energies.cpu(), dtype=torch.float64)
+        c.factors = model.model[6].nsb.factors.double()
+        o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+        assert float(((out[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < 1e-5, kern
+        assert rel_err(out[K.FORCES], o["forces"]) < 1e-4, kern
+        assert rel_err(out[K.STRESSES], o["stresses"]) < 1e-4, kern
+        assert rel_err(out[K.EDGE_ATTR], o["edge_attr"]) < 1e-5, kern
+        for b in range(blocks):
+            assert rel_err(out[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) < 1e-4, (kern, b)
