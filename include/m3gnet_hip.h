@@ -150,6 +150,28 @@ int m3g_atom_featurizer(int32_t num_types, int32_t dim, const float* weight, int
 int m3g_atom_ref(int32_t num_types, const float* elemental_energies, int64_t n_atoms, const int64_t* atom_types,
                  float* out, void* stream);
 
+/* ---- graph construction on the GPU -------------------------------------
+ * Periodic neighbour list: replaces get_all_neighbors_with_cell_shifts (data/material_graph.py:168-193, pymatgen
+ * Structure.get_all_neighbors).  pos [N,3] and lattice [S,3,3] are DEVICE fp64 (pymatgen works in double), batch
+ * [N] int64 sorted.  Output order: centre atom, image shift lexicographic, neighbour index.  Two phases because the
+ * edge count is data dependent: *_count synchronises the stream and returns E, the caller allocates, *_fill writes.
+ * max_images >= (2rx+1)(2ry+1)(2rz+1) of every structure, r_p = ceil((cutoff+1e-8) |a_q x a_r| / V). */
+int m3g_neighbor_scratch_bytes(int64_t n_atoms, int64_t n_structs, int64_t max_images, size_t* bytes);
+int m3g_neighbor_count(int64_t n_atoms, int64_t n_structs, int64_t max_images, const double* pos, const double* lattice,
+                       const int64_t* batch, double cutoff, void* scratch, size_t scratch_bytes, int64_t* host_n_edges,
+                       void* stream);
+int m3g_neighbor_fill(int64_t n_atoms, int64_t n_structs, int64_t max_images, const int64_t* batch, double cutoff,
+                      void* scratch, int64_t n_edges, int64_t* edge_index /* [2,E] */, int32_t* edge_cell_shift /* [E,3] */,
+                      double* distances /* [E] */, void* stream);
+/* Three-body index: replaces compute_threebody (data/material_graph.py:196-254), same triplet order.  distances are
+ * the fp32 edge lengths the reference thresholds (material_graph.py:191,224). */
+int m3g_threebody_scratch_bytes(int64_t n_atoms, int64_t n_edges, size_t* bytes);
+int m3g_threebody_count(int64_t n_atoms, int64_t n_edges, const int64_t* edge_index, const float* distances,
+                        float threebody_cutoff, void* scratch, size_t scratch_bytes, int64_t* host_n_triplets, void* stream);
+int m3g_threebody_fill(int64_t n_atoms, int64_t n_edges, const int64_t* edge_index, void* scratch, int64_t n_triplets,
+                       int64_t* triplet_edge_index /* [2,T] */, int64_t* num_triplet_i /* [N] or NULL */,
+                       int32_t* num_triplet_ij /* [E] or NULL */, void* stream);
+
 /* ---- measurement: per-stage device time from HIP events recorded on the call's own stream ---------
  * m3g_profile_enable(plan, 1) makes every following m3g_energy_forces record an event pair around each
  * stage launch; m3g_profile_read synchronises those events, returns per-stage totals since the last

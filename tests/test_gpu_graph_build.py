@@ -1,0 +1,149 @@
+"""GPU graph construction against the host builder, element by element.
+
+Both builders emit the canonical order (centre, periodic image lexicographic, neighbour), so index tensors must
+be IDENTICAL (integer work: bit-exact); distances are fp64 on both sides and compared to 1e-12 relative.
+Counts pinned by the reference's own fixtures: Al/Na 132 edges at r_c = 5... are in tests/golden (case_alna)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, build_engine_model, load_oracle_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _host(lat, pos, cutoff, tb):
+    from torch_m3gnet.data.neighbors import neighbor_list, threebody_index
+
+    ei, sh, d = neighbor_list(lat, pos, cutoff)
+    tei, nti, ntij = threebody_index(len(pos), ei, d.astype(np.float32), tb)
+    return ei, sh, d, tei, nti, ntij
+
+
+def _gpu(lats, poss, cutoff, tb):
+    from torch_m3gnet.data.graph_gpu import neighbor_list_gpu, threebody_index_gpu
+
+    lat = torch.tensor(np.stack(lats), dtype=torch.float64, device="cuda")
+    pos = torch.tensor(np.concatenate(poss), dtype=torch.float64, device="cuda")
+    batch = torch.tensor(np.repeat(np.arange(len(poss)), [len(p) for p in poss]), device="cuda")
+    ei, sh, d = neighbor_list_gpu(lat, pos, batch, cutoff)
+    tei, nti, ntij = threebody_index_gpu(pos.size(0), ei, d, tb)
+    return [t.cpu().numpy() for t in (ei, sh, d, tei, nti, ntij)]
+
+
+def _assert_same(host, gpu):
+    names = ["edge_index", "edge_cell_shift", "distances", "triplet_edge_index", "num_triplet_i", "num_triplet_ij"]
+    for n, h, g in zip(names, host, gpu):
+        assert h.shape == g.shape, (n, h.shape, g.shape)
+        if n == "distances":
+            np.testing.assert_allclose(g, h, rtol=1e-12, atol=1e-12)
+        else:
+            assert h.dtype == g.dtype, (n, h.dtype, g.dtype)
+            np.testing.assert_array_equal(g, h, err_msg=n)
+
+
+def _cells():
+    rng = np.random.default_rng(5)
+    out = {}
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    out["cu_primitive_like"] = (np.eye(3) * a, base * a)                                  # many self images
+    grid = np.stack(np.meshgrid(*[np.arange(2)] * 3, indexing="ij"), -1).reshape(-1, 1, 3)
+    out["cu_2x2x2"] = (np.eye(3) * 2 * a, ((grid + base[None]).reshape(-1, 3) * a) + rng.uniform(-.02, .02, (32, 3)))
+    tri = np.array([[4.1, 0.3, -0.2], [1.7, 5.2, 0.4], [-0.9, 1.1, 6.3]])
+    out["triclinic_unwrapped"] = (tri, rng.uniform(-1.5, 2.5, (11, 3)) @ tri)                # atoms outside the home cell
+    out["single_atom_small_cell"] = (np.diag([2.1, 2.6, 3.3]), np.zeros((1, 3)))           # only self images
+    out["skewed_left_handed"] = (np.array([[0, 5.0, 0.5], [6.0, 0, 0], [2.5, 2.5, 7.0]]), rng.uniform(0, 1, (17, 3)) @
+                                 np.array([[0, 5.0, 0.5], [6.0, 0, 0], [2.5, 2.5, 7.0]]))    # det < 0
+    return out
+
+
+@pytest.mark.parametrize("name", list(_cells()))
+@pytest.mark.parametrize("cutoff,tb", [(5.0, 4.0), (3.3, 3.3)])
+def test_single_structure_matches_host_builder(name, cutoff, tb):
+    lat, pos = _cells()[name]
+    _assert_same(_host(lat, pos, cutoff, tb), _gpu([lat], [pos], cutoff, tb))
+
+
+def test_reference_fixture_counts():
+    """The reference's own test structures (tests/conftest.py:89-115: fcc Al + bcc Na, nearest-neighbour distance 3.0,
+    cutoff 3.0001).  The golden case_alna holds the graph the reference's compute_threebody produced for the ideal
+    lattices (48 + 16 edges, 640 triplets); the GPU builder must reproduce that edge set and the triplet counts."""
+    _, cfg, _, graph, _ = load_oracle_case("alna", "ref")
+    r = 3.0
+    lat_al, lat_na = r * np.sqrt(2) * np.eye(3), r / np.sqrt(3) * 2 * np.eye(3)
+    lats = [lat_al, lat_na]
+    poss = [np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]]) @ lat_al, np.array([[0, 0, 0], [0.5, 0.5, 0.5]]) @ lat_na]
+    ei, sh, d, tei, nti, ntij = _gpu(lats, poss, cfg.cutoff, cfg.threebody_cutoff)
+    assert ei.shape[1] == graph["edge_index"].shape[1] == 64
+    assert tei.shape[1] == graph["triplet_edge_index"].shape[1] == 640
+    np.testing.assert_allclose(d, 3.0, atol=1e-9)
+
+    def keyset(ei_, sh_):   # the fixture predates the canonical order: compare as sets
+        return sorted(map(tuple, np.concatenate([ei_.T, sh_], 1).tolist()))
+    assert keyset(ei, sh) == keyset(graph["edge_index"].numpy(), graph["edge_cell_shift"].numpy())
+    np.testing.assert_array_equal(nti, np.bincount(graph["edge_index"][0].numpy()[graph["triplet_edge_index"][0].numpy()], minlength=6))
+
+
+def test_batched_structures_match_concatenated_host_graphs():
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+
+    cells = _cells()
+    names = ["cu_2x2x2", "triclinic_unwrapped", "single_atom_small_cell", "skewed_left_handed"]
+    rng = np.random.default_rng(0)
+    zs = [rng.integers(1, 95, len(cells[n][1])) for n in names]
+    host = Batch.from_data_list([MaterialGraph.from_arrays(cells[n][0], cells[n][1], z, 5.0, 4.0) for n, z in zip(names, zs)])
+    dev = batch_from_arrays([cells[n][0] for n in names], [cells[n][1] for n in names], zs, 5.0, 4.0)
+    for key in ("edge_index", "edge_cell_shift", "triplet_edge_index", "num_triplet_i", "num_triplet_ij", "batch", "atom_types"):
+        assert torch.equal(dev[key].cpu(), host[key]), key
+    torch.testing.assert_close(dev["pos"].cpu(), host["pos"])
+    torch.testing.assert_close(dev["lattice"].cpu(), host["lattice"])
+    assert dev["num_nodes"] == host["num_nodes"] and dev["num_edges"] == host["num_edges"] and dev["num_triplets"] == host["num_triplets"]
+
+
+def test_gpu_built_graph_gives_the_same_energy_and_forces():
+    """End to end: structure arrays -> GPU graph -> engine equals host graph -> engine bit for bit."""
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+
+    model, cfg = build_engine_model("cu32", "ref")
+    model = model.cuda()
+    lat, pos = _cells()["cu_2x2x2"]
+    z = np.full(len(pos), 29)
+    host = Batch.from_data_list([MaterialGraph.from_arrays(lat, pos, z, cfg.cutoff, cfg.threebody_cutoff)]).to("cuda")
+    dev = batch_from_arrays([lat], [pos], [z], cfg.cutoff, cfg.threebody_cutoff)
+    a, b = model(host), model(dev)
+    assert torch.equal(a["total_energy"], b["total_energy"])
+    assert torch.equal(a["forces"], b["forces"])
+
+
+def test_large_supercell_counts_and_properties():
+    """BASELINE config 3 (10,000 Cu atoms): 420,000 edges / 3,060,000 triplets, built on the GPU."""
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(25), indexing="ij"), -1)
+    pos = (g.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a
+    pos = pos + np.random.default_rng(0).uniform(-0.025, 0.025, pos.shape)
+    lat = np.diag([10 * a, 10 * a, 25 * a])
+    gr = batch_from_arrays([lat], [pos], [np.full(len(pos), 29)], 5.0, 4.0)
+    assert gr["num_edges"] == 420_000 and gr["num_triplets"] == 3_060_000
+    ei, sh = gr["edge_index"], gr["edge_cell_shift"]
+    assert bool((ei[0, 1:] >= ei[0, :-1]).all())                         # centre sorted
+    # every edge has its reverse: (j, i, -shift)
+    fwd = torch.cat([ei.t(), sh.long()], 1)
+    rev = torch.cat([ei.flip(0).t(), -sh.long()], 1)
+    def key(t):
+        t = t + torch.tensor([0, 0, 8, 8, 8], device=t.device)
+        return (((t[:, 0] * 10_000 + t[:, 1]) * 17 + t[:, 2]) * 17 + t[:, 3]) * 17 + t[:, 4]
+    assert torch.equal(key(fwd).sort().values, key(rev).sort().values)
+    # distances recomputed from the emitted shifts are inside the cutoff
+    p = torch.tensor(pos, device="cuda")
+    r = p[ei[1]] + sh.double() @ torch.tensor(lat, device="cuda") - p[ei[0]]
+    d = r.norm(dim=1)
+    assert float(d.max()) <= 5.0 + 1e-8 and float(d.min()) > 1.0
+    tei = gr["triplet_edge_index"]
+    assert bool((ei[0][tei[0]] == ei[0][tei[1]]).all()) and bool((tei[0] != tei[1]).all())
+    assert int(gr["num_triplet_ij"].sum()) == gr["num_triplets"] == int(gr["num_triplet_i"].sum())

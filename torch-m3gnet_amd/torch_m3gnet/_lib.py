@@ -58,6 +58,16 @@ SYMBOLS = {
                                       C.c_void_p, C.c_void_p]),
     "m3g_atom_featurizer": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "m3g_atom_ref": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "m3g_neighbor_scratch_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
+    "m3g_neighbor_count": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                     C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
+    "m3g_neighbor_fill": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "m3g_threebody_scratch_bytes": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
+    "m3g_threebody_count": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_int64), C.c_void_p]),
+    "m3g_threebody_fill": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "m3g_debug_read_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "m3g_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "m3g_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_float),

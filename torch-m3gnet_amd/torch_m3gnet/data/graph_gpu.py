@@ -1,0 +1,121 @@
+"""Graph construction on the GPU: periodic neighbour list + three-body indices (C ABI: m3g_neighbor_*,
+m3g_threebody_*; csrc/m3g_graph_build.hip).  Replaces the reference's pymatgen search and its O(T) Python
+triplet loop (data/material_graph.py:168-254) for whole batches of structures in one call."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import MaterialGraphKey as K
+from .material_graph import Batch
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def max_images(lattices: np.ndarray, cutoff: float) -> int:
+    """Upper bound of (2rx+1)(2ry+1)(2rz+1) over the structures (same formula as the kernel)."""
+    lat = np.asarray(lattices, dtype=np.float64).reshape(-1, 3, 3)
+    vol = np.abs(np.linalg.det(lat))
+    out = 1
+    for L, v in zip(lat, vol):
+        n = 1
+        for p in range(3):
+            q, r = (p + 1) % 3, (p + 2) % 3
+            n *= 2 * int(np.ceil((cutoff + 1e-8) * np.linalg.norm(np.cross(L[q], L[r])) / v)) + 1
+        out = max(out, n)
+    return out
+
+
+def neighbor_list_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Tensor, cutoff: float):
+    """lattice [S,3,3] f64, pos [N,3] f64, batch [N] i64 (sorted), all on the GPU.
+    Returns edge_index [2,E] i64, edge_cell_shift [E,3] i32, distances [E] f64 (device tensors)."""
+    lib = _lib.load_library()
+    dev = pos.device
+    lattice = lattice.to(torch.float64).contiguous()
+    pos = pos.to(torch.float64).contiguous()
+    batch = batch.to(torch.int64).contiguous()
+    N, S = int(pos.size(0)), int(lattice.size(0))
+    M = max_images(lattice.cpu().numpy(), cutoff)
+    nbytes = C.c_size_t()
+    _lib.check(lib.m3g_neighbor_scratch_bytes(N, S, M, C.byref(nbytes)))
+    scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    n_edges = C.c_int64()
+    with torch.cuda.device(dev):
+        _lib.check(lib.m3g_neighbor_count(N, S, M, _ptr(pos), _ptr(lattice), _ptr(batch), float(cutoff), _ptr(scratch), nbytes.value,
+                                          C.byref(n_edges), _stream()))
+        E = int(n_edges.value)
+        ei = torch.empty(2, E, dtype=torch.int64, device=dev)
+        shift = torch.empty(E, 3, dtype=torch.int32, device=dev)
+        dist = torch.empty(E, dtype=torch.float64, device=dev)
+        _lib.check(lib.m3g_neighbor_fill(N, S, M, _ptr(batch), float(cutoff), _ptr(scratch), E, _ptr(ei), _ptr(shift), _ptr(dist), _stream()))
+        torch.cuda.current_stream().synchronize()   # scratch is released when this function returns
+    return ei, shift, dist
+
+
+def threebody_index_gpu(num_nodes: int, edge_index: torch.Tensor, distances: torch.Tensor, threebody_cutoff: float):
+    """edge_index [2,E] i64 (sorted by centre), distances [E] (narrowed to fp32 like the reference).
+    Returns triplet_edge_index [2,T] i64, num_triplet_i [N] i64, num_triplet_ij [E] i32 (device tensors)."""
+    lib = _lib.load_library()
+    dev = edge_index.device
+    ei = edge_index.to(torch.int64).contiguous()
+    d32 = distances.to(torch.float32).contiguous()
+    N, E = int(num_nodes), int(ei.size(1))
+    nbytes = C.c_size_t()
+    _lib.check(lib.m3g_threebody_scratch_bytes(N, E, C.byref(nbytes)))
+    scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    n_t = C.c_int64()
+    with torch.cuda.device(dev):
+        _lib.check(lib.m3g_threebody_count(N, E, _ptr(ei), _ptr(d32), float(threebody_cutoff), _ptr(scratch), nbytes.value,
+                                           C.byref(n_t), _stream()))
+        T = int(n_t.value)
+        tei = torch.empty(2, T, dtype=torch.int64, device=dev)
+        nti = torch.empty(N, dtype=torch.int64, device=dev)
+        ntij = torch.empty(E, dtype=torch.int32, device=dev)
+        _lib.check(lib.m3g_threebody_fill(N, E, _ptr(ei), _ptr(scratch), T, _ptr(tei), _ptr(nti), _ptr(ntij), _stream()))
+        torch.cuda.current_stream().synchronize()
+    return tei, nti, ntij
+
+
+def batch_from_arrays(lattices: Sequence, cart_coords: Sequence, atomic_numbers: Sequence, cutoff: float, threebody_cutoff: float,
+                      device="cuda") -> Batch:
+    """Build a whole batch of periodic structures on the GPU (lists of [3,3], [n_s,3], [n_s] arrays).
+    Equivalent to Batch.from_data_list([MaterialGraph.from_arrays(...) ...]).to(device), without the host search."""
+    if threebody_cutoff > cutoff:
+        raise ValueError("Three body cutoff raidus should be smaller than two body.")
+    lat = np.stack([np.asarray(L, dtype=np.float64).reshape(3, 3) for L in lattices])
+    sizes = [len(p) for p in cart_coords]
+    pos = np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1, 3) for p in cart_coords])
+    z = np.concatenate([np.asarray(a).reshape(-1) for a in atomic_numbers])
+    batch = np.repeat(np.arange(len(sizes)), sizes)
+    dev = torch.device(device)
+    lat_d = torch.tensor(lat, device=dev)
+    pos_d = torch.tensor(pos, device=dev)
+    batch_d = torch.tensor(batch, dtype=torch.int64, device=dev)
+    ei, shift, dist = neighbor_list_gpu(lat_d, pos_d, batch_d, cutoff)
+    tei, nti, ntij = threebody_index_gpu(len(pos), ei, dist, threebody_cutoff)
+    g = Batch.__new__(Batch)
+    dict.__init__(g)
+    g[K.POS] = pos_d.to(torch.float)
+    g[K.ATOM_TYPES] = torch.tensor(z - 1, dtype=torch.long, device=dev)
+    g[K.NUM_TRIPLET_I] = nti
+    g[K.EDGE_INDEX] = ei
+    g[K.EDGE_CELL_SHIFT] = shift
+    g[K.NUM_TRIPLET_IJ] = ntij
+    g[K.TRIPLET_EDGE_INDEX] = tei
+    g[K.LATTICE] = lat_d.to(torch.float)
+    g[K.BATCH] = batch_d
+    g[K.NUM_NODES] = int(len(pos))
+    g[K.NUM_EDGES] = int(ei.size(1))
+    g[K.NUM_TRIPLETS] = int(tei.size(1))
+    g["num_graphs"] = len(sizes)
+    return g
