@@ -55,6 +55,11 @@ def _cells():
     out["single_atom_small_cell"] = (np.diag([2.1, 2.6, 3.3]), np.zeros((1, 3)))           # only self images
     out["skewed_left_handed"] = (np.array([[0, 5.0, 0.5], [6.0, 0, 0], [2.5, 2.5, 7.0]]), rng.uniform(0, 1, (17, 3)) @
                                  np.array([[0, 5.0, 0.5], [6.0, 0, 0], [2.5, 2.5, 7.0]]))    # det < 0
+    out["two_bins_per_axis"] = (np.eye(3) * 10.7, rng.uniform(0, 10.7, (60, 3)))            # linked cells with nb = 2: +-1 reach the same bin
+    out["three_bins_sheared"] = (np.array([[16.0, 0, 0], [4.0, 15.5, 0], [-3.0, 2.0, 17.0]]), rng.uniform(0, 1, (150, 3)) @
+                                 np.array([[16.0, 0, 0], [4.0, 15.5, 0], [-3.0, 2.0, 17.0]]))
+    slab = rng.uniform(0, 1, (40, 3)) * np.array([8.0, 8.0, 6.0])
+    out["slab_in_vacuum"] = (np.diag([8.0, 8.0, 400.0]), slab)                                  # bins coarsened over empty space
     return out
 
 

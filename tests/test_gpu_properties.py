@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from helpers import build_engine_model, engine_graph, fcc_cu_graph, load_oracle_case, random_cell_graph, rel_err
+from oracle import m3gnet_oracle as orc
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -348,3 +349,76 @@ def test_hyperparameter_sweep_against_oracle(l_max, n_max, dim, blocks, cut, tb_
         assert rel_err(out[K.EDGE_ATTR], o["edge_attr"]) < 1e-5, kern
         for b in range(blocks):
             assert rel_err(out[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) < 1e-4, (kern, b)
+
+
+# ---- PBC-consistent virial -------------------------------------------------------------
+def _strained_energy(params, cfg, consts, graph, eps):
+    """fp64 oracle energy with positions and lattice strained by (1 + eps), topology and cell shifts fixed."""
+    g = dict(graph)
+    dfm = torch.eye(3, dtype=torch.float64) + eps
+    g["pos"] = graph["pos"].double() @ dfm
+    g["lattice"] = graph["lattice"].double() @ dfm
+    return orc.energy_forces(params, cfg, consts, g, want_forces=False)["total_energy"].double()
+
+
+@pytest.mark.parametrize("case", ["cu32", "mix"])
+def test_pair_virial_is_the_strain_derivative(case):
+    """sigma_ab V = -dE/d eps_ab, checked against central differences of the fp64 oracle energy (doc mode, so the
+    three-body term contributes).  Tolerance 2e-3 of max|sigma V|: fp32 engine, h = 1e-4 differences."""
+    from torch_m3gnet.nn import Gradient
+
+    params, cfg, consts, graph, _ = load_oracle_case(case, "doc", dtype=torch.float64)
+    model, _ = build_engine_model(case, "doc")
+    model = Gradient(model.model, pair_virial=True).cuda()
+    out = model(engine_graph(graph))
+    lat = graph["lattice"].double().reshape(-1, 3, 3)
+    vol = torch.linalg.det(lat).abs()
+    sv = out["stresses"].double().cpu() * vol[:, None]
+    voigt = [(0, 0), (1, 1), (2, 2), (1, 2), (2, 0), (0, 1)]
+    h = 1e-4
+    fd = torch.zeros_like(sv)
+    for k, (a, b) in enumerate(voigt):
+        eps = torch.zeros(3, 3, dtype=torch.float64)
+        eps[a, b] += 0.5 * h
+        eps[b, a] += 0.5 * h
+        fd[:, k] = -(_strained_energy(params, cfg, consts, graph, eps) - _strained_energy(params, cfg, consts, graph, -eps)) / (2 * h)
+    assert float((sv - fd).abs().max() / fd.abs().max()) < 2e-3, (sv, fd)
+
+
+def test_pair_virial_equals_reference_formula_without_boundary_crossings():
+    """A cluster in a large box (no edge crosses the cell): both formulas are the same sum."""
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+    from torch_m3gnet.nn import Gradient
+
+    model, cfg = build_engine_model("cu32", "doc")
+    rng = np.random.default_rng(3)
+    pos = 20.0 + rng.uniform(-3.0, 3.0, (24, 3))
+    g = Batch.from_data_list([MaterialGraph.from_arrays(np.eye(3) * 40.0, pos, np.full(24, 29), cfg.cutoff, cfg.threebody_cutoff)]).to("cuda")
+    assert int(g["edge_cell_shift"].abs().sum()) == 0
+    ref = model.cuda()(g)["stresses"]
+    pair = Gradient(model.model, pair_virial=True).cuda()(g)["stresses"]
+    # sum pos (x) F cancels to ~1e-6 of its terms (|pos| ~ 20): compare relative to the largest component
+    assert float((ref - pair).abs().max() / pair.abs().max()) < 5e-4
+
+
+def test_pair_virial_is_invariant_under_lattice_translation_of_an_atom():
+    """Moving one atom by a lattice vector (with its cell shifts adjusted) changes the reference formula but not the
+    pair virial -- the reason row 4 exists (the reference's own stress test is skipped, tests/test_model.py:123)."""
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+    from torch_m3gnet.nn import Gradient
+
+    model, cfg = build_engine_model("cu32", "doc")
+    lat = np.eye(3) * 7.22
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    grid = np.stack(np.meshgrid(*[np.arange(2)] * 3, indexing="ij"), -1).reshape(-1, 1, 3)
+    pos = (grid + base[None]).reshape(-1, 3) * 3.61 + np.random.default_rng(0).uniform(-0.05, 0.05, (32, 3))
+    pos2 = pos.copy()
+    pos2[5] += lat[0] - 2 * lat[2]
+    z = np.full(32, 29)
+    pv = Gradient(model.model, pair_virial=True).cuda()
+    outs = []
+    for p in (pos, pos2):
+        g = Batch.from_data_list([MaterialGraph.from_arrays(lat, p, z, cfg.cutoff, cfg.threebody_cutoff)]).to("cuda")
+        outs.append((pv(g)["stresses"].cpu(), model.cuda()(g)["stresses"].cpu()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-6 * float(outs[0][0].abs().max()) + 1e-9)
+    assert float((outs[0][1] - outs[1][1]).abs().max()) > 10 * float((outs[0][0] - outs[1][0]).abs().max())

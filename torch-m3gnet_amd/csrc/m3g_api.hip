@@ -316,6 +316,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->edge_kernel = value;
     return M3G_OK;
   }
+  if (strcmp(name, "stress_mode") == 0) {
+    if (value != 0 && value != 1) { set_error("stress_mode must be 0 (reference: sum pos (x) F / V) or 1 (pair virial)"); return M3G_ERR_VALUE; }
+    plan->stress_mode = value;
+    return M3G_OK;
+  }
   if (strcmp(name, "stamps") == 0) {  // diagnostic: forward edge kernel with s_memtime phase stamps
     plan->stamp_target = value == 2 ? 1 : 0;   // 1: forward edge kernel, 2: reverse edge-MLP kernel
     if (value && !plan->d_stamps) {
@@ -539,7 +544,10 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     M3G_STAGE(ST_GEOM_REV);
     if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, 2 * c.B + 1, io->forces, s);
     else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, s);
-    if (io->stresses) launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);
+    if (io->stresses) {
+      if (plan->stress_mode == 1) launch_stress_pair(t, w, io->lattice, io->stresses, s);
+      else launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);
+    }
   } else if (io->stresses) {
     set_error("stresses require forces");
     return M3G_ERR_VALUE;

@@ -196,6 +196,48 @@ __global__ void __launch_bounds__(256) k_stress(int64_t N, const int32_t* __rest
   }
 }
 
+// PBC-consistent virial (docs/gradient.md:47-84): with every pair vector r_e = d_e u_e
+// straining as r -> (1 + eps) r, dE/d eps = sum_e r_e (x) dE/dr_e over the directed edges, so
+//   sigma = -(1/V) sum_e r_e (x) dE/dr_e      (same sign convention as the reference's sum_a pos_a (x) F_a / V, to
+// which it reduces when no edge crosses a cell boundary).  One thread per atom sums its own CSR row; the tensor is
+// symmetric up to rounding and stored symmetrised.  d and dr are both in scaled length, so the scale cancels.
+__global__ void __launch_bounds__(256) k_stress_pair(int64_t N, const int32_t* __restrict__ batch, const int32_t* __restrict__ row_ptr,
+                                                     const float* __restrict__ lattice, const float* __restrict__ u,
+                                                     const float* __restrict__ dist, const float* __restrict__ dr,
+                                                     float* __restrict__ stresses) {
+  int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool live = a < N;
+  int s = live ? batch[a] : -1;
+  float val[6] = {0, 0, 0, 0, 0, 0};
+  if (live) {
+    const float* L = lattice + (int64_t)s * 9;
+    float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
+    float inv = -1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
+    for (int e = row_ptr[a]; e < row_ptr[a + 1]; ++e) {
+      const float d = dist[e];
+      const float rx = d * u[e * 3], ry = d * u[e * 3 + 1], rz = d * u[e * 3 + 2];
+      const float gx = dr[e * 3], gy = dr[e * 3 + 1], gz = dr[e * 3 + 2];
+      val[0] += rx * gx; val[1] += ry * gy; val[2] += rz * gz;
+      val[3] += 0.5f * (ry * gz + rz * gy); val[4] += 0.5f * (rz * gx + rx * gz); val[5] += 0.5f * (rx * gy + ry * gx);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) val[k] *= inv;
+  }
+  int s0 = __shfl(s, 0);
+  bool uniform = __all(s == s0 || !live);
+  if (uniform && s0 >= 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float v = val[k];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&stresses[(int64_t)s0 * 6 + k], v);
+    }
+  } else if (live) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) atomicAdd(&stresses[(int64_t)s * 6 + k], val[k]);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_triplet_angles(int64_t T, const int64_t* __restrict__ tei, const float* __restrict__ u,
                                                         float* __restrict__ out) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -246,6 +288,12 @@ void launch_stress(const Consts& c, const Topo& t, const float* pos, const float
   (void)c;
   (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
   if (t.N > 0) hipLaunchKernelGGL(k_stress, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, pos, lattice, forces, stresses);
+}
+
+void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s) {
+  (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
+  if (t.N > 0)
+    hipLaunchKernelGGL(k_stress_pair, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, t.row_ptr, lattice, w.u, w.d, w.dr, stresses);
 }
 
 void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s) {

@@ -9,10 +9,10 @@
 // (sx, sy, sz) lexicographic, then neighbour index -- the same order torch_m3gnet/data/neighbors.py produces, so
 // both builders can be compared element by element.
 // Geometry in fp64 like pymatgen (inclusion d <= cutoff is decided in double; the stored tensors are narrowed by
-// the caller).  Brute force inside each structure (every atom x every image x every atom, positions staged
-// through LDS): integer/byte work, HBM/L2-bound, fine up to a few 10^4 atoms per structure; a linked-cell
-// version is the planned follow-up.  Count -> exclusive scan (hipCUB) -> fill, so no atomics and a deterministic
-// result.
+// the caller).  Linked cells: atoms are radix-sorted (hipCUB) into bins at least one cutoff wide, and one thread per
+// (atom, periodic image) tests only the bins of that image within reach -- O(N) pair tests for large cells, and
+// the plain all-images x all-atoms search when the cell is smaller than the cutoff (one bin).  Integer/byte work,
+// L2-bound.  Count -> exclusive scan (hipCUB) -> fill, so no atomics and a deterministic result.
 #include <hipcub/hipcub.hpp>
 
 #include "m3g_internal.h"
@@ -24,18 +24,26 @@ static inline size_t align_up_g(size_t x, size_t a = 256) { return (x + a - 1) /
 struct StructInfo {   // per structure, device
   double lat[9];      // rows
   double inv[9];      // inverse (frac = cart . inv)
-  int reps[3];
+  int reps[3];        // images needed along each lattice vector
+  int nb[3];          // linked-cell bins along each lattice vector (bin width >= cutoff, or 1 bin when the cell is smaller)
+  int reach[3];       // bins to look at either side: 1, or reps when the axis has a single bin
   int n_img;          // (2 rx + 1)(2 ry + 1)(2 rz + 1)
   int first, count;   // atom range
 };
 
 struct NbScratch {
   StructInfo* info;       // [S]
+  int64_t* bin_off;       // [S+1] bins per structure, then exclusive offsets (global bin id = bin_off[s] + local bin)
   double* pos_w;          // [N,3] wrapped into the home cell
   int32_t* wrap;          // [N,3] integer offset removed by the wrap
+  int32_t* binc;          // [N,3] bin coordinates of each atom
+  int32_t *bin_key, *bin_key_s, *iota, *perm;   // [N] global bin id per atom, sorted copy, atom ids, atoms ordered by bin
+  int32_t* bin_start;     // [Bmax+1] first slot of each bin in perm
+  double* pos_s;          // [N,3] wrapped positions in bin order
   int64_t* counts;        // [N*M + 1] matches per (atom, image), then exclusive offsets
-  void* scan_tmp;
-  size_t scan_tmp_bytes;
+  void* tmp;              // scan / sort temporary
+  size_t tmp_bytes;
+  int64_t max_bins;
   size_t total;
 };
 
@@ -44,22 +52,35 @@ static NbScratch nb_carve(int64_t N, int64_t S, int64_t M, void* base) {
   char* p = (char*)base;
   size_t off = 0;
   auto take = [&](size_t bytes) { void* r = p ? (void*)(p + off) : nullptr; off += align_up_g(bytes); return r; };
+  w.max_bins = 2 * N + 8 * S;   // k_struct_info keeps every structure within 2 count + 8 bins
   w.info = (StructInfo*)take(sizeof(StructInfo) * (size_t)(S + 1));
+  w.bin_off = (int64_t*)take(sizeof(int64_t) * (size_t)(S + 2));
   w.pos_w = (double*)take(sizeof(double) * 3 * (size_t)(N + 1));
   w.wrap = (int32_t*)take(sizeof(int32_t) * 3 * (size_t)(N + 1));
+  w.binc = (int32_t*)take(sizeof(int32_t) * 3 * (size_t)(N + 1));
+  w.bin_key = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
+  w.bin_key_s = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
+  w.iota = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
+  w.perm = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
+  w.bin_start = (int32_t*)take(sizeof(int32_t) * (size_t)(w.max_bins + 2));
+  w.pos_s = (double*)take(sizeof(double) * 3 * (size_t)(N + 1));
   w.counts = (int64_t*)take(sizeof(int64_t) * (size_t)(N * M + 2));
-  size_t tmp = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const int64_t*)nullptr, (int64_t*)nullptr, (int)(N * M + 1));
-  w.scan_tmp_bytes = tmp;
-  w.scan_tmp = take(tmp);
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const int64_t*)nullptr, (int64_t*)nullptr, (int)(N * M + 1));
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const int64_t*)nullptr, (int64_t*)nullptr, (int)(S + 1));
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t3, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr,
+                                           (int32_t*)nullptr, (int)N);
+  w.tmp_bytes = std::max(t1, std::max(t2, t3));
+  w.tmp = take(w.tmp_bytes);
   w.total = off;
   return w;
 }
 
-// one thread per structure: inverse lattice, image ranges, atom range (batch must be sorted/contiguous)
+// one thread per structure: inverse lattice, image ranges, bin grid, atom range (batch must be sorted/contiguous)
 __global__ void k_struct_info(int64_t N, int64_t S, const double* __restrict__ lattice, const int64_t* __restrict__ batch,
-                              double cutoff, StructInfo* info, int* flags) {
+                              double cutoff, StructInfo* info, int64_t* nbins, int* flags) {
   int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s == 0) nbins[S] = 0;
   if (s >= S) return;
   StructInfo si;
   const double* L = lattice + s * 9;
@@ -73,14 +94,6 @@ __global__ void k_struct_info(int64_t N, int64_t S, const double* __restrict__ l
   si.inv[0] = c0x / det; si.inv[3] = c0y / det; si.inv[6] = c0z / det;
   si.inv[1] = c1x / det; si.inv[4] = c1y / det; si.inv[7] = c1z / det;
   si.inv[2] = c2x / det; si.inv[5] = c2y / det; si.inv[8] = c2z / det;
-  // images needed along lattice vector p: ceil(cutoff / height_p), height_p = V / |a_q x a_r|
-  const double area[3] = {sqrt(c0x * c0x + c0y * c0y + c0z * c0z), sqrt(c1x * c1x + c1y * c1y + c1z * c1z),
-                          sqrt(c2x * c2x + c2y * c2y + c2z * c2z)};
-  si.n_img = 1;
-  for (int p = 0; p < 3; ++p) {
-    si.reps[p] = (int)ceil((cutoff + 1e-8) * area[p] / vol);
-    si.n_img *= 2 * si.reps[p] + 1;
-  }
   // atom range by binary search on the sorted batch vector
   int64_t lo = 0, hi = N;
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (batch[mid] < s) lo = mid + 1; else hi = mid; }
@@ -89,12 +102,30 @@ __global__ void k_struct_info(int64_t N, int64_t S, const double* __restrict__ l
   int64_t lo2 = lo;
   while (lo2 < hi) { int64_t mid = (lo2 + hi) >> 1; if (batch[mid] < s + 1) lo2 = mid + 1; else hi = mid; }
   si.count = (int)(lo2 - lo);
+  // images needed along lattice vector p: ceil(cutoff / height_p), height_p = V / |a_q x a_r|;
+  // bins along p: as many as fit with width >= cutoff (so a neighbour is at most one bin away)
+  const double area[3] = {sqrt(c0x * c0x + c0y * c0y + c0z * c0z), sqrt(c1x * c1x + c1y * c1y + c1z * c1z),
+                          sqrt(c2x * c2x + c2y * c2y + c2z * c2z)};
+  si.n_img = 1;
+  for (int p = 0; p < 3; ++p) {
+    si.reps[p] = (int)ceil((cutoff + 1e-8) * area[p] / vol);
+    si.n_img *= 2 * si.reps[p] + 1;
+    const double nbf = floor(vol / (area[p] * (cutoff + 2e-8)));
+    si.nb[p] = nbf >= 1.0 ? (nbf > 1024.0 ? 1024 : (int)nbf) : 1;
+  }
+  while ((int64_t)si.nb[0] * si.nb[1] * si.nb[2] > 2 * (int64_t)si.count + 8) {   // empty space: coarser bins, never finer
+    int p = si.nb[0] >= si.nb[1] ? (si.nb[0] >= si.nb[2] ? 0 : 2) : (si.nb[1] >= si.nb[2] ? 1 : 2);
+    si.nb[p] = (si.nb[p] + 1) / 2;
+  }
+  for (int p = 0; p < 3; ++p) si.reach[p] = si.nb[p] == 1 ? si.reps[p] : 1;
   info[s] = si;
+  nbins[s] = (int64_t)si.nb[0] * si.nb[1] * si.nb[2];
   if (!(vol > 0.0)) atomicOr(flags, 1);
 }
 
 __global__ void k_wrap_positions(int64_t N, int64_t S, const double* __restrict__ pos, const int64_t* __restrict__ batch,
-                                 const StructInfo* __restrict__ info, double* pos_w, int32_t* wrap, int* flags) {
+                                 const StructInfo* __restrict__ info, const int64_t* __restrict__ bin_off, double* pos_w,
+                                 int32_t* wrap, int32_t* binc, int32_t* bin_key, int32_t* iota, int* flags) {
   int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (a >= N) return;
   int64_t s = batch[a];
@@ -102,81 +133,100 @@ __global__ void k_wrap_positions(int64_t N, int64_t S, const double* __restrict_
   const StructInfo& si = info[s];
   const double x = pos[a * 3], y = pos[a * 3 + 1], z = pos[a * 3 + 2];
   double f[3], w[3];
+  int b[3];
   for (int p = 0; p < 3; ++p) {
     f[p] = x * si.inv[0 + p] + y * si.inv[3 + p] + z * si.inv[6 + p];
     w[p] = floor(f[p]);
     wrap[a * 3 + p] = (int32_t)w[p];
     f[p] -= w[p];
+    b[p] = min(si.nb[p] - 1, max(0, (int)(f[p] * si.nb[p])));
+    binc[a * 3 + p] = b[p];
   }
   for (int c = 0; c < 3; ++c) pos_w[a * 3 + c] = f[0] * si.lat[0 + c] + f[1] * si.lat[3 + c] + f[2] * si.lat[6 + c];
+  bin_key[a] = (int32_t)(bin_off[s] + ((int64_t)b[0] * si.nb[1] + b[1]) * si.nb[2] + b[2]);
+  iota[a] = (int32_t)a;
 }
 
-// one thread per (atom i, image); FILL = false counts matches, true writes them at the scanned offset
-constexpr int kNbTile = 512;
+// bin_start[g] = first slot of bin g in the bin-sorted atom list; also gathers the wrapped positions in that order
+__global__ void k_bin_ranges(int64_t N, int64_t S, const int64_t* __restrict__ bin_off, const int32_t* __restrict__ keys_sorted,
+                             const int32_t* __restrict__ perm, const double* __restrict__ pos_w, int32_t* bin_start, double* pos_s) {
+  int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (g < N) {
+    const int64_t a = perm[g];
+    pos_s[g * 3] = pos_w[a * 3]; pos_s[g * 3 + 1] = pos_w[a * 3 + 1]; pos_s[g * 3 + 2] = pos_w[a * 3 + 2];
+  }
+  if (g > bin_off[S]) return;
+  int64_t lo = 0, hi = N;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < g) lo = mid + 1; else hi = mid; }
+  bin_start[g] = (int32_t)lo;
+}
+
+// One thread per (atom i, image).  The thread walks the bins of that image that can hold a neighbour (at most
+// 3x3x3, or the single bin of a small cell for every image), counting (FILL = false) or writing (FILL = true)
+// its matches into the slot range the exclusive scan assigned; the fill pass then orders its own short segment
+// by neighbour index so the result is canonical and independent of the bin traversal.
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const int64_t* __restrict__ batch,
-                                                   const StructInfo* __restrict__ info, const double* __restrict__ pos_w,
-                                                   const int32_t* __restrict__ wrap, double cutoff, int64_t* __restrict__ counts,
-                                                   int64_t E, int64_t* __restrict__ edge_index, int32_t* __restrict__ shift,
-                                                   double* __restrict__ dist) {
-  __shared__ double spos[kNbTile * 3];
+                                                   const StructInfo* __restrict__ info, const int64_t* __restrict__ bin_off,
+                                                   const int32_t* __restrict__ bin_start, const int32_t* __restrict__ perm,
+                                                   const double* __restrict__ pos_s, const double* __restrict__ pos_w,
+                                                   const int32_t* __restrict__ binc, const int32_t* __restrict__ wrap, double cutoff,
+                                                   int64_t* __restrict__ counts, int64_t E, int64_t* __restrict__ edge_index,
+                                                   int32_t* __restrict__ shift, double* __restrict__ dist) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const bool live = t < N * M;
-  const int64_t i = live ? t / M : N - 1;   // padding threads follow the last atom: same structure, same barrier trip count
-  const int img = live ? (int)(t % M) : 0;
+  if (t >= N * M) return;
+  const int64_t i = t / M;
+  const int img = (int)(t % M);
   const int s = (int)batch[i];
   const StructInfo& si = info[s];
-  // are all threads of this block in the same structure?  then stage neighbour positions through LDS
-  const int64_t t_first = blockIdx.x * (int64_t)blockDim.x, t_last = min(t_first + blockDim.x - 1, N * M - 1);
-  const bool uniform = batch[t_first / M] == batch[t_last / M];
-  bool active = live && img < si.n_img;
-  int sx = 0, sy = 0, sz = 0;
-  double ox = 0, oy = 0, oz = 0;
-  if (active) {
-    const int ny = 2 * si.reps[1] + 1, nz = 2 * si.reps[2] + 1;
-    sx = img / (ny * nz) - si.reps[0];
-    sy = (img / nz) % ny - si.reps[1];
-    sz = img % nz - si.reps[2];
-    // image displacement minus this atom's wrapped position: |pos_w[j] + o| is the pair distance
-    ox = sx * si.lat[0] + sy * si.lat[3] + sz * si.lat[6] - pos_w[i * 3];
-    oy = sx * si.lat[1] + sy * si.lat[4] + sz * si.lat[7] - pos_w[i * 3 + 1];
-    oz = sx * si.lat[2] + sy * si.lat[5] + sz * si.lat[8] - pos_w[i * 3 + 2];
+  if (img >= si.n_img) { if (!FILL) counts[t] = 0; return; }
+  const int ny = 2 * si.reps[1] + 1, nz = 2 * si.reps[2] + 1;
+  const int sh[3] = {img / (ny * nz) - si.reps[0], (img / nz) % ny - si.reps[1], img % nz - si.reps[2]};
+  int lo[3], hi[3];
+  bool any = true;
+  for (int p = 0; p < 3; ++p) {   // bins b' of the image whose unwrapped coordinate b' + s nb is within reach of this atom's bin
+    const int b = binc[i * 3 + p];
+    lo[p] = max(0, b - si.reach[p] - sh[p] * si.nb[p]);
+    hi[p] = min(si.nb[p] - 1, b + si.reach[p] - sh[p] * si.nb[p]);
+    any = any && lo[p] <= hi[p];
   }
+  // image displacement minus this atom's wrapped position: |pos_w[j] + o| is the pair distance
+  const double ox = sh[0] * si.lat[0] + sh[1] * si.lat[3] + sh[2] * si.lat[6] - pos_w[i * 3];
+  const double oy = sh[0] * si.lat[1] + sh[1] * si.lat[4] + sh[2] * si.lat[7] - pos_w[i * 3 + 1];
+  const double oz = sh[0] * si.lat[2] + sh[1] * si.lat[5] + sh[2] * si.lat[8] - pos_w[i * 3 + 2];
   const double c2 = (cutoff + 1e-8) * (cutoff + 1e-8);
-  int64_t n = 0;
-  int64_t out = FILL && live ? counts[t] : 0;
-  const int first = si.first, count = si.count;
-  auto visit = [&](int j, double px, double py, double pz) {
-    const double dx = px + ox, dy = py + oy, dz = pz + oz;
-    const double d2 = dx * dx + dy * dy + dz * dz;
-    if (d2 <= c2 && d2 > 1e-16) {
-      if (FILL) {
-        if (out < E) {
-          edge_index[out] = i;
-          edge_index[E + out] = j;
-          shift[out * 3 + 0] = sx - wrap[(int64_t)j * 3 + 0] + wrap[i * 3 + 0];
-          shift[out * 3 + 1] = sy - wrap[(int64_t)j * 3 + 1] + wrap[i * 3 + 1];
-          shift[out * 3 + 2] = sz - wrap[(int64_t)j * 3 + 2] + wrap[i * 3 + 2];
-          dist[out] = sqrt(d2);
+  const int64_t begin = FILL ? counts[t] : 0;
+  int64_t out = begin;
+  if (any) {
+    const int64_t b0 = bin_off[s];
+    for (int bx = lo[0]; bx <= hi[0]; ++bx)
+      for (int by = lo[1]; by <= hi[1]; ++by) {
+        const int64_t g0 = b0 + ((int64_t)bx * si.nb[1] + by) * si.nb[2];
+        const int k0 = bin_start[g0 + lo[2]], k1 = bin_start[g0 + hi[2] + 1];   // bins along z are consecutive slots
+        for (int k = k0; k < k1; ++k) {
+          const double dx = pos_s[(int64_t)k * 3] + ox, dy = pos_s[(int64_t)k * 3 + 1] + oy, dz = pos_s[(int64_t)k * 3 + 2] + oz;
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          if (d2 <= c2 && d2 > 1e-16) {
+            if (FILL && out < E) { edge_index[E + out] = perm[k]; dist[out] = sqrt(d2); }
+            ++out;
+          }
         }
-        ++out;
       }
-      ++n;
-    }
-  };
-  if (uniform) {
-    for (int j0 = 0; j0 < count; j0 += kNbTile) {
-      const int m = min(kNbTile, count - j0);
-      __syncthreads();
-      for (int k = threadIdx.x; k < m * 3; k += blockDim.x) spos[k] = pos_w[(int64_t)(first + j0) * 3 + k];
-      __syncthreads();
-      if (active)
-        for (int k = 0; k < m; ++k) visit(first + j0 + k, spos[k * 3], spos[k * 3 + 1], spos[k * 3 + 2]);
-    }
-  } else if (active) {
-    for (int j = first; j < first + count; ++j) visit(j, pos_w[(int64_t)j * 3], pos_w[(int64_t)j * 3 + 1], pos_w[(int64_t)j * 3 + 2]);
   }
-  if (!FILL && live) counts[t] = n;
+  if (!FILL) { counts[t] = out; return; }
+  const int64_t end = out < E ? out : E;
+  for (int64_t a = begin + 1; a < end; ++a) {   // insertion sort of this (atom, image) segment by neighbour index
+    const int64_t j = edge_index[E + a];
+    const double d = dist[a];
+    int64_t b = a;
+    while (b > begin && edge_index[E + b - 1] > j) { edge_index[E + b] = edge_index[E + b - 1]; dist[b] = dist[b - 1]; --b; }
+    edge_index[E + b] = j; dist[b] = d;
+  }
+  for (int64_t a = begin; a < end; ++a) {
+    const int64_t j = edge_index[E + a];
+    edge_index[a] = i;
+    for (int p = 0; p < 3; ++p) shift[a * 3 + p] = sh[p] - wrap[j * 3 + p] + wrap[i * 3 + p];
+  }
 }
 
 // ---- three-body ------------------------------------------------------------------------------------------------
@@ -274,13 +324,17 @@ extern "C" int m3g_neighbor_count(int64_t N, int64_t S, int64_t max_images, cons
   M3G_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int), s));
   *host_n_edges = 0;
   if (N == 0 || S == 0) return M3G_OK;
-  hipLaunchKernelGGL(k_struct_info, g_for(S), dim3(256), 0, s, N, S, lattice, batch, cutoff, w.info, flags);
-  hipLaunchKernelGGL(k_wrap_positions, g_for(N), dim3(256), 0, s, N, S, pos, batch, w.info, w.pos_w, w.wrap, flags);
+  hipLaunchKernelGGL(k_struct_info, g_for(S), dim3(256), 0, s, N, S, lattice, batch, cutoff, w.info, w.bin_off, flags);
+  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, w.bin_off, w.bin_off, (int)(S + 1), s));
+  hipLaunchKernelGGL(k_wrap_positions, g_for(N), dim3(256), 0, s, N, S, pos, batch, w.info, w.bin_off, w.pos_w, w.wrap, w.binc, w.bin_key,
+                     w.iota, flags);
+  M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w.tmp, w.tmp_bytes, w.bin_key, w.bin_key_s, w.iota, w.perm, (int)N, 0, 32, s));
+  hipLaunchKernelGGL(k_bin_ranges, g_for(w.max_bins + 1), dim3(256), 0, s, N, S, w.bin_off, w.bin_key_s, w.perm, w.pos_w, w.bin_start, w.pos_s);
   const int64_t NM = N * max_images;
-  hipLaunchKernelGGL((k_neighbors<false>), g_for(NM), dim3(256), 0, s, N, max_images, batch, w.info, w.pos_w, w.wrap, cutoff, w.counts,
-                     (int64_t)0, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL((k_neighbors<false>), g_for(NM), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm, w.pos_s,
+                     w.pos_w, w.binc, w.wrap, cutoff, w.counts, (int64_t)0, nullptr, nullptr, nullptr);
   M3G_HIP_CHECK(hipMemsetAsync(w.counts + NM, 0, sizeof(int64_t), s));
-  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, w.scan_tmp_bytes, w.counts, w.counts, (int)(NM + 1), s));
+  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, w.counts, w.counts, (int)(NM + 1), s));
   int h_flags = 0;
   M3G_HIP_CHECK(hipMemcpyAsync(host_n_edges, w.counts + NM, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipMemcpyAsync(&h_flags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -297,8 +351,8 @@ extern "C" int m3g_neighbor_fill(int64_t N, int64_t S, int64_t max_images, const
   if (n_edges == 0 || N == 0) return M3G_OK;
   if (!scratch || !edge_index || !edge_cell_shift || !distances) { set_error("m3g_neighbor_fill: null argument"); return M3G_ERR_VALUE; }
   NbScratch w = nb_carve(N, S, max_images, scratch);
-  hipLaunchKernelGGL((k_neighbors<true>), g_for(N * max_images), dim3(256), 0, s, N, max_images, batch, w.info, w.pos_w, w.wrap, cutoff,
-                     w.counts, n_edges, edge_index, edge_cell_shift, distances);
+  hipLaunchKernelGGL((k_neighbors<true>), g_for(N * max_images), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm,
+                     w.pos_s, w.pos_w, w.binc, w.wrap, cutoff, w.counts, n_edges, edge_index, edge_cell_shift, distances);
   M3G_HIP_CHECK(hipGetLastError());
   return M3G_OK;
 }

@@ -130,6 +130,7 @@ struct m3g_plan {
   float* d_weights = nullptr;
   float* d_mfma_fwd = nullptr;   // [num_blocks][MfmaFwdLayout.total]
   float* d_mfma_rev = nullptr;   // [num_blocks][MfmaRevLayout.total]
+  int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
   int stamp_target = 0;          // which kernel runs its stamped variant: 0 forward edge block, 1 reverse edge-MLP kernel
   unsigned long long* d_stamps = nullptr;  // option "stamps": diagnostic phase-cycle sums [256][16][12] of the fwd edge kernel
@@ -206,6 +207,7 @@ void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, cons
                              hipStream_t s);
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s);
+void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s);
 void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s);
 void launch_distance_only(float length_scale, const Topo& t, const float* pos, const float* lattice,
                           const int32_t* shift, float* u, float* d, hipStream_t s);

@@ -26,14 +26,11 @@ def max_images(lattices: np.ndarray, cutoff: float) -> int:
     """Upper bound of (2rx+1)(2ry+1)(2rz+1) over the structures (same formula as the kernel)."""
     lat = np.asarray(lattices, dtype=np.float64).reshape(-1, 3, 3)
     vol = np.abs(np.linalg.det(lat))
-    out = 1
-    for L, v in zip(lat, vol):
-        n = 1
-        for p in range(3):
-            q, r = (p + 1) % 3, (p + 2) % 3
-            n *= 2 * int(np.ceil((cutoff + 1e-8) * np.linalg.norm(np.cross(L[q], L[r])) / v)) + 1
-        out = max(out, n)
-    return out
+    n = np.ones(len(lat), dtype=np.int64)
+    for p in range(3):
+        area = np.linalg.norm(np.cross(lat[:, (p + 1) % 3], lat[:, (p + 2) % 3]), axis=1)
+        n *= 2 * np.ceil((cutoff + 1e-8) * area / vol).astype(np.int64) + 1
+    return int(n.max()) if len(n) else 1
 
 
 def neighbor_list_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Tensor, cutoff: float):

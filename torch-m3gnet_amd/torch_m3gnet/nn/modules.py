@@ -370,9 +370,13 @@ class Gradient(torch.nn.Module):
     The wrapped `model` must be the Sequential laid out by `build_model` (model/build.py:37-76);
     forces come from the engine's analytic reverse pass, not from autograd."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, pair_virial: bool = False):
+        """`pair_virial=False` reproduces the reference's stress formula sum_a pos_a (x) F_a / V (nn/gradient.py:39-62,
+        absolute positions -- not invariant under a lattice translation of an atom); `pair_virial=True` returns the
+        strain derivative -(1/V) sum_e r_e (x) dE/dr_e over the pair vectors (docs/gradient.md:47-84)."""
         super().__init__()
         self.model = model
+        self.pair_virial = bool(pair_virial)
         self._engine = None
 
     @property
@@ -381,6 +385,7 @@ class Gradient(torch.nn.Module):
             from ..engine import Engine
 
             self._engine = Engine(self.model)
+            self._engine.set_option("stress_mode", 1 if self.pair_virial else 0)
         return self._engine
 
     def forward(self, graph, forces: bool = True, extras: bool = True):
