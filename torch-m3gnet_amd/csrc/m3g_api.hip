@@ -282,6 +282,7 @@ extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (plan->d_weights) (void)hipFree(plan->d_weights);
   if (plan->d_mfma_fwd) (void)hipFree(plan->d_mfma_fwd);
   if (plan->d_mfma_rev) (void)hipFree(plan->d_mfma_rev);
+  if (plan->d_mfma_revf) (void)hipFree(plan->d_mfma_revf);
   if (plan->d_stamps) (void)hipFree(plan->d_stamps);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
   delete plan;
@@ -314,6 +315,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
   if (strcmp(name, "edge_kernel") == 0) {
     if (value != 0 && value != 1) { set_error("edge_kernel must be 0 (VALU baseline) or 1 (MFMA)"); return M3G_ERR_VALUE; }
     plan->edge_kernel = value;
+    return M3G_OK;
+  }
+  if (strcmp(name, "rev_kernel") == 0) {
+    if (value != 0 && value != 1) { set_error("rev_kernel must be 0 (node-MLP + edge-MLP kernel pair) or 1 (fused)"); return M3G_ERR_VALUE; }
+    plan->rev_kernel = value;
     return M3G_OK;
   }
   if (strcmp(name, "stress_mode") == 0) {
@@ -457,6 +463,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   const float* W = plan->d_weights;
   Topo t = topo_carve(N, E, T, S, const_cast<void*>(io->topo));
   const bool mfma = plan->edge_kernel == 1;
+  const bool fused_rev = mfma && plan->rev_kernel == 1;
   Work w = work_carve(c, mfma, N, E, T, S, nullptr);
   if (!workspace || workspace_bytes < w.total_bytes) { set_error("workspace too small: %zu < %zu", workspace_bytes, w.total_bytes); return M3G_ERR_SIZE; }
   w = work_carve(c, mfma, N, E, T, S, workspace);
@@ -521,7 +528,10 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
           M3G_HIP_CHECK(hipMemsetAsync(w.dd, 0, sizeof(float) * E, s));
           M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
       }
-      if (mfma) {
+      if (mfma && fused_rev) {
+        M3G_STAGE(ST_EDGE_REV);
+        launch_edge_rev_fused(plan, c, t, w, b, dx_cur, /*de_is_zero=*/b == c.B - 1, s);
+      } else if (mfma) {
         { M3G_STAGE(ST_EDGE_REV_NODE); launch_edge_rev_node_mlp(plan, c, t, w, b, dx_cur, s); }
         M3G_STAGE(ST_EDGE_REV);
         launch_edge_rev_edge_mlp(plan, c, t, w, b, dx_cur, /*de_is_zero=*/b == c.B - 1, s);
@@ -538,11 +548,11 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     }
     {
       M3G_STAGE(ST_EMBED_REV);
-      if (mfma) launch_embed_edges_reverse_soa(W + wl.adj, w.h, w.de_soa, w.dh_parts + (size_t)2 * c.B * E * kRP, E, s);
+      if (mfma) launch_embed_edges_reverse_soa(W + wl.adj, w.h, w.de_soa, w.dh_parts + (size_t)(fused_rev ? c.B : 2 * c.B) * E * kRP, E, s);
       else launch_embed_reverse(c, W, wl, t, w, s);
     }
     M3G_STAGE(ST_GEOM_REV);
-    if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, 2 * c.B + 1, io->forces, s);
+    if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, (fused_rev ? c.B : 2 * c.B) + 1, io->forces, s);
     else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, s);
     if (io->stresses) {
       if (plan->stress_mode == 1) launch_stress_pair(t, w, io->lattice, io->stresses, s);

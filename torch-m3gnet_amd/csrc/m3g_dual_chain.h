@@ -1,0 +1,98 @@
+// bf16x3 MFMA chains over the dual-use LDS weight image (layout and bank analysis: m3g_dual_image.h).
+//   chain_dual    acc[ob] += W[rows ob*16..][:] . x          (A operand by row reads, 2 x ds_read_b64 per fragment part)
+//   chain_dual_t  acc[ob] += W[:][cols ob*16..]^T . d        (A operand by 2 x ds_read_b64_tr_b16 per fragment part)
+// Both consume accumulator-layout operands (block b, register r of lane (m, q) = feature b*16 + 4q + r of edge m).
+#pragma once
+#include <cstring>
+
+#include "m3g_dual_image.h"
+#include "m3g_mfma_common.h"
+
+namespace m3g {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+using lds_s16x4_ptr = __attribute__((address_space(3))) s16x4*;
+
+__device__ __forceinline__ bf16x8 join_halves(s16x4 a, s16x4 b) {
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// rows [RB0*16, (RB0+OB)*16) of a ROWS-row image; x holds 64 input features in blocks XOFF .. XOFF+3
+template <int OB, int KS, int ROWS, int XOFF = 0, int AOFF = 0, int RB0 = 0, int NX, int NA>
+__device__ __forceinline__ void chain_dual(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
+  static_assert(KS == 2, "the image holds 64 input features");
+  static_assert(XOFF + 2 * KS <= NX && AOFF + OB <= NA && (RB0 + OB) * 16 <= ROWS, "chain_dual operand out of range");
+  const int m = lane & 15, q = lane >> 4, sw = dual_swz(m);
+  const char* base = reinterpret_cast<const char*>(img) + m * 128;
+  static_for<KS>([&]<int s>() {
+    bf16x8 bh, bl;
+    split8(x[XOFF + 2 * s], x[XOFF + 2 * s + 1], bh, bl);
+    const char* u0 = base + ((((2 * s) * 4 + q) ^ sw) << 3);
+    const char* u1 = base + ((((2 * s + 1) * 4 + q) ^ sw) << 3);
+    static_for<OB>([&]<int ob>() {
+      constexpr int roff = (RB0 + ob) * 2048, lo = ROWS * 128;
+      const bf16x8 ah = join_halves(*(const s16x4*)(u0 + roff), *(const s16x4*)(u1 + roff));
+      const bf16x8 al = join_halves(*(const s16x4*)(u0 + roff + lo), *(const s16x4*)(u1 + roff + lo));
+      acc[AOFF + ob] = mfma_bf16(ah, bh, acc[AOFF + ob]);
+      acc[AOFF + ob] = mfma_bf16(ah, bl, acc[AOFF + ob]);
+      acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
+    });
+  });
+}
+
+// transposed: d holds ROWS/16 blocks of output-feature gradients starting at block DOFF (KS = ROWS/32 k-steps);
+// acc[AOFF .. AOFF+3] receive the 64 input-feature gradients.  EXEC must be all ones (ds_read_b64_tr_b16).
+template <int OB, int KS, int ROWS, int DOFF = 0, int AOFF = 0, int KB0 = 0, int ND, int NA>
+__device__ __forceinline__ void chain_dual_t(const float* img, const f32x4 (&d)[ND], f32x4 (&acc)[NA], int lane) {
+  static_assert(OB == 4, "64 input features");
+  static_assert(DOFF + 2 * KS <= ND && AOFF + OB <= NA && (KB0 + 2 * KS) * 16 <= ROWS, "chain_dual_t operand out of range");
+  const int q = lane >> 4, qp = (lane & 15) >> 2, p = lane & 3;
+  const int row_lo = 4 * q + qp, sw = dual_swz(row_lo);
+  const char* base = reinterpret_cast<const char*>(img) + row_lo * 128;
+  static_for<KS>([&]<int s>() {
+    bf16x8 bh, bl;
+    split8(d[DOFF + 2 * s], d[DOFF + 2 * s + 1], bh, bl);
+    static_for<OB>([&]<int ob>() {
+      const char* u = base + (((4 * ob + p) ^ sw) << 3);
+      constexpr int r0 = (KB0 + 2 * s) * 2048, r1 = (KB0 + 2 * s + 1) * 2048, lo = ROWS * 128;
+      const bf16x8 ah = join_halves(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0)),
+                                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1)));
+      const bf16x8 al = join_halves(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0 + lo)),
+                                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1 + lo)));
+      acc[AOFF + ob] = mfma_bf16(ah, bh, acc[AOFF + ob]);
+      acc[AOFF + ob] = mfma_bf16(ah, bl, acc[AOFF + ob]);
+      acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
+    });
+  });
+}
+
+// host: img receives ROWS*64 floats (hi part, then lo part); get(row, col) with col < 64
+template <class F>
+inline void pack_dual_image(float* img, int rows, F get) {
+  auto rne = [](float w) {
+    uint32_t u;
+    memcpy(&u, &w, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto tof = [](uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  uint16_t* hi = reinterpret_cast<uint16_t*>(img);
+  uint16_t* lo = hi + (size_t)rows * 64;
+  for (int row = 0; row < rows; ++row)
+    for (int col = 0; col < 64; ++col) {
+      const float w = get(row, col);
+      const uint16_t h = rne(w);
+      const size_t idx = (size_t)(dual_unit_byte(row, col >> 2) >> 1) + (col & 3);
+      hi[idx] = h;
+      lo[idx] = rne(w - tof(h));
+    }
+}
+
+}  // namespace m3g

@@ -23,62 +23,22 @@
 
 #include "m3g_device.h"
 #include "m3g_internal.h"
+#include "m3g_dual_chain.h"
+#include "m3g_mfma_common.h"
 
 namespace m3g {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kFwdLdsFloats = 8 * kTbSteps * 64 + 2 * (8 * 4 * 4 * 64 + 2 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 64);
 constexpr int kRevMlpFloats = 8 * 4 * 4 * 64 + 4 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 8 * 4 * 64 + 64 * 4;   // node-MLP reverse image
 constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;                // + three-body images
 constexpr int kWaves = 16;      // forward kernel: 16 waves = 4 per SIMD (<= 128 VGPRs)
+constexpr int kWavesRevFused = 8;
 constexpr int kWavesRev = 12;   // reverse kernels hold layer-1 pre-activations across the recompute: 3 per SIMD (<= 168 VGPRs)
 constexpr int kTileEdges = 16;
 constexpr int kTileFloats = 4 * 64 * 4;     // one 64-feature tile image: [4 blk][64 lanes][4]
 // Nothing is saved for the reverse pass except the per-block edge-feature images and node tables: with the dense
 // chains on bf16x3 the matrix work is cheap, and recomputing both layers of both MLPs in the reverse kernels costs less
 // than streaming 2 KB of pre-activations per edge and block through HBM (measured history: DESIGN.md section 4).
-
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f.template operator()<I>(), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
-__device__ __forceinline__ float fsigmoid(float p) { return __builtin_amdgcn_rcpf(1.f + __expf(-p)); }
-__device__ __forceinline__ float fsilu(float p) { return p * fsigmoid(p); }
-__device__ __forceinline__ float fdsilu(float p) {
-  float s = fsigmoid(p);
-  return s * (1.f + p * (1.f - s));
-}
-
-// ---- the dense chains run on v_mfma_f32_16x16x32_bf16 with split operands ("bf16x3") ----------------------------
-// a = a_hi + a_lo (both bf16; the residual a - a_hi is formed exactly in fp32), a.b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi,
-// accumulated in fp32: 3 MFMAs at 16x the fp32-MFMA rate.  bf16 keeps the fp32 exponent range, which the tiny gradient
-// operands of the reverse pass need (f16 would flush them).  Parity effect (tools/split_precision_study.py, same
-// arithmetic emulated in the oracle): force error 1.1e-5 of max|F| vs 7e-6 for plain fp32 -- budget 1e-4.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-
-// B operand of one k-step (32 features = accumulator blocks a, b): element j < 4 from a, j >= 4 from b
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
-  static_for<4>([&]<int j>() {
-    hi[j] = (__bf16)a[j];
-    hi[4 + j] = (__bf16)b[j];
-  });
-  static_for<4>([&]<int j>() {
-    lo[j] = (__bf16)(a[j] - (float)hi[j]);
-    lo[4 + j] = (__bf16)(b[j] - (float)hi[4 + j]);
-  });
-}
 
 // acc[AOFF + ob] += W(ob-th 16-row block, :) . x[XOFF .. XOFF + 2*KS)   (chain image: m3g_pack_mfma.hip)
 template <int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
@@ -96,11 +56,6 @@ __device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f3
       acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
     });
   });
-}
-
-template <int N>
-__device__ __forceinline__ void zero(f32x4 (&v)[N]) {
-  static_for<N>([&]<int i>() { v[i] = f32x4{0.f, 0.f, 0.f, 0.f}; });
 }
 
 // bias as one k-step: A = bias image (lanes < 16 carry b[ob*16 + lane]), B = 1 on lane quarter 0
@@ -522,6 +477,162 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fused reverse
+// One kernel per block instead of the two above: with the dual-use weight images (m3g_dual_image.h: one LDS copy of
+// each matrix read by rows for the recompute and through ds_read_b64_tr_b16 for the transposed products) both MLPs'
+// weights fit in LDS together (150 KB), so a tile goes  e_in -> e1 (three-body update) -> e2 (edge MLP forward)
+// -> node-MLP reverse -> edge-MLP reverse -> three-body reverse  without leaving registers.  Against the split
+// kernels this drops the node->edge hand-over buffer (256 B written + read per edge), the second read of the edge
+// features, the second table gather, and one dh slice; block 0 also skips the dp1 rows nobody reads.
+constexpr int kRevFusedFloats = 8 * kTbSteps * 64 + 8 * 4 * 64 + 2 * (128 * 64 + 2 * 64 * 64 + 2 * 4 * 64 + 64 * 4);
+
+template <bool KEEP_P1>
+__device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlpFused& L, const f32x4 (&x)[4], f32x4 (&p1)[8],
+                                                 f32x4 (&p2)[8], int lane) {
+  chain_dual<8, 2, 128>(lds + L.w1c, x, p1, lane);
+  bias_step<4, 0>(lds + L.b2, p2, lane);
+  bias_step<4, 4>(lds + L.b2 + 4 * 64, p2, lane);
+  if (KEEP_P1) {
+    f32x4 hid[8];
+    static_for<8>([&]<int ob>() {
+      static_for<4>([&]<int r>() {
+        const float p = p1[ob][r], sg = fsigmoid(p);
+        hid[ob][r] = p * sg;
+        p1[ob][r] = sg * (1.f + p * (1.f - sg));
+      });
+    });
+    chain_dual<4, 2, 64, 0, 0>(lds + L.w2d, hid, p2, lane);
+    chain_dual<4, 2, 64, 4, 4>(lds + L.w2g, hid, p2, lane);
+  } else {
+    static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); }); });
+    chain_dual<4, 2, 64, 0, 0>(lds + L.w2d, p1, p2, lane);
+    chain_dual<4, 2, 64, 4, 4>(lds + L.w2g, p1, p2, lane);
+  }
+}
+
+// reverse of one conv GatedMLP at input tile x (recomputing both layers), dual-image version of mlp_reverse_mfma
+template <bool NEED_DP1>
+__device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlpFused& L, int mlp, const RevArgs& a, int64_t edge,
+                                                 int64_t ci, int64_t cj, const f32x4& hv, const f32x4 (&x)[4],
+                                                 const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane) {
+  const int qd = lane >> 4;
+  f32x4 p1[8], d2[8];
+  gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
+  mlp_preacts_dual<true>(lds, L, x, p1, d2, lane);
+  static_for<4>([&]<int ob>() {
+    static_for<4>([&]<int r>() {
+      const float p2d = d2[ob][r], p2g = d2[4 + ob][r];
+      const f32x4 w = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + r) * 4);
+      const float s_lin = w[0] * hv[0] + w[1] * hv[1] + w[2] * hv[2] + w[3] * hv[3];
+      const float sg = fsigmoid(p2g), sgd = fsigmoid(p2d), sd = p2d * sgd;
+      const float du = d_upd[ob][r];
+      const float d_out = du * s_lin, d_s = du * sd * sg;
+      dhv[0] += d_s * w[0]; dhv[1] += d_s * w[1]; dhv[2] += d_s * w[2]; dhv[3] += d_s * w[3];
+      d2[ob][r] = d_out * sg * (sgd * (1.f + p2d * (1.f - sgd)));
+      d2[4 + ob][r] = d_out * sd * sg * (1.f - sg);
+    });
+    asm volatile("" : "+v"(dhv[0]), "+v"(dhv[1]), "+v"(dhv[2]), "+v"(dhv[3]));   // see mlp_reverse_mfma
+  });
+  f32x4 dp1[8];
+  zero(dp1);
+  chain_dual_t<4, 2, 64, 0, 0>(lds + L.w2d, d2, dp1, lane);
+  chain_dual_t<4, 2, 64, 4, 4>(lds + L.w2g, d2, dp1, lane);
+  static_for<8>([&]<int ob>() { dp1[ob] *= p1[ob]; });
+  if (NEED_DP1 && edge < a.E) {
+    float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
+    static_for<8>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
+  }
+  zero(contrib);
+  chain_dual_t<4, 4, 128>(lds + L.w1c, dp1, contrib, lane);
+}
+
+template <int TBS, bool NEED_DP1, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRevFusedLayout L) {
+  __shared__ __attribute__((aligned(16))) float lds[kRevFusedFloats + 4];  // + tile-queue head
+  int* q_head = reinterpret_cast<int*>(lds + kRevFusedFloats);
+  load_image(lds, a.img, kRevFusedFloats, q_head);
+  const int lane = threadIdx.x & 63, qd = lane >> 4;
+  TileQueue queue(a.tiles, q_head);
+  int ticket = queue.fetch(lane);
+  if (ticket >= queue.count) return;
+  int ci_i, cj_i;
+  load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, ci_i, cj_i);
+  for (;;) {
+    const int64_t tile = queue.base + ticket;
+    ticket = queue.fetch(lane);  // next tile's ticket and end atoms one tile ahead (see the forward kernel)
+    const bool has_next = ticket < queue.count;
+    int nci = 0, ncj = 0;
+    if (has_next) load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
+    int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
+    asm volatile("" : "+v"(lv));
+    const int64_t edge = tile * kTileEdges + (lane & 15);
+    const int64_t ec = edge < a.E ? edge : a.E - 1;
+    const int64_t ci = ci_i, cj = cj_i;
+    float* de_tile = a.de_soa + tile * kTileFloats + lane * 4;
+    const float* e_tile = a.e_tile + tile * kTileFloats + lane * 4;
+    const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
+    f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
+    float mb[TBS];
+    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
+    f32x4 x[4], de[4], contrib[4];
+    static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+    {  // e1 = e_in + three-body gated update (the edge MLP's input)
+      f32x4 p[8];
+      tb_preact<TBS>(lds + L.tb, mb, p, lv);
+      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
+    }
+    {
+      f32x4 x2[4];
+      {  // e2 = e1 + edge MLP forward (the node MLP's input)
+        f32x4 p1[8], p2[8];
+        gather_tables(a.TA, a.TB, 0, ci, cj, qd, p1);
+        mlp_preacts_dual<false>(lds, L.mlp[0], x, p1, p2, lv);
+        static_for<4>([&]<int ob>() {
+          static_for<4>([&]<int r>() {
+            const f32x4 w = *(const f32x4*)(lds + L.mlp[0].wl + (ob * 16 + 4 * qd + r) * 4);
+            const float s_lin = w[0] * hv[0] + w[1] * hv[1] + w[2] * hv[2] + w[3] * hv[3];
+            x2[ob][r] = x[ob][r] + fsilu(p2[ob][r]) * fsigmoid(p2[4 + ob][r]) * s_lin;
+          });
+        });
+      }
+      // node-message MLP reverse: d msg[e] = dx_new[centre(e)]
+      f32x4 dmsg[4];
+      const float* xrow = a.dx_new + ci * kDP + 4 * qd;
+      static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
+      mlp_reverse_dual<NEED_DP1>(lds, L.mlp[1], 1, a, edge, ci, cj, hv, x2, dmsg, contrib, dhv, lv);
+    }
+    // dL/d e2 = what flows in from later blocks + the node MLP's contribution
+    if (a.de_is_zero) {
+      static_for<4>([&]<int blk>() { de[blk] = contrib[blk]; });
+    } else {
+      static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + contrib[blk]; });
+    }
+    mlp_reverse_dual<NEED_DP1>(lds, L.mlp[0], 0, a, edge, ci, cj, hv, x, de, contrib, dhv, lv);
+    static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
+      de[blk] += contrib[blk];
+      *(f32x4*)(de_tile + blk * 256) = de[blk];
+    });
+    // three-body gated update, reverse
+    f32x4 d8[8];
+    tb_preact<TBS>(lds + L.tb, mb, d8, lv);
+    static_for<4>([&]<int blk>() {
+      static_for<4>([&]<int r>() {
+        const float p = d8[blk][r], sgd = fsigmoid(p), sg = fsigmoid(d8[4 + blk][r]);
+        d8[blk][r] = de[blk][r] * sg * (sgd * (1.f + p * (1.f - sgd)));
+        d8[4 + blk][r] = de[blk][r] * (p * sgd) * sg * (1.f - sg);
+      });
+    });
+    f32x4 dmv[1];
+    zero(dmv);
+    chain<1, 4>(lds + L.tbT, d8, dmv, lv);
+    store_dh(a.dh, edge, a.E, dhv, qd);
+    if (edge < a.E) *(f32x4*)(a.dm + edge * kCP + 4 * qd) = dmv[0];
+    if (!has_next) break;
+    ci_i = nci;
+    cj_i = ncj;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- helpers
 // tile-SoA element index of (edge, feature)
 __device__ __forceinline__ int64_t soa_index(int64_t edge, int o) {
@@ -696,6 +807,23 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
     return;
   }
   M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS>), grid, block, 0, s, ae, L));
+}
+
+void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
+                           bool de_is_zero, hipStream_t s) {
+  const int64_t tiles = tiles_for(t.E);
+  if (tiles == 0) return;
+  const MfmaRevFusedLayout L = mfma_rev_fused_layout();
+  const float* img = plan->d_mfma_revf + (size_t)b * L.total;
+  RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], w.de_soa, nullptr,
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr};
+  constexpr int WV = kWavesRevFused;
+  dim3 grid(grid_for_tiles(tiles)), block(64 * WV);
+  if (b > 0) {
+    M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_fused<TBS, true, WV>), grid, block, 0, s, ar, L));
+  } else {   // x^0 has no position dependence: nobody reads block 0's dp1 rows
+    M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_fused<TBS, false, WV>), grid, block, 0, s, ar, L));
+  }
 }
 
 }  // namespace m3g

@@ -116,8 +116,23 @@ struct MfmaRevLayout {
   int total_e;      // edge-MLP image size (MLP part + tb + tbT)
   int per_block;    // total_e + total_n; block b: [edge image | node image]
 };
+// fused reverse kernel (one per block): dual-use images (m3g_dual_image.h) serve the recompute and the transposed
+// products from one LDS copy, so both MLPs fit together
+struct MfmaMlpFused {
+  int w1c;        // dual image, 128 rows (dense 0-63 | gate 64-127 layer-1 outputs) x 64 edge features
+  int w2d, w2g;   // dual images, 64 x 64
+  int b2;         // bias images (as the forward kernel's)
+  int wl;         // [64][4] plain
+};
+struct MfmaRevFusedLayout {
+  int tb;    // direct three-body image (forward recompute)
+  int tbT;   // chain [1][8] rows: c
+  MfmaMlpFused mlp[2];   // 0: edge update, 1: node message
+  int total;
+};
 MfmaFwdLayout mfma_fwd_layout();
 MfmaRevLayout mfma_rev_layout();
+MfmaRevFusedLayout mfma_rev_fused_layout();
 
 }  // namespace m3g
 
@@ -130,6 +145,8 @@ struct m3g_plan {
   float* d_weights = nullptr;
   float* d_mfma_fwd = nullptr;   // [num_blocks][MfmaFwdLayout.total]
   float* d_mfma_rev = nullptr;   // [num_blocks][MfmaRevLayout.total]
+  float* d_mfma_revf = nullptr;  // [num_blocks][MfmaRevFusedLayout.total]
+  int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
   int stamp_target = 0;          // which kernel runs its stamped variant: 0 forward edge block, 1 reverse edge-MLP kernel
@@ -239,6 +256,8 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
                               hipStream_t s);
 void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
                               bool de_is_zero, hipStream_t s);
+void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
+                           bool de_is_zero, hipStream_t s);
 void launch_embed_edges_soa(const Consts& c, const float* adj_t, const float* h, float* soa, int64_t E, hipStream_t s);
 void launch_embed_edges_reverse_soa(const float* adj, const float* h, const float* de_soa, float* dh_slice, int64_t E, hipStream_t s);
 void launch_embed_nodes_only(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,

@@ -1,0 +1,58 @@
+// Shared device helpers of the MFMA edge kernels: vector types, compile-time loops, activation derivatives and the
+// bf16x3 operand split.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+namespace m3g {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f.template operator()<I>(), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ float fsigmoid(float p) { return __builtin_amdgcn_rcpf(1.f + __expf(-p)); }
+__device__ __forceinline__ float fsilu(float p) { return p * fsigmoid(p); }
+__device__ __forceinline__ float fdsilu(float p) {
+  float s = fsigmoid(p);
+  return s * (1.f + p * (1.f - s));
+}
+
+// ---- the dense chains run on v_mfma_f32_16x16x32_bf16 with split operands ("bf16x3") ----------------------------
+// a = a_hi + a_lo (both bf16; the residual a - a_hi is formed exactly in fp32), a.b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi,
+// accumulated in fp32: 3 MFMAs at 16x the fp32-MFMA rate.  bf16 keeps the fp32 exponent range, which the tiny gradient
+// operands of the reverse pass need (f16 would flush them).  Parity effect (tools/split_precision_study.py, same
+// arithmetic emulated in the oracle): force error 1.1e-5 of max|F| vs 7e-6 for plain fp32 -- budget 1e-4.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// B operand of one k-step (32 features = accumulator blocks a, b): element j < 4 from a, j >= 4 from b
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+  static_for<4>([&]<int j>() {
+    hi[j] = (__bf16)a[j];
+    hi[4 + j] = (__bf16)b[j];
+  });
+  static_for<4>([&]<int j>() {
+    lo[j] = (__bf16)(a[j] - (float)hi[j]);
+    lo[4 + j] = (__bf16)(b[j] - (float)hi[4 + j]);
+  });
+}
+
+template <int N>
+__device__ __forceinline__ void zero(f32x4 (&v)[N]) {
+  static_for<N>([&]<int i>() { v[i] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+}
+
+}  // namespace m3g

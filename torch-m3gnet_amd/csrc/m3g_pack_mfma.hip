@@ -3,6 +3,7 @@
 // entries of ThreeBodyInteration.gated_mlp (nn/interaction.py:180-185) and of M3GNetConv (nn/conv.py:39-61).
 #include <cstring>
 
+#include "m3g_dual_chain.h"
 #include "m3g_internal.h"
 
 namespace m3g {
@@ -41,6 +42,23 @@ MfmaRevLayout mfma_rev_layout() {
   L.tbT = take(1 * 8 * 4 * 64);
   L.total_e = off;
   L.per_block = L.total_e + L.total_n;
+  return L;
+}
+
+MfmaRevFusedLayout mfma_rev_fused_layout() {
+  MfmaRevFusedLayout L{};
+  int off = 0;
+  auto take = [&](int n) { int r = off; off += n; return r; };
+  L.tb = take(8 * kTbSteps * 64);
+  L.tbT = take(1 * 8 * 4 * 64);
+  for (int m = 0; m < 2; ++m) {
+    L.mlp[m].w1c = take(128 * 64);
+    L.mlp[m].w2d = take(64 * 64);
+    L.mlp[m].w2g = take(64 * 64);
+    L.mlp[m].b2 = take(2 * 4 * 64);
+    L.mlp[m].wl = take(64 * 4);
+  }
+  L.total = off;
   return L;
 }
 
@@ -92,7 +110,9 @@ int pack_mfma_images(m3g_plan* plan) {
   const int D = cfg.embedding_dim, R = cfg.n_max, C = cfg.l_max * cfg.n_max, B = cfg.num_blocks;
   const MfmaFwdLayout F = mfma_fwd_layout();
   const MfmaRevLayout Rv = mfma_rev_layout();
-  std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.per_block, 0.f);
+  const MfmaRevFusedLayout Rf = mfma_rev_fused_layout();
+  std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.per_block, 0.f),
+      revf((size_t)std::max(B, 1) * Rf.total, 0.f);
   for (int b = 0; b < B; ++b) {
     float* f = fwd.data() + (size_t)b * F.total;
     float* r = rev.data() + (size_t)b * Rv.per_block;  // [edge-MLP image | node-MLP image]
@@ -107,12 +127,15 @@ int pack_mfma_images(m3g_plan* plan) {
     };
     direct_image(f + F.tb, 8, kTbSteps, tbw);
     direct_image(r + Rv.tb, 8, kTbSteps, tbw);
+    float* rf = revf.data() + (size_t)b * Rf.total;
+    direct_image(rf + Rf.tb, 8, kTbSteps, tbw);
     // reverse three-body: rows = c (16), k = 0..127 over (dense f | gate f)
     chain_image(r + Rv.tbT, 1, 4, [&](int row, int k) -> float {
       const float* w = k < 64 ? wd : wg;
       int o = k & 63;
       return (row < C && o < D) ? w[(size_t)o * C + row] : 0.f;
     });
+    memcpy(rf + Rf.tbT, r + Rv.tbT, sizeof(float) * 8 * 4 * 64);
     const char* mlps[2] = {".concat_edge_update", ".concat_node_update"};
     const char* lins[2] = {".edge_linear.weight", ".node_linear.weight"};
     for (int m = 0; m < 2; ++m) {
@@ -156,10 +179,19 @@ int pack_mfma_images(m3g_plan* plan) {
       chain_image(rm + Rv.mlp.w1cT, 4, 4, [&](int row, int k) -> float { return w1c(k, row); });
       for (int o = 0; o < 64; ++o)
         for (int rr = 0; rr < 4; ++rr) rm[Rv.mlp.wl + o * 4 + rr] = (o < D && rr < R) ? wl[(size_t)o * R + rr] : 0.f;
+      // fused reverse kernel: one dual-use image per matrix
+      pack_dual_image(rf + Rf.mlp[m].w1c, 128, w1c);
+      pack_dual_image(rf + Rf.mlp[m].w2d, 64, sq(w2d));
+      pack_dual_image(rf + Rf.mlp[m].w2g, 64, sq(w2g));
+      bias_image(rf + Rf.mlp[m].b2);
+      memcpy(rf + Rf.mlp[m].wl, rm + Rv.mlp.wl, sizeof(float) * 64 * 4);
     }
   }
   if (plan->d_mfma_fwd) { (void)hipFree(plan->d_mfma_fwd); plan->d_mfma_fwd = nullptr; }
   if (plan->d_mfma_rev) { (void)hipFree(plan->d_mfma_rev); plan->d_mfma_rev = nullptr; }
+  if (plan->d_mfma_revf) { (void)hipFree(plan->d_mfma_revf); plan->d_mfma_revf = nullptr; }
+  M3G_HIP_CHECK(hipMalloc((void**)&plan->d_mfma_revf, revf.size() * sizeof(float)));
+  M3G_HIP_CHECK(hipMemcpy(plan->d_mfma_revf, revf.data(), revf.size() * sizeof(float), hipMemcpyHostToDevice));
   M3G_HIP_CHECK(hipMalloc((void**)&plan->d_mfma_fwd, fwd.size() * sizeof(float)));
   M3G_HIP_CHECK(hipMalloc((void**)&plan->d_mfma_rev, rev.size() * sizeof(float)));
   M3G_HIP_CHECK(hipMemcpy(plan->d_mfma_fwd, fwd.data(), fwd.size() * sizeof(float), hipMemcpyHostToDevice));
