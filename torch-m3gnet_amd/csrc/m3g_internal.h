@@ -162,6 +162,7 @@ struct m3g_plan {
 namespace m3g {
 
 // ---- topology view (device arrays carved from the caller's topo buffer) -----------------------------
+constexpr int kTbRows = 128;   // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
 struct Topo {
   int64_t N, E, T, S;
   int32_t* src;      // [E] centre of each edge
@@ -173,8 +174,19 @@ struct Topo {
   int32_t* t1_e2;    // [T]
   int32_t* t2_ptr;   // [E+1] triplets grouped by second edge e2
   int32_t* t2_e1;    // [T]
+  // "active" edges = edges that take part in at least one triplet (d <= three-body cutoff and a partner exists); the
+  // three-body kernels run over this compacted list so no lane idles on the edges beyond the three-body cutoff
+  int32_t* act_list;   // [A] active edge ids, ascending
+  int32_t* act_scan;   // [E+1] number of active edges before e (compacted id of e when e is active)
+  int32_t* arow_ptr;   // [N+1] compacted rows of centre i: arow_ptr[i] .. arow_ptr[i+1]
+  int32_t* t1_e2c;     // [T] t1_e2 in compacted ids
+  int32_t* t2_e1c;     // [T] t2_e1 in compacted ids
+  int32_t* act_dst;    // [A] neighbour atom of each active edge (saves a dependent load when staging)
+  int32_t* tb_win;     // [6 * blocks] per three-body workgroup: compacted-row window [lo, hi) staged in LDS, then the
+                       // ranges [t_lo, t_hi) of its rows' partner lists in t1_e2c and in t2_e1c
+  int32_t* n_act;      // device scalar A (= flags + 2)
   int32_t* batch;    // [N]
-  int32_t* flags;    // [4] malformed-graph flags
+  int32_t* flags;    // [4] malformed-graph flags; [2] = A
   void* sort_tmp;    // scratch for the radix sorts
   size_t sort_tmp_bytes;
   size_t total_bytes;

@@ -6,8 +6,10 @@
 //
 // Triplets are CSR-grouped by e1 (forward, and the e1 half of the reverse) and by e2 (the e2 half of the
 // reverse), so every sum is a private register accumulation -- no atomics, run-to-run reproducible.
-// One thread per edge row, 256 consecutive rows per workgroup.  The partners of those rows are edges of the
-// same centre atoms, i.e. one contiguous window of the centre-sorted edge list: the workgroup stages that
+// Rows are the ACTIVE edges only (edges inside the three-body cutoff that have a partner; Topo::act_list): with
+// r_c = 5 / r_3 = 4 on fcc Cu 24 of an atom's 42 edges carry no triplet, and a thread per edge left 57 % of the
+// lanes idle.  One thread per active row, 256 consecutive rows per workgroup.  The partners of those rows are
+// active edges of the same centre atoms, i.e. one contiguous window of the compacted list: the workgroup stages that
 // window's unit vectors and per-edge payload rows (g = q*v[dst] for the forward / e1 half, dS = fc*dm for the e2
 // half) in LDS once -- the per-atom triplet tile -- and the triplet loops read LDS instead of gathering from
 // L2.  Partners outside the staged window (only possible for degrees beyond the LDS budget) fall back to global
@@ -16,8 +18,8 @@
 
 namespace m3g {
 
-constexpr int kTbRows = 256;   // edge rows per workgroup
-constexpr int kTbCap = 384;    // staged window capacity in edges: 256 rows + boundary rows (overflow -> global reads); 18 KB -> 8 WGs per CU
+constexpr int kTbListCap = 3072;   // staged partner ids (128 rows x 24 partners; longer lists continue from global memory)
+constexpr int kTbCap = 192;    // staged window capacity: kTbRows (128) rows + boundary rows (overflow -> global reads); 9 KB per workgroup
 
 template <int L>
 __device__ __forceinline__ void legendre(float x, float* P, float* dP) {
@@ -32,23 +34,22 @@ __device__ __forceinline__ void legendre(float x, float* P, float* dP) {
 
 struct TbArgs {
   int64_t E;
-  const int32_t *src, *dst, *row_ptr;
-  const int32_t *t_ptr, *t_other;     // triplet CSR of this pass (by e1: partner = e2; by e2: partner = e1)
+  const int32_t *act_list, *act_dst, *tb_win, *n_act;
+  const int32_t *t_ptr, *t_other;     // triplet CSR of this pass (by e1: partner = e2; by e2: partner = e1), partners as compacted ids
   const float *u, *fc3, *fc3p, *q, *qp, *v;
   const float* dm;                    // reverse: dL/dm [E][kCP]
   float* m;                           // forward out [E][kCP]
   float *dd, *du, *dgq;               // reverse in/out
 };
 
-// payload of edge e for this pass: MODE 0/1 -> g[e,:] = q*v[dst];  MODE 2 -> dS[e,:] = fc3*dm
+// payload of edge e (neighbour atom k) for this pass: MODE 0/1 -> g[e,:] = q*v[k];  MODE 2 -> dS[e,:] = fc3*dm
 template <int C, int MODE>
-__device__ __forceinline__ void payload(const TbArgs& a, int64_t e, float* out) {
+__device__ __forceinline__ void payload(const TbArgs& a, int64_t e, int64_t k, float* out) {
   if (MODE == 2) {
     const float f = a.fc3[e];
 #pragma unroll
     for (int c = 0; c < C; ++c) out[c] = f * a.dm[e * kCP + c];
   } else {
-    const int64_t k = a.dst[e];
 #pragma unroll
     for (int c = 0; c < C; ++c) out[c] = a.q[e * kCP + c] * a.v[k * kCP + c];
   }
@@ -60,47 +61,82 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_tile(Consts c, TbArgs a) 
   constexpr int C = L * R;
   __shared__ float su[kTbCap * 3];
   __shared__ float sp[kTbCap * C];
-  const int64_t eb = (int64_t)blockIdx.x * kTbRows;
-  const int64_t elast = (eb + kTbRows - 1 < a.E ? eb + kTbRows - 1 : a.E - 1);
-  const int lo = a.row_ptr[a.src[eb]];
-  const int hi_full = a.row_ptr[a.src[elast] + 1];
+  // independent first-level loads: A, this workgroup's window, this thread's row
+  const int A = *a.n_act;
+  const int rb = blockIdx.x * kTbRows;
+  if (rb >= A) return;                       // the grid is sized for the worst case A = E
+  __shared__ int s_other[kTbListCap];
+  const int lo = a.tb_win[6 * blockIdx.x];
+  const int hi_full = a.tb_win[6 * blockIdx.x + 1];
+  const int t_lo = a.tb_win[6 * blockIdx.x + (MODE == 2 ? 4 : 2)];
+  const int t_hi = a.tb_win[6 * blockIdx.x + (MODE == 2 ? 5 : 3)];
+  // the rows' partner lists are one contiguous range of t_other: staged once, coalesced, as window-relative ids --
+  // a global load per triplet inside the loop serialises ~17 L2 round trips per thread
+  const int n_list = (t_hi - t_lo) < kTbListCap ? (t_hi - t_lo) : kTbListCap;
+  for (int k = threadIdx.x; k < n_list; k += kTbRows) s_other[k] = a.t_other[t_lo + k] - lo;
+  const int r = rb + threadIdx.x;
+  const bool live = r < A;
+  const int64_t e = a.act_list[live ? r : A - 1];
+  const int64_t e_next = r + 1 < A ? a.act_list[live ? r + 1 : A - 1] : a.E;
+  const int64_t kd = a.act_dst[live ? r : A - 1];
   const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
   for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
-    const int64_t e = lo + idx;
-    su[idx * 3 + 0] = a.u[e * 3];
-    su[idx * 3 + 1] = a.u[e * 3 + 1];
-    su[idx * 3 + 2] = a.u[e * 3 + 2];
+    const int64_t es = a.act_list[lo + idx];
+    su[idx * 3 + 0] = a.u[es * 3];
+    su[idx * 3 + 1] = a.u[es * 3 + 1];
+    su[idx * 3 + 2] = a.u[es * 3 + 2];
     float row[C];
-    payload<C, MODE>(a, e, row);
+    payload<C, MODE>(a, es, a.act_dst[lo + idx], row);
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) sp[idx * C + cc] = row[cc];
   }
-  __syncthreads();
-  const int64_t e = eb + threadIdx.x;
-  if (e >= a.E) return;
+  // edges without triplets keep m = 0 (MODE 0) / dg = 0 (MODE 2): every thread clears the gap after its own row
+  // (and the first row the edges before it), so no separate memset pass over the [E,16] arrays is needed
+  if (MODE != 1 && live) {
+    float* z = MODE == 0 ? a.m : a.dgq;
+    for (int64_t g = (r == 0 ? 0 : e + 1); g < e_next; ++g) {
+      if (g == e) continue;
+#pragma unroll
+      for (int k = 0; k < kCP; k += 4) *(float4*)(z + g * kCP + k) = float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // everything this row needs from global memory is requested before the barrier, so the triplet loop and the
+  // epilogue wait on nothing but LDS (the pointers are not restrict: loads placed after the stores would stay there)
   const int t0 = a.t_ptr[e], t1 = a.t_ptr[e + 1];
   const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
-  float acc[C], own[C];
-#pragma unroll
-  for (int k = 0; k < C; ++k) acc[k] = 0.f;
+  const float fc = a.fc3[e];
+  float own[C], qv[C], qpv[C], vv[C];
+  float fcp = 0.f, dd0 = 0.f, du0 = 0.f, du1 = 0.f, du2 = 0.f;
+  if (MODE != 0) { dd0 = a.dd[e]; du0 = a.du[e * 3]; du1 = a.du[e * 3 + 1]; du2 = a.du[e * 3 + 2]; }
   if (MODE == 1) {
+    fcp = a.fc3p[e];
 #pragma unroll
     for (int k = 0; k < C; ++k) own[k] = a.dm[e * kCP + k];           // dm of this e1
   } else if (MODE == 2) {
-    payload<C, 0>(a, e, own);                                         // g of this e2
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      qv[k] = a.q[e * kCP + k]; qpv[k] = a.qp[e * kCP + k]; vv[k] = a.v[kd * kCP + k];
+      own[k] = qv[k] * vv[k];                                         // g of this e2
+    }
   }
+  __syncthreads();
+  if (!live) return;
+  float acc[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) acc[k] = 0.f;
   float ax = 0.f, ay = 0.f, az = 0.f;
   for (int t = t0; t < t1; ++t) {
-    const int eo = a.t_other[t];
-    const int idx = eo - lo;
+    const int kk = t - t_lo;
+    const int idx = kk < kTbListCap ? s_other[kk] : a.t_other[t] - lo;
     float vx, vy, vz, pr[C];
     if (idx >= 0 && idx < n) {
       vx = su[idx * 3]; vy = su[idx * 3 + 1]; vz = su[idx * 3 + 2];
 #pragma unroll
       for (int k = 0; k < C; ++k) pr[k] = sp[idx * C + k];
     } else {
-      vx = a.u[(int64_t)eo * 3]; vy = a.u[(int64_t)eo * 3 + 1]; vz = a.u[(int64_t)eo * 3 + 2];
-      payload<C, MODE>(a, eo, pr);
+      const int64_t eo = a.act_list[lo + idx];
+      vx = a.u[eo * 3]; vy = a.u[eo * 3 + 1]; vz = a.u[eo * 3 + 2];
+      payload<C, MODE>(a, eo, a.act_dst[lo + idx], pr);
     }
     const float raw = ux * vx + uy * vy + uz * vz;
     const float cs = fminf(1.f, fmaxf(-1.f, raw));
@@ -136,32 +172,36 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_tile(Consts c, TbArgs a) 
     }
   }
   if (MODE == 0) {
-    const float f = a.fc3[e];
 #pragma unroll
-    for (int k = 0; k < kCP; ++k) a.m[e * kCP + k] = k < C ? f * acc[k < C ? k : 0] : 0.f;
+    for (int k = 0; k < kCP; k += 4) {
+      float4 o;
+      o.x = k + 0 < C ? fc * acc[k + 0 < C ? k + 0 : 0] : 0.f;
+      o.y = k + 1 < C ? fc * acc[k + 1 < C ? k + 1 : 0] : 0.f;
+      o.z = k + 2 < C ? fc * acc[k + 2 < C ? k + 2 : 0] : 0.f;
+      o.w = k + 3 < C ? fc * acc[k + 3 < C ? k + 3 : 0] : 0.f;
+      *(float4*)(a.m + e * kCP + k) = o;
+    }
   } else if (MODE == 1) {
-    if (t0 == t1) return;
-    const float f = a.fc3[e];
     float dfc = 0.f;
 #pragma unroll
     for (int k = 0; k < C; ++k) dfc += own[k] * acc[k];               // acc = S[e1,:]
-    a.dd[e] += a.fc3p[e] * dfc;
-    a.du[e * 3] += f * ax; a.du[e * 3 + 1] += f * ay; a.du[e * 3 + 2] += f * az;   // dS = fc * dm
+    a.dd[e] = dd0 + fcp * dfc;
+    a.du[e * 3] = du0 + fc * ax; a.du[e * 3 + 1] = du1 + fc * ay; a.du[e * 3 + 2] = du2 + fc * az;   // dS = fc * dm
   } else {
-    if (t0 != t1) { a.du[e * 3] += ax; a.du[e * 3 + 1] += ay; a.du[e * 3 + 2] += az; }
-    const int64_t k = a.dst[e];
-    float ddv = 0.f;
+    a.du[e * 3] = du0 + ax; a.du[e * 3 + 1] = du1 + ay; a.du[e * 3 + 2] = du2 + az;
+    float ddv = 0.f, val[kCP];
 #pragma unroll
     for (int cc = 0; cc < kCP; ++cc) {
-      float val = 0.f;
+      val[cc] = 0.f;
       if (cc < C) {
         const float dg = acc[cc < C ? cc : 0];                         // acc = dg[e2,:]
-        ddv += dg * a.v[k * kCP + cc] * a.qp[e * kCP + cc];
-        val = dg * a.q[e * kCP + cc];
+        ddv += dg * vv[cc < C ? cc : 0] * qpv[cc < C ? cc : 0];
+        val[cc] = dg * qv[cc < C ? cc : 0];
       }
-      a.dgq[e * kCP + cc] = val;
     }
-    if (t0 != t1) a.dd[e] += ddv;
+#pragma unroll
+    for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + e * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
+    a.dd[e] = dd0 + ddv;
   }
 }
 
@@ -190,16 +230,20 @@ static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 
 
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s) {
   if (t.E == 0) return;
-  TbArgs a{t.E, t.src, t.dst, t.row_ptr, t.t1_ptr, t.t1_e2, w.u, w.fc3, w.fc3p, w.q, w.qp, v, nullptr, m, nullptr, nullptr, nullptr};
+  if (t.T == 0) { (void)hipMemsetAsync(m, 0, sizeof(float) * t.E * kCP, s); return; }   // no active row to clear the gaps
+  TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, w.u, w.fc3, w.fc3p, w.q, w.qp, v, nullptr, m, nullptr,
+           nullptr, nullptr};
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_tile<L, R, 0>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }
 
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s) {
   if (t.E == 0) return;
-  TbArgs a1{t.E, t.src, t.dst, t.row_ptr, t.t1_ptr, t.t1_e2, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd, w.du, w.dg};
+  if (t.T == 0) { (void)hipMemsetAsync(w.dg, 0, sizeof(float) * t.E * kCP, s); return; }
+  TbArgs a1{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd,
+            w.du, w.dg};
   TbArgs a2 = a1;
   a2.t_ptr = t.t2_ptr;
-  a2.t_other = t.t2_e1;
+  a2.t_other = t.t2_e1c;
   M3G_DISPATCH_LR(c.L, c.R, {
     hipLaunchKernelGGL((k_threebody_tile<L, R, 1>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a1);
     hipLaunchKernelGGL((k_threebody_tile<L, R, 2>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a2);

@@ -18,9 +18,10 @@ static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a
 
 size_t topo_sort_tmp_bytes(int64_t E, int64_t T) {
   size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
-  size_t cub = 0;
+  size_t cub = 0, scan = 0;
   (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)m, 0, 64, 0);
-  return align_up(cub) + 2 * align_up(m * sizeof(uint64_t));
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(E + 1));
+  return align_up(std::max(cub, scan)) + 2 * align_up(m * sizeof(uint64_t));
 }
 
 Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
@@ -38,8 +39,16 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   t.t1_e2 = (int32_t*)take(sizeof(int32_t) * (T + 1));
   t.t2_ptr = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.t2_e1 = (int32_t*)take(sizeof(int32_t) * (T + 1));
+  t.act_list = (int32_t*)take(sizeof(int32_t) * (E + 1));
+  t.act_scan = (int32_t*)take(sizeof(int32_t) * (E + 2));
+  t.arow_ptr = (int32_t*)take(sizeof(int32_t) * (N + 2));
+  t.act_dst = (int32_t*)take(sizeof(int32_t) * (E + 1));
+  t.tb_win = (int32_t*)take(sizeof(int32_t) * 6 * (E / kTbRows + 2));
+  t.t1_e2c = (int32_t*)take(sizeof(int32_t) * (T + 1));
+  t.t2_e1c = (int32_t*)take(sizeof(int32_t) * (T + 1));
   t.batch = (int32_t*)take(sizeof(int32_t) * (N + 1));
   t.flags = (int32_t*)take(sizeof(int32_t) * 4);
+  t.n_act = t.flags ? t.flags + 2 : nullptr;
   t.sort_tmp_bytes = topo_sort_tmp_bytes(E, T);
   t.sort_tmp = take(t.sort_tmp_bytes);
   t.total_bytes = off;
@@ -106,6 +115,46 @@ __global__ void k_low_word(int64_t n, const uint64_t* __restrict__ keys, int32_t
   if (i < n) out[i] = (int32_t)(keys[i] & 0xffffffffu);
 }
 
+// active-edge compaction: flag -> exclusive scan -> scatter; compacted row pointers and partner lists
+__global__ void k_active_flags(int64_t E, const int32_t* __restrict__ t1_ptr, int32_t* flag) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e <= E) flag[e] = e < E && t1_ptr[e + 1] > t1_ptr[e] ? 1 : 0;
+}
+__global__ void k_active_scatter(int64_t N, int64_t E, const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ scan,
+                                 const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst, int32_t* act_list,
+                                 int32_t* act_dst, int32_t* arow_ptr, int32_t* n_act) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e < E && t1_ptr[e + 1] > t1_ptr[e]) { act_list[scan[e]] = (int32_t)e; act_dst[scan[e]] = dst[e]; }
+  if (e <= N) arow_ptr[e] = scan[row_ptr[e]];
+  if (e == 0) *n_act = scan[E];
+}
+// window of compacted rows (all active edges of the centres touched) per three-body workgroup
+__global__ void k_tb_windows(int64_t blocks, const int32_t* __restrict__ n_act, const int32_t* __restrict__ act_list,
+                             const int32_t* __restrict__ src, const int32_t* __restrict__ arow_ptr,
+                             const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ t2_ptr, int32_t* win) {
+  int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= blocks) return;
+  const int A = *n_act;
+  const int64_t rb = b * kTbRows;
+  int w[6] = {0, 0, 0, 0, 0, 0};
+  if (rb < A) {
+    const int64_t rlast = rb + kTbRows - 1 < A ? rb + kTbRows - 1 : A - 1;
+    const int ef = act_list[rb], el = act_list[rlast];
+    w[0] = arow_ptr[src[ef]];
+    w[1] = arow_ptr[src[el] + 1];
+    w[2] = t1_ptr[ef]; w[3] = t1_ptr[el + 1];
+    w[4] = t2_ptr[ef]; w[5] = t2_ptr[el + 1];
+  }
+  for (int k = 0; k < 6; ++k) win[6 * b + k] = w[k];
+}
+__global__ void k_compact_partners(int64_t T, const int32_t* __restrict__ scan, const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                   int32_t* ac, int32_t* bc) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  ac[t] = scan[a[t]];
+  bc[t] = scan[b[t]];
+}
+
 static inline int bits_for(int64_t n) {
   int b = 1;
   while ((int64_t(1) << b) < n) ++b;
@@ -164,6 +213,14 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
     }
     hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, keysB, ptr);
   }
+  // compaction of the edges that take part in triplets (act_scan doubles as the flag array before the scan)
+  hipLaunchKernelGGL(k_active_flags, grid(E + 1), dim3(TPB), 0, s, E, t.t1_ptr, t.act_scan);
+  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, t.act_scan, t.act_scan, (int)(E + 1), s));
+  hipLaunchKernelGGL(k_active_scatter, grid(std::max(E, N) + 1), dim3(TPB), 0, s, N, E, t.t1_ptr, t.act_scan, t.row_ptr, t.dst, t.act_list,
+                     t.act_dst, t.arow_ptr, t.n_act);
+  hipLaunchKernelGGL(k_tb_windows, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t2_ptr,
+                     t.tb_win);
+  if (T > 0) hipLaunchKernelGGL(k_compact_partners, grid(T), dim3(TPB), 0, s, T, t.act_scan, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c);
   M3G_HIP_CHECK(hipGetLastError());
   if (host_flags) {
     M3G_HIP_CHECK(hipMemcpyAsync(host_flags, t.flags, sizeof(int32_t), hipMemcpyDeviceToHost, s));
