@@ -32,7 +32,10 @@ constexpr int kFwdLdsFloats = 8 * kTbSteps * 64 + 2 * (8 * 4 * 4 * 64 + 2 * (4 *
 constexpr int kRevMlpFloats = 8 * 4 * 4 * 64 + 4 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 8 * 4 * 64 + 64 * 4;   // node-MLP reverse image
 constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;                // + three-body images
 constexpr int kWaves = 16;      // forward kernel: 16 waves = 4 per SIMD (<= 128 VGPRs)
-constexpr int kWavesRevFused = 8;
+#ifndef M3G_WAVES_REV_FUSED
+#define M3G_WAVES_REV_FUSED 8   // 2 waves per SIMD, 256 VGPRs, no spills (12 waves: 168 VGPRs and ~120 spilled, slower)
+#endif
+constexpr int kWavesRevFused = M3G_WAVES_REV_FUSED;
 constexpr int kWavesRev = 12;   // reverse kernels hold layer-1 pre-activations across the recompute: 3 per SIMD (<= 168 VGPRs)
 constexpr int kTileEdges = 16;
 constexpr int kTileFloats = 4 * 64 * 4;     // one 64-feature tile image: [4 blk][64 lanes][4]
@@ -280,7 +283,8 @@ struct RevArgs {
   const float *h, *m, *dx_new;
   const float *TA, *TB;   // node tables of this block
   const float* e_tile;    // node kernel: edge features AFTER the block (input of the node MLP);
-                          // edge kernel: edge features BEFORE the block (three-body update + edge MLP are recomputed)
+                          // edge / fused kernel: edge features BEFORE the block (three-body update + edge MLP are recomputed)
+  const float* e2_tile;   // fused kernel: edge features AFTER the block
   float* de_soa;   // edge kernel: in dL/d e after this block (unless de_is_zero), out dL/d e before this block
   float* dcn;      // node kernel -> edge kernel: the node MLP's contribution to dL/d e2 (tile-SoA)
   int de_is_zero;  // last block: nothing flows in from later blocks
@@ -481,7 +485,8 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
 // One kernel per block instead of the two above: with the dual-use weight images (m3g_dual_image.h: one LDS copy of
 // each matrix read by rows for the recompute and through ds_read_b64_tr_b16 for the transposed products) both MLPs'
 // weights fit in LDS together (150 KB), so a tile goes  e_in -> e1 (three-body update) -> e2 (edge MLP forward)
-// -> node-MLP reverse -> edge-MLP reverse -> three-body reverse  without leaving registers.  Against the split
+// -> node-MLP reverse -> edge-MLP reverse -> three-body reverse  without leaving registers (e2 itself is read back
+// from the forward pass's output image rather than evaluated a second time).  Against the split
 // kernels this drops the node->edge hand-over buffer (256 B written + read per edge), the second read of the edge
 // features, the second table gather, and one dh slice; block 0 also skips the dp1 rows nobody reads.
 constexpr int kRevFusedFloats = 8 * kTbSteps * 64 + 8 * 4 * 64 + 2 * (128 * 64 + 2 * 64 * 64 + 2 * 4 * 64 + 64 * 4);
@@ -582,19 +587,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
     }
     {
+      // e2 (the node MLP's input) is what the forward kernel stored as the next block's edge features: reading it back
+      // (256 B/edge) is cheaper for this issue-bound kernel than a second evaluation of the edge MLP
       f32x4 x2[4];
-      {  // e2 = e1 + edge MLP forward (the node MLP's input)
-        f32x4 p1[8], p2[8];
-        gather_tables(a.TA, a.TB, 0, ci, cj, qd, p1);
-        mlp_preacts_dual<false>(lds, L.mlp[0], x, p1, p2, lv);
-        static_for<4>([&]<int ob>() {
-          static_for<4>([&]<int r>() {
-            const f32x4 w = *(const f32x4*)(lds + L.mlp[0].wl + (ob * 16 + 4 * qd + r) * 4);
-            const float s_lin = w[0] * hv[0] + w[1] * hv[1] + w[2] * hv[2] + w[3] * hv[3];
-            x2[ob][r] = x[ob][r] + fsilu(p2[ob][r]) * fsigmoid(p2[4 + ob][r]) * s_lin;
-          });
-        });
-      }
+      const float* e2_tile = a.e2_tile + tile * kTileFloats + lane * 4;
+      static_for<4>([&]<int blk>() { x2[blk] = *(const f32x4*)(e2_tile + blk * 256); });
       // node-message MLP reverse: d msg[e] = dx_new[centre(e)]
       f32x4 dmsg[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
@@ -788,7 +785,7 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_n = plan->d_mfma_rev + (size_t)b * L.per_block + L.total_e;
-  RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b + 1], w.de_soa, w.dcn, 0, w.dm,
+  RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b + 1], nullptr, w.de_soa, w.dcn, 0, w.dm,
              w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr};
   hipLaunchKernelGGL(k_edge_rev_node_mlp, dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L);
 }
@@ -799,7 +796,7 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_e = plan->d_mfma_rev + (size_t)b * L.per_block;
-  RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], w.de_soa, w.dcn,
+  RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], nullptr, w.de_soa, w.dcn,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
   if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3) {  // diagnostic build
@@ -815,7 +812,7 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
   if (tiles == 0) return;
   const MfmaRevFusedLayout L = mfma_rev_fused_layout();
   const float* img = plan->d_mfma_revf + (size_t)b * L.total;
-  RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], w.de_soa, nullptr,
+  RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr};
   constexpr int WV = kWavesRevFused;
   dim3 grid(grid_for_tiles(tiles)), block(64 * WV);
