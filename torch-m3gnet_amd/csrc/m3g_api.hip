@@ -163,6 +163,8 @@ Work work_carve(const Consts& c, bool mfma, int64_t N, int64_t E, int64_t T, int
     w.dcn = take(tiles16 * 1024);
     w.dh_parts = take((size_t)(2 * c.B + 1) * e * kRP);
     w.msg = take(e * kDP);
+    w.seg_head = take((tiles16 + 1) * 4 * kDP);
+    w.seg_first = take((n + 1) * 4 * kDP);
   } else {
     // vector-ALU baseline path: in-place row-major edge features and saved pre-activations [E,512] per block
     w.TA = take(n * 4 * kDP); w.TB = take(n * 4 * kDP);
@@ -492,7 +494,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     if (mfma) {
       { M3G_STAGE(ST_EDGE_FWD); launch_edge_block_mfma(plan, c, t, w, b, s); }
       M3G_STAGE(ST_NODE_SUM);
-      launch_node_sum(t, w.x[b], w.msg, w.x[b + 1], s);
+      launch_node_sum_seg(t, w, w.x[b], w.x[b + 1], s);
     } else {
       M3G_STAGE(ST_EDGE_FWD);
       if (N > 0) M3G_HIP_CHECK(hipMemcpyAsync(w.x[b + 1], w.x[b], sizeof(float) * N * kDP, hipMemcpyDeviceToDevice, s));

@@ -109,6 +109,57 @@ __device__ __forceinline__ void load_ends(const int32_t* __restrict__ src, const
   cj = dst ? dst[ec] : 0;
 }
 
+// ---- per-centre sums inside a tile -------------------------------------------------------------------------------
+// The 16 edges of a tile sit on the 16 lanes of a DPP row and edges of one centre are consecutive, so the sum over a
+// centre's edges is a segmented inclusive scan along the row: 4 row_shr steps, each a DPP-sourced FMA with a 0/1 mask
+// (valid because runs are contiguous: equal centres n lanes apart imply equal centres in between).  The last lane of
+// a run then holds the run's sum.
+struct SegMasks {
+  float m1, m2, m4, m8;
+  bool run_end;    // this lane's edge is the last of its run inside the tile
+  bool first_run;  // the run contains the tile's column 0
+};
+template <int N>
+__device__ __forceinline__ int row_shr_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xf, 0xf, false); }
+template <int N>
+__device__ __forceinline__ float row_shr_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ SegMasks seg_masks(int ci, int lane) {
+  SegMasks k;
+  k.m1 = row_shr_i<1>(ci, -1) == ci ? 1.f : 0.f;
+  k.m2 = row_shr_i<2>(ci, -1) == ci ? 1.f : 0.f;
+  k.m4 = row_shr_i<4>(ci, -1) == ci ? 1.f : 0.f;
+  k.m8 = row_shr_i<8>(ci, -1) == ci ? 1.f : 0.f;
+  const int next = __builtin_amdgcn_update_dpp(-1, ci, 0x100 + 1, 0xf, 0xf, false);   // row_shl:1 -> lane m+1 (fill -1 at m = 15)
+  k.run_end = next != ci;
+  k.first_run = ci == __builtin_amdgcn_readlane(ci, 0);
+  return k;
+}
+template <int N>
+__device__ __forceinline__ void seg_scan(f32x4 (&v)[N], const SegMasks& k) {
+  static_for<N>([&]<int b>() {
+    static_for<4>([&]<int r>() {
+      float x = v[b][r];
+      x = fmaf(row_shr_f<1>(x), k.m1, x);
+      x = fmaf(row_shr_f<2>(x), k.m2, x);
+      x = fmaf(row_shr_f<4>(x), k.m4, x);
+      x = fmaf(row_shr_f<8>(x), k.m8, x);
+      v[b][r] = x;
+    });
+  });
+}
+// run-end lanes store their run's sum: the tile's first run into seg_head[tile], a run starting mid-tile into
+// seg_first[centre]; row = 4*kDP floats, this call covers blocks [B0, B0+N) of it
+template <int B0, int N>
+__device__ __forceinline__ void seg_store(const f32x4 (&v)[N], const SegMasks& k, float* seg_head, float* seg_first, int64_t tile,
+                                          int64_t ci, int qd) {
+  if (k.run_end) {
+    float* row = (k.first_run ? seg_head + tile * (4 * kDP) : seg_first + ci * (4 * kDP)) + 4 * qd;
+    static_for<N>([&]<int b>() { *(f32x4*)(row + (B0 + b) * 16) = v[b]; });
+  }
+}
+
 __device__ __forceinline__ void load_image(float* lds, const float* __restrict__ src, int n_floats, int* lds_head) {
   for (int i = threadIdx.x * 4; i < n_floats; i += blockDim.x * 4) *(f32x4*)(lds + i) = *(const f32x4*)(src + i);
   if (threadIdx.x == 0) *lds_head = 0;
@@ -142,7 +193,7 @@ struct FwdArgs {
   const float *h, *m, *TA, *TB;
   const float* e_in;       // [tiles][4][64][4] edge features before this block
   float* e_out;            // same shape, after this block
-  float* msg;              // [E][64] row-major
+  float *seg_head, *seg_first;   // per-centre message sums (see seg_scan)
   unsigned long long* stamps;  // diagnostic build: [gridDim.x][kWaves][12] phase cycle sums
 };
 
@@ -258,11 +309,13 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
     });
     st.template mark<6>();  // e2 residual + store
     mlp_forward_mfma<ST, 7>(lds, L.mlp[1], 1, a, ci, cj, hb, x, out, lv, st);  // node message (nn/conv.py:77-89)
-    if (edge < a.E) {
-      float* mrow = a.msg + edge * kDP + 4 * qd;
-      static_for<4>([&]<int blk>() { *(f32x4*)(mrow + blk * 16) = out[blk]; });
+    {  // sum of the messages per centre instead of a [E,64] message array + a node-side pass over it (nn/conv.py:82-88)
+      if (edge >= a.E) static_for<4>([&]<int blk>() { out[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; });   // padding lanes of the last tile
+      const SegMasks sk = seg_masks((int)ci, lane);
+      seg_scan(out, sk);
+      seg_store<0>(out, sk, a.seg_head, a.seg_first, tile, ci, qd);
     }
-    st.template mark<11>();  // message store
+    st.template mark<11>();  // message sums
     if (!has_next) break;
     ci_i = nci;
     cj_i = ncj;
@@ -721,6 +774,23 @@ __global__ void __launch_bounds__(256) k_node_sum(int64_t N, const int32_t* __re
   x_new[i * kDP + o] = (a0 + a1) + (a2 + a3);
 }
 
+// x_new[i,:] = x[i,:] + sum of centre i's run sums: the run its row starts with mid-tile (seg_first[i]) and the first runs
+// of the tiles whose column 0 belongs to it (seg_head[t]); fixed order, no atomics
+__global__ void __launch_bounds__(256) k_node_sum_seg(int64_t N, const int32_t* __restrict__ row_ptr, const float* __restrict__ x,
+                                                      const float* __restrict__ seg_head, const float* __restrict__ seg_first,
+                                                      float* __restrict__ x_new) {
+  int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  int o = threadIdx.x & 63;
+  if (i >= N) return;
+  const int r0 = row_ptr[i], r1 = row_ptr[i + 1];
+  float acc = x[i * kDP + o];
+  if (r1 > r0) {
+    if (r0 & 15) acc += seg_first[i * (4 * kDP) + o];
+    for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t) acc += seg_head[(int64_t)t * (4 * kDP) + o];
+  }
+  x_new[i * kDP + o] = acc;
+}
+
 static inline int grid_for_tiles(int64_t tiles) {
   int64_t wgs = (tiles + kWaves - 1) / kWaves;
   wgs = (wgs + 7) / 8 * 8;
@@ -764,7 +834,7 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
     FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], w.e_blk[b],
-              w.e_blk[b + 1], w.msg, plan->d_stamps};
+              w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
     if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3) {  // diagnostic build of the default configuration
       hipLaunchKernelGGL((k_edge_block_mfma<3, true>), grid, block, 0, s, a, L);
@@ -776,6 +846,11 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
 
 void launch_node_sum(const Topo& t, const float* x_old, const float* msg, float* x_new, hipStream_t s) {
   if (t.N > 0) hipLaunchKernelGGL(k_node_sum, dim3((unsigned)((t.N + 3) / 4)), dim3(256), 0, s, t.N, t.row_ptr, x_old, msg, x_new);
+}
+
+void launch_node_sum_seg(const Topo& t, const Work& w, const float* x_old, float* x_new, hipStream_t s) {
+  if (t.N > 0)
+    hipLaunchKernelGGL(k_node_sum_seg, dim3((unsigned)((t.N + 3) / 4)), dim3(256), 0, s, t.N, t.row_ptr, x_old, w.seg_head, w.seg_first, x_new);
 }
 
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
