@@ -544,7 +544,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
       { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], s); }
       if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
         M3G_STAGE(ST_NODE_REV);
-        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, s);
+        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
       }
     }

@@ -345,6 +345,7 @@ struct RevArgs {
   float* dh;       // [E][4] slice of this kernel (store only)
   float* dp1;      // [E][256]  each kernel writes its MLP's 128 columns
   unsigned long long* stamps;  // diagnostic build only
+  float *seg_head, *seg_first;   // fused kernel: per-centre sums of the dp1 rows (see seg_scan)
 };
 
 // reverse of one conv GatedMLP whose edge-feature input tile is x: both layers are recomputed, then
@@ -569,10 +570,11 @@ __device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlp
 }
 
 // reverse of one conv GatedMLP at input tile x (recomputing both layers), dual-image version of mlp_reverse_mfma
-template <bool NEED_DP1>
-__device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlpFused& L, int mlp, const RevArgs& a, int64_t edge,
-                                                 int64_t ci, int64_t cj, const f32x4& hv, const f32x4 (&x)[4],
+template <bool NEED_DP1, int MLP>
+__device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlpFused& L, const RevArgs& a, int64_t edge, int64_t tile,
+                                                 int64_t ci, int64_t cj, const SegMasks& sk, const f32x4& hv, const f32x4 (&x)[4],
                                                  const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane) {
+  constexpr int mlp = MLP;
   const int qd = lane >> 4;
   f32x4 p1[8], d2[8];
   gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
@@ -602,6 +604,14 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
   }
   zero(contrib);
   chain_dual_t<4, 4, 128>(lds + L.w1c, dp1, contrib, lane);
+  if (NEED_DP1) {
+    // sum of the dp1 rows per centre (the x_i half of the node reverse): scanned here, so the node kernel reads a few
+    // partial rows per atom instead of every row of the centre.  The rows themselves are still stored above for the
+    // x_j half, which is a gather by neighbour.
+    if (edge >= a.E) zero(dp1);   // padding lanes of the last tile
+    seg_scan(dp1, sk);
+    seg_store<MLP * 8>(dp1, sk, a.seg_head, a.seg_first, tile, ci, qd);
+  }
 }
 
 template <int TBS, bool NEED_DP1, int WAVES>
@@ -626,6 +636,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
     const int64_t ci = ci_i, cj = cj_i;
+    const SegMasks sk = seg_masks((int)ci, lane);
     float* de_tile = a.de_soa + tile * kTileFloats + lane * 4;
     const float* e_tile = a.e_tile + tile * kTileFloats + lane * 4;
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
@@ -649,7 +660,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       f32x4 dmsg[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
       static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
-      mlp_reverse_dual<NEED_DP1>(lds, L.mlp[1], 1, a, edge, ci, cj, hv, x2, dmsg, contrib, dhv, lv);
+      mlp_reverse_dual<NEED_DP1, 1>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv);
     }
     // dL/d e2 = what flows in from later blocks + the node MLP's contribution
     if (a.de_is_zero) {
@@ -657,7 +668,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     } else {
       static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + contrib[blk]; });
     }
-    mlp_reverse_dual<NEED_DP1>(lds, L.mlp[0], 0, a, edge, ci, cj, hv, x, de, contrib, dhv, lv);
+    mlp_reverse_dual<NEED_DP1, 0>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
       *(f32x4*)(de_tile + blk * 256) = de[blk];
@@ -861,7 +872,7 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_n = plan->d_mfma_rev + (size_t)b * L.per_block + L.total_e;
   RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b + 1], nullptr, w.de_soa, w.dcn, 0, w.dm,
-             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr};
+             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_edge_rev_node_mlp, dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L);
 }
 
@@ -872,7 +883,7 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_e = plan->d_mfma_rev + (size_t)b * L.per_block;
   RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], nullptr, w.de_soa, w.dcn,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps};
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps, nullptr, nullptr};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
   if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3) {  // diagnostic build
     hipLaunchKernelGGL((k_edge_rev_edge_mlp<3, true>), grid, block, 0, s, ae, L);
@@ -888,7 +899,7 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
   const MfmaRevFusedLayout L = mfma_rev_fused_layout();
   const float* img = plan->d_mfma_revf + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr};
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first};
   constexpr int WV = kWavesRevFused;
   dim3 grid(grid_for_tiles(tiles)), block(64 * WV);
   if (b > 0) {

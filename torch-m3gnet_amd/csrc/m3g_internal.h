@@ -253,7 +253,7 @@ void launch_embed_reverse(const Consts& c, const float* W, const WeightLayout& w
 void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const float* x, float* v,
                      float* TA, float* TB, hipStream_t s);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
-                         const float* v, const float* dx_new, float* dx_out, hipStream_t s);
+                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, hipStream_t s);
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
                     const float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                     bool want_grad, hipStream_t s);

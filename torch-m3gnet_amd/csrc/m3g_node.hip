@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ in_ptr,
                                                       const int32_t* __restrict__ in_edge, const float* __restrict__ dp1,
                                                       const float* __restrict__ dgq, const float* __restrict__ v,
-                                                      const float* __restrict__ dx_new, float* __restrict__ dx_out) {
+                                                      const float* __restrict__ dx_new, float* __restrict__ dx_out,
+                                                      const float* __restrict__ seg_head, const float* __restrict__ seg_first) {
   __shared__ float4 sA[kNodesRev][64], sB[kNodesRev][64];   // row / in-edge sums of dp1, 256 columns as 64 float4
   __shared__ float tv[kNodesRev][kCP];
   __shared__ float part[4][kNodesRev][kDP];
@@ -120,9 +121,22 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
   for (int nb = wv; nb < kNodesRev; nb += 4) {
     const int64_t i = n0 + nb;
     float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    float dv = 0.f, dvv = 0.f;
     if (i < N) {
       const int e1 = row_ptr[i + 1];
       int e = row_ptr[i];
+      if (seg_head) {
+        // the fused reverse kernel already summed the rows of each centre inside its tiles: add the partial rows
+        // (run starting mid-tile + first runs of the tiles whose column 0 belongs to this centre)
+        if (e1 > e) {
+          if (e & 15) a0 = reinterpret_cast<const float4*>(seg_first)[i * 64 + ln];
+          for (int t = (e + 15) >> 4; t <= (e1 - 1) >> 4; ++t) {
+            const float4 u = reinterpret_cast<const float4*>(seg_head)[(int64_t)t * 64 + ln];
+            a1.x += u.x; a1.y += u.y; a1.z += u.z; a1.w += u.w;
+          }
+        }
+        e = e1;
+      }
       for (; e + 1 < e1; e += 2) {
         const float4 u = rows[(int64_t)e * 64], w2 = rows[(int64_t)(e + 1) * 64];
         a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
@@ -132,33 +146,45 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
         const float4 u = rows[(int64_t)e * 64];
         a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
       }
+      // in-edge rows: 8 whole 1-KB rows in flight per wave (random rows: latency-bound unless enough bytes are in
+      // flight); lanes 0-15 also pick up the matching dL/dg row elements for the v-gradient (same edge list)
       const int k1 = in_ptr[i + 1];
       int k = in_ptr[i];
-      for (; k + 1 < k1; k += 2) {
-        const int f0 = in_edge[k], f1 = in_edge[k + 1];
-        const float4 u = rows[(int64_t)f0 * 64], w2 = rows[(int64_t)f1 * 64];
-        b0.x += u.x; b0.y += u.y; b0.z += u.z; b0.w += u.w;
-        b1.x += w2.x; b1.y += w2.y; b1.z += w2.z; b1.w += w2.w;
+      float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f), b3 = b2;
+      const int cq = ln & 15;
+      for (; k + 7 < k1; k += 8) {
+        int f[8];
+        float4 u[8];
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = in_edge[k + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { u[j] = rows[(int64_t)f[j] * 64]; g[j] = dgq[(int64_t)f[j] * kCP + cq]; }
+#pragma unroll
+        for (int j = 0; j < 8; j += 4) {
+          b0.x += u[j].x; b0.y += u[j].y; b0.z += u[j].z; b0.w += u[j].w;
+          b1.x += u[j + 1].x; b1.y += u[j + 1].y; b1.z += u[j + 1].z; b1.w += u[j + 1].w;
+          b2.x += u[j + 2].x; b2.y += u[j + 2].y; b2.z += u[j + 2].z; b2.w += u[j + 2].w;
+          b3.x += u[j + 3].x; b3.y += u[j + 3].y; b3.z += u[j + 3].z; b3.w += u[j + 3].w;
+          dv += (g[j] + g[j + 1]) + (g[j + 2] + g[j + 3]);
+        }
       }
-      if (k < k1) {
-        const float4 u = rows[(int64_t)in_edge[k] * 64];
+      for (; k < k1; ++k) {
+        const int f0 = in_edge[k];
+        const float4 u = rows[(int64_t)f0 * 64];
         b0.x += u.x; b0.y += u.y; b0.z += u.z; b0.w += u.w;
+        dv += dgq[(int64_t)f0 * kCP + cq];
+      }
+      b0.x += b2.x; b0.y += b2.y; b0.z += b2.z; b0.w += b2.w;
+      b1.x += b3.x; b1.y += b3.y; b1.z += b3.z; b1.w += b3.w;
+      if (ln < kCP) {
+        const float vv = v[i * kCP + ln];
+        dvv = ln < C ? dv * vv * (1.f - vv) : 0.f;
       }
     }
     sA[nb][ln] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
     sB[nb][ln] = make_float4(b0.x + b1.x, b0.y + b1.y, b0.z + b1.z, b0.w + b1.w);
-  }
-  if (tid < kNodesRev * kCP) {
-    const int nb = tid / kCP, c = tid % kCP;
-    const int64_t i = n0 + nb;
-    float val = 0.f;
-    if (i < N && c < C) {
-      float dv = 0.f;
-      for (int k = in_ptr[i]; k < in_ptr[i + 1]; ++k) dv += dgq[(int64_t)in_edge[k] * kCP + c];
-      const float vv = v[i * kCP + c];
-      val = dv * vv * (1.f - vv);
-    }
-    tv[nb][c] = val;
+    if (ln < kCP) tv[nb][ln] = dvv;
   }
   __syncthreads();
   // phase 2: quarter pq of the threads handles table columns [pq*64, pq*64+64) for output feature k
@@ -320,10 +346,10 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
 }
 
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
-                         const float* v, const float* dx_new, float* dx_out, hipStream_t s) {
+                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, hipStream_t s) {
   if (t.N > 0)
     hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge,
-                       w.dp1, w.dg, v, dx_new, dx_out);
+                       w.dp1, w.dg, v, dx_new, dx_out, row_sums_in_seg ? w.seg_head : nullptr, row_sums_in_seg ? w.seg_first : nullptr);
 }
 
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
