@@ -480,7 +480,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     M3G_STAGE(ST_EMBED);
     if (mfma) {
       launch_embed_nodes_only(c, W, wl, t, io->atom_types, w, s);
-      launch_embed_edges_soa(c, W + wl.adj_t, w.h, w.e_blk[0], E, s);
+      if (!fused_rev || c.B == 0) launch_embed_edges_soa(c, W + wl.adj_t, w.h, w.e_blk[0], E, s);   // fused path: block 0 forms e0 in its kernels
     } else {
       launch_embed(c, W, wl, t, io->atom_types, w, s);
     }
@@ -550,11 +550,12 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     }
     {
       M3G_STAGE(ST_EMBED_REV);
-      if (mfma) launch_embed_edges_reverse_soa(W + wl.adj, w.h, w.de_soa, w.dh_parts + (size_t)(fused_rev ? c.B : 2 * c.B) * E * kRP, E, s);
+      if (fused_rev) { /* block 0's fused reverse kernel already added the embedding's dL/dh share */ }
+      else if (mfma) launch_embed_edges_reverse_soa(W + wl.adj, w.h, w.de_soa, w.dh_parts + (size_t)2 * c.B * E * kRP, E, s);
       else launch_embed_reverse(c, W, wl, t, w, s);
     }
     M3G_STAGE(ST_GEOM_REV);
-    if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, (fused_rev ? c.B : 2 * c.B) + 1, io->forces, s);
+    if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, fused_rev ? c.B : 2 * c.B + 1, io->forces, s);
     else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, s);
     if (io->stresses) {
       if (plan->stress_mode == 1) launch_stress_pair(t, w, io->lattice, io->stresses, s);

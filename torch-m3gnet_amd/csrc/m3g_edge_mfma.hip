@@ -28,7 +28,7 @@
 
 namespace m3g {
 
-constexpr int kFwdLdsFloats = 8 * kTbSteps * 64 + 2 * (8 * 4 * 4 * 64 + 2 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 64);
+constexpr int kFwdLdsFloats = 8 * kTbSteps * 64 + 2 * (8 * 4 * 4 * 64 + 2 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 64) + 4 * 64;
 constexpr int kRevMlpFloats = 8 * 4 * 4 * 64 + 4 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 8 * 4 * 64 + 64 * 4;   // node-MLP reverse image
 constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;                // + three-body images
 constexpr int kWaves = 16;      // forward kernel: 16 waves = 4 per SIMD (<= 128 VGPRs)
@@ -259,7 +259,9 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
   st.template mark<S0 + 3>();  // gating
 }
 
-template <int TBS, bool ST = false>
+// FIRST: block 0 forms its input e0 = SiLU(W_adj h) (nn/featurizer.py:128-132) from the radial basis instead of reading
+// an embedded-edge image that a separate kernel would have to write (256 B/edge) first
+template <int TBS, bool ST = false, bool FIRST = false>
 __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kFwdLdsFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kFwdLdsFloats);
@@ -290,10 +292,16 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
     const float* e_tile = a.e_in + tile * kTileFloats + lane * 4;
     float* e_otile = a.e_out + tile * kTileFloats + lane * 4;
     f32x4 x[4];
-    static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+    if (!FIRST) static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
     float mb[TBS];
     static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
     const float hb = a.h[ec * kRP + qd];
+    if (FIRST) {
+      static_for<4>([&]<int blk>() {
+        x[blk] = mfma16(lds[L.adj + blk * 64 + lv], hb, f32x4{0.f, 0.f, 0.f, 0.f});
+        static_for<4>([&]<int r>() { x[blk][r] = fsilu(x[blk][r]); });
+      });
+    }
     st.template mark<0>();  // tile loads issued
     {  // three-body gated update (nn/interaction.py:220-221)
       f32x4 p[8];
@@ -543,7 +551,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
 // from the forward pass's output image rather than evaluated a second time).  Against the split
 // kernels this drops the node->edge hand-over buffer (256 B written + read per edge), the second read of the edge
 // features, the second table gather, and one dh slice; block 0 also skips the dp1 rows nobody reads.
-constexpr int kRevFusedFloats = 8 * kTbSteps * 64 + 8 * 4 * 64 + 2 * (128 * 64 + 2 * 64 * 64 + 2 * 4 * 64 + 64 * 4);
+constexpr int kRevFusedFloats = 8 * kTbSteps * 64 + 8 * 4 * 64 + 2 * (128 * 64 + 2 * 64 * 64 + 2 * 4 * 64 + 64 * 4) + 4 * 64 + 64 * 4;
 
 template <bool KEEP_P1>
 __device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlpFused& L, const f32x4 (&x)[4], f32x4 (&p1)[8],
@@ -644,7 +652,16 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     float mb[TBS];
     static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
     f32x4 x[4], de[4], contrib[4];
-    static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+    constexpr bool FIRST = !NEED_DP1;   // block 0: its input is the edge embedding e0 = SiLU(W_adj h), formed here
+    if (FIRST) {
+      const float hb = a.h[ec * kRP + qd];
+      static_for<4>([&]<int blk>() {
+        x[blk] = mfma16(lds[L.adj + blk * 64 + lv], hb, f32x4{0.f, 0.f, 0.f, 0.f});
+        static_for<4>([&]<int r>() { x[blk][r] = fsilu(x[blk][r]); });
+      });
+    } else {
+      static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+    }
     {  // e1 = e_in + three-body gated update (the edge MLP's input)
       f32x4 p[8];
       tb_preact<TBS>(lds + L.tb, mb, p, lv);
@@ -671,8 +688,21 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     mlp_reverse_dual<NEED_DP1, 0>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
-      *(f32x4*)(de_tile + blk * 256) = de[blk];
+      if (!FIRST) *(f32x4*)(de_tile + blk * 256) = de[blk];
     });
+    if (FIRST) {
+      // edge embedding, reverse (nothing upstream of e0 but the radial basis): dL/dh += W_adj^T (dL/de0 * SiLU'(W_adj h))
+      const float hb = a.h[ec * kRP + qd];
+      static_for<4>([&]<int blk>() {
+        const f32x4 pe = mfma16(lds[L.adj + blk * 64 + lv], hb, f32x4{0.f, 0.f, 0.f, 0.f});
+        static_for<4>([&]<int r>() {
+          const f32x4 w = *(const f32x4*)(lds + L.adjp + (blk * 16 + 4 * qd + r) * 4);
+          const float t = de[blk][r] * fdsilu(pe[r]);
+          dhv[0] += t * w[0]; dhv[1] += t * w[1]; dhv[2] += t * w[2]; dhv[3] += t * w[3];
+        });
+        asm volatile("" : "+v"(dhv[0]), "+v"(dhv[1]), "+v"(dhv[2]), "+v"(dhv[3]));
+      });
+    }
     // three-body gated update, reverse
     f32x4 d8[8];
     tb_preact<TBS>(lds + L.tb, mb, d8, lv);
@@ -849,6 +879,8 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
     if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3) {  // diagnostic build of the default configuration
       hipLaunchKernelGGL((k_edge_block_mfma<3, true>), grid, block, 0, s, a, L);
+    } else if (b == 0 && plan->rev_kernel == 1) {   // the fused reverse kernel recomputes e0 as well: no embedded-edge image at all
+      M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS, false, true>), grid, block, 0, s, a, L));
     } else {
       M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS>), grid, block, 0, s, a, L));
     }

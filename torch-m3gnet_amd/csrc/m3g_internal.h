@@ -97,7 +97,12 @@ struct MfmaMlpFwd {                     // offsets in floats inside the forward 
   int b2;    // [2 (dense,gate)][4 ob][64]  bias as a k-step: lanes < 16 hold b[ob*16+lane], others 0
   int wl;    // direct [4 ob][1 step][64]   W_l [64][R<=4]
 };
-struct MfmaFwdLayout { int tb; /* direct [8 ob][kTbSteps][64]: dense ob0-3, gate ob4-7 */ MfmaMlpFwd mlp[2]; int total; };
+struct MfmaFwdLayout {
+  int tb;    // direct [8 ob][kTbSteps][64]: dense ob0-3, gate ob4-7
+  MfmaMlpFwd mlp[2];
+  int adj;   // direct [4 ob][1][64]: edge embedding W_adj [64][R<=4] (block 0 forms e0 = SiLU(W_adj h) itself)
+  int total;
+};
 // reverse images: one per conv MLP (two kernels per block: node MLP first, then edge MLP + three-body update)
 struct MfmaMlpRev {
   int w1c;           // forward layer-1 image: nothing is saved by the forward pass, both layers are recomputed
@@ -128,6 +133,8 @@ struct MfmaRevFusedLayout {
   int tb;    // direct three-body image (forward recompute)
   int tbT;   // chain [1][8] rows: c
   MfmaMlpFused mlp[2];   // 0: edge update, 1: node message
+  int adj;   // direct [4 ob][1][64] edge embedding W_adj (block 0 only: e0 and its reverse are formed in the kernel)
+  int adjp;  // [64][4] plain copy of W_adj for the dL/dh accumulation
   int total;
 };
 MfmaFwdLayout mfma_fwd_layout();

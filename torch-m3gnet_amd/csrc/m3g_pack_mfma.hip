@@ -20,6 +20,7 @@ MfmaFwdLayout mfma_fwd_layout() {
     L.mlp[m].b2 = take(2 * 4 * 64);
     L.mlp[m].wl = take(4 * 1 * 64);
   }
+  L.adj = take(4 * 64);
   L.total = off;
   return L;
 }
@@ -58,6 +59,8 @@ MfmaRevFusedLayout mfma_rev_fused_layout() {
     L.mlp[m].b2 = take(2 * 4 * 64);
     L.mlp[m].wl = take(64 * 4);
   }
+  L.adj = take(4 * 64);
+  L.adjp = take(64 * 4);
   L.total = off;
   return L;
 }
@@ -136,6 +139,14 @@ int pack_mfma_images(m3g_plan* plan) {
       return (row < C && o < D) ? w[(size_t)o * C + row] : 0.f;
     });
     memcpy(rf + Rf.tbT, r + Rv.tbT, sizeof(float) * 8 * 4 * 64);
+    {  // edge embedding (nn/featurizer.py:128-132, "model.5.linear.weight" [D,R])
+      const float* wadj = plan->params.at("model.5.linear.weight").data();
+      auto adj = [&](int row, int k) -> float { return (row < D && k < R) ? wadj[(size_t)row * R + k] : 0.f; };
+      direct_image(f + F.adj, 4, 1, adj);
+      direct_image(rf + Rf.adj, 4, 1, adj);
+      for (int o = 0; o < 64; ++o)
+        for (int rr = 0; rr < 4; ++rr) rf[Rf.adjp + o * 4 + rr] = adj(o, rr);
+    }
     const char* mlps[2] = {".concat_edge_update", ".concat_node_update"};
     const char* lins[2] = {".edge_linear.weight", ".node_linear.weight"};
     for (int m = 0; m < 2; ++m) {
