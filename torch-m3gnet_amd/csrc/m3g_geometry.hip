@@ -148,20 +148,31 @@ __global__ void __launch_bounds__(256) k_geometry_reverse(Consts c, int64_t E, c
 }
 
 // F_i = (sum_{e in row(i)} dr_e - sum_{e: dst(e)=i} dr_e) / length_scale   (no atomics: both CSR lists)
+// 16 lanes per atom (a DPP row): each lane takes every 16th edge of both lists, then the row is reduced -- a thread per
+// atom left 160 waves on the whole chip walking 84 dependent 12-byte gathers each.
 __global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_t N, const int32_t* __restrict__ row_ptr,
                                                       const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_edge,
                                                       const float* __restrict__ dr, float* __restrict__ forces) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= N) return;
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t i = gid >> 4;
+  const int l = (int)(gid & 15);
   float fx = 0.f, fy = 0.f, fz = 0.f;
-  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { fx += dr[e * 3]; fy += dr[e * 3 + 1]; fz += dr[e * 3 + 2]; }
-  for (int k = in_ptr[i]; k < in_ptr[i + 1]; ++k) {
-    int e = in_edge[k];
-    fx -= dr[e * 3]; fy -= dr[e * 3 + 1]; fz -= dr[e * 3 + 2];
+  if (i < N) {
+    for (int e = row_ptr[i] + l; e < row_ptr[i + 1]; e += 16) { fx += dr[(int64_t)e * 3]; fy += dr[(int64_t)e * 3 + 1]; fz += dr[(int64_t)e * 3 + 2]; }
+    for (int k = in_ptr[i] + l; k < in_ptr[i + 1]; k += 16) {
+      const int64_t e = in_edge[k];
+      fx -= dr[e * 3]; fy -= dr[e * 3 + 1]; fz -= dr[e * 3 + 2];
+    }
   }
-  forces[i * 3 + 0] = fx / length_scale;
-  forces[i * 3 + 1] = fy / length_scale;
-  forces[i * 3 + 2] = fz / length_scale;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {   // fixed-order tree inside the 16-lane group
+    fx += __shfl_xor(fx, off, 16); fy += __shfl_xor(fy, off, 16); fz += __shfl_xor(fz, off, 16);
+  }
+  if (i < N && l == 0) {
+    forces[i * 3 + 0] = fx / length_scale;
+    forces[i * 3 + 1] = fy / length_scale;
+    forces[i * 3 + 2] = fz / length_scale;
+  }
 }
 
 // virial: sum_a pos_a (x) F_a / V in Voigt order xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62)
@@ -279,7 +290,7 @@ void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, cons
   if (t.E > 0)
     hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, c, t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, w.dr);
   if (t.N > 0)
-    hipLaunchKernelGGL(k_force_gather, grid_for(t.N), dim3(256), 0, s, c.length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge,
+    hipLaunchKernelGGL(k_force_gather, grid_for(t.N * 16), dim3(256), 0, s, c.length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge,
                        w.dr, forces);
 }
 

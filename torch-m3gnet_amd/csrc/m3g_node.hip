@@ -218,64 +218,94 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
   }
 }
 
-// ---- S5 readout (+ fused reverse): one wave per atom, lanes = feature ------------------------------------------
+// ---- S5 readout (+ fused reverse): one wave per kRA atoms, lanes = feature ----------------------------------------
+// Every weight element a lane reads from L2 is used for kRA atoms (a wave per atom re-read all seven 16-KB matrices for
+// each atom and spent its time waiting on them).
+constexpr int kRA = 4;
 __global__ void __launch_bounds__(256) k_readout(Consts c, int64_t N, const float* __restrict__ W, ReadoutW rw,
                                                  size_t elemental_off, const int64_t* __restrict__ types,
                                                  const float* __restrict__ x, float* __restrict__ scaled_atomic,
                                                  float* __restrict__ dx) {
-  __shared__ float bufA[4][kDP], bufB[4][kDP];
-  int wv = threadIdx.x >> 6, o = threadIdx.x & 63;
-  int64_t a = (int64_t)blockIdx.x * 4 + wv;
-  bool live = a < N;
-  int64_t aa = live ? a : 0;
-  bufA[wv][o] = x[aa * kDP + o];
+  __shared__ float bufA[4][kRA][kDP], bufB[4][kRA][kDP];
+  const int wv = threadIdx.x >> 6, o = threadIdx.x & 63;
+  const int64_t a0 = ((int64_t)blockIdx.x * 4 + wv) * kRA;
+#pragma unroll
+  for (int j = 0; j < kRA; ++j) bufA[wv][j][o] = x[(a0 + j < N ? a0 + j : 0) * kDP + o];
   __syncthreads();
-  float pd1 = W[rw.b1d + o], pg1 = W[rw.b1g + o];
-  for (int k = 0; k < kDP; ++k) {
-    float xv = bufA[wv][k];
-    pd1 += W[rw.w1d_t + k * kDP + o] * xv;
-    pg1 += W[rw.w1g_t + k * kDP + o] * xv;
+  float pd1[kRA], pg1[kRA], pd2[kRA], pg2[kRA];
+  {
+    const float bd = W[rw.b1d + o], bg = W[rw.b1g + o];
+#pragma unroll
+    for (int j = 0; j < kRA; ++j) { pd1[j] = bd; pg1[j] = bg; }
+    for (int k = 0; k < kDP; ++k) {
+      const float wd = W[rw.w1d_t + k * kDP + o], wg = W[rw.w1g_t + k * kDP + o];
+#pragma unroll
+      for (int j = 0; j < kRA; ++j) { const float xv = bufA[wv][j][k]; pd1[j] += wd * xv; pg1[j] += wg * xv; }
+    }
   }
+#pragma unroll
+  for (int j = 0; j < kRA; ++j) { bufA[wv][j][o] = silu_f(pd1[j]); bufB[wv][j][o] = silu_f(pg1[j]); }
   __syncthreads();
-  bufA[wv][o] = silu_f(pd1);
-  bufB[wv][o] = silu_f(pg1);
-  __syncthreads();
-  float pd2 = W[rw.b2d + o], pg2 = W[rw.b2g + o];
-  for (int k = 0; k < kDP; ++k) {
-    pd2 += W[rw.w2d_t + k * kDP + o] * bufA[wv][k];
-    pg2 += W[rw.w2g_t + k * kDP + o] * bufB[wv][k];
+  {
+    const float bd = W[rw.b2d + o], bg = W[rw.b2g + o];
+#pragma unroll
+    for (int j = 0; j < kRA; ++j) { pd2[j] = bd; pg2[j] = bg; }
+    for (int k = 0; k < kDP; ++k) {
+      const float wd = W[rw.w2d_t + k * kDP + o], wg = W[rw.w2g_t + k * kDP + o];
+#pragma unroll
+      for (int j = 0; j < kRA; ++j) { pd2[j] += wd * bufA[wv][j][k]; pg2[j] += wg * bufB[wv][j][k]; }
+    }
   }
-  float od = W[rw.w3d + o] * silu_f(pd2), og = W[rw.w3g + o] * silu_f(pg2);
-  for (int off = 32; off > 0; off >>= 1) { od += __shfl_xor(od, off); og += __shfl_xor(og, off); }
-  od += W[rw.b3];
-  og += W[rw.b3 + 1];
-  float sg = sigmoid_f(og);
-  if (live && o == 0) {
-    int64_t ty = types[a];
-    ty = ty < 0 ? 0 : (ty >= c.num_types ? c.num_types - 1 : ty);
-    scaled_atomic[a] = W[elemental_off + ty] / c.energy_scale + od * sg;
+  const float w3d = W[rw.w3d + o], w3g = W[rw.w3g + o];
+  float od[kRA], og[kRA], sg[kRA];
+#pragma unroll
+  for (int j = 0; j < kRA; ++j) {
+    od[j] = w3d * silu_f(pd2[j]);
+    og[j] = w3g * silu_f(pg2[j]);
+    for (int off = 32; off > 0; off >>= 1) { od[j] += __shfl_xor(od[j], off); og[j] += __shfl_xor(og[j], off); }
+    od[j] += W[rw.b3];
+    og[j] += W[rw.b3 + 1];
+    sg[j] = sigmoid_f(og[j]);
+    if (a0 + j < N && o == 0) {
+      int64_t ty = types[a0 + j];
+      ty = ty < 0 ? 0 : (ty >= c.num_types ? c.num_types - 1 : ty);
+      scaled_atomic[a0 + j] = W[elemental_off + ty] / c.energy_scale + od[j] * sg[j];
+    }
   }
   if (dx == nullptr) return;  // uniform
   // reverse: dL/d eps = energy_scale
-  float d_od = c.energy_scale * sg, d_og = c.energy_scale * od * sg * (1.f - sg);
-  float d_pd2 = d_od * W[rw.w3d + o] * dsilu_f(pd2), d_pg2 = d_og * W[rw.w3g + o] * dsilu_f(pg2);
-  __syncthreads();
-  bufA[wv][o] = d_pd2;
-  bufB[wv][o] = d_pg2;
-  __syncthreads();
-  float d_hd1 = 0.f, d_hg1 = 0.f;
-  for (int j = 0; j < kDP; ++j) {
-    d_hd1 += W[rw.w2d + j * kDP + o] * bufA[wv][j];
-    d_hg1 += W[rw.w2g + j * kDP + o] * bufB[wv][j];
+#pragma unroll
+  for (int j = 0; j < kRA; ++j) {
+    const float d_od = c.energy_scale * sg[j], d_og = c.energy_scale * od[j] * sg[j] * (1.f - sg[j]);
+    bufA[wv][j][o] = d_od * w3d * dsilu_f(pd2[j]);
+    bufB[wv][j][o] = d_og * w3g * dsilu_f(pg2[j]);
   }
-  float d_pd1 = d_hd1 * dsilu_f(pd1), d_pg1 = d_hg1 * dsilu_f(pg1);
   __syncthreads();
-  bufA[wv][o] = d_pd1;
-  bufB[wv][o] = d_pg1;
+  float d_hd1[kRA], d_hg1[kRA];
+#pragma unroll
+  for (int j = 0; j < kRA; ++j) { d_hd1[j] = 0.f; d_hg1[j] = 0.f; }
+  for (int k = 0; k < kDP; ++k) {
+    const float wd = W[rw.w2d + k * kDP + o], wg = W[rw.w2g + k * kDP + o];
+#pragma unroll
+    for (int j = 0; j < kRA; ++j) { d_hd1[j] += wd * bufA[wv][j][k]; d_hg1[j] += wg * bufB[wv][j][k]; }
+  }
+#pragma unroll
+  for (int j = 0; j < kRA; ++j) {
+    bufA[wv][j][o] = d_hd1[j] * dsilu_f(pd1[j]);
+    bufB[wv][j][o] = d_hg1[j] * dsilu_f(pg1[j]);
+  }
   __syncthreads();
-  float acc = 0.f;
-  for (int j = 0; j < kDP; ++j) acc += W[rw.w1d + j * kDP + o] * bufA[wv][j] + W[rw.w1g + j * kDP + o] * bufB[wv][j];
-  if (live) dx[a * kDP + o] = acc;
+  float acc[kRA];
+#pragma unroll
+  for (int j = 0; j < kRA; ++j) acc[j] = 0.f;
+  for (int k = 0; k < kDP; ++k) {
+    const float wd = W[rw.w1d + k * kDP + o], wg = W[rw.w1g + k * kDP + o];
+#pragma unroll
+    for (int j = 0; j < kRA; ++j) acc[j] += wd * bufA[wv][j][k] + wg * bufB[wv][j][k];
+  }
+#pragma unroll
+  for (int j = 0; j < kRA; ++j)
+    if (a0 + j < N) dx[(a0 + j) * kDP + o] = acc[j];
 }
 
 // per-structure energy sum: wave-level pre-reduction when the wave's atoms share a structure
@@ -357,7 +387,7 @@ void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, con
                     bool want_grad, hipStream_t s) {
   (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
   if (t.N > 0) {
-    hipLaunchKernelGGL(k_readout, grid_for(t.N, 4), dim3(256), 0, s, c, t.N, W, wl.ro, wl.elemental, types, x, scaled_atomic,
+    hipLaunchKernelGGL(k_readout, grid_for(t.N, 4 * kRA), dim3(256), 0, s, c, t.N, W, wl.ro, wl.elemental, types, x, scaled_atomic,
                        want_grad ? w.dx : nullptr);
     hipLaunchKernelGGL(k_energy_sum, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, scaled_atomic, scaled_total);
   }
