@@ -25,16 +25,15 @@ __device__ __forceinline__ void chain_dual(const float* img, const f32x4 (&x)[NX
   static_assert(KS == 2, "the image holds 64 input features");
   static_assert(XOFF + 2 * KS <= NX && AOFF + OB <= NA && (RB0 + OB) * 16 <= ROWS, "chain_dual operand out of range");
   const int m = lane & 15, q = lane >> 4, sw = dual_swz(m);
-  const char* base = reinterpret_cast<const char*>(img) + m * 128;
+  const char* base = reinterpret_cast<const char*>(img) + (m >> 3) * 1024 + (m & 7) * 64;
   static_for<KS>([&]<int s>() {
     bf16x8 bh, bl;
     split8(x[XOFF + 2 * s], x[XOFF + 2 * s + 1], bh, bl);
-    const char* u0 = base + ((((2 * s) * 4 + q) ^ sw) << 3);
-    const char* u1 = base + ((((2 * s + 1) * 4 + q) ^ sw) << 3);
+    const char* u = base + (((s * 4 + q) ^ sw) << 3);
     static_for<OB>([&]<int ob>() {
-      constexpr int roff = (RB0 + ob) * 2048, lo = ROWS * 128;
-      const bf16x8 ah = join_halves(*(const s16x4*)(u0 + roff), *(const s16x4*)(u1 + roff));
-      const bf16x8 al = join_halves(*(const s16x4*)(u0 + roff + lo), *(const s16x4*)(u1 + roff + lo));
+      constexpr int roff = (RB0 + ob) * 2048, plane = 512, lo = ROWS * 128;
+      const bf16x8 ah = join_halves(*(const s16x4*)(u + roff), *(const s16x4*)(u + roff + plane));
+      const bf16x8 al = join_halves(*(const s16x4*)(u + roff + lo), *(const s16x4*)(u + roff + lo + plane));
       acc[AOFF + ob] = mfma_bf16(ah, bh, acc[AOFF + ob]);
       acc[AOFF + ob] = mfma_bf16(ah, bl, acc[AOFF + ob]);
       acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
@@ -50,13 +49,15 @@ __device__ __forceinline__ void chain_dual_t(const float* img, const f32x4 (&d)[
   static_assert(DOFF + 2 * KS <= ND && AOFF + OB <= NA && (KB0 + 2 * KS) * 16 <= ROWS, "chain_dual_t operand out of range");
   const int q = lane >> 4, qp = (lane & 15) >> 2, p = lane & 3;
   const int row_lo = 4 * q + qp, sw = dual_swz(row_lo);
-  const char* base = reinterpret_cast<const char*>(img) + row_lo * 128;
+  const char* base = reinterpret_cast<const char*>(img) + (row_lo >> 3) * 1024 + (row_lo & 7) * 64;
   static_for<KS>([&]<int s>() {
     bf16x8 bh, bl;
     split8(d[DOFF + 2 * s], d[DOFF + 2 * s + 1], bh, bl);
     static_for<OB>([&]<int ob>() {
-      const char* u = base + (((4 * ob + p) ^ sw) << 3);
-      constexpr int r0 = (KB0 + 2 * s) * 2048, r1 = (KB0 + 2 * s + 1) * 2048, lo = ROWS * 128;
+      // input-feature block ob = chunks 4*ob + p: plane ob & 1, cp = (ob >> 1) * 4 + p
+      constexpr int plane = 512, lo = ROWS * 128;
+      const char* u = base + (ob & 1) * plane + ((((ob >> 1) * 4 + p) ^ sw) << 3);
+      constexpr int r0 = (KB0 + 2 * s) * 2048, r1 = (KB0 + 2 * s + 1) * 2048;
       const bf16x8 ah = join_halves(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0)),
                                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1)));
       const bf16x8 al = join_halves(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0 + lo)),
@@ -89,7 +90,7 @@ inline void pack_dual_image(float* img, int rows, F get) {
     for (int col = 0; col < 64; ++col) {
       const float w = get(row, col);
       const uint16_t h = rne(w);
-      const size_t idx = (size_t)(dual_unit_byte(row, col >> 2) >> 1) + (col & 3);
+      const size_t idx = (size_t)(dual_unit_byte(rows, row, col >> 2) >> 1) + (col & 3);
       hi[idx] = h;
       lo[idx] = rne(w - tof(h));
     }

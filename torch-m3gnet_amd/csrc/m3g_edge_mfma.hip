@@ -123,7 +123,8 @@ template <int N>
 __device__ __forceinline__ int row_shr_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xf, 0xf, false); }
 template <int N>
 __device__ __forceinline__ float row_shr_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, false));
+  // bound_ctrl: lanes without a source read 0, which lets the compiler fold the DPP move into the consuming v_fmac
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
 }
 __device__ __forceinline__ SegMasks seg_masks(int ci, int lane) {
   SegMasks k;
