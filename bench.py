@@ -12,7 +12,8 @@ With N > 1 each rank owns one independent supercell (structures are independent,
 scaling, no data-path collective; the per-structure energies are all-gathered over RCCL every step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      fp32-MFMA roofline of the dominant kernel, its duration measured live with HIP events
+  roofline      HBM roofline (algorithmic bytes) of the dominant kernel, its duration measured live with HIP events in the
+                library; PMC-measured traffic and the matrix-pipe view of the same launch attached
   cpu_baseline  the CPU oracle (oracle/m3gnet_oracle.py, a plain-torch port of the reference) timed on the
                 host cores on a bounded sample (2,048-atom Cu supercell), rank 0, N = 1 only
 """
@@ -37,17 +38,22 @@ FLOPS_PER_EDGE_BLOCK = 134_144      # a14 65,536+384, a15 65,5
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 matrix peak (no xf32/TF32 on gfx950)
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (about 6.3 TB/s achievable)
-# The three fused edge kernels (m3g_edge_mfma.hip).  Algorithmic figures per edge and launch:
-#   bytes = edge-feature images the kernel must read/write (64 fp32 = 256 B each); FLOPs from SURVEY.md 8(d).
+# The fused MFMA edge kernels (m3g_edge_mfma.hip).  Algorithmic figures per edge and launch:
+#   bytes = edge-feature images the kernel must move under ideal fusion (256 B each): forward read e +
+#           write e; reverse read saved e + read and write dL/de;   FLOPs from SURVEY.md 8(d) (backward = 1x forward).
 #   MFMA counts per 16-edge tile: v_mfma_f32_16x16x32_bf16 (16,384 FLOP) / v_mfma_f32_16x16x4_f32 (2,048 FLOP).
 EDGE_KERNELS = {
     "edge_block_fwd": dict(kernel="k_edge_block_mfma", alg_bytes_per_edge=2 * 256, alg_flops_per_edge=134_144,
                            bf16_mfma_per_tile=192, f32_mfma_per_tile=48),
+    "edge_rev_fused": dict(kernel="k_edge_rev_fused", alg_bytes_per_edge=3 * 256, alg_flops_per_edge=134_144,
+                           bf16_mfma_per_tile=396, f32_mfma_per_tile=48),
+    # split reverse kernels (option rev_kernel = 0)
     "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", alg_bytes_per_edge=2 * 256, alg_flops_per_edge=65_920,
                               bf16_mfma_per_tile=192, f32_mfma_per_tile=8),
     "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", alg_bytes_per_edge=4 * 256, alg_flops_per_edge=68_224,
                               bf16_mfma_per_tile=204, f32_mfma_per_tile=56),
 }
+PMC_TRAFFIC_FILE = "r01b_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE of this build (tools/pmc_traffic.py)
 
 
 def log(msg):
@@ -210,7 +216,7 @@ def main():
     if rank == 0:
         per_launch = {k: (ms / max(cnt, 1), cnt) for k, (ms, cnt) in stages.items() if cnt}
         tiles = (n_edges + 15) // 16
-        pmc_path = ROOT / "profiles" / "r01_final_pmc_hbm_traffic.json"
+        pmc_path = ROOT / "profiles" / PMC_TRAFFIC_FILE
         pmc = json.loads(pmc_path.read_text()) if (pmc_path.exists() and tuple(args.cells) == (10, 10, 25)) else {}
 
         def kernel_roofline(stage):
@@ -237,9 +243,11 @@ def main():
         views = {st: kernel_roofline(st) for st in EDGE_KERNELS if st in per_launch}
         dom = max(views, key=lambda k: views[k]["avg_launch_ms"])   # dominant kernel = longest average launch
         roofline = views[dom]
-        roofline["note"] = ("dense chains run as 3x bf16 split MFMAs (fp32 accumulate) and nothing is saved for the reverse "
-                            "pass, so the fused edge kernels are bandwidth/latency-bound, not matrix-bound; `achieved` uses "
-                            "the algorithmic bytes of DESIGN.md section 4, `traffic` is PMC-measured HBM bytes per launch")
+        roofline["note"] = ("dense chains run as 3x bf16 split MFMAs (fp32 accumulate) and the reverse pass recomputes every "
+                            "activation in one fused kernel per block: the kernel is instruction-issue/latency-bound (PMC: VALU "
+                            "~59 %, MFMA ~31 % of SIMD cycles at 2 waves/SIMD), below both the HBM and the matrix roofline; "
+                            "`achieved` uses the ideal-fusion algorithmic bytes of DESIGN.md section 4, `traffic` is PMC-measured "
+                            "HBM bytes per launch, `mfma_view` prices the same launch against the matrix peaks")
         out = {
             "metric": "atom-steps/sec (energy+forces) on 10k-atom PBC batch", "value": value, "unit": "atom-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -84,8 +84,12 @@ int m3g_plan_set_param(m3g_plan* plan, const char* key, const float* host_data, 
  * HOST pointers. */
 int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data, int64_t numel);
 
-/* Engine options (not part of the reference): "edge_kernel" = 1 fused fp32-MFMA edge blocks (default),
- * 0 = vector-ALU baseline kernels (also selectable with the environment variable M3G_EDGE_KERNEL). */
+/* Engine options (not part of the reference):
+ *   "edge_kernel" = 1 fused MFMA edge blocks (default), 0 = vector-ALU baseline kernels (also M3G_EDGE_KERNEL in the env);
+ *   "rev_kernel"  = 1 one fused reverse kernel per block (default), 0 = node-MLP + edge-MLP kernel pair (A/B testing);
+ *   "stress_mode" = 0 the reference's sum pos (x) F / V (nn/gradient.py:39-62, default), 1 = pair virial
+ *                   -(1/V) sum_e r_e (x) dE/dr_e (docs/gradient.md:47-84), invariant under lattice translations;
+ *   "stamps"      diagnostic builds with in-kernel cycle stamps (m3g_debug_read_stamps). */
 int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value);
 
 /* Pack and upload everything set so far (synchronous).  Must be called before any compute call

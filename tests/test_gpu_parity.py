@@ -83,3 +83,21 @@ def test_both_edge_kernels_against_oracle(case, mode, edge_kernel):
     assert rel_err(g[K.FORCES], o["forces"]) < F_TOL
     assert rel_err(g[K.EDGE_ATTR], o["edge_attr"]) < 1e-5
     assert rel_err(g[K.NODE_FEATURES], o["x"]) < 1e-5
+
+
+def test_fused_and_split_reverse_kernels_agree():
+    """rev_kernel = 1 (one fused reverse kernel per block on dual-use LDS weight images, per-centre sums in the kernel,
+    edge embedding folded into block 0) against rev_kernel = 0 (node-MLP + edge-MLP kernel pair, separate embedding
+    kernels): same math, different summation order -> forces agree to 2e-6 of max|F|, energies to 1e-6."""
+    case, mode = "tio", "doc"
+    params, cfg, consts, graph, expect = load_oracle_case(case, mode)
+    model, _ = build_engine_model(case, mode)
+    model = model.cuda()
+    outs = []
+    for rk in (1, 0):
+        model.engine.set_option("rev_kernel", rk)
+        o = model(engine_graph(graph))
+        outs.append((o["total_energy"].clone(), o["forces"].clone()))
+    model.engine.set_option("rev_kernel", 1)
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-6
+    assert rel_err(outs[0][1], outs[1][1]) < 2e-6

@@ -184,11 +184,11 @@ using namespace m3g;
 
 // ---- stage profiler ---------------------------------------------------------------------------------
 enum StageId { ST_GEOM = 0, ST_EMBED, ST_NODE_PRE, ST_THREEBODY, ST_EDGE_FWD, ST_NODE_SUM, ST_READOUT, ST_OUTPUTS, ST_EDGE_REV_NODE,
-               ST_EDGE_REV, ST_THREEBODY_REV, ST_NODE_REV, ST_EMBED_REV, ST_GEOM_REV, ST_COUNT };
+               ST_EDGE_REV, ST_THREEBODY_REV, ST_NODE_REV, ST_EMBED_REV, ST_GEOM_REV, ST_EDGE_REV_FUSED, ST_COUNT };
 // edge_block_fwd / edge_rev_node_mlp / edge_rev_edge_mlp each time exactly ONE kernel launch (the MFMA kernels)
 static const char* kStageNames[ST_COUNT] = {"geometry_basis", "embed", "node_pre", "threebody_fwd", "edge_block_fwd", "node_sum",
                                             "readout", "optional_outputs", "edge_rev_node_mlp", "edge_rev_edge_mlp", "threebody_rev",
-                                            "node_rev", "embed_rev", "geometry_rev_forces"};
+                                            "node_rev", "embed_rev", "geometry_rev_forces", "edge_rev_fused"};
 struct StageTimer {
   const m3g_plan* p;
   hipStream_t s;
@@ -531,7 +531,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
           M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
       }
       if (mfma && fused_rev) {
-        M3G_STAGE(ST_EDGE_REV);
+        M3G_STAGE(ST_EDGE_REV_FUSED);
         launch_edge_rev_fused(plan, c, t, w, b, dx_cur, /*de_is_zero=*/b == c.B - 1, s);
       } else if (mfma) {
         { M3G_STAGE(ST_EDGE_REV_NODE); launch_edge_rev_node_mlp(plan, c, t, w, b, dx_cur, s); }
