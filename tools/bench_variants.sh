@@ -10,7 +10,7 @@ for v in "$@"; do
 import json,sys
 d=json.loads(open("gpurun_out/bench_var_%s.json"%sys.argv[1]).read().strip().splitlines()[-1])
 s=d["config"]["stage_ms_per_step"]
-print(sys.argv[1], "ms/step %.4f"%d["ms_per_step"], {k: s[k] for k in ("edge_block_fwd","edge_rev_edge_mlp","node_rev","threebody_rev","threebody_fwd") if k in s})
+print(sys.argv[1], "ms/step %.4f"%d["ms_per_step"], {k: s[k] for k in ("edge_block_fwd","edge_rev_fused","edge_rev_edge_mlp","node_rev","threebody_rev","threebody_fwd") if k in s})
 PY
 done
 cp /tmp/base.so $L/libm3gnet_hip.so

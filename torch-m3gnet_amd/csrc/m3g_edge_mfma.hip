@@ -578,7 +578,19 @@ __device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlp
   }
 }
 
-// reverse of one conv GatedMLP at input tile x (recomputing both layers), dual-image version of mlp_reverse_mfma
+// Scheduling fence between the phases of the fused reverse kernel: the machine scheduler otherwise interleaves
+// neighbouring phases to hide latency inside ONE wave, which inflates live ranges past the 168 registers that allow a
+// third wave per SIMD -- and a third wave hides more latency than the interleaving does.
+#ifndef M3G_NO_SCHED_FENCE
+#define M3G_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define M3G_SCHED_FENCE() ((void)0)
+#endif
+
+// reverse of one conv GatedMLP at input tile x (recomputing both layers), dual-image version of mlp_reverse_mfma.
+// The dense and the gate branch are independent between layer 1 and the final product, so each is carried through
+// layer 2, and later through the transposed layers, on its own: 16 instead of 32 registers for the hidden values and
+// for dL/dp1, which is what lets the kernel approach three waves per SIMD.
 template <bool NEED_DP1, int MLP>
 __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlpFused& L, const RevArgs& a, int64_t edge, int64_t tile,
                                                  int64_t ci, int64_t cj, const SegMasks& sk, const f32x4& hv, const f32x4 (&x)[4],
@@ -587,7 +599,22 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
   const int qd = lane >> 4;
   f32x4 p1[8], d2[8];
   gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
-  mlp_preacts_dual<true>(lds, L, x, p1, d2, lane);
+  chain_dual<8, 2, 128>(lds + L.w1c, x, p1, lane);
+  M3G_SCHED_FENCE();
+  bias_step<4, 0>(lds + L.b2, d2, lane);
+  bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
+  static_for<2>([&]<int half>() {   // 0: dense branch (p1[0..3] -> d2[0..3]), 1: gate branch
+    f32x4 hid[4];
+    static_for<4>([&]<int ob>() {
+      static_for<4>([&]<int r>() {
+        const float p = p1[4 * half + ob][r], sg = fsigmoid(p);
+        hid[ob][r] = p * sg;
+        p1[4 * half + ob][r] = sg * (1.f + p * (1.f - sg));   // p1 is only needed again as SiLU'(p1)
+      });
+    });
+    chain_dual<4, 2, 64, 0, 4 * half>(lds + (half == 0 ? L.w2d : L.w2g), hid, d2, lane);
+    M3G_SCHED_FENCE();
+  });
   static_for<4>([&]<int ob>() {
     static_for<4>([&]<int r>() {
       const float p2d = d2[ob][r], p2g = d2[4 + ob][r];
@@ -602,25 +629,28 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
     });
     asm volatile("" : "+v"(dhv[0]), "+v"(dhv[1]), "+v"(dhv[2]), "+v"(dhv[3]));   // see mlp_reverse_mfma
   });
-  f32x4 dp1[8];
-  zero(dp1);
-  chain_dual_t<4, 2, 64, 0, 0>(lds + L.w2d, d2, dp1, lane);
-  chain_dual_t<4, 2, 64, 4, 4>(lds + L.w2g, d2, dp1, lane);
-  static_for<8>([&]<int ob>() { dp1[ob] *= p1[ob]; });
-  if (NEED_DP1 && edge < a.E) {
-    float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
-    static_for<8>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
-  }
   zero(contrib);
-  chain_dual_t<4, 4, 128>(lds + L.w1c, dp1, contrib, lane);
-  if (NEED_DP1) {
-    // sum of the dp1 rows per centre (the x_i half of the node reverse): scanned here, so the node kernel reads a few
-    // partial rows per atom instead of every row of the centre.  The rows themselves are still stored above for the
-    // x_j half, which is a gather by neighbour.
-    if (edge >= a.E) zero(dp1);   // padding lanes of the last tile
-    seg_scan(dp1, sk);
-    seg_store<MLP * 8>(dp1, sk, a.seg_head, a.seg_first, tile, ci, qd);
-  }
+  M3G_SCHED_FENCE();
+  static_for<2>([&]<int half>() {
+    f32x4 dp1[4];
+    zero(dp1);
+    chain_dual_t<4, 2, 64, 4 * half, 0>(lds + (half == 0 ? L.w2d : L.w2g), d2, dp1, lane);
+    static_for<4>([&]<int ob>() { dp1[ob] *= p1[4 * half + ob]; });
+    if (NEED_DP1 && edge < a.E) {
+      float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + half * kDP + 4 * qd;
+      static_for<4>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
+    }
+    chain_dual_t<4, 2, 128, 0, 0, 4 * half>(lds + L.w1c, dp1, contrib, lane);   // rows half*64 .. +63 of W1c
+    if (NEED_DP1) {
+      // sum of the dp1 rows per centre (the x_i half of the node reverse): scanned here, so the node kernel reads a few
+      // partial rows per atom instead of every row of the centre.  The rows themselves are still stored above for the
+      // x_j half, which is a gather by neighbour.
+      if (edge >= a.E) zero(dp1);   // padding lanes of the last tile
+      seg_scan(dp1, sk);
+      seg_store<MLP * 8 + 4 * half>(dp1, sk, a.seg_head, a.seg_first, tile, ci, qd);
+    }
+    M3G_SCHED_FENCE();
+  });
 }
 
 template <int TBS, bool NEED_DP1, int WAVES>
@@ -654,6 +684,28 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
     f32x4 x[4], de[4], contrib[4];
     constexpr bool FIRST = !NEED_DP1;   // block 0: its input is the edge embedding e0 = SiLU(W_adj h), formed here
+    {
+      // Node-message MLP first: its input e2 is what the forward kernel stored as the next block's edge features
+      // (reading it back, 256 B/edge, is cheaper for this issue-bound kernel than a second evaluation of the edge
+      // MLP), so nothing of the edge-MLP side has to stay in registers across it.
+      f32x4 x2[4];
+      const float* e2_tile = a.e2_tile + tile * kTileFloats + lane * 4;
+      static_for<4>([&]<int blk>() { x2[blk] = *(const f32x4*)(e2_tile + blk * 256); });
+      // d msg[e] = dx_new[centre(e)]
+      f32x4 dmsg[4];
+      const float* xrow = a.dx_new + ci * kDP + 4 * qd;
+      static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
+      mlp_reverse_dual<NEED_DP1, 1>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv);
+    }
+    // dL/d e2 = what flows in from later blocks + the node MLP's contribution
+    if (a.de_is_zero) {
+      static_for<4>([&]<int blk>() { de[blk] = contrib[blk]; });
+    } else {
+      static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + contrib[blk]; });
+    }
+    // the opaque copy also pins the order: without it the scheduler hoists the e1 computation above the node phase
+    asm volatile("" : "+v"(lv));
+    M3G_SCHED_FENCE();
     if (FIRST) {
       const float hb = a.h[ec * kRP + qd];
       static_for<4>([&]<int blk>() {
@@ -667,24 +719,6 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       f32x4 p[8];
       tb_preact<TBS>(lds + L.tb, mb, p, lv);
       static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
-    }
-    {
-      // e2 (the node MLP's input) is what the forward kernel stored as the next block's edge features: reading it back
-      // (256 B/edge) is cheaper for this issue-bound kernel than a second evaluation of the edge MLP
-      f32x4 x2[4];
-      const float* e2_tile = a.e2_tile + tile * kTileFloats + lane * 4;
-      static_for<4>([&]<int blk>() { x2[blk] = *(const f32x4*)(e2_tile + blk * 256); });
-      // node-message MLP reverse: d msg[e] = dx_new[centre(e)]
-      f32x4 dmsg[4];
-      const float* xrow = a.dx_new + ci * kDP + 4 * qd;
-      static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
-      mlp_reverse_dual<NEED_DP1, 1>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv);
-    }
-    // dL/d e2 = what flows in from later blocks + the node MLP's contribution
-    if (a.de_is_zero) {
-      static_for<4>([&]<int blk>() { de[blk] = contrib[blk]; });
-    } else {
-      static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + contrib[blk]; });
     }
     mlp_reverse_dual<NEED_DP1, 0>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
