@@ -488,13 +488,14 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   for (int b = 0; b < c.B; ++b) {
     {
       M3G_STAGE(ST_NODE_PRE);
-      launch_node_pre(c, W, wl.blk[b], t, w.x[b], w.v[b], mfma ? w.TAb[b] : w.TA, mfma ? w.TBb[b] : w.TB, s);
+      // MFMA path: block b > 0 forms x^b = x^(b-1) + per-centre message sums of block b-1 while loading it
+      launch_node_pre(c, W, wl.blk[b], t, w, (mfma && b > 0) ? w.x[b - 1] : nullptr, w.x[b], w.v[b], mfma ? w.TAb[b] : w.TA,
+                      mfma ? w.TBb[b] : w.TB, s);
     }
     { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }
     if (mfma) {
       { M3G_STAGE(ST_EDGE_FWD); launch_edge_block_mfma(plan, c, t, w, b, s); }
-      M3G_STAGE(ST_NODE_SUM);
-      launch_node_sum_seg(t, w, w.x[b], w.x[b + 1], s);
+      (void)ST_NODE_SUM;   // the per-centre sums are consumed by the next node_pre / the readout
     } else {
       M3G_STAGE(ST_EDGE_FWD);
       if (N > 0) M3G_HIP_CHECK(hipMemcpyAsync(w.x[b + 1], w.x[b], sizeof(float) * N * kDP, hipMemcpyDeviceToDevice, s));
@@ -502,7 +503,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     }
   }
   const bool want_f = io->forces != nullptr;
-  { M3G_STAGE(ST_READOUT); launch_readout(c, W, wl, t, io->atom_types, w.x[c.B], w, ea, st, io->total_energy, want_f, s); }
+  { M3G_STAGE(ST_READOUT); launch_readout(c, W, wl, t, io->atom_types, (mfma && c.B > 0) ? w.x[c.B - 1] : nullptr, w.x[c.B], w, ea, st,
+                                          io->total_energy, want_f, s); }
   StageTimer* st_out = new StageTimer(plan, ST_OUTPUTS, s);
 
   if (io->node_features) launch_copy_strided(w.x[c.B], kDP, io->node_features, c.D, c.D, N, s);

@@ -257,12 +257,12 @@ void launch_embed(const Consts& c, const float* W, const WeightLayout& wl, const
                   const Work& w, hipStream_t s);
 void launch_embed_reverse(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const Work& w,
                           hipStream_t s);
-void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const float* x, float* v,
-                     float* TA, float* TB, hipStream_t s);
+void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* x_prev, float* x,
+                     float* v, float* TA, float* TB, hipStream_t s);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
                          const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, hipStream_t s);
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
-                    const float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
+                    const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                     bool want_grad, hipStream_t s);
 void launch_gather_rows(const float* table, int64_t n, int width, int table_stride, int table_rows, bool transposed,
                         const int64_t* idx, float* out, hipStream_t s);

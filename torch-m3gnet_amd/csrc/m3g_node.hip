@@ -50,18 +50,38 @@ __global__ void __launch_bounds__(256) k_embed_edges_reverse(int R, int64_t E, c
   }
 }
 
+// x_new[i,k] = x_prev[i,k] + the per-centre message sums the forward edge kernel left as partial rows (seg_head /
+// seg_first, see m3g_edge_mfma.hip seg_scan): folded into the consumers of x_new instead of a kernel of its own
+struct NodeSums {
+  const float* x_prev;      // null: x is already final
+  const float *seg_head, *seg_first;
+  const int32_t* row_ptr;
+  float* x_out;             // where the summed features are kept for later stages
+};
+__device__ __forceinline__ float node_feature(const NodeSums& ns, const float* __restrict__ x, int64_t i, int k) {
+  if (!ns.x_prev) return x[i * kDP + k];
+  float acc = ns.x_prev[i * kDP + k];
+  const int r0 = ns.row_ptr[i], r1 = ns.row_ptr[i + 1];
+  if (r1 > r0) {
+    if (r0 & 15) acc += ns.seg_first[i * (4 * kDP) + k];
+    for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t) acc += ns.seg_head[(int64_t)t * (4 * kDP) + k];
+  }
+  ns.x_out[i * kDP + k] = acc;
+  return acc;
+}
+
 // ---- S2: v = sigmoid(W1 x + b1);  TA = [W1a_e x + b1_e | W1a_n x + b1_n];  TB = [W1b_e x | W1b_n x] ----
 constexpr int kNodesPerBlock = 16;  // weights (128 KB per block of W1a/W1b) are read once per 16 atoms
 __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float* __restrict__ W, BlockW bw,
-                                                  const float* __restrict__ x, float* __restrict__ v, float* __restrict__ TA,
-                                                  float* __restrict__ TB) {
+                                                  const float* __restrict__ x, NodeSums ns, float* __restrict__ v,
+                                                  float* __restrict__ TA, float* __restrict__ TB) {
   __shared__ float xs[kNodesPerBlock][kDP];
   int64_t n0 = (int64_t)blockIdx.x * kNodesPerBlock;
   int tid = threadIdx.x;
   for (int idx = tid; idx < kNodesPerBlock * kDP; idx += 256) {
     int nb = idx >> 6, k = idx & 63;
     int64_t a = n0 + nb;
-    xs[nb][k] = a < N ? x[a * kDP + k] : 0.f;
+    xs[nb][k] = a < N ? node_feature(ns, x, a, k) : 0.f;
   }
   __syncthreads();
   // table column o in [0, 4*kDP): MLP e for o < 2*kDP, MLP n otherwise
@@ -74,6 +94,7 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
   for (int nb = 0; nb < kNodesPerBlock; ++nb) { accA[nb] = bias; accB[nb] = 0.f; }
   const float* wa = W + mw.w1a_t + oo;
   const float* wb = W + mw.w1b_t + oo;
+#pragma unroll 8
   for (int k = 0; k < kDP; ++k) {
     float a = wa[k * 2 * kDP], b = wb[k * 2 * kDP];
 #pragma unroll
@@ -224,13 +245,13 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
 constexpr int kRA = 4;
 __global__ void __launch_bounds__(256) k_readout(Consts c, int64_t N, const float* __restrict__ W, ReadoutW rw,
                                                  size_t elemental_off, const int64_t* __restrict__ types,
-                                                 const float* __restrict__ x, float* __restrict__ scaled_atomic,
+                                                 const float* __restrict__ x, NodeSums ns, float* __restrict__ scaled_atomic,
                                                  float* __restrict__ dx) {
   __shared__ float bufA[4][kRA][kDP], bufB[4][kRA][kDP];
   const int wv = threadIdx.x >> 6, o = threadIdx.x & 63;
   const int64_t a0 = ((int64_t)blockIdx.x * 4 + wv) * kRA;
 #pragma unroll
-  for (int j = 0; j < kRA; ++j) bufA[wv][j][o] = x[(a0 + j < N ? a0 + j : 0) * kDP + o];
+  for (int j = 0; j < kRA; ++j) bufA[wv][j][o] = a0 + j < N ? node_feature(ns, x, a0 + j, o) : 0.f;
   __syncthreads();
   float pd1[kRA], pg1[kRA], pd2[kRA], pg2[kRA];
   {
@@ -369,10 +390,12 @@ void launch_embed_reverse(const Consts& c, const float* W, const WeightLayout& w
     hipLaunchKernelGGL(k_embed_edges_reverse, grid_for(t.E, 4), dim3(256), 0, s, c.R, t.E, W + wl.adj_t, w.h, w.de, w.dh);
 }
 
-void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const float* x, float* v,
-                     float* TA, float* TB, hipStream_t s) {
+// x_prev != nullptr: x (= x_prev + the per-centre message sums in w.seg_*) is formed here and stored to x
+void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* x_prev, float* x,
+                     float* v, float* TA, float* TB, hipStream_t s) {
+  NodeSums ns{x_prev, w.seg_head, w.seg_first, t.row_ptr, x};
   if (t.N > 0)
-    hipLaunchKernelGGL(k_node_pre, grid_for(t.N, kNodesPerBlock), dim3(256), 0, s, c.C, t.N, W, bw, x, v, TA, TB);
+    hipLaunchKernelGGL(k_node_pre, grid_for(t.N, kNodesPerBlock), dim3(256), 0, s, c.C, t.N, W, bw, x, ns, v, TA, TB);
 }
 
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
@@ -383,11 +406,12 @@ void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, cons
 }
 
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
-                    const float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
+                    const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                     bool want_grad, hipStream_t s) {
+  NodeSums ns{x_prev, w.seg_head, w.seg_first, t.row_ptr, x};
   (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
   if (t.N > 0) {
-    hipLaunchKernelGGL(k_readout, grid_for(t.N, 4 * kRA), dim3(256), 0, s, c, t.N, W, wl.ro, wl.elemental, types, x, scaled_atomic,
+    hipLaunchKernelGGL(k_readout, grid_for(t.N, 4 * kRA), dim3(256), 0, s, c, t.N, W, wl.ro, wl.elemental, types, x, ns, scaled_atomic,
                        want_grad ? w.dx : nullptr);
     hipLaunchKernelGGL(k_energy_sum, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, scaled_atomic, scaled_total);
   }

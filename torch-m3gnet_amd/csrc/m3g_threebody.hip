@@ -8,7 +8,7 @@
 // reverse), so every sum is a private register accumulation -- no atomics, run-to-run reproducible.
 // Rows are the ACTIVE edges only (edges inside the three-body cutoff that have a partner; Topo::act_list): with
 // r_c = 5 / r_3 = 4 on fcc Cu 24 of an atom's 42 edges carry no triplet, and a thread per edge left 57 % of the
-// lanes idle.  One thread per active row, 256 consecutive rows per workgroup.  The partners of those rows are
+// lanes idle.  One thread per active row, 128 consecutive rows per workgroup.  The partners of those rows are
 // active edges of the same centre atoms, i.e. one contiguous window of the compacted list: the workgroup stages that
 // window's unit vectors and per-edge payload rows (g = q*v[dst] for the forward / e1 half, dS = fc*dm for the e2
 // half) in LDS once -- the per-atom triplet tile -- and the triplet loops read LDS instead of gathering from
@@ -35,41 +35,24 @@ __device__ __forceinline__ void legendre(float x, float* P, float* dP) {
 struct TbArgs {
   int64_t E;
   const int32_t *act_list, *act_dst, *tb_win, *n_act;
-  const int32_t *t_ptr, *t_other;     // triplet CSR of this pass (by e1: partner = e2; by e2: partner = e1), partners as compacted ids
-  const float *u, *fc3, *fc3p, *q, *qp, *v;
-  const float* dm;                    // reverse: dL/dm [E][kCP]
-  float* m;                           // forward out [E][kCP]
-  float *dd, *du, *dgq;               // reverse in/out
+  const int32_t *t_ptr, *t_other;     // triplets grouped by e1, partners e2 as compacted ids
+  const float *u, *fc3, *q, *v;
+  float* m;                           // out [E][kCP]
 };
 
-// payload of edge e (neighbour atom k) for this pass: MODE 0/1 -> g[e,:] = q*v[k];  MODE 2 -> dS[e,:] = fc3*dm
-template <int C, int MODE>
-__device__ __forceinline__ void payload(const TbArgs& a, int64_t e, int64_t k, float* out) {
-  if (MODE == 2) {
-    const float f = a.fc3[e];
-#pragma unroll
-    for (int c = 0; c < C; ++c) out[c] = f * a.dm[e * kCP + c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < C; ++c) out[c] = a.q[e * kCP + c] * a.v[k * kCP + c];
-  }
-}
-
-// MODE 0: forward (rows = e1);  MODE 1: reverse e1 half (d fc(d_e1), d u_e1);  MODE 2: reverse e2 half
-template <int L, int R, int MODE>
-__global__ void __launch_bounds__(kTbRows) k_threebody_tile(Consts c, TbArgs a) {
+// Forward: m[e1,:] = fc(d_e1) sum_t Y_l(cos_t) g[e2(t),:]
+template <int L, int R>
+__global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   constexpr int C = L * R;
   __shared__ float su[kTbCap * 3];
   __shared__ float sp[kTbCap * C];
+  __shared__ int s_other[kTbListCap];
   // independent first-level loads: A, this workgroup's window, this thread's row
   const int A = *a.n_act;
   const int rb = blockIdx.x * kTbRows;
   if (rb >= A) return;                       // the grid is sized for the worst case A = E
-  __shared__ int s_other[kTbListCap];
-  const int lo = a.tb_win[6 * blockIdx.x];
-  const int hi_full = a.tb_win[6 * blockIdx.x + 1];
-  const int t_lo = a.tb_win[6 * blockIdx.x + (MODE == 2 ? 4 : 2)];
-  const int t_hi = a.tb_win[6 * blockIdx.x + (MODE == 2 ? 5 : 3)];
+  const int lo = a.tb_win[6 * blockIdx.x], hi_full = a.tb_win[6 * blockIdx.x + 1];
+  const int t_lo = a.tb_win[6 * blockIdx.x + 2], t_hi = a.tb_win[6 * blockIdx.x + 3];
   // the rows' partner lists are one contiguous range of t_other: staged once, coalesced, as window-relative ids --
   // a global load per triplet inside the loop serialises ~17 L2 round trips per thread
   const int n_list = (t_hi - t_lo) < kTbListCap ? (t_hi - t_lo) : kTbListCap;
@@ -78,53 +61,33 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_tile(Consts c, TbArgs a) 
   const bool live = r < A;
   const int64_t e = a.act_list[live ? r : A - 1];
   const int64_t e_next = r + 1 < A ? a.act_list[live ? r + 1 : A - 1] : a.E;
-  const int64_t kd = a.act_dst[live ? r : A - 1];
   const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
   for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
-    const int64_t es = a.act_list[lo + idx];
+    const int64_t es = a.act_list[lo + idx], ks = a.act_dst[lo + idx];
     su[idx * 3 + 0] = a.u[es * 3];
     su[idx * 3 + 1] = a.u[es * 3 + 1];
     su[idx * 3 + 2] = a.u[es * 3 + 2];
-    float row[C];
-    payload<C, MODE>(a, es, a.act_dst[lo + idx], row);
 #pragma unroll
-    for (int cc = 0; cc < C; ++cc) sp[idx * C + cc] = row[cc];
+    for (int cc = 0; cc < C; ++cc) sp[idx * C + cc] = a.q[es * kCP + cc] * a.v[ks * kCP + cc];
   }
-  // edges without triplets keep m = 0 (MODE 0) / dg = 0 (MODE 2): every thread clears the gap after its own row
-  // (and the first row the edges before it), so no separate memset pass over the [E,16] arrays is needed
-  if (MODE != 1 && live) {
-    float* z = MODE == 0 ? a.m : a.dgq;
+  // edges without triplets keep m = 0: every thread clears the gap after its own row (the first row also the edges
+  // before it), so no separate memset pass over the [E,16] array is needed
+  if (live) {
     for (int64_t g = (r == 0 ? 0 : e + 1); g < e_next; ++g) {
       if (g == e) continue;
 #pragma unroll
-      for (int k = 0; k < kCP; k += 4) *(float4*)(z + g * kCP + k) = float4{0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < kCP; k += 4) *(float4*)(a.m + g * kCP + k) = float4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  // everything this row needs from global memory is requested before the barrier, so the triplet loop and the
-  // epilogue wait on nothing but LDS (the pointers are not restrict: loads placed after the stores would stay there)
+  // everything this row needs from global memory is requested before the barrier
   const int t0 = a.t_ptr[e], t1 = a.t_ptr[e + 1];
   const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
   const float fc = a.fc3[e];
-  float own[C], qv[C], qpv[C], vv[C];
-  float fcp = 0.f, dd0 = 0.f, du0 = 0.f, du1 = 0.f, du2 = 0.f;
-  if (MODE != 0) { dd0 = a.dd[e]; du0 = a.du[e * 3]; du1 = a.du[e * 3 + 1]; du2 = a.du[e * 3 + 2]; }
-  if (MODE == 1) {
-    fcp = a.fc3p[e];
-#pragma unroll
-    for (int k = 0; k < C; ++k) own[k] = a.dm[e * kCP + k];           // dm of this e1
-  } else if (MODE == 2) {
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-      qv[k] = a.q[e * kCP + k]; qpv[k] = a.qp[e * kCP + k]; vv[k] = a.v[kd * kCP + k];
-      own[k] = qv[k] * vv[k];                                         // g of this e2
-    }
-  }
   __syncthreads();
   if (!live) return;
   float acc[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) acc[k] = 0.f;
-  float ax = 0.f, ay = 0.f, az = 0.f;
   for (int t = t0; t < t1; ++t) {
     const int kk = t - t_lo;
     const int idx = kk < kTbListCap ? s_other[kk] : a.t_other[t] - lo;
@@ -134,75 +97,181 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_tile(Consts c, TbArgs a) 
 #pragma unroll
       for (int k = 0; k < C; ++k) pr[k] = sp[idx * C + k];
     } else {
-      const int64_t eo = a.act_list[lo + idx];
+      const int64_t eo = a.act_list[lo + idx], ko = a.act_dst[lo + idx];
       vx = a.u[eo * 3]; vy = a.u[eo * 3 + 1]; vz = a.u[eo * 3 + 2];
-      payload<C, MODE>(a, eo, a.act_dst[lo + idx], pr);
+#pragma unroll
+      for (int k = 0; k < C; ++k) pr[k] = a.q[eo * kCP + k] * a.v[ko * kCP + k];
     }
+    const float cs = fminf(1.f, fmaxf(-1.f, ux * vx + uy * vy + uz * vz));
+    float P[L], dP[L];
+    legendre<L>(cs, P, dP);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float y = c.ynorm[l] * P[l];
+#pragma unroll
+      for (int nn = 0; nn < R; ++nn) acc[l * R + nn] += y * pr[l * R + nn];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kCP; k += 4) {
+    float4 o;
+    o.x = k + 0 < C ? fc * acc[k + 0 < C ? k + 0 : 0] : 0.f;
+    o.y = k + 1 < C ? fc * acc[k + 1 < C ? k + 1 : 0] : 0.f;
+    o.z = k + 2 < C ? fc * acc[k + 2 < C ? k + 2 : 0] : 0.f;
+    o.w = k + 3 < C ? fc * acc[k + 3 < C ? k + 3 : 0] : 0.f;
+    *(float4*)(a.m + e * kCP + k) = o;
+  }
+}
+
+// Reverse, both halves in one launch (rows = active edges, once as e1 and once as e2 of their triplets): the two passes
+// share the staged unit vectors, the row data and -- what these latency-bound kernels pay most for -- the chain of
+// dependent loads in front of the barrier.  Payload rows g (for the e1 half) and dS = fc*dm (for the e2 half) are both
+// staged; partner ids are kept as one byte each (window-relative; 255 = outside the staged window, read from global).
+struct TbRevArgs {
+  int64_t E;
+  const int32_t *act_list, *act_dst, *tb_win, *n_act;
+  const int32_t *t1_ptr, *t1_other, *t2_ptr, *t2_other;
+  const float *u, *fc3, *fc3p, *q, *qp, *v, *dm;
+  float *dd, *du, *dgq;
+};
+constexpr int kTbRevList = 4096;   // staged partner ids per list (bytes)
+
+template <int L, int R>
+__global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a) {
+  constexpr int C = L * R;
+  __shared__ float su[kTbCap * 3];
+  __shared__ float sg[kTbCap * C];
+  __shared__ float ss[kTbCap * C];
+  __shared__ unsigned char s1[kTbRevList], s2[kTbRevList];
+  const int A = *a.n_act;
+  const int rb = blockIdx.x * kTbRows;
+  if (rb >= A) return;
+  const int lo = a.tb_win[6 * blockIdx.x], hi_full = a.tb_win[6 * blockIdx.x + 1];
+  const int t1_lo = a.tb_win[6 * blockIdx.x + 2], t1_hi = a.tb_win[6 * blockIdx.x + 3];
+  const int t2_lo = a.tb_win[6 * blockIdx.x + 4], t2_hi = a.tb_win[6 * blockIdx.x + 5];
+  const int r = rb + threadIdx.x;
+  const bool live = r < A;
+  const int64_t e = a.act_list[live ? r : A - 1];
+  const int64_t e_next = r + 1 < A ? a.act_list[live ? r + 1 : A - 1] : a.E;
+  const int64_t kd = a.act_dst[live ? r : A - 1];
+  const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
+  const int n1 = (t1_hi - t1_lo) < kTbRevList ? (t1_hi - t1_lo) : kTbRevList;
+  const int n2 = (t2_hi - t2_lo) < kTbRevList ? (t2_hi - t2_lo) : kTbRevList;
+  for (int k = threadIdx.x; k < n1; k += kTbRows) { const int d = a.t1_other[t1_lo + k] - lo; s1[k] = (unsigned char)(d >= 0 && d < n && d < 255 ? d : 255); }
+  for (int k = threadIdx.x; k < n2; k += kTbRows) { const int d = a.t2_other[t2_lo + k] - lo; s2[k] = (unsigned char)(d >= 0 && d < n && d < 255 ? d : 255); }
+  for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
+    const int64_t es = a.act_list[lo + idx], ks = a.act_dst[lo + idx];
+    su[idx * 3 + 0] = a.u[es * 3];
+    su[idx * 3 + 1] = a.u[es * 3 + 1];
+    su[idx * 3 + 2] = a.u[es * 3 + 2];
+    const float f = a.fc3[es];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+      sg[idx * C + cc] = a.q[es * kCP + cc] * a.v[ks * kCP + cc];
+      ss[idx * C + cc] = f * a.dm[es * kCP + cc];
+    }
+  }
+  // edges without triplets keep dg = 0: every thread clears the gap after its own row (the first row also the edges before it)
+  if (live) {
+    for (int64_t g = (r == 0 ? 0 : e + 1); g < e_next; ++g) {
+      if (g == e) continue;
+#pragma unroll
+      for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + g * kCP + k) = float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // this row's own data, requested before the barrier
+  const int t10 = a.t1_ptr[e], t11 = a.t1_ptr[e + 1], t20 = a.t2_ptr[e], t21 = a.t2_ptr[e + 1];
+  const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
+  const float fc = a.fc3[e], fcp = a.fc3p[e];
+  const float dd0 = a.dd[e], du0 = a.du[e * 3], du1 = a.du[e * 3 + 1], du2 = a.du[e * 3 + 2];
+  float dmv[C], gv[C], qv[C], qpv[C], vv[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    dmv[k] = a.dm[e * kCP + k];
+    qv[k] = a.q[e * kCP + k]; qpv[k] = a.qp[e * kCP + k]; vv[k] = a.v[kd * kCP + k];
+    gv[k] = qv[k] * vv[k];
+  }
+  __syncthreads();
+  if (!live) return;
+  // partner (window-relative id, or the global fallback) -> unit vector and payload row
+  auto fetch = [&](int id, const int32_t* list, int t, const float* sp, bool want_s, float& vx, float& vy, float& vz, float* pr) {
+    if (id != 255) {
+      vx = su[id * 3]; vy = su[id * 3 + 1]; vz = su[id * 3 + 2];
+#pragma unroll
+      for (int k = 0; k < C; ++k) pr[k] = sp[id * C + k];
+    } else {
+      const int64_t eo = a.act_list[list[t]], ko = a.act_dst[list[t]];
+      vx = a.u[eo * 3]; vy = a.u[eo * 3 + 1]; vz = a.u[eo * 3 + 2];
+      const float f = a.fc3[eo];
+#pragma unroll
+      for (int k = 0; k < C; ++k) pr[k] = want_s ? f * a.dm[eo * kCP + k] : a.q[eo * kCP + k] * a.v[ko * kCP + k];
+    }
+  };
+  float S[C], dg[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) { S[k] = 0.f; dg[k] = 0.f; }
+  float a1x = 0.f, a1y = 0.f, a1z = 0.f, a2x = 0.f, a2y = 0.f, a2z = 0.f;
+  for (int t = t10; t < t11; ++t) {      // this edge as e1: S += Y g[e2], d cos += dm1 dY g[e2]
+    const int kk = t - t1_lo;
+    float vx, vy, vz, pr[C];
+    fetch(kk < kTbRevList ? s1[kk] : 255, a.t1_other, t, sg, false, vx, vy, vz, pr);
     const float raw = ux * vx + uy * vy + uz * vz;
     const float cs = fminf(1.f, fmaxf(-1.f, raw));
     float P[L], dP[L];
     legendre<L>(cs, P, dP);
-    if (MODE == 0) {
+    float dcos = 0.f;
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const float y = c.ynorm[l] * P[l];
+    for (int l = 0; l < L; ++l) {
+      const float y = c.ynorm[l] * P[l], dy = c.ynorm[l] * dP[l];
 #pragma unroll
-        for (int nn = 0; nn < R; ++nn) acc[l * R + nn] += y * pr[l * R + nn];
+      for (int nn = 0; nn < R; ++nn) {
+        const int k = l * R + nn;
+        S[k] += y * pr[k];
+        dcos += dmv[k] * dy * pr[k];
       }
-    } else {
-      const bool inside = raw >= -1.f && raw <= 1.f;   // torch.clamp passes the gradient only inside [-1, 1]
-      float dcos = 0.f;
+    }
+    dcos = (raw >= -1.f && raw <= 1.f) ? dcos : 0.f;   // torch.clamp passes the gradient only inside [-1, 1]
+    a1x += dcos * vx; a1y += dcos * vy; a1z += dcos * vz;
+  }
+  for (int t = t20; t < t21; ++t) {      // this edge as e2: dg += dS[e1] Y, d cos += dS[e1] dY g_own
+    const int kk = t - t2_lo;
+    float vx, vy, vz, pr[C];
+    fetch(kk < kTbRevList ? s2[kk] : 255, a.t2_other, t, ss, true, vx, vy, vz, pr);
+    const float raw = ux * vx + uy * vy + uz * vz;
+    const float cs = fminf(1.f, fmaxf(-1.f, raw));
+    float P[L], dP[L];
+    legendre<L>(cs, P, dP);
+    float dcos = 0.f;
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const float y = c.ynorm[l] * P[l], dy = c.ynorm[l] * dP[l];
+    for (int l = 0; l < L; ++l) {
+      const float y = c.ynorm[l] * P[l], dy = c.ynorm[l] * dP[l];
 #pragma unroll
-        for (int nn = 0; nn < R; ++nn) {
-          const int k = l * R + nn;
-          if (MODE == 1) {            // pr = g[e2]: S += Y g;  dcos += dm1 dY g
-            acc[k] += y * pr[k];
-            dcos += own[k] * dy * pr[k];
-          } else {                    // pr = dS[e1]: dg += dS Y;  dcos += dS dY g_own
-            acc[k] += pr[k] * y;
-            dcos += pr[k] * dy * own[k];
-          }
-        }
+      for (int nn = 0; nn < R; ++nn) {
+        const int k = l * R + nn;
+        dg[k] += pr[k] * y;
+        dcos += pr[k] * dy * gv[k];
       }
-      dcos = inside ? dcos : 0.f;
-      ax += dcos * vx; ay += dcos * vy; az += dcos * vz;
+    }
+    dcos = (raw >= -1.f && raw <= 1.f) ? dcos : 0.f;
+    a2x += dcos * vx; a2y += dcos * vy; a2z += dcos * vz;
+  }
+  float dfc = 0.f, ddv = 0.f, val[kCP];
+#pragma unroll
+  for (int k = 0; k < kCP; ++k) {
+    val[k] = 0.f;
+    if (k < C) {
+      const int kc = k < C ? k : 0;
+      dfc += dmv[kc] * S[kc];
+      ddv += dg[kc] * vv[kc] * qpv[kc];
+      val[k] = dg[kc] * qv[kc];
     }
   }
-  if (MODE == 0) {
 #pragma unroll
-    for (int k = 0; k < kCP; k += 4) {
-      float4 o;
-      o.x = k + 0 < C ? fc * acc[k + 0 < C ? k + 0 : 0] : 0.f;
-      o.y = k + 1 < C ? fc * acc[k + 1 < C ? k + 1 : 0] : 0.f;
-      o.z = k + 2 < C ? fc * acc[k + 2 < C ? k + 2 : 0] : 0.f;
-      o.w = k + 3 < C ? fc * acc[k + 3 < C ? k + 3 : 0] : 0.f;
-      *(float4*)(a.m + e * kCP + k) = o;
-    }
-  } else if (MODE == 1) {
-    float dfc = 0.f;
-#pragma unroll
-    for (int k = 0; k < C; ++k) dfc += own[k] * acc[k];               // acc = S[e1,:]
-    a.dd[e] = dd0 + fcp * dfc;
-    a.du[e * 3] = du0 + fc * ax; a.du[e * 3 + 1] = du1 + fc * ay; a.du[e * 3 + 2] = du2 + fc * az;   // dS = fc * dm
-  } else {
-    a.du[e * 3] = du0 + ax; a.du[e * 3 + 1] = du1 + ay; a.du[e * 3 + 2] = du2 + az;
-    float ddv = 0.f, val[kCP];
-#pragma unroll
-    for (int cc = 0; cc < kCP; ++cc) {
-      val[cc] = 0.f;
-      if (cc < C) {
-        const float dg = acc[cc < C ? cc : 0];                         // acc = dg[e2,:]
-        ddv += dg * vv[cc < C ? cc : 0] * qpv[cc < C ? cc : 0];
-        val[cc] = dg * qv[cc < C ? cc : 0];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + e * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
-    a.dd[e] = dd0 + ddv;
-  }
+  for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + e * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
+  a.dd[e] = (dd0 + fcp * dfc) + ddv;
+  a.du[e * 3] = (du0 + fc * a1x) + a2x;
+  a.du[e * 3 + 1] = (du1 + fc * a1y) + a2y;
+  a.du[e * 3 + 2] = (du2 + fc * a1z) + a2z;
 }
 
 static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 1) / kTbRows)); }
@@ -231,23 +300,16 @@ static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s) {
   if (t.E == 0) return;
   if (t.T == 0) { (void)hipMemsetAsync(m, 0, sizeof(float) * t.E * kCP, s); return; }   // no active row to clear the gaps
-  TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, w.u, w.fc3, w.fc3p, w.q, w.qp, v, nullptr, m, nullptr,
-           nullptr, nullptr};
-  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_tile<L, R, 0>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
+  TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, w.u, w.fc3, w.q, v, m};
+  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }
 
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s) {
   if (t.E == 0) return;
   if (t.T == 0) { (void)hipMemsetAsync(w.dg, 0, sizeof(float) * t.E * kCP, s); return; }
-  TbArgs a1{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd,
-            w.du, w.dg};
-  TbArgs a2 = a1;
-  a2.t_ptr = t.t2_ptr;
-  a2.t_other = t.t2_e1c;
-  M3G_DISPATCH_LR(c.L, c.R, {
-    hipLaunchKernelGGL((k_threebody_tile<L, R, 1>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a1);
-    hipLaunchKernelGGL((k_threebody_tile<L, R, 2>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a2);
-  });
+  TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, w.u, w.fc3, w.fc3p, w.q, w.qp, v,
+              w.dm, w.dd, w.du, w.dg};
+  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }
 
 }  // namespace m3g
