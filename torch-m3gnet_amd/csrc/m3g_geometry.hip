@@ -6,22 +6,24 @@
 
 namespace m3g {
 
-__device__ __forceinline__ float sinc_pi(float x) {  // torch.sinc: sin(pi x)/(pi x)
+// torch.sinc: sin(pi x)/(pi x), and cos(pi x) from the same argument reduction
+__device__ __forceinline__ float sinc_cos_pi(float x, float& cos_px) {
   const float kPi = 3.14159265358979323846f;
-  float px = kPi * x;
-  return x == 0.f ? 1.f : sinf(px) / px;
+  float px = kPi * x, sn;
+  sincosf(px, &sn, &cos_px);
+  return x == 0.f ? 1.f : sn / px;
 }
 
 // radial basis h_m(d) and dh_m/dd (nn/featurizer.py:84-96)
 __device__ __forceinline__ void radial_basis(const Consts& c, float d, float* h, float* hp) {
-  const float kPi = 3.14159265358979323846f;
 #pragma unroll
   for (int m = 0; m < kRCap; ++m) {
     if (m < c.R) {
       float x1 = c.a1[m] * d, x2 = c.a2[m] * d;
-      float s1 = sinc_pi(x1), s2 = sinc_pi(x2);
+      float c1, c2;
+      float s1 = sinc_cos_pi(x1, c1), s2 = sinc_cos_pi(x2, c2);
       float f = c.coeff[m] * (s1 + s2);
-      float df = c.coeff[m] * ((cosf(kPi * x1) - s1) + (cosf(kPi * x2) - s2)) / d;
+      float df = c.coeff[m] * ((c1 - s1) + (c2 - s2)) / d;
       if (m == 0) {
         h[0] = f;
         hp[0] = df;
@@ -40,7 +42,9 @@ __device__ __forceinline__ void radial_basis(const Consts& c, float d, float* h,
 __device__ __forceinline__ void sph_bessel(int L, float x, float* j, float* dj) {
   float seq[kLCap + 1];
   if (x > 1e-8f) {
-    float sx = sinf(x) / x, cx = cosf(x);
+    float sn, cx;
+    sincosf(x, &sn, &cx);
+    float sx = sn / x;
     seq[0] = sx;
     seq[1] = (sx - cx) / x;
 #pragma unroll
@@ -62,7 +66,7 @@ __device__ __forceinline__ void sph_bessel(int L, float x, float* j, float* dj) 
   (void)L;
 }
 
-template <bool FULL>
+template <bool FULL, int L, int R>
 __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int32_t* __restrict__ src,
                                                   const int32_t* __restrict__ dst, const int32_t* __restrict__ batch,
                                                   const float* __restrict__ pos, const float* __restrict__ lattice,
@@ -90,11 +94,9 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int
   if (!FULL) return;
   float hh[kRCap], hd[kRCap];
   radial_basis(c, d, hh, hd);
-#pragma unroll
-  for (int m = 0; m < kRP; ++m) {
-    h[e * kRP + m] = hh[m];
-    hp[e * kRP + m] = hd[m];
-  }
+  // every per-edge row leaves as 16-byte stores (a scalar store per element touched 64 cache lines per instruction)
+  *(float4*)(h + e * kRP) = float4{hh[0], hh[1], hh[2], hh[3]};
+  *(float4*)(hp + e * kRP) = float4{hd[0], hd[1], hd[2], hd[3]};
   // three-body cutoff envelope (nn/interaction.py:389-400) and its derivative
   float rho = d / c.rc3;
   float f = 0.f, fp = 0.f;
@@ -105,21 +107,31 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int
   }
   fc3[e] = f;
   fc3p[e] = fp;
-  // q[e,c] = chi_ln(d) fc(d),  c = l*R + n  (nn/interaction.py:268-281)
+  // q[e,c] = chi_ln(d) fc(d),  c = l*R + n  (nn/interaction.py:268-281); beyond the three-body cutoff both factors of
+  // every product are multiplied by an exact zero, so the Bessel functions are not evaluated there
+  float qr[kCP], qpr[kCP];
 #pragma unroll
-  for (int cc = 0; cc < kCP; ++cc) { q[e * kCP + cc] = 0.f; qp[e * kCP + cc] = 0.f; }
-  for (int n = 0; n < c.R; ++n) {
-    float jl[kLCap], djl[kLCap];
-    for (int l = 0; l < c.L; ++l) {
-      // the argument differs per (l,n): z_ln * d / rc
-      float x = c.zeros[l][n] * d / c.rc;
-      sph_bessel(c.L, x, jl, djl);
-      float chi = jl[l] / c.factors[l][n];
-      float dchi = djl[l] * (c.zeros[l][n] / c.rc) / c.factors[l][n];
-      int cc = l * c.R + n;
-      q[e * kCP + cc] = chi * f;
-      qp[e * kCP + cc] = dchi * f + chi * fp;
+  for (int cc = 0; cc < kCP; ++cc) { qr[cc] = 0.f; qpr[cc] = 0.f; }
+  if (rho <= 1.f) {
+#pragma unroll
+    for (int n = 0; n < R; ++n) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        float jl[kLCap], djl[kLCap];
+        // the argument differs per (l,n): z_ln * d / rc
+        float x = c.zeros[l][n] * d / c.rc;
+        sph_bessel(L, x, jl, djl);
+        float chi = jl[l] / c.factors[l][n];
+        float dchi = djl[l] * (c.zeros[l][n] / c.rc) / c.factors[l][n];
+        qr[l * R + n] = chi * f;
+        qpr[l * R + n] = dchi * f + chi * fp;
+      }
     }
+  }
+#pragma unroll
+  for (int cc = 0; cc < kCP; cc += 4) {
+    *(float4*)(q + e * kCP + cc) = float4{qr[cc], qr[cc + 1], qr[cc + 2], qr[cc + 3]};
+    *(float4*)(qp + e * kCP + cc) = float4{qpr[cc], qpr[cc + 1], qpr[cc + 2], qpr[cc + 3]};
   }
 }
 
@@ -272,8 +284,8 @@ static inline dim3 grid_for(int64_t n, int tpb = 256) { return dim3((unsigned)((
 void launch_geometry(const Consts& c, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
                      const Work& w, hipStream_t s) {
   if (t.E == 0) return;
-  hipLaunchKernelGGL(k_geometry<true>, grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos, lattice, shift,
-                     w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p);
+  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_geometry<true, L, R>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos,
+                                               lattice, shift, w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p));
 }
 
 void launch_distance_only(float length_scale, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
@@ -281,7 +293,7 @@ void launch_distance_only(float length_scale, const Topo& t, const float* pos, c
   if (t.E == 0) return;
   Consts c{};
   c.length_scale = length_scale;
-  hipLaunchKernelGGL(k_geometry<false>, grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos, lattice, shift,
+  hipLaunchKernelGGL((k_geometry<false, 1, 1>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos, lattice, shift,
                      u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 

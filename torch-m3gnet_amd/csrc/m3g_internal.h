@@ -169,6 +169,28 @@ struct m3g_plan {
 namespace m3g {
 
 // ---- topology view (device arrays carved from the caller's topo buffer) -----------------------------
+// compile-time dispatch on (l_max, n_max) <= (4, 4): BODY sees constexpr int L, R
+#define M3G_DISPATCH_LR(L_, R_, BODY)                         \
+  switch ((L_) * 8 + (R_)) {                                  \
+    case 1 * 8 + 1: { constexpr int L = 1, R = 1; BODY; } break; \
+    case 1 * 8 + 2: { constexpr int L = 1, R = 2; BODY; } break; \
+    case 1 * 8 + 3: { constexpr int L = 1, R = 3; BODY; } break; \
+    case 1 * 8 + 4: { constexpr int L = 1, R = 4; BODY; } break; \
+    case 2 * 8 + 1: { constexpr int L = 2, R = 1; BODY; } break; \
+    case 2 * 8 + 2: { constexpr int L = 2, R = 2; BODY; } break; \
+    case 2 * 8 + 3: { constexpr int L = 2, R = 3; BODY; } break; \
+    case 2 * 8 + 4: { constexpr int L = 2, R = 4; BODY; } break; \
+    case 3 * 8 + 1: { constexpr int L = 3, R = 1; BODY; } break; \
+    case 3 * 8 + 2: { constexpr int L = 3, R = 2; BODY; } break; \
+    case 3 * 8 + 3: { constexpr int L = 3, R = 3; BODY; } break; \
+    case 3 * 8 + 4: { constexpr int L = 3, R = 4; BODY; } break; \
+    case 4 * 8 + 1: { constexpr int L = 4, R = 1; BODY; } break; \
+    case 4 * 8 + 2: { constexpr int L = 4, R = 2; BODY; } break; \
+    case 4 * 8 + 3: { constexpr int L = 4, R = 3; BODY; } break; \
+    case 4 * 8 + 4: { constexpr int L = 4, R = 4; BODY; } break; \
+    default: break;                                           \
+  }
+
 constexpr int kTbRows = 128;   // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
 struct Topo {
   int64_t N, E, T, S;

@@ -276,27 +276,6 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
 
 static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 1) / kTbRows)); }
 
-#define M3G_DISPATCH_LR(L_, R_, BODY)                         \
-  switch ((L_) * 8 + (R_)) {                                  \
-    case 1 * 8 + 1: { constexpr int L = 1, R = 1; BODY; } break; \
-    case 1 * 8 + 2: { constexpr int L = 1, R = 2; BODY; } break; \
-    case 1 * 8 + 3: { constexpr int L = 1, R = 3; BODY; } break; \
-    case 1 * 8 + 4: { constexpr int L = 1, R = 4; BODY; } break; \
-    case 2 * 8 + 1: { constexpr int L = 2, R = 1; BODY; } break; \
-    case 2 * 8 + 2: { constexpr int L = 2, R = 2; BODY; } break; \
-    case 2 * 8 + 3: { constexpr int L = 2, R = 3; BODY; } break; \
-    case 2 * 8 + 4: { constexpr int L = 2, R = 4; BODY; } break; \
-    case 3 * 8 + 1: { constexpr int L = 3, R = 1; BODY; } break; \
-    case 3 * 8 + 2: { constexpr int L = 3, R = 2; BODY; } break; \
-    case 3 * 8 + 3: { constexpr int L = 3, R = 3; BODY; } break; \
-    case 3 * 8 + 4: { constexpr int L = 3, R = 4; BODY; } break; \
-    case 4 * 8 + 1: { constexpr int L = 4, R = 1; BODY; } break; \
-    case 4 * 8 + 2: { constexpr int L = 4, R = 2; BODY; } break; \
-    case 4 * 8 + 3: { constexpr int L = 4, R = 3; BODY; } break; \
-    case 4 * 8 + 4: { constexpr int L = 4, R = 4; BODY; } break; \
-    default: break;                                           \
-  }
-
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s) {
   if (t.E == 0) return;
   if (t.T == 0) { (void)hipMemsetAsync(m, 0, sizeof(float) * t.E * kCP, s); return; }   // no active row to clear the gaps
