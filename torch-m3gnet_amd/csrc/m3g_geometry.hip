@@ -145,11 +145,13 @@ __global__ void __launch_bounds__(256) k_geometry_reverse(Consts c, int64_t E, c
   // dL/dh arrives in `dh_parts` slices (one per reverse kernel that produced a share); summed here, in a fixed order
   float dhs[kRP] = {0.f, 0.f, 0.f, 0.f};
   for (int p = 0; p < dh_parts; ++p) {
-#pragma unroll
-    for (int m = 0; m < kRP; ++m) dhs[m] += dh[((int64_t)p * E + e) * kRP + m];
+    const float4 t = *(const float4*)(dh + ((int64_t)p * E + e) * kRP);
+    dhs[0] += t.x; dhs[1] += t.y; dhs[2] += t.z; dhs[3] += t.w;
   }
-#pragma unroll
-  for (int m = 0; m < kRP; ++m) g += dhs[m] * hp[e * kRP + m];
+  {
+    const float4 t = *(const float4*)(hp + e * kRP);
+    g += dhs[0] * t.x + dhs[1] * t.y + dhs[2] * t.z + dhs[3] * t.w;
+  }
   float ux = u[e * 3], uy = u[e * 3 + 1], uz = u[e * 3 + 2];
   float ax = du[e * 3], ay = du[e * 3 + 1], az = du[e * 3 + 2];
   float proj = ax * ux + ay * uy + az * uz;

@@ -21,6 +21,20 @@ namespace m3g {
 constexpr int kTbListCap = 3072;   // staged partner ids (128 rows x 24 partners; longer lists continue from global memory)
 constexpr int kTbCap = 192;    // staged window capacity: kTbRows (128) rows + boundary rows (overflow -> global reads); 9 KB per workgroup
 
+// first C floats of a 16-float (64-byte aligned) row as 16-byte loads: a scalar load per element makes every lane of a
+// wave touch its own cache line once per element
+template <int C>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, float* out) {
+#pragma unroll
+  for (int k = 0; k < C; k += 4) {
+    const float4 t = *(const float4*)(row + k);
+    out[k] = t.x;
+    if (k + 1 < C) out[k + 1] = t.y;
+    if (k + 2 < C) out[k + 2] = t.z;
+    if (k + 3 < C) out[k + 3] = t.w;
+  }
+}
+
 template <int L>
 __device__ __forceinline__ void legendre(float x, float* P, float* dP) {
   P[0] = 1.f; dP[0] = 0.f;
@@ -67,8 +81,11 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
     su[idx * 3 + 0] = a.u[es * 3];
     su[idx * 3 + 1] = a.u[es * 3 + 1];
     su[idx * 3 + 2] = a.u[es * 3 + 2];
+    float qr[C], vr[C];
+    load_row<C>(a.q + es * kCP, qr);
+    load_row<C>(a.v + ks * kCP, vr);
 #pragma unroll
-    for (int cc = 0; cc < C; ++cc) sp[idx * C + cc] = a.q[es * kCP + cc] * a.v[ks * kCP + cc];
+    for (int cc = 0; cc < C; ++cc) sp[idx * C + cc] = qr[cc] * vr[cc];
   }
   // edges without triplets keep m = 0: every thread clears the gap after its own row (the first row also the edges
   // before it), so no separate memset pass over the [E,16] array is needed
@@ -165,10 +182,14 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
     su[idx * 3 + 1] = a.u[es * 3 + 1];
     su[idx * 3 + 2] = a.u[es * 3 + 2];
     const float f = a.fc3[es];
+    float qr[C], vr[C], dr[C];
+    load_row<C>(a.q + es * kCP, qr);
+    load_row<C>(a.v + ks * kCP, vr);
+    load_row<C>(a.dm + es * kCP, dr);
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
-      sg[idx * C + cc] = a.q[es * kCP + cc] * a.v[ks * kCP + cc];
-      ss[idx * C + cc] = f * a.dm[es * kCP + cc];
+      sg[idx * C + cc] = qr[cc] * vr[cc];
+      ss[idx * C + cc] = f * dr[cc];
     }
   }
   // edges without triplets keep dg = 0: every thread clears the gap after its own row (the first row also the edges before it)
@@ -185,12 +206,12 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   const float fc = a.fc3[e], fcp = a.fc3p[e];
   const float dd0 = a.dd[e], du0 = a.du[e * 3], du1 = a.du[e * 3 + 1], du2 = a.du[e * 3 + 2];
   float dmv[C], gv[C], qv[C], qpv[C], vv[C];
+  load_row<C>(a.dm + e * kCP, dmv);
+  load_row<C>(a.q + e * kCP, qv);
+  load_row<C>(a.qp + e * kCP, qpv);
+  load_row<C>(a.v + kd * kCP, vv);
 #pragma unroll
-  for (int k = 0; k < C; ++k) {
-    dmv[k] = a.dm[e * kCP + k];
-    qv[k] = a.q[e * kCP + k]; qpv[k] = a.qp[e * kCP + k]; vv[k] = a.v[kd * kCP + k];
-    gv[k] = qv[k] * vv[k];
-  }
+  for (int k = 0; k < C; ++k) gv[k] = qv[k] * vv[k];
   __syncthreads();
   if (!live) return;
   // partner (window-relative id, or the global fallback) -> unit vector and payload row
