@@ -125,7 +125,10 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
 // kNodesRev atoms per workgroup: phase 1 streams the dp1 rows (HBM-bound gather: a wave reads a whole 1-KB row per
 // instruction, 16 B per lane), phase 2 applies the transposed first-layer weights once for all atoms of the group
 // (the 128 KB of W1a/W1b would otherwise be re-read from L2 for every atom).
-constexpr int kNodesRev = 8;
+#ifndef M3G_NODES_REV
+#define M3G_NODES_REV 4   // measured: 4 -> 0.259, 8 -> 0.288, 16 -> 0.293 ms per step (one atom per wave keeps more independent gathers in flight)
+#endif
+constexpr int kNodesRev = M3G_NODES_REV;
 __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const float* __restrict__ W, BlockW bw,
                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ in_ptr,
                                                       const int32_t* __restrict__ in_edge, const float* __restrict__ dp1,
