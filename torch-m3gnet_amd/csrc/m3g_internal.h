@@ -191,7 +191,10 @@ namespace m3g {
     default: break;                                           \
   }
 
-constexpr int kTbRows = 128;   // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
+#ifndef M3G_TB_ROWS
+#define M3G_TB_ROWS 128
+#endif
+constexpr int kTbRows = M3G_TB_ROWS;   // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
 struct Topo {
   int64_t N, E, T, S;
   int32_t* src;      // [E] centre of each edge

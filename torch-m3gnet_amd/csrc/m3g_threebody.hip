@@ -18,8 +18,8 @@
 
 namespace m3g {
 
-constexpr int kTbListCap = 3072;   // staged partner ids (128 rows x 24 partners; longer lists continue from global memory)
-constexpr int kTbCap = 192;    // staged window capacity: kTbRows (128) rows + boundary rows (overflow -> global reads); 9 KB per workgroup
+constexpr int kTbListCap = 24 * kTbRows;   // staged partner ids (24 partners per row; longer lists continue from global memory)
+constexpr int kTbCap = kTbRows + 64 < 255 ? kTbRows + 64 : 255;   // staged window: the rows + boundary rows (overflow -> global reads); < 256 so a partner id fits a byte
 
 // first C floats of a 16-float (64-byte aligned) row as 16-byte loads: a scalar load per element makes every lane of a
 // wave touch its own cache line once per element
@@ -151,7 +151,7 @@ struct TbRevArgs {
   const float *u, *fc3, *fc3p, *q, *qp, *v, *dm;
   float *dd, *du, *dgq;
 };
-constexpr int kTbRevList = 4096;   // staged partner ids per list (bytes)
+constexpr int kTbRevList = 32 * kTbRows;   // staged partner ids per list (bytes)
 
 template <int L, int R>
 __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a) {
