@@ -255,7 +255,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
   st.template mark<S0 + 1>();  // both layers
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
-    static_for<4>([&]<int r>() { out[ob][r] = fsilu(p2[ob][r]) * fsigmoid(p2[4 + ob][r]) * out[ob][r]; });
+    static_for<4>([&]<int r>() { out[ob][r] = fgated(p2[ob][r], p2[4 + ob][r]) * out[ob][r]; });
   });
   st.template mark<S0 + 3>();  // gating
 }
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
     {  // three-body gated update (nn/interaction.py:220-221)
       f32x4 p[8];
       tb_preact<TBS>(lds + L.tb, mb, p, lv);
-      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
+      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
     }
     st.template mark<1>();  // three-body MLP
     f32x4 out[4];
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
       f32x4 x[4], p[8];
       static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
       tb_preact<TBS>(lds + L.tb, mb, p, lv);
-      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
+      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
       st.template mark<1>();   // tile loads + three-body recompute
       // dL/d e2 = what flows in from later blocks + the node MLP's contribution (both loaded here, at the tile start)
       const float* dcn_tile = a.dcn + tile * kTileFloats + lane * 4;
@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     {  // e1 = e_in + three-body gated update (the edge MLP's input)
       f32x4 p[8];
       tb_preact<TBS>(lds + L.tb, mb, p, lv);
-      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fsilu(p[blk][r]) * fsigmoid(p[4 + blk][r]); }); });
+      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
     }
     mlp_reverse_dual<NEED_DP1, 0>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution

@@ -22,6 +22,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 
 __device__ __forceinline__ float fsigmoid(float p) { return __builtin_amdgcn_rcpf(1.f + __expf(-p)); }
 __device__ __forceinline__ float fsilu(float p) { return p * fsigmoid(p); }
+// SiLU(p) * sigmoid(g) = p / ((1 + e^-p)(1 + e^-g)): one reciprocal for the gated product instead of two sigmoids
+// (each factor is >= 1, an overflowing exponential gives inf -> rcp 0, the correct limit)
+__device__ __forceinline__ float fgated(float p, float g) {
+  return p * __builtin_amdgcn_rcpf((1.f + __expf(-p)) * (1.f + __expf(-g)));
+}
 __device__ __forceinline__ float fdsilu(float p) {
   float s = fsigmoid(p);
   return s * (1.f + p * (1.f - s));
