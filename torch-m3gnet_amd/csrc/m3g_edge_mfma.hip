@@ -1,24 +1,27 @@
-// Edge block on the matrix cores: stage S4 (three-body gated update + M3GNetConv edge and node MLPs) and its
-// reverse B4, fused per 16-edge tile, fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32; gfx950 has no xf32).
-// Reference: nn/interaction.py:220-221, nn/conv.py:63-97, nn/core.py:61-62; algebra: oracle/staged.py.
+// Edge block on the matrix cores: stage S4 (three-body gated update + M3GNetConv edge and node MLPs + per-centre message
+// sums) and its reverse B4, fused per 16-edge tile.  Dense chains: bf16x3 split operands on v_mfma_f32_16x16x32_bf16
+// with fp32 accumulation (gfx950 has no xf32); small K <= 16 products on exact-fp32 v_mfma_f32_16x16x4_f32.
+// Reference: nn/interaction.py:220-221, nn/conv.py:63-97, nn/core.py:61-62, nn/featurizer.py:128-132; algebra:
+// oracle/staged.py.  Design notes and measured history: DESIGN.md section 4.
 //
 // Formulation: every dense layer is computed TRANSPOSED, Y^T[feature, edge] = W[feature, k] . X^T[k, edge]:
 //   * the 16 edges of a tile sit on the MFMA column index (lane & 15); lane quarter qd = lane >> 4 holds, in the
 //     4 accumulator registers of 16-feature block blk, features blk*16 + 4*qd + {0..3}; all per-edge elementwise
 //     work (SiLU / sigmoid gating, residuals, W_l h) is therefore lane-local;
-//   * an accumulator block is directly the B operand of the next layer (k-step (blk, reg) consumes the four
-//     features blk*16 + 4*qd + reg); the matching k permutation is folded into the weight images
-//     (m3g_pack_mfma.hip), which a workgroup copies into LDS once and every wave re-reads as the A operand
-//     (ds_read_b32 of 64 consecutive floats per k-step: conflict-free);
+//   * an accumulator block is directly the B operand of the next layer; the matching k permutation is folded into the
+//     weight images (m3g_pack_mfma.hip, m3g_dual_image.h), which a workgroup copies into LDS once and every wave
+//     re-reads as the A operand;
 //   * layer-1 accumulators start from the gathered per-node tables TA[i] + TB[j] (x_i / x_j parts, bias folded);
-//     layer-2 biases enter as one extra k-step against a constant-one operand.
-// Why 16x16x4 and not 32x32x2 (same FLOP rate): every per-tile array is half the size (~100 live VGPRs instead of
-// 232), so 4 waves per SIMD are resident instead of 2 and cover each other's store bursts and gather latency; a
-// lane's 4 accumulator registers are 4 consecutive features, so every tile load/store is a 16-byte access
-// (1 KiB per wave instruction) and row-major rows get 64-byte segments.
-// Tile-SoA images ([tile][blk][64 lanes][4]) carry edge features between blocks and the saved layer-1
-// pre-activations.  One persistent workgroup (16 waves, 4 per SIMD) per CU; workgroups sharing an XCD
+//     layer-2 biases enter as one extra k-step against a constant-one operand;
+//   * a lane's 4 accumulator registers are 4 consecutive features, so every tile load/store is a 16-byte access
+//     (1 KiB per wave instruction);
+//   * the 16 edge lanes are a DPP row and a centre's edges are consecutive, so sums over a centre's edges (messages in
+//     the forward kernel, dp1 rows in the reverse kernel) are segmented scans along the row (seg_scan).
+// Tile-SoA images ([tile][blk][64 lanes][4]) carry the edge features between blocks; nothing else is saved for the
+// reverse pass.  One persistent workgroup per CU (forward 16 waves, fused reverse 8 waves); workgroups sharing an XCD
 // (blockIdx % 8) walk a contiguous edge range so their TA/TB rows stay in that XCD's L2.
+// Kernels: k_edge_block_mfma (forward), k_edge_rev_fused (reverse, one launch per block), and the earlier reverse pair
+// k_edge_rev_node_mlp / k_edge_rev_edge_mlp kept behind option rev_kernel = 0 for A/B tests.
 #include <utility>
 
 #include "m3g_device.h"
