@@ -285,6 +285,7 @@ extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (plan->d_mfma_fwd) (void)hipFree(plan->d_mfma_fwd);
   if (plan->d_mfma_rev) (void)hipFree(plan->d_mfma_rev);
   if (plan->d_mfma_revf) (void)hipFree(plan->d_mfma_revf);
+  if (plan->d_node_img) (void)hipFree(plan->d_node_img);
   if (plan->d_stamps) (void)hipFree(plan->d_stamps);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
   delete plan;
@@ -489,8 +490,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     {
       M3G_STAGE(ST_NODE_PRE);
       // MFMA path: block b > 0 forms x^b = x^(b-1) + per-centre message sums of block b-1 while loading it
-      launch_node_pre(c, W, wl.blk[b], t, w, (mfma && b > 0) ? w.x[b - 1] : nullptr, w.x[b], w.v[b], mfma ? w.TAb[b] : w.TA,
-                      mfma ? w.TBb[b] : w.TB, s);
+      if (mfma) launch_node_pre_mfma(plan, c, t, w, b, b > 0 ? w.x[b - 1] : nullptr, w.x[b], w.v[b], w.TAb[b], w.TBb[b], s);
+      else launch_node_pre(c, W, wl.blk[b], t, w, nullptr, w.x[b], w.v[b], w.TA, w.TB, s);
     }
     { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }
     if (mfma) {

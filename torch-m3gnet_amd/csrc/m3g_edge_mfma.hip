@@ -164,8 +164,22 @@ __device__ __forceinline__ void seg_store(const f32x4 (&v)[N], const SegMasks& k
   }
 }
 
+// weight image -> LDS with 8 independent 16-byte loads in flight per thread: a plain load-store loop is a chain of
+// dependent L2 round trips (one per blockDim*16 bytes) at the start of every launch
 __device__ __forceinline__ void load_image(float* lds, const float* __restrict__ src, int n_floats, int* lds_head) {
-  for (int i = threadIdx.x * 4; i < n_floats; i += blockDim.x * 4) *(f32x4*)(lds + i) = *(const f32x4*)(src + i);
+  constexpr int kBatch = 8;
+  const int n_vec = n_floats >> 2, nt = (int)blockDim.x;
+  for (int base = 0; base < n_vec; base += nt * kBatch) {
+    f32x4 t[kBatch];
+    static_for<kBatch>([&]<int j>() {
+      const int i = base + j * nt + (int)threadIdx.x;
+      t[j] = i < n_vec ? *(const f32x4*)(src + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    });
+    static_for<kBatch>([&]<int j>() {
+      const int i = base + j * nt + (int)threadIdx.x;
+      if (i < n_vec) *(f32x4*)(lds + 4 * i) = t[j];
+    });
+  }
   if (threadIdx.x == 0) *lds_head = 0;
   __syncthreads();
 }
@@ -870,6 +884,84 @@ __global__ void __launch_bounds__(256) k_node_sum_seg(int64_t N, const int32_t* 
   x_new[i * kDP + o] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------- node tables
+// S2 on the matrix pipe: [TA | TB | v]^T (528 rows) = W (528 x 64) . x^T (64 x 16 atoms) per 16-atom tile, exact-fp32
+// v_mfma_f32_16x16x4_f32, the whole weight image (135 KB) resident in LDS.  Replaces the vector-ALU k_node_pre, which
+// re-read 128 KB of weights from L2 for every 16 atoms.  x^b = x^(b-1) + the per-centre message sums of block b-1 is
+// formed while the tile is loaded (x_prev != nullptr) and written back for the later stages.
+constexpr int kNodeXPitch = 68;   // floats per staged x row: 64 + 4 keeps 16-byte alignment and spreads the 16 rows over the banks
+__global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
+                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
+                                                       const int32_t* __restrict__ row_ptr, float* __restrict__ x,
+                                                       float* __restrict__ v, float* __restrict__ TA, float* __restrict__ TB) {
+  __shared__ __attribute__((aligned(16))) float lds[kNodeImgFloats + 4 * 16 * kNodeXPitch];
+  {  // image -> LDS, 16 independent 16-byte loads in flight per thread (a load-store-load chain would pay one L2 round trip
+     // per 4 KB of the 137 KB image)
+    constexpr int kVec = kNodeImgFloats / 4, kBatch = 16;
+    for (int base = 0; base < kVec; base += 256 * kBatch) {
+      f32x4 t[kBatch];
+      static_for<kBatch>([&]<int j>() {
+        const int i = base + j * 256 + (int)threadIdx.x;
+        t[j] = i < kVec ? *(const f32x4*)(img + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      });
+      static_for<kBatch>([&]<int j>() {
+        const int i = base + j * 256 + (int)threadIdx.x;
+        if (i < kVec) *(f32x4*)(lds + 4 * i) = t[j];
+      });
+    }
+  }
+  __syncthreads();
+  const float* bias = lds + kNodeRowBlocks * 16 * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
+  float* xs = lds + kNodeImgFloats + wave * 16 * kNodeXPitch;
+  const int64_t tiles = (N + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    // stage the tile's x rows: lane (m, q) brings features 16q .. 16q+15 of atom m
+    const int64_t atom = tile * 16 + m;
+    const bool live = atom < N;
+    f32x4 xr[4];
+    static_for<4>([&]<int j>() { xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+    if (live) {
+      const float* src = (x_prev ? x_prev : x) + atom * kDP + 16 * q;
+      static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
+      if (x_prev) {
+        const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
+        if (r1 > r0) {
+          if (r0 & 15) static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_first + atom * (4 * kDP) + 16 * q + 4 * j); });
+          for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
+            static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
+        }
+        static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+      }
+    }
+    static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
+    // (only this wave reads xs: LDS operations of a wave complete in order)
+    float b[16];
+    static_for<16>([&]<int s>() { b[s] = xs[m * kNodeXPitch + 4 * s + q]; });
+    int lv = lane;
+    asm volatile("" : "+v"(lv));   // keep the image reads inside the tile loop
+    static_for<kNodeRowBlocks / 3>([&]<int g>() {   // three independent accumulator chains in flight
+      f32x4 acc[3];
+      static_for<3>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (3 * g + j) * 16 + 4 * q); });
+      static_for<16>([&]<int s>() {
+        static_for<3>([&]<int j>() { acc[j] = mfma16(lds[((3 * g + j) * 16 + s) * 64 + lv], b[s], acc[j]); });
+      });
+      if (live) {
+        static_for<3>([&]<int j>() {
+          constexpr int ob = 3 * g + j;
+          if (ob < 16) *(f32x4*)(TA + atom * (4 * kDP) + ob * 16 + 4 * q) = acc[j];
+          else if (ob < 32) *(f32x4*)(TB + atom * (4 * kDP) + (ob - 16) * 16 + 4 * q) = acc[j];
+          else {
+            f32x4 o;
+            static_for<4>([&]<int r>() { o[r] = 4 * q + r < C ? fsigmoid(acc[j][r]) : 0.f; });
+            *(f32x4*)(v + atom * kCP + 4 * q) = o;
+          }
+        });
+      }
+    });
+  }
+}
+
 static inline int grid_for_tiles(int64_t tiles) {
   int64_t wgs = (tiles + kWaves - 1) / kWaves;
   wgs = (wgs + 7) / 8 * 8;
@@ -927,6 +1019,15 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
 
 void launch_node_sum(const Topo& t, const float* x_old, const float* msg, float* x_new, hipStream_t s) {
   if (t.N > 0) hipLaunchKernelGGL(k_node_sum, dim3((unsigned)((t.N + 3) / 4)), dim3(256), 0, s, t.N, t.row_ptr, x_old, msg, x_new);
+}
+
+void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
+                          float* v, float* TA, float* TB, hipStream_t s) {
+  if (t.N == 0) return;
+  const int64_t tiles = (t.N + 15) / 16;
+  int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
+  hipLaunchKernelGGL(k_node_pre_mfma, dim3(wgs), dim3(256), 0, s, c.C, t.N, plan->d_node_img + (size_t)b * kNodeImgFloats, x_prev,
+                     w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB);
 }
 
 void launch_node_sum_seg(const Topo& t, const Work& w, const float* x_old, float* x_new, hipStream_t s) {

@@ -137,6 +137,10 @@ struct MfmaRevFusedLayout {
   int adjp;  // [64][4] plain copy of W_adj for the dL/dh accumulation
   int total;
 };
+// k_node_pre_mfma image: direct fp32 image of the 528 x 64 matrix [W1a (TA columns 0-255) | W1b (TB columns) | W_sigmoid1
+// (v, 16 rows)] -- 33 row blocks x 16 k-steps x 64 lanes -- followed by the 528 row biases (b1 for TA, 0 for TB, b_sigmoid1)
+constexpr int kNodeRowBlocks = 33;
+constexpr int kNodeImgFloats = kNodeRowBlocks * 16 * 64 + kNodeRowBlocks * 16;
 MfmaFwdLayout mfma_fwd_layout();
 MfmaRevLayout mfma_rev_layout();
 MfmaRevFusedLayout mfma_rev_fused_layout();
@@ -153,6 +157,7 @@ struct m3g_plan {
   float* d_mfma_fwd = nullptr;   // [num_blocks][MfmaFwdLayout.total]
   float* d_mfma_rev = nullptr;   // [num_blocks][MfmaRevLayout.total]
   float* d_mfma_revf = nullptr;  // [num_blocks][MfmaRevFusedLayout.total]
+  float* d_node_img = nullptr;   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
@@ -284,6 +289,8 @@ void launch_embed_reverse(const Consts& c, const float* W, const WeightLayout& w
                           hipStream_t s);
 void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* x_prev, float* x,
                      float* v, float* TA, float* TB, hipStream_t s);
+void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
+                          float* v, float* TA, float* TB, hipStream_t s);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
                          const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, hipStream_t s);
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,

@@ -114,6 +114,7 @@ int pack_mfma_images(m3g_plan* plan) {
   const MfmaFwdLayout F = mfma_fwd_layout();
   const MfmaRevLayout Rv = mfma_rev_layout();
   const MfmaRevFusedLayout Rf = mfma_rev_fused_layout();
+  std::vector<float> node((size_t)std::max(B, 1) * kNodeImgFloats, 0.f);
   std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.per_block, 0.f),
       revf((size_t)std::max(B, 1) * Rf.total, 0.f);
   for (int b = 0; b < B; ++b) {
@@ -146,6 +147,37 @@ int pack_mfma_images(m3g_plan* plan) {
       direct_image(rf + Rf.adj, 4, 1, adj);
       for (int o = 0; o < 64; ++o)
         for (int rr = 0; rr < 4; ++rr) rf[Rf.adjp + o * 4 + rr] = adj(o, rr);
+    }
+    {  // node tables on the matrix pipe (k_node_pre_mfma): rows = table columns, k = node feature
+      float* ni = node.data() + (size_t)b * kNodeImgFloats;
+      const char* names[2] = {".concat_edge_update", ".concat_node_update"};
+      const float* w1[2][2];   // [mlp][dense|gate]  [D, 3D]
+      const float* b1[2][2];
+      for (int m = 0; m < 2; ++m) {
+        w1[m][0] = plan->params.at(cv + names[m] + ".dense.0.weight").data();
+        w1[m][1] = plan->params.at(cv + names[m] + ".gate.0.weight").data();
+        b1[m][0] = plan->params.at(cv + names[m] + ".dense.0.bias").data();
+        b1[m][1] = plan->params.at(cv + names[m] + ".gate.0.bias").data();
+      }
+      const float* ws = plan->params.at(tb + ".linear_sigmoid1.weight").data();   // [C, D]
+      const float* bs = plan->params.at(tb + ".linear_sigmoid1.bias").data();
+      auto row_w = [&](int row, int k) -> float {
+        if (k >= D) return 0.f;
+        if (row < 512) {
+          const int part = row / 256, o = row % 256, m = o / 128, oo = o % 128, g = oo / 64, f = oo % 64;   // part 0: x_i (W1a), 1: x_j (W1b)
+          return f < D ? w1[m][g][(size_t)f * 3 * D + part * D + k] : 0.f;
+        }
+        const int cidx = row - 512;
+        return cidx < C ? ws[(size_t)cidx * D + k] : 0.f;
+      };
+      direct_image(ni, kNodeRowBlocks, 16, row_w);
+      float* bias = ni + kNodeRowBlocks * 16 * 64;
+      for (int row = 0; row < kNodeRowBlocks * 16; ++row) {
+        float v = 0.f;
+        if (row < 256) { const int m = row / 128, oo = row % 128, g = oo / 64, f = oo % 64; v = f < D ? b1[m][g][f] : 0.f; }
+        else if (row >= 512) { const int cidx = row - 512; v = cidx < C ? bs[cidx] : 0.f; }
+        bias[row] = v;
+      }
     }
     const char* mlps[2] = {".concat_edge_update", ".concat_node_update"};
     const char* lins[2] = {".edge_linear.weight", ".node_linear.weight"};
@@ -200,6 +232,9 @@ int pack_mfma_images(m3g_plan* plan) {
   }
   if (plan->d_mfma_fwd) { (void)hipFree(plan->d_mfma_fwd); plan->d_mfma_fwd = nullptr; }
   if (plan->d_mfma_rev) { (void)hipFree(plan->d_mfma_rev); plan->d_mfma_rev = nullptr; }
+  if (plan->d_node_img) { (void)hipFree(plan->d_node_img); plan->d_node_img = nullptr; }
+  M3G_HIP_CHECK(hipMalloc((void**)&plan->d_node_img, node.size() * sizeof(float)));
+  M3G_HIP_CHECK(hipMemcpy(plan->d_node_img, node.data(), node.size() * sizeof(float), hipMemcpyHostToDevice));
   if (plan->d_mfma_revf) { (void)hipFree(plan->d_mfma_revf); plan->d_mfma_revf = nullptr; }
   M3G_HIP_CHECK(hipMalloc((void**)&plan->d_mfma_revf, revf.size() * sizeof(float)));
   M3G_HIP_CHECK(hipMemcpy(plan->d_mfma_revf, revf.data(), revf.size() * sizeof(float), hipMemcpyHostToDevice));
