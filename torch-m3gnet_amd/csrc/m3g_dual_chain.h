@@ -8,6 +8,15 @@
 #include "m3g_dual_image.h"
 #include "m3g_mfma_common.h"
 
+// Wave priority around the MFMA chains: with two waves per SIMD the arbiter otherwise lets the other wave's VALU stream
+// delay the chain's MFMA issue; raised priority keeps the matrix pipe fed while that VALU work fills the gaps
+// (measured on the fused reverse kernel: 0.973 -> 0.925 ms per step).
+#ifndef M3G_NO_CHAIN_PRIO
+#define M3G_CHAIN_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define M3G_CHAIN_PRIO(p) ((void)0)
+#endif
+
 namespace m3g {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -26,6 +35,7 @@ __device__ __forceinline__ void chain_dual(const float* img, const f32x4 (&x)[NX
   static_assert(XOFF + 2 * KS <= NX && AOFF + OB <= NA && (RB0 + OB) * 16 <= ROWS, "chain_dual operand out of range");
   const int m = lane & 15, q = lane >> 4, sw = dual_swz(m);
   const char* base = reinterpret_cast<const char*>(img) + (m >> 3) * 1024 + (m & 7) * 64;
+  M3G_CHAIN_PRIO(1);
   static_for<KS>([&]<int s>() {
     bf16x8 bh, bl;
     split8(x[XOFF + 2 * s], x[XOFF + 2 * s + 1], bh, bl);
@@ -39,6 +49,7 @@ __device__ __forceinline__ void chain_dual(const float* img, const f32x4 (&x)[NX
       acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
     });
   });
+  M3G_CHAIN_PRIO(0);
 }
 
 // transposed: d holds ROWS/16 blocks of output-feature gradients starting at block DOFF (KS = ROWS/32 k-steps);
@@ -50,6 +61,7 @@ __device__ __forceinline__ void chain_dual_t(const float* img, const f32x4 (&d)[
   const int q = lane >> 4, qp = (lane & 15) >> 2, p = lane & 3;
   const int row_lo = 4 * q + qp, sw = dual_swz(row_lo);
   const char* base = reinterpret_cast<const char*>(img) + (row_lo >> 3) * 1024 + (row_lo & 7) * 64;
+  M3G_CHAIN_PRIO(1);
   static_for<KS>([&]<int s>() {
     bf16x8 bh, bl;
     split8(d[DOFF + 2 * s], d[DOFF + 2 * s + 1], bh, bl);
@@ -67,6 +79,7 @@ __device__ __forceinline__ void chain_dual_t(const float* img, const f32x4 (&d)[
       acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
     });
   });
+  M3G_CHAIN_PRIO(0);
 }
 
 // host: img receives ROWS*64 floats (hi part, then lo part); get(row, col) with col < 64

@@ -46,12 +46,18 @@ constexpr int kTileFloats = 4 * 64 * 4;     // one 64-feature tile image: [4 blk
 // chains on bf16x3 the matrix work is cheap, and recomputing both layers of both MLPs in the reverse kernels costs less
 // than streaming 2 KB of pre-activations per edge and block through HBM (measured history: DESIGN.md section 4).
 
+#ifdef M3G_USE_FWD_CHAIN_PRIO
+#define M3G_FWD_CHAIN_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define M3G_FWD_CHAIN_PRIO(p) ((void)0)
+#endif
 // acc[AOFF + ob] += W(ob-th 16-row block, :) . x[XOFF .. XOFF + 2*KS)   (chain image: m3g_pack_mfma.hip)
 template <int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
 __device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
   static_assert(XOFF + 2 * KS <= NX && AOFF + OB <= NA, "chain operand out of range");
   const bf16x8* hi_img = reinterpret_cast<const bf16x8*>(img) + lane;
   const bf16x8* lo_img = hi_img + OB * KS * 64;
+  M3G_FWD_CHAIN_PRIO(1);
   static_for<KS>([&]<int s>() {
     bf16x8 bh, bl;
     split8(x[XOFF + 2 * s], x[XOFF + 2 * s + 1], bh, bl);
@@ -62,6 +68,7 @@ __device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f3
       acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
     });
   });
+  M3G_FWD_CHAIN_PRIO(0);
 }
 
 // bias as one k-step: A = bias image (lanes < 16 carry b[ob*16 + lane]), B = 1 on lane quarter 0
@@ -287,6 +294,9 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
   const int lane = threadIdx.x & 63, qd = lane >> 4;
   TileQueue queue(a.tiles, q_head);
   Stamps<ST> st;
+#ifdef M3G_FWD_STATIC_PRIO
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= M3G_FWD_STATIC_PRIO) __builtin_amdgcn_s_setprio(1);
+#endif
   int ticket = queue.fetch(lane);
   if (ticket >= queue.count) return;
   int ci_i, cj_i;
@@ -677,6 +687,9 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
   load_image(lds, a.img, kRevFusedFloats, q_head);
   const int lane = threadIdx.x & 63, qd = lane >> 4;
   TileQueue queue(a.tiles, q_head);
+#ifdef M3G_REV_STATIC_PRIO
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= M3G_REV_STATIC_PRIO) __builtin_amdgcn_s_setprio(1);
+#endif
   int ticket = queue.fetch(lane);
   if (ticket >= queue.count) return;
   int ci_i, cj_i;
