@@ -89,6 +89,9 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *   "rev_kernel"  = 1 one fused reverse kernel per block (default), 0 = node-MLP + edge-MLP kernel pair (A/B testing);
  *   "stress_mode" = 0 the reference's sum pos (x) F / V (nn/gradient.py:39-62, default), 1 = pair virial
  *                   -(1/V) sum_e r_e (x) dE/dr_e (docs/gradient.md:47-84), invariant under lattice translations;
+ *   "overlap"     = 1 the three-body reverse of a block runs on an internal side stream beside the node reverse's gather
+ *                   (fork/join with events on the caller's stream), 0 = everything on the caller's stream (default: the
+ *                   cross-stream waits measured slower than the overlap gains on the benchmark workload);
  *   "stamps"      diagnostic builds with in-kernel cycle stamps (m3g_debug_read_stamps). */
 int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value);
 

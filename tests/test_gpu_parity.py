@@ -101,3 +101,20 @@ def test_fused_and_split_reverse_kernels_agree():
     model.engine.set_option("rev_kernel", 1)
     assert rel_err(outs[0][0], outs[1][0]) < 1e-6
     assert rel_err(outs[0][1], outs[1][1]) < 2e-6
+
+
+def test_side_stream_overlap_option_gives_identical_results():
+    """Option "overlap" = 1 runs each block's three-body reverse on an internal side stream beside the node reverse's
+    gather (fork/join by events): same kernels, same order of every sum -> bitwise identical energies and forces."""
+    case, mode = "mix", "doc"
+    params, cfg, consts, graph, expect = load_oracle_case(case, mode)
+    model, _ = build_engine_model(case, mode)
+    model = model.cuda()
+    outs = []
+    for ov in (0, 1, 1):
+        model.engine.set_option("overlap", ov)
+        o = model(engine_graph(graph))
+        outs.append((o["total_energy"].clone(), o["forces"].clone()))
+    model.engine.set_option("overlap", 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
+    assert rel_err(outs[1][1], outs[0][1]) < 1e-6 and torch.equal(outs[1][1], outs[2][1])

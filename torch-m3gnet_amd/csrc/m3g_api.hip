@@ -288,6 +288,9 @@ extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (plan->d_node_img) (void)hipFree(plan->d_node_img);
   if (plan->d_stamps) (void)hipFree(plan->d_stamps);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
+  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+  if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+  if (plan->side_stream) (void)hipStreamDestroy(plan->side_stream);
   delete plan;
 }
 
@@ -323,6 +326,10 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
   if (strcmp(name, "rev_kernel") == 0) {
     if (value != 0 && value != 1) { set_error("rev_kernel must be 0 (node-MLP + edge-MLP kernel pair) or 1 (fused)"); return M3G_ERR_VALUE; }
     plan->rev_kernel = value;
+    return M3G_OK;
+  }
+  if (strcmp(name, "overlap") == 0) {
+    plan->overlap = value != 0;
     return M3G_OK;
   }
   if (strcmp(name, "stress_mode") == 0) {
@@ -448,6 +455,15 @@ extern "C" int m3g_workspace_bytes(const m3g_plan* plan, int64_t N, int64_t E, i
   return M3G_OK;
 }
 
+static bool ensure_side_stream(const m3g_plan* plan) {
+  if (plan->side_stream) return true;
+  if (hipStreamCreateWithFlags(&plan->side_stream, hipStreamNonBlocking) != hipSuccess) { plan->side_stream = nullptr; return false; }
+  if (hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess)
+    return false;
+  return true;
+}
+
 extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes,
                                  void* stream_) {
   if (!plan || !io) { set_error("m3g_energy_forces: null argument"); return M3G_ERR_VALUE; }
@@ -544,11 +560,24 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         M3G_STAGE(ST_EDGE_REV);
         launch_edge_block_reverse(c, W, wl.blk[b], t, w, b, dx_cur, s);
       }
-      { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], s); }
-      if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
-        M3G_STAGE(ST_NODE_REV);
-        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, s);
+      if (b > 0 && fused_rev && plan->overlap && !plan->profile && ensure_side_stream(plan)) {
+        // the node reverse's dp1 gather needs nothing from the three-body reverse: run that short latency-bound kernel on a
+        // side stream beside it, then add the v-gradient share (which needs its dL/dg) once both are done
+        M3G_HIP_CHECK(hipEventRecord(plan->ev_fork, s));
+        M3G_HIP_CHECK(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
+        launch_threebody_reverse(c, t, w, w.v[b], plan->side_stream);
+        M3G_HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
+        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*with_v_term=*/false, s);
+        M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_join, 0));
+        launch_node_reverse_v_term(c, W, wl.blk[b], t, w, w.v[b], dx_alt, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
+      } else {
+        { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], s); }
+        if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
+          M3G_STAGE(ST_NODE_REV);
+          launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*with_v_term=*/true, s);
+          float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
+        }
       }
     }
     {

@@ -165,6 +165,12 @@ struct m3g_plan {
   unsigned long long* d_stamps = nullptr;  // option "stamps": diagnostic phase-cycle sums [256][16][12] of the fwd edge kernel
   bool committed = false;
   // opt-in stage profiler (m3g_profile_*): event pairs recorded around stage launches
+  // side stream: the three-body reverse of a block (short, latency-bound, does not fill the chip) runs beside the node
+  // reverse's dp1 gather (HBM-bound); fork/join with events, created on first use
+  mutable hipStream_t side_stream = nullptr;
+  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int overlap = 0;               // option "overlap": 1 = use the side stream (measured 2 % SLOWER on the 10k-atom step: two fork/join
+                                 // pairs of cross-stream event waits cost more than the ~40 us of kernel time they hide), default off
   mutable bool profile = false;
   mutable std::vector<hipEvent_t> ev_pool;
   mutable std::vector<int> ev_stage;   // stage id of pair k (events 2k, 2k+1)
@@ -292,7 +298,9 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
 void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
                           float* v, float* TA, float* TB, hipStream_t s);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
-                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, hipStream_t s);
+                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool with_v_term, hipStream_t s);
+void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,
+                                float* dx_out, hipStream_t s);
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
                     const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                     bool want_grad, hipStream_t s);

@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
                                                       const int32_t* __restrict__ in_edge, const float* __restrict__ dp1,
                                                       const float* __restrict__ dgq, const float* __restrict__ v,
                                                       const float* __restrict__ dx_new, float* __restrict__ dx_out,
-                                                      const float* __restrict__ seg_head, const float* __restrict__ seg_first) {
+                                                      const float* __restrict__ seg_head, const float* __restrict__ seg_first,
+                                                      int with_v_term) {
   __shared__ float4 sA[kNodesRev][64], sB[kNodesRev][64];   // row / in-edge sums of dp1, 256 columns as 64 float4
   __shared__ float tv[kNodesRev][kCP];
   __shared__ float part[4][kNodesRev][kDP];
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = in_edge[k + j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { u[j] = rows[(int64_t)f[j] * 64]; g[j] = dgq[(int64_t)f[j] * kCP + cq]; }
+        for (int j = 0; j < 8; ++j) { u[j] = rows[(int64_t)f[j] * 64]; g[j] = with_v_term ? dgq[(int64_t)f[j] * kCP + cq] : 0.f; }
 #pragma unroll
         for (int j = 0; j < 8; j += 4) {
           b0.x += u[j].x; b0.y += u[j].y; b0.z += u[j].z; b0.w += u[j].w;
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
         const int f0 = in_edge[k];
         const float4 u = rows[(int64_t)f0 * 64];
         b0.x += u.x; b0.y += u.y; b0.z += u.z; b0.w += u.w;
-        dv += dgq[(int64_t)f0 * kCP + cq];
+        if (with_v_term) dv += dgq[(int64_t)f0 * kCP + cq];
       }
       b0.x += b2.x; b0.y += b2.y; b0.z += b2.z; b0.w += b2.w;
       b1.x += b3.x; b1.y += b3.y; b1.z += b3.z; b1.w += b3.w;
@@ -239,6 +240,39 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
     float acc = dx_new[i * kDP + k] + ((part[0][nb][k] + part[1][nb][k]) + (part[2][nb][k] + part[3][nb][k]));
     for (int c = 0; c < C; ++c) acc += tv[nb][c] * W[bw.tb_w1 + c * kDP + k];
     dx_out[i * kDP + k] = acc;
+  }
+}
+
+// the v-gradient share of the node reverse on its own (dx_out += (dv v (1-v)) W1), for when k_node_reverse ran without it
+// beside the three-body reverse that produces dL/dg: 16 lanes per atom gather the dL/dg rows of the incoming edges
+__global__ void __launch_bounds__(256) k_node_reverse_v_term(int C, int64_t N, const float* __restrict__ W, size_t tb_w1,
+                                                             const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_edge,
+                                                             const float* __restrict__ dgq, const float* __restrict__ v,
+                                                             float* __restrict__ dx_out) {
+  __shared__ float tv[16][kCP];
+  const int g = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const int64_t i = (int64_t)blockIdx.x * 16 + g;
+  float dv = 0.f;
+  if (i < N) {
+    int k = in_ptr[i];
+    const int k1 = in_ptr[i + 1];
+    for (; k + 3 < k1; k += 4) {
+      const int f0 = in_edge[k], f1 = in_edge[k + 1], f2 = in_edge[k + 2], f3 = in_edge[k + 3];
+      dv += (dgq[(int64_t)f0 * kCP + cq] + dgq[(int64_t)f1 * kCP + cq]) + (dgq[(int64_t)f2 * kCP + cq] + dgq[(int64_t)f3 * kCP + cq]);
+    }
+    for (; k < k1; ++k) dv += dgq[(int64_t)in_edge[k] * kCP + cq];
+    const float vv = v[i * kCP + cq];
+    dv = cq < C ? dv * vv * (1.f - vv) : 0.f;
+  }
+  tv[g][cq] = dv;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 16 * kDP; idx += 256) {
+    const int nb = idx >> 6, k = idx & 63;
+    const int64_t a = (int64_t)blockIdx.x * 16 + nb;
+    if (a >= N) continue;
+    float acc = 0.f;
+    for (int cc = 0; cc < C; ++cc) acc += tv[nb][cc] * W[tb_w1 + cc * kDP + k];
+    dx_out[a * kDP + k] += acc;
   }
 }
 
@@ -402,10 +436,18 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
 }
 
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
-                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, hipStream_t s) {
+                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool with_v_term, hipStream_t s) {
   if (t.N > 0)
     hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge,
-                       w.dp1, w.dg, v, dx_new, dx_out, row_sums_in_seg ? w.seg_head : nullptr, row_sums_in_seg ? w.seg_first : nullptr);
+                       w.dp1, w.dg, v, dx_new, dx_out, row_sums_in_seg ? w.seg_head : nullptr, row_sums_in_seg ? w.seg_first : nullptr,
+                       with_v_term ? 1 : 0);
+}
+
+void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,
+                                float* dx_out, hipStream_t s) {
+  if (t.N > 0)
+    hipLaunchKernelGGL(k_node_reverse_v_term, grid_for(t.N, 16), dim3(256), 0, s, c.C, t.N, W, bw.tb_w1, t.in_ptr, t.in_edge, w.dg, v,
+                       dx_out);
 }
 
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
