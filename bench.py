@@ -142,14 +142,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for the rehearsal mode below (several ranks sharing one GPU)
+    backend = os.environ.get("M3G_BENCH_BACKEND", "nccl")   # "gloo": control-flow rehearsal of the N > 1 path on a one-GPU box
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from torch_m3gnet.data import MaterialGraphKey as K
 
@@ -161,12 +167,13 @@ def main():
     n_atoms = int(graph[K.POS].size(0))
     n_edges = int(graph[K.EDGE_INDEX].size(1))
     n_trip = int(graph[K.TRIPLET_EDGE_INDEX].size(1))
-    energies_all = torch.empty(world, 1, device=device) if world > 1 else None
+    gather_dev = device if backend == "nccl" else torch.device("cpu")
+    energies_all = torch.empty(world, 1, device=gather_dev) if world > 1 else None
 
     def step():
         model(graph, forces=True, extras=False)
         if world > 1:
-            dist.all_gather_into_tensor(energies_all, graph[K.TOTAL_ENERGY].view(1, 1))
+            dist.all_gather_into_tensor(energies_all, graph[K.TOTAL_ENERGY].view(1, 1).to(gather_dev))
 
     t_topo0 = time.perf_counter()
     step()  # first call: plan commit + topology build (index-only, cached on the graph) + workspace allocation
@@ -197,7 +204,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=gather_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
