@@ -162,7 +162,6 @@ Work work_carve(const Consts& c, bool mfma, int64_t N, int64_t E, int64_t T, int
     w.de_soa = take(tiles16 * 1024);
     w.dcn = take(tiles16 * 1024);
     w.dh_parts = take((size_t)(2 * c.B + 1) * e * kRP);
-    w.msg = take(e * kDP);
     w.seg_head = take((tiles16 + 1) * 4 * kDP);
     w.seg_first = take((n + 1) * 4 * kDP);
   } else {

@@ -861,42 +861,6 @@ __global__ void __launch_bounds__(256) k_embed_edges_reverse_soa(int64_t E, int6
   if (qd == 0 && edge < E) *(f32x4*)(dh + edge * kRP) = f32x4{d0, d1, d2, d3};   // this kernel's own slice
 }
 
-// x_new[i,:] = x[i,:] + sum_{e in row(i)} msg[e,:]   (nn/conv.py:82-88): one wave per atom, no atomics
-__global__ void __launch_bounds__(256) k_node_sum(int64_t N, const int32_t* __restrict__ row_ptr, const float* __restrict__ x,
-                                                  const float* __restrict__ msg, float* __restrict__ x_new) {
-  int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  int o = threadIdx.x & 63;
-  if (i >= N) return;
-  float a0 = x[i * kDP + o], a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  const int e1 = row_ptr[i + 1];
-  int e = row_ptr[i];
-  for (; e + 4 <= e1; e += 4) {
-    a0 += msg[(int64_t)e * kDP + o];
-    a1 += msg[(int64_t)(e + 1) * kDP + o];
-    a2 += msg[(int64_t)(e + 2) * kDP + o];
-    a3 += msg[(int64_t)(e + 3) * kDP + o];
-  }
-  for (; e < e1; ++e) a0 += msg[(int64_t)e * kDP + o];
-  x_new[i * kDP + o] = (a0 + a1) + (a2 + a3);
-}
-
-// x_new[i,:] = x[i,:] + sum of centre i's run sums: the run its row starts with mid-tile (seg_first[i]) and the first runs
-// of the tiles whose column 0 belongs to it (seg_head[t]); fixed order, no atomics
-__global__ void __launch_bounds__(256) k_node_sum_seg(int64_t N, const int32_t* __restrict__ row_ptr, const float* __restrict__ x,
-                                                      const float* __restrict__ seg_head, const float* __restrict__ seg_first,
-                                                      float* __restrict__ x_new) {
-  int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  int o = threadIdx.x & 63;
-  if (i >= N) return;
-  const int r0 = row_ptr[i], r1 = row_ptr[i + 1];
-  float acc = x[i * kDP + o];
-  if (r1 > r0) {
-    if (r0 & 15) acc += seg_first[i * (4 * kDP) + o];
-    for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t) acc += seg_head[(int64_t)t * (4 * kDP) + o];
-  }
-  x_new[i * kDP + o] = acc;
-}
-
 // ---------------------------------------------------------------------------------------------- node tables
 // S2 on the matrix pipe: [TA | TB | v]^T (528 rows) = W (528 x 64) . x^T (64 x 16 atoms) per 16-atom tile, exact-fp32
 // v_mfma_f32_16x16x4_f32, the whole weight image (135 KB) resident in LDS.  Replaces the vector-ALU k_node_pre, which
@@ -1030,10 +994,6 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
   }
 }
 
-void launch_node_sum(const Topo& t, const float* x_old, const float* msg, float* x_new, hipStream_t s) {
-  if (t.N > 0) hipLaunchKernelGGL(k_node_sum, dim3((unsigned)((t.N + 3) / 4)), dim3(256), 0, s, t.N, t.row_ptr, x_old, msg, x_new);
-}
-
 void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
                           float* v, float* TA, float* TB, hipStream_t s) {
   if (t.N == 0) return;
@@ -1041,11 +1001,6 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
   int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
   hipLaunchKernelGGL(k_node_pre_mfma, dim3(wgs), dim3(256), 0, s, c.C, t.N, plan->d_node_img + (size_t)b * kNodeImgFloats, x_prev,
                      w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB);
-}
-
-void launch_node_sum_seg(const Topo& t, const Work& w, const float* x_old, float* x_new, hipStream_t s) {
-  if (t.N > 0)
-    hipLaunchKernelGGL(k_node_sum_seg, dim3((unsigned)((t.N + 3) / 4)), dim3(256), 0, s, t.N, t.row_ptr, x_old, w.seg_head, w.seg_first, x_new);
 }
 
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,

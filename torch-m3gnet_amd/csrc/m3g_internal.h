@@ -266,7 +266,6 @@ struct Work {
   float* de_soa;
   float* dcn;                 // tile-SoA: node-MLP kernel's contribution to dL/de2 (store-only there, loaded by the edge-MLP kernel)
   float* dh_parts;            // [2B+1][E,kRP]: every reverse kernel stores its dL/dh share in its own slice (no read-modify-write)
-  float* msg;                 // [E,kDP] (split reverse / diagnostic paths)
   // per-centre sums formed inside the MFMA edge kernels (rows of a centre are consecutive edges): seg_head[t] = sum of the
   // tile's first run (the centre owning column 0), seg_first[i] = sum of the run in which centre i's row starts mid-tile
   float* seg_head;            // [tiles][4*kDP]
@@ -314,8 +313,6 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
 // pack_mfma.hip / edge_mfma.hip
 int pack_mfma_images(m3g_plan* plan);
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s);
-void launch_node_sum(const Topo& t, const float* x_old, const float* msg, float* x_new, hipStream_t s);
-void launch_node_sum_seg(const Topo& t, const Work& w, const float* x_old, float* x_new, hipStream_t s);
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
                               hipStream_t s);
 void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
