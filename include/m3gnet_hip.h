@@ -92,6 +92,9 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *   "overlap"     = 1 the three-body reverse of a block runs on an internal side stream beside the node reverse's gather
  *                   (fork/join with events on the caller's stream), 0 = everything on the caller's stream (default: the
  *                   cross-stream waits measured slower than the overlap gains on the benchmark workload);
+ *   "graph_replay" = 1 m3g_energy_forces captures its launch sequence into a hipGraph the first time it sees a given
+ *                   (m3g_io contents, workspace, stream, options) and replays it on later identical calls (launch-bound
+ *                   small systems); every buffer of the call must stay alive at the same address.  Default 0;
  *   "stamps"      diagnostic builds with in-kernel cycle stamps (m3g_debug_read_stamps). */
 int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value);
 

@@ -118,3 +118,28 @@ def test_side_stream_overlap_option_gives_identical_results():
     model.engine.set_option("overlap", 0)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
     assert rel_err(outs[1][1], outs[0][1]) < 1e-6 and torch.equal(outs[1][1], outs[2][1])
+
+
+def test_graph_replay_gives_identical_results_and_tracks_inputs():
+    """Option "graph_replay": the launch sequence is captured into a hipGraph on the first call and replayed afterwards.
+    Same kernels, same order -> bitwise identical outputs; positions updated IN PLACE are picked up by the replay."""
+    case, mode = "cu32", "doc"
+    params, cfg, consts, graph, expect = load_oracle_case(case, mode)
+    model, _ = build_engine_model(case, mode)
+    model = model.cuda()
+    g = engine_graph(graph)
+    ref = model(g)
+    e0, f0 = ref["total_energy"].clone(), ref["forces"].clone()
+    model.engine.set_option("graph_replay", 1)
+    try:
+        for _ in range(3):   # capture, then two replays
+            out = model(g)
+            assert torch.equal(out["total_energy"], e0) and torch.equal(out["forces"], f0)
+        g["pos"].add_(0.01 * torch.randn_like(g["pos"]))   # same storage, new values
+        moved = model(g)
+        e1, f1 = moved["total_energy"].clone(), moved["forces"].clone()
+        assert not torch.equal(e1, e0)
+    finally:
+        model.engine.set_option("graph_replay", 0)
+    plain = model(g)
+    assert torch.equal(plain["total_energy"], e1) and torch.equal(plain["forces"], f1)

@@ -181,6 +181,8 @@ Work work_carve(const Consts& c, bool mfma, int64_t N, int64_t E, int64_t T, int
 
 using namespace m3g;
 
+static void drop_graphs(const m3g_plan* plan);
+
 // ---- stage profiler ---------------------------------------------------------------------------------
 enum StageId { ST_GEOM = 0, ST_EMBED, ST_NODE_PRE, ST_THREEBODY, ST_EDGE_FWD, ST_NODE_SUM, ST_READOUT, ST_OUTPUTS, ST_EDGE_REV_NODE,
                ST_EDGE_REV, ST_THREEBODY_REV, ST_NODE_REV, ST_EMBED_REV, ST_GEOM_REV, ST_EDGE_REV_FUSED, ST_COUNT };
@@ -286,6 +288,7 @@ extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (plan->d_mfma_revf) (void)hipFree(plan->d_mfma_revf);
   if (plan->d_node_img) (void)hipFree(plan->d_node_img);
   if (plan->d_stamps) (void)hipFree(plan->d_stamps);
+  drop_graphs(plan);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
   if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
   if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
@@ -327,6 +330,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->rev_kernel = value;
     return M3G_OK;
   }
+  if (strcmp(name, "graph_replay") == 0) {
+    plan->graph_replay = value != 0;
+    if (!plan->graph_replay) drop_graphs(plan);
+    return M3G_OK;
+  }
   if (strcmp(name, "overlap") == 0) {
     plan->overlap = value != 0;
     return M3G_OK;
@@ -359,6 +367,7 @@ extern "C" int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out /* [256*
 
 extern "C" int m3g_plan_commit(m3g_plan* plan) {
   if (!plan) { set_error("m3g_plan_commit: null plan"); return M3G_ERR_VALUE; }
+  drop_graphs(plan);   // captured launch sequences point at the buffers this call replaces
   const m3g_config& cfg = plan->cfg;
   for (auto& kv : expected_params(cfg))
     if (!plan->params.count(kv.first)) { set_error("parameter '%s' was never set", kv.first.c_str()); return M3G_ERR_STATE; }
@@ -463,10 +472,66 @@ static bool ensure_side_stream(const m3g_plan* plan) {
   return true;
 }
 
+static void drop_graphs(const m3g_plan* plan) {
+  for (auto& g : plan->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  plan->graphs.clear();
+}
+
+// replay path of m3g_energy_forces: launches a cached graph, or captures one around the normal enqueue code.
+// The legacy default stream cannot be captured: calls on it run the graph on an internal stream, ordered after the
+// caller's stream and before its later work by a fork/join pair of events.
+static int energy_forces_graph(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes, hipStream_t caller) {
+  hipStream_t s = caller;
+  const bool via_side = caller == nullptr;
+  if (via_side) {
+    if (!ensure_side_stream(plan)) { set_error("graph_replay: could not create the internal stream"); return M3G_ERR_HIP; }
+    s = plan->side_stream;
+    M3G_HIP_CHECK(hipEventRecord(plan->ev_fork, caller));
+    M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_fork, 0));
+  }
+  auto join = [&]() -> int {
+    if (via_side) {
+      M3G_HIP_CHECK(hipEventRecord(plan->ev_join, s));
+      M3G_HIP_CHECK(hipStreamWaitEvent(caller, plan->ev_join, 0));
+    }
+    return M3G_OK;
+  };
+  std::vector<unsigned char> key(sizeof(m3g_io) + sizeof(void*) * 2 + sizeof(size_t) + 4 * sizeof(int));
+  unsigned char* k = key.data();
+  memcpy(k, io, sizeof(m3g_io)); k += sizeof(m3g_io);
+  memcpy(k, &workspace, sizeof(void*)); k += sizeof(void*);
+  memcpy(k, &s, sizeof(void*)); k += sizeof(void*);
+  memcpy(k, &workspace_bytes, sizeof(size_t)); k += sizeof(size_t);
+  const int opts[4] = {plan->edge_kernel, plan->rev_kernel, plan->stress_mode, plan->overlap};
+  memcpy(k, opts, sizeof(opts));
+  for (auto& g : plan->graphs)
+    if (g.key == key) { M3G_HIP_CHECK(hipGraphLaunch(g.exec, s)); return join(); }
+  if (plan->graphs.size() >= 8) drop_graphs(plan);   // bounded cache
+  m3g_plan::GraphEntry ge;
+  ge.key = key;
+  M3G_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  plan->capturing = true;
+  const int rc = m3g_energy_forces(plan, io, workspace, workspace_bytes, (void*)s);
+  plan->capturing = false;
+  hipError_t e = hipStreamEndCapture(s, &ge.graph);
+  if (rc != M3G_OK) { if (ge.graph) (void)hipGraphDestroy(ge.graph); return rc; }
+  if (e != hipSuccess || !ge.graph) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return M3G_ERR_HIP; }
+  e = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(ge.graph); set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return M3G_ERR_HIP; }
+  plan->graphs.push_back(ge);
+  M3G_HIP_CHECK(hipGraphLaunch(ge.exec, s));
+  return join();
+}
+
 extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes,
                                  void* stream_) {
   if (!plan || !io) { set_error("m3g_energy_forces: null argument"); return M3G_ERR_VALUE; }
   if (!plan->committed) { set_error("m3g_energy_forces: plan parameters not committed"); return M3G_ERR_STATE; }
+  if (plan->graph_replay && !plan->capturing && !plan->profile && !plan->overlap)
+    return energy_forces_graph(plan, io, workspace, workspace_bytes, (hipStream_t)stream_);
   const int64_t N = io->n_atoms, E = io->n_edges, T = io->n_triplets, S = io->n_structs;
   if (N < 0 || E < 0 || T < 0 || S < 0) { set_error("negative size"); return M3G_ERR_VALUE; }
   if (!io->total_energy || !io->topo || (N > 0 && (!io->pos || !io->atom_types)) || (S > 0 && !io->lattice) ||

@@ -171,6 +171,13 @@ struct m3g_plan {
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int overlap = 0;               // option "overlap": 1 = use the side stream (measured 2 % SLOWER on the 10k-atom step: two fork/join
                                  // pairs of cross-stream event waits cost more than the ~40 us of kernel time they hide), default off
+  // hipGraph replay (option "graph_replay"): the launch sequence of one m3g_energy_forces call is captured once per
+  // distinct (io, workspace, stream, options) and replayed while those stay identical -- for small systems the ~36
+  // launches of a step are launch-bound.  The caller must then keep every buffer of the call alive and at the same address.
+  int graph_replay = 0;
+  struct GraphEntry { std::vector<unsigned char> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+  mutable std::vector<GraphEntry> graphs;
+  mutable bool capturing = false;
   mutable bool profile = false;
   mutable std::vector<hipEvent_t> ev_pool;
   mutable std::vector<int> ev_stage;   // stage id of pair k (events 2k, 2k+1)
