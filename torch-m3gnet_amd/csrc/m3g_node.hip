@@ -129,6 +129,10 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
 #define M3G_NODES_REV 4   // measured: 4 -> 0.259, 8 -> 0.288, 16 -> 0.293 ms per step (one atom per wave keeps more independent gathers in flight)
 #endif
 constexpr int kNodesRev = M3G_NODES_REV;
+#ifndef M3G_NR_BATCH
+#define M3G_NR_BATCH 8
+#endif
+constexpr int kNrBatch = M3G_NR_BATCH;   // rows in flight per wave in the dp1 gather (multiple of 4)
 __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const float* __restrict__ W, BlockW bw,
                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ in_ptr,
                                                       const int32_t* __restrict__ in_edge, const float* __restrict__ dp1,
@@ -177,28 +181,27 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
       int k = in_ptr[i];
       float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f), b3 = b2;
       const int cq = ln & 15;
-      for (; k + 7 < k1; k += 8) {
-        int f[8];
-        float4 u[8];
-        float g[8];
+      // kNrBatch whole 1-KB rows in flight per wave, the remainder in one guarded batch as well (a row-at-a-time tail
+      // is a dependent round trip per row)
+      for (; k < k1; k += kNrBatch) {
+        int f[kNrBatch];
+        float4 u[kNrBatch];
+        float g[kNrBatch];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = in_edge[k + j];
+        for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_edge[k + j] : -1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { u[j] = rows[(int64_t)f[j] * 64]; g[j] = with_v_term ? dgq[(int64_t)f[j] * kCP + cq] : 0.f; }
+        for (int j = 0; j < kNrBatch; ++j) {
+          u[j] = f[j] >= 0 ? rows[(int64_t)f[j] * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+          g[j] = (with_v_term && f[j] >= 0) ? dgq[(int64_t)f[j] * kCP + cq] : 0.f;
+        }
 #pragma unroll
-        for (int j = 0; j < 8; j += 4) {
+        for (int j = 0; j < kNrBatch; j += 4) {
           b0.x += u[j].x; b0.y += u[j].y; b0.z += u[j].z; b0.w += u[j].w;
           b1.x += u[j + 1].x; b1.y += u[j + 1].y; b1.z += u[j + 1].z; b1.w += u[j + 1].w;
           b2.x += u[j + 2].x; b2.y += u[j + 2].y; b2.z += u[j + 2].z; b2.w += u[j + 2].w;
           b3.x += u[j + 3].x; b3.y += u[j + 3].y; b3.z += u[j + 3].z; b3.w += u[j + 3].w;
           dv += (g[j] + g[j + 1]) + (g[j + 2] + g[j + 3]);
         }
-      }
-      for (; k < k1; ++k) {
-        const int f0 = in_edge[k];
-        const float4 u = rows[(int64_t)f0 * 64];
-        b0.x += u.x; b0.y += u.y; b0.z += u.z; b0.w += u.w;
-        if (with_v_term) dv += dgq[(int64_t)f0 * kCP + cq];
       }
       b0.x += b2.x; b0.y += b2.y; b0.z += b2.z; b0.w += b2.w;
       b1.x += b3.x; b1.y += b3.y; b1.z += b3.z; b1.w += b3.w;
