@@ -228,3 +228,15 @@ def test_unfused_layout_is_rejected():
 
     with pytest.raises(RuntimeError, match="module order of build_model"):
         nn.Gradient(torch.nn.Sequential(nn.ScaleLength(1.0), nn.DistanceAndAngle())).engine
+
+
+def test_torch_free_c_abi_host_is_built_and_links():
+    """`make` also builds tests/c_abi/m3g_c_abi_check.cpp, a host of the C ABI without torch (exercised on the GPU by
+    tests/test_gpu_c_abi.py).  Here: the binary exists, resolves libm3gnet_hip.so through its rpath and prints its usage."""
+    import subprocess
+    from pathlib import Path
+
+    binary = Path(__file__).resolve().parent.parent / "torch-m3gnet_amd" / "lib" / "m3g_c_abi_check"
+    assert binary.exists(), "run `make -C torch-m3gnet_amd` (or __graft_entry__.build())"
+    proc = subprocess.run([str(binary)], capture_output=True, text=True, timeout=60)
+    assert proc.returncode == 1 and "usage:" in proc.stderr
