@@ -597,7 +597,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   if (io->edge_weights) launch_copy_strided(w.h, kRP, io->edge_weights, c.R, c.R, E, s);
   if (io->triplet_angles) launch_triplet_angles(t, io->triplet_edge_index, w.u, io->triplet_angles, s);
   if (io->mid_edge_features)
-    for (int b = 0; b < c.B; ++b) launch_copy_strided(w.m[b], kCP, io->mid_edge_features + (size_t)b * E * c.C, c.C, c.C, E, s);
+    for (int b = 0; b < c.B; ++b)   // the aggregate is kept per active edge: expand to the reference's [E, l_max*n_max]
+      launch_copy_expand_rows(t.act_id, w.m[b], kCP, io->mid_edge_features + (size_t)b * E * c.C, c.C, c.C, E, s);
   delete st_out;
 
   // ---------------- reverse ----------------

@@ -215,7 +215,8 @@ struct FwdArgs {
   int64_t E, tiles;
   const float* img;        // forward weight image of this block
   const int32_t *src, *dst;
-  const float *h, *m, *TA, *TB;
+  const float *h, *m, *TA, *TB;   // m: three-body aggregate, one row per ACTIVE edge (Topo::act_id)
+  const int32_t* act_id;
   const float* e_in;       // [tiles][4][64][4] edge features before this block
   float* e_out;            // same shape, after this block
   float *seg_head, *seg_first;   // per-centre message sums (see seg_scan)
@@ -322,7 +323,8 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
     f32x4 x[4];
     if (!FIRST) static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
     float mb[TBS];
-    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
+    const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
+    static_for<TBS>([&]<int s>() { mb[s] = arow >= 0 ? a.m[(int64_t)arow * kCP + 4 * s + qd] : 0.f; });
     const float hb = a.h[ec * kRP + qd];
     if (FIRST) {
       static_for<4>([&]<int blk>() {
@@ -369,7 +371,8 @@ struct RevArgs {
   int64_t E, tiles;
   const float* img;     // reverse image of this kernel's MLP (edge image also carries the three-body images)
   const int32_t *src, *dst;
-  const float *h, *m, *dx_new;
+  const float *h, *m, *dx_new;   // m (and dm below): one row per ACTIVE edge (Topo::act_id)
+  const int32_t* act_id;
   const float *TA, *TB;   // node tables of this block
   const float* e_tile;    // node kernel: edge features AFTER the block (input of the node MLP);
                           // edge / fused kernel: edge features BEFORE the block (three-body update + edge MLP are recomputed)
@@ -522,7 +525,8 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
     float mb[TBS];
-    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
+    const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
+    static_for<TBS>([&]<int s>() { mb[s] = arow >= 0 ? a.m[(int64_t)arow * kCP + 4 * s + qd] : 0.f; });
     f32x4 de[4], contrib[4];
     {
       // recompute e1 = e_in + three-body gated update: the edge MLP's input
@@ -558,7 +562,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
     zero(dmv);
     chain<1, 4>(lds + L.tbT, d8, dmv, lv);
     store_dh(a.dh, edge, a.E, dhv, qd);
-    if (edge < a.E) *(f32x4*)(a.dm + edge * kCP + 4 * qd) = dmv[0];  // rows c = 4*qd + reg
+    if (edge < a.E && arow >= 0) *(f32x4*)(a.dm + (int64_t)arow * kCP + 4 * qd) = dmv[0];  // rows c = 4*qd + reg
     st.template mark<7>();   // de store + three-body reverse + dm/dh stores
     if (!has_next) break;
     ci_i = nci;
@@ -711,7 +715,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
     float mb[TBS];
-    static_for<TBS>([&]<int s>() { mb[s] = a.m[ec * kCP + 4 * s + qd]; });
+    const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
+    static_for<TBS>([&]<int s>() { mb[s] = arow >= 0 ? a.m[(int64_t)arow * kCP + 4 * s + qd] : 0.f; });
     f32x4 x[4], de[4], contrib[4];
     constexpr bool FIRST = !NEED_DP1;   // block 0: its input is the edge embedding e0 = SiLU(W_adj h), formed here
     {
@@ -782,7 +787,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     zero(dmv);
     chain<1, 4>(lds + L.tbT, d8, dmv, lv);
     store_dh(a.dh, edge, a.E, dhv, qd);
-    if (edge < a.E) *(f32x4*)(a.dm + edge * kCP + 4 * qd) = dmv[0];
+    if (edge < a.E && arow >= 0) *(f32x4*)(a.dm + (int64_t)arow * kCP + 4 * qd) = dmv[0];
     if (!has_next) break;
     ci_i = nci;
     cj_i = ncj;
@@ -981,7 +986,7 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
   const int64_t tiles = tiles_for(t.E);
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
-    FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], w.e_blk[b],
+    FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], t.act_id, w.e_blk[b],
               w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
     if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3) {  // diagnostic build of the default configuration
@@ -1010,7 +1015,7 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_n = plan->d_mfma_rev + (size_t)b * L.per_block + L.total_e;
-  RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b + 1], nullptr, w.de_soa, w.dcn, 0, w.dm,
+  RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b + 1], nullptr, w.de_soa, w.dcn, 0, w.dm,
              w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_edge_rev_node_mlp, dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L);
 }
@@ -1021,7 +1026,7 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_e = plan->d_mfma_rev + (size_t)b * L.per_block;
-  RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], nullptr, w.de_soa, w.dcn,
+  RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], nullptr, w.de_soa, w.dcn,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps, nullptr, nullptr};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
   if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3) {  // diagnostic build
@@ -1037,7 +1042,7 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
   if (tiles == 0) return;
   const MfmaRevFusedLayout L = mfma_rev_fused_layout();
   const float* img = plan->d_mfma_revf + (size_t)b * L.total;
-  RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
+  RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first};
   constexpr int WV = kWavesRevFused;
   dim3 grid(grid_for_tiles(tiles)), block(64 * WV);

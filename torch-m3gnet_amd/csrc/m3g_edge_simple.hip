@@ -92,14 +92,15 @@ __global__ void __launch_bounds__(256) k_edge_block(Consts c, int64_t E, const f
                                                     const float* __restrict__ h, const float* __restrict__ m,
                                                     const float* __restrict__ TA, const float* __restrict__ TB,
                                                     float* __restrict__ e_io, float* __restrict__ act,
-                                                    float* __restrict__ x_new) {
+                                                    float* __restrict__ x_new, const int32_t* __restrict__ act_id) {
   __shared__ TileLds L;
   int tid = threadIdx.x, o = tid & 63, eg = tid >> 6;
   int64_t e0 = (int64_t)blockIdx.x * TE;
   {
     int le = tid / kCP, cc = tid % kCP;  // 256 threads = 16 edges x 16
     int64_t e = e0 + le;
-    L.ms[le][cc] = e < E ? m[e * kCP + cc] : 0.f;
+    const int arow = e < E ? act_id[e] : -1;   // m, dm: one row per active edge
+    L.ms[le][cc] = arow >= 0 ? m[(int64_t)arow * kCP + cc] : 0.f;
     if (cc < kRP) L.hs[le][cc] = e < E ? h[e * kRP + cc] : 0.f;
     if (cc == 0) { L.ss[le] = e < E ? src[e] : 0; L.ds[le] = e < E ? dst[e] : 0; }
   }
@@ -230,14 +231,15 @@ __global__ void __launch_bounds__(256) k_edge_block_reverse(Consts c, int64_t E,
                                                             const float* __restrict__ m, const float* __restrict__ act,
                                                             const float* __restrict__ dx_new, float* __restrict__ de_io,
                                                             float* __restrict__ dm, float* __restrict__ dh,
-                                                            float* __restrict__ dp1) {
+                                                            float* __restrict__ dp1, const int32_t* __restrict__ act_id) {
   __shared__ TileLdsRev L;
   int tid = threadIdx.x, k = tid & 63, eg = tid >> 6;
   int64_t e0 = (int64_t)blockIdx.x * TE;
   {
     int le = tid / kCP, cc = tid % kCP;
     int64_t e = e0 + le;
-    L.ms[le][cc] = e < E ? m[e * kCP + cc] : 0.f;
+    const int arow = e < E ? act_id[e] : -1;   // m, dm: one row per active edge
+    L.ms[le][cc] = arow >= 0 ? m[(int64_t)arow * kCP + cc] : 0.f;
     if (cc < kRP) L.hs[le][cc] = e < E ? h[e * kRP + cc] : 0.f;
     if (cc == 0) L.ss[le] = e < E ? src[e] : 0;
   }
@@ -281,7 +283,8 @@ __global__ void __launch_bounds__(256) k_edge_block_reverse(Consts c, int64_t E,
         for (int o = 0; o < kDP; ++o)
           acc += L.A[le][o] * W[bw.tb_wd + o * kCP + cc] + L.G[le][o] * W[bw.tb_wg + o * kCP + cc];
       }
-      dm[e * kCP + cc] = acc;
+      const int arow = act_id[e];
+      if (arow >= 0) dm[(int64_t)arow * kCP + cc] = acc;
     }
   }
 }
@@ -292,14 +295,14 @@ void launch_edge_block(const Consts& c, const float* W, const BlockW& bw, const 
                        float* x_new, hipStream_t s) {
   if (t.E == 0) return;
   hipLaunchKernelGGL(k_edge_block, grid_for(t.E, TE), dim3(256), 0, s, c, t.E, W, bw, t.src, t.dst, w.h, w.m[b], w.TA, w.TB,
-                     w.e, w.act[b], x_new);
+                     w.e, w.act[b], x_new, t.act_id);
 }
 
 void launch_edge_block_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, int b,
                                const float* dx_new, hipStream_t s) {
   if (t.E == 0) return;
   hipLaunchKernelGGL(k_edge_block_reverse, grid_for(t.E, TE), dim3(256), 0, s, c, t.E, W, bw, t.src, w.h, w.m[b], w.act[b],
-                     dx_new, w.de, w.dm, w.dh, w.dp1);
+                     dx_new, w.de, w.dm, w.dh, w.dp1, t.act_id);
 }
 
 }  // namespace m3g

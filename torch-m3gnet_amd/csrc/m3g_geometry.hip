@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int
                                                   const int32_t* __restrict__ shift, float* __restrict__ u,
                                                   float* __restrict__ dist, float* __restrict__ h, float* __restrict__ hp,
                                                   float* __restrict__ q, float* __restrict__ qp, float* __restrict__ fc3,
-                                                  float* __restrict__ fc3p) {
+                                                  float* __restrict__ fc3p, const int32_t* __restrict__ act_id) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= E) return;
   int i = src[e], j = dst[e], s = batch[i];
@@ -107,31 +107,31 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int
   }
   fc3[e] = f;
   fc3p[e] = fp;
-  // q[e,c] = chi_ln(d) fc(d),  c = l*R + n  (nn/interaction.py:268-281); beyond the three-body cutoff both factors of
-  // every product are multiplied by an exact zero, so the Bessel functions are not evaluated there
+  // q[ar,c] = chi_ln(d) fc(d),  c = l*R + n  (nn/interaction.py:268-281), one row per ACTIVE edge (ar = act_id[e]): an edge
+  // without triplets -- beyond the three-body cutoff or without a partner -- needs no row and no Bessel evaluation
+  const int ar = act_id[e];
+  if (ar < 0) return;
   float qr[kCP], qpr[kCP];
 #pragma unroll
   for (int cc = 0; cc < kCP; ++cc) { qr[cc] = 0.f; qpr[cc] = 0.f; }
-  if (rho <= 1.f) {
 #pragma unroll
-    for (int n = 0; n < R; ++n) {
+  for (int n = 0; n < R; ++n) {
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        float jl[kLCap], djl[kLCap];
-        // the argument differs per (l,n): z_ln * d / rc
-        float x = c.zeros[l][n] * d / c.rc;
-        sph_bessel(L, x, jl, djl);
-        float chi = jl[l] / c.factors[l][n];
-        float dchi = djl[l] * (c.zeros[l][n] / c.rc) / c.factors[l][n];
-        qr[l * R + n] = chi * f;
-        qpr[l * R + n] = dchi * f + chi * fp;
-      }
+    for (int l = 0; l < L; ++l) {
+      float jl[kLCap], djl[kLCap];
+      // the argument differs per (l,n): z_ln * d / rc
+      float x = c.zeros[l][n] * d / c.rc;
+      sph_bessel(L, x, jl, djl);
+      float chi = jl[l] / c.factors[l][n];
+      float dchi = djl[l] * (c.zeros[l][n] / c.rc) / c.factors[l][n];
+      qr[l * R + n] = chi * f;
+      qpr[l * R + n] = dchi * f + chi * fp;
     }
   }
 #pragma unroll
   for (int cc = 0; cc < kCP; cc += 4) {
-    *(float4*)(q + e * kCP + cc) = float4{qr[cc], qr[cc + 1], qr[cc + 2], qr[cc + 3]};
-    *(float4*)(qp + e * kCP + cc) = float4{qpr[cc], qpr[cc + 1], qpr[cc + 2], qpr[cc + 3]};
+    *(float4*)(q + (int64_t)ar * kCP + cc) = float4{qr[cc], qr[cc + 1], qr[cc + 2], qr[cc + 3]};
+    *(float4*)(qp + (int64_t)ar * kCP + cc) = float4{qpr[cc], qpr[cc + 1], qpr[cc + 2], qpr[cc + 3]};
   }
 }
 
@@ -287,7 +287,7 @@ void launch_geometry(const Consts& c, const Topo& t, const float* pos, const flo
                      const Work& w, hipStream_t s) {
   if (t.E == 0) return;
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_geometry<true, L, R>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos,
-                                               lattice, shift, w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p));
+                                               lattice, shift, w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p, t.act_id));
 }
 
 void launch_distance_only(float length_scale, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
@@ -296,7 +296,7 @@ void launch_distance_only(float length_scale, const Topo& t, const float* pos, c
   Consts c{};
   c.length_scale = length_scale;
   hipLaunchKernelGGL((k_geometry<false, 1, 1>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos, lattice, shift,
-                     u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                     u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,

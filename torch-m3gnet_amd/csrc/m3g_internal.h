@@ -220,6 +220,8 @@ struct Topo {
   int32_t* row_ptr;  // [N+1] edges of centre i: row_ptr[i] .. row_ptr[i+1]
   int32_t* in_ptr;   // [N+1] incoming edges of atom j (dst == j)
   int32_t* in_edge;  // [E]
+  int32_t* in_pair;  // [E][2] (in_edge[k], act_id[in_edge[k]]): the k-th incoming edge and its compact three-body row (-1: none),
+                     // one 8-byte load in the node reverse gather
   int32_t* t1_ptr;   // [E+1] triplets grouped by first edge e1
   int32_t* t1_e2;    // [T]
   int32_t* t2_ptr;   // [E+1] triplets grouped by second edge e2
@@ -228,6 +230,8 @@ struct Topo {
   // three-body kernels run over this compacted list so no lane idles on the edges beyond the three-body cutoff
   int32_t* act_list;   // [A] active edge ids, ascending
   int32_t* act_scan;   // [E+1] number of active edges before e (compacted id of e when e is active)
+  int32_t* act_id;     // [E] compacted id of edge e, -1 for an edge without triplets: the per-edge three-body arrays
+                       // (q, q', m, dm, dg) hold rows for ACTIVE edges only, indexed by this id
   int32_t* arow_ptr;   // [N+1] compacted rows of centre i: arow_ptr[i] .. arow_ptr[i+1]
   int32_t* t1_e2c;     // [T] t1_e2 in compacted ids
   int32_t* t2_e1c;     // [T] t2_e1 in compacted ids
@@ -312,6 +316,8 @@ void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, con
                     bool want_grad, hipStream_t s);
 void launch_gather_rows(const float* table, int64_t n, int width, int table_stride, int table_rows, bool transposed,
                         const int64_t* idx, float* out, hipStream_t s);
+void launch_copy_expand_rows(const int32_t* row_id, const float* in, int in_stride, float* out, int out_stride, int width, int64_t n,
+                             hipStream_t s);
 void launch_copy_strided(const float* in, int in_stride, float* out, int out_stride, int width, int64_t rows,
                          hipStream_t s);
 // threebody.hip

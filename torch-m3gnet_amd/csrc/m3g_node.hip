@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
                                                       const float* __restrict__ dgq, const float* __restrict__ v,
                                                       const float* __restrict__ dx_new, float* __restrict__ dx_out,
                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
-                                                      int with_v_term) {
+                                                      int with_v_term, const int2* __restrict__ in_pair) {
   __shared__ float4 sA[kNodesRev][64], sB[kNodesRev][64];   // row / in-edge sums of dp1, 256 columns as 64 float4
   __shared__ float tv[kNodesRev][kCP];
   __shared__ float part[4][kNodesRev][kDP];
@@ -184,15 +184,16 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
       // kNrBatch whole 1-KB rows in flight per wave, the remainder in one guarded batch as well (a row-at-a-time tail
       // is a dependent round trip per row)
       for (; k < k1; k += kNrBatch) {
-        int f[kNrBatch];
+        int2 f[kNrBatch];   // (edge id, compact three-body row or -1)
         float4 u[kNrBatch];
         float g[kNrBatch];
 #pragma unroll
-        for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_edge[k + j] : -1;
+        for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_pair[k + j] : make_int2(-1, -1);
 #pragma unroll
         for (int j = 0; j < kNrBatch; ++j) {
-          u[j] = f[j] >= 0 ? rows[(int64_t)f[j] * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-          g[j] = (with_v_term && f[j] >= 0) ? dgq[(int64_t)f[j] * kCP + cq] : 0.f;
+          u[j] = f[j].x >= 0 ? rows[(int64_t)f[j].x * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+          // dL/dg holds one row per ACTIVE edge; other edges contribute nothing
+          g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < kNrBatch; j += 4) {
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
 __global__ void __launch_bounds__(256) k_node_reverse_v_term(int C, int64_t N, const float* __restrict__ W, size_t tb_w1,
                                                              const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_edge,
                                                              const float* __restrict__ dgq, const float* __restrict__ v,
-                                                             float* __restrict__ dx_out) {
+                                                             float* __restrict__ dx_out, const int2* __restrict__ in_pair) {
   __shared__ float tv[16][kCP];
   const int g = threadIdx.x >> 4, cq = threadIdx.x & 15;
   const int64_t i = (int64_t)blockIdx.x * 16 + g;
@@ -259,11 +260,10 @@ __global__ void __launch_bounds__(256) k_node_reverse_v_term(int C, int64_t N, c
   if (i < N) {
     int k = in_ptr[i];
     const int k1 = in_ptr[i + 1];
-    for (; k + 3 < k1; k += 4) {
-      const int f0 = in_edge[k], f1 = in_edge[k + 1], f2 = in_edge[k + 2], f3 = in_edge[k + 3];
-      dv += (dgq[(int64_t)f0 * kCP + cq] + dgq[(int64_t)f1 * kCP + cq]) + (dgq[(int64_t)f2 * kCP + cq] + dgq[(int64_t)f3 * kCP + cq]);
-    }
-    for (; k < k1; ++k) dv += dgq[(int64_t)in_edge[k] * kCP + cq];
+    auto row = [&](int kk) { const int ar = in_pair[kk].y; return ar >= 0 ? dgq[(int64_t)ar * kCP + cq] : 0.f; };   // one row per active edge
+    for (; k + 3 < k1; k += 4) dv += (row(k) + row(k + 1)) + (row(k + 2) + row(k + 3));
+    for (; k < k1; ++k) dv += row(k);
+    (void)in_edge;
     const float vv = v[i * kCP + cq];
     dv = cq < C ? dv * vv * (1.f - vv) : 0.f;
   }
@@ -411,6 +411,18 @@ __global__ void __launch_bounds__(256) k_copy_strided(int64_t rows, int width, c
   out[r * out_stride + o] = in[r * in_stride + o];
 }
 
+// out[e, :width] = rows[row_id[e], :width], zeros where row_id[e] < 0 (per-edge view of an array kept per ACTIVE edge)
+__global__ void __launch_bounds__(256) k_copy_expand_rows(int64_t n, int width, const int32_t* __restrict__ row_id,
+                                                          const float* __restrict__ in, int in_stride, float* __restrict__ out,
+                                                          int out_stride) {
+  int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (id >= n * width) return;
+  int64_t e = id / width;
+  int o = (int)(id % width);
+  const int r = row_id[e];
+  out[e * out_stride + o] = r >= 0 ? in[(int64_t)r * in_stride + o] : 0.f;
+}
+
 static inline dim3 grid_for(int64_t n, int tpb = 256) { return dim3((unsigned)((n + tpb - 1) / tpb)); }
 
 void launch_embed(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
@@ -443,14 +455,14 @@ void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, cons
   if (t.N > 0)
     hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge,
                        w.dp1, w.dg, v, dx_new, dx_out, row_sums_in_seg ? w.seg_head : nullptr, row_sums_in_seg ? w.seg_first : nullptr,
-                       with_v_term ? 1 : 0);
+                       with_v_term ? 1 : 0, reinterpret_cast<const int2*>(t.in_pair));
 }
 
 void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,
                                 float* dx_out, hipStream_t s) {
   if (t.N > 0)
     hipLaunchKernelGGL(k_node_reverse_v_term, grid_for(t.N, 16), dim3(256), 0, s, c.C, t.N, W, bw.tb_w1, t.in_ptr, t.in_edge, w.dg, v,
-                       dx_out);
+                       dx_out, reinterpret_cast<const int2*>(t.in_pair));
 }
 
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
@@ -477,6 +489,11 @@ void launch_gather_rows(const float* table, int64_t n, int width, int table_stri
 void launch_copy_strided(const float* in, int in_stride, float* out, int out_stride, int width, int64_t rows,
                          hipStream_t s) {
   if (rows > 0) hipLaunchKernelGGL(k_copy_strided, grid_for(rows * width), dim3(256), 0, s, rows, width, in, in_stride, out, out_stride);
+}
+
+void launch_copy_expand_rows(const int32_t* row_id, const float* in, int in_stride, float* out, int out_stride, int width, int64_t n,
+                             hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_copy_expand_rows, grid_for(n * width), dim3(256), 0, s, n, width, row_id, in, in_stride, out, out_stride);
 }
 
 }  // namespace m3g

@@ -50,8 +50,8 @@ struct TbArgs {
   int64_t E;
   const int32_t *act_list, *act_dst, *tb_win, *n_act;
   const int32_t *t_ptr, *t_other;     // triplets grouped by e1, partners e2 as compacted ids
-  const float *u, *fc3, *q, *v;
-  float* m;                           // out [E][kCP]
+  const float *u, *fc3, *q, *v;       // q: one row per active edge
+  float* m;                           // out [A][kCP], one row per active edge
 };
 
 // Forward: m[e1,:] = fc(d_e1) sum_t Y_l(cos_t) g[e2(t),:]
@@ -74,7 +74,6 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   const int r = rb + threadIdx.x;
   const bool live = r < A;
   const int64_t e = a.act_list[live ? r : A - 1];
-  const int64_t e_next = r + 1 < A ? a.act_list[live ? r + 1 : A - 1] : a.E;
   const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
   for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
     const int64_t es = a.act_list[lo + idx], ks = a.act_dst[lo + idx];
@@ -82,19 +81,10 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
     su[idx * 3 + 1] = a.u[es * 3 + 1];
     su[idx * 3 + 2] = a.u[es * 3 + 2];
     float qr[C], vr[C];
-    load_row<C>(a.q + es * kCP, qr);
+    load_row<C>(a.q + (int64_t)(lo + idx) * kCP, qr);   // compact rows: the window is contiguous
     load_row<C>(a.v + ks * kCP, vr);
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) sp[idx * C + cc] = qr[cc] * vr[cc];
-  }
-  // edges without triplets keep m = 0: every thread clears the gap after its own row (the first row also the edges
-  // before it), so no separate memset pass over the [E,16] array is needed
-  if (live) {
-    for (int64_t g = (r == 0 ? 0 : e + 1); g < e_next; ++g) {
-      if (g == e) continue;
-#pragma unroll
-      for (int k = 0; k < kCP; k += 4) *(float4*)(a.m + g * kCP + k) = float4{0.f, 0.f, 0.f, 0.f};
-    }
   }
   // everything this row needs from global memory is requested before the barrier
   const int t0 = a.t_ptr[e], t1 = a.t_ptr[e + 1];
@@ -117,7 +107,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
       const int64_t eo = a.act_list[lo + idx], ko = a.act_dst[lo + idx];
       vx = a.u[eo * 3]; vy = a.u[eo * 3 + 1]; vz = a.u[eo * 3 + 2];
 #pragma unroll
-      for (int k = 0; k < C; ++k) pr[k] = a.q[eo * kCP + k] * a.v[ko * kCP + k];
+      for (int k = 0; k < C; ++k) pr[k] = a.q[(int64_t)(lo + idx) * kCP + k] * a.v[ko * kCP + k];
     }
     const float cs = fminf(1.f, fmaxf(-1.f, ux * vx + uy * vy + uz * vz));
     float P[L], dP[L];
@@ -136,7 +126,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
     o.y = k + 1 < C ? fc * acc[k + 1 < C ? k + 1 : 0] : 0.f;
     o.z = k + 2 < C ? fc * acc[k + 2 < C ? k + 2 : 0] : 0.f;
     o.w = k + 3 < C ? fc * acc[k + 3 < C ? k + 3 : 0] : 0.f;
-    *(float4*)(a.m + e * kCP + k) = o;
+    *(float4*)(a.m + (int64_t)r * kCP + k) = o;
   }
 }
 
@@ -168,9 +158,9 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   const int t2_lo = a.tb_win[6 * blockIdx.x + 4], t2_hi = a.tb_win[6 * blockIdx.x + 5];
   const int r = rb + threadIdx.x;
   const bool live = r < A;
-  const int64_t e = a.act_list[live ? r : A - 1];
-  const int64_t e_next = r + 1 < A ? a.act_list[live ? r + 1 : A - 1] : a.E;
-  const int64_t kd = a.act_dst[live ? r : A - 1];
+  const int rr = live ? r : A - 1;           // compact row of this thread
+  const int64_t e = a.act_list[rr];
+  const int64_t kd = a.act_dst[rr];
   const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
   const int n1 = (t1_hi - t1_lo) < kTbRevList ? (t1_hi - t1_lo) : kTbRevList;
   const int n2 = (t2_hi - t2_lo) < kTbRevList ? (t2_hi - t2_lo) : kTbRevList;
@@ -183,21 +173,13 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
     su[idx * 3 + 2] = a.u[es * 3 + 2];
     const float f = a.fc3[es];
     float qr[C], vr[C], dr[C];
-    load_row<C>(a.q + es * kCP, qr);
+    load_row<C>(a.q + (int64_t)(lo + idx) * kCP, qr);    // q, dm: one row per active edge, the window is contiguous
     load_row<C>(a.v + ks * kCP, vr);
-    load_row<C>(a.dm + es * kCP, dr);
+    load_row<C>(a.dm + (int64_t)(lo + idx) * kCP, dr);
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
       sg[idx * C + cc] = qr[cc] * vr[cc];
       ss[idx * C + cc] = f * dr[cc];
-    }
-  }
-  // edges without triplets keep dg = 0: every thread clears the gap after its own row (the first row also the edges before it)
-  if (live) {
-    for (int64_t g = (r == 0 ? 0 : e + 1); g < e_next; ++g) {
-      if (g == e) continue;
-#pragma unroll
-      for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + g * kCP + k) = float4{0.f, 0.f, 0.f, 0.f};
     }
   }
   // this row's own data, requested before the barrier
@@ -206,9 +188,9 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   const float fc = a.fc3[e], fcp = a.fc3p[e];
   const float dd0 = a.dd[e], du0 = a.du[e * 3], du1 = a.du[e * 3 + 1], du2 = a.du[e * 3 + 2];
   float dmv[C], gv[C], qv[C], qpv[C], vv[C];
-  load_row<C>(a.dm + e * kCP, dmv);
-  load_row<C>(a.q + e * kCP, qv);
-  load_row<C>(a.qp + e * kCP, qpv);
+  load_row<C>(a.dm + (int64_t)rr * kCP, dmv);
+  load_row<C>(a.q + (int64_t)rr * kCP, qv);
+  load_row<C>(a.qp + (int64_t)rr * kCP, qpv);
   load_row<C>(a.v + kd * kCP, vv);
 #pragma unroll
   for (int k = 0; k < C; ++k) gv[k] = qv[k] * vv[k];
@@ -221,11 +203,12 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
 #pragma unroll
       for (int k = 0; k < C; ++k) pr[k] = sp[id * C + k];
     } else {
-      const int64_t eo = a.act_list[list[t]], ko = a.act_dst[list[t]];
+      const int64_t ro = list[t];
+      const int64_t eo = a.act_list[ro], ko = a.act_dst[ro];
       vx = a.u[eo * 3]; vy = a.u[eo * 3 + 1]; vz = a.u[eo * 3 + 2];
       const float f = a.fc3[eo];
 #pragma unroll
-      for (int k = 0; k < C; ++k) pr[k] = want_s ? f * a.dm[eo * kCP + k] : a.q[eo * kCP + k] * a.v[ko * kCP + k];
+      for (int k = 0; k < C; ++k) pr[k] = want_s ? f * a.dm[ro * kCP + k] : a.q[ro * kCP + k] * a.v[ko * kCP + k];
     }
   };
   float S[C], dg[C];
@@ -288,7 +271,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
     }
   }
 #pragma unroll
-  for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + e * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
+  for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + (int64_t)r * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
   a.dd[e] = (dd0 + fcp * dfc) + ddv;
   a.du[e * 3] = (du0 + fc * a1x) + a2x;
   a.du[e * 3 + 1] = (du1 + fc * a1y) + a2y;
@@ -299,14 +282,14 @@ static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 
 
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s) {
   if (t.E == 0) return;
-  if (t.T == 0) { (void)hipMemsetAsync(m, 0, sizeof(float) * t.E * kCP, s); return; }   // no active row to clear the gaps
+  if (t.T == 0) return;   // no active edge: every consumer reads zeros through act_id < 0
   TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, w.u, w.fc3, w.q, v, m};
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }
 
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s) {
   if (t.E == 0) return;
-  if (t.T == 0) { (void)hipMemsetAsync(w.dg, 0, sizeof(float) * t.E * kCP, s); return; }
+  if (t.T == 0) return;
   TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, w.u, w.fc3, w.fc3p, w.q, w.qp, v,
               w.dm, w.dd, w.du, w.dg};
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));

@@ -35,12 +35,14 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   t.row_ptr = (int32_t*)take(sizeof(int32_t) * (N + 1));
   t.in_ptr = (int32_t*)take(sizeof(int32_t) * (N + 1));
   t.in_edge = (int32_t*)take(sizeof(int32_t) * (E + 1));
+  t.in_pair = (int32_t*)take(sizeof(int32_t) * 2 * (E + 1));
   t.t1_ptr = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.t1_e2 = (int32_t*)take(sizeof(int32_t) * (T + 1));
   t.t2_ptr = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.t2_e1 = (int32_t*)take(sizeof(int32_t) * (T + 1));
   t.act_list = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.act_scan = (int32_t*)take(sizeof(int32_t) * (E + 2));
+  t.act_id = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.arow_ptr = (int32_t*)take(sizeof(int32_t) * (N + 2));
   t.act_dst = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.tb_win = (int32_t*)take(sizeof(int32_t) * 6 * (E / kTbRows + 2));
@@ -122,9 +124,13 @@ __global__ void k_active_flags(int64_t E, const int32_t* __restrict__ t1_ptr, in
 }
 __global__ void k_active_scatter(int64_t N, int64_t E, const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ scan,
                                  const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst, int32_t* act_list,
-                                 int32_t* act_dst, int32_t* arow_ptr, int32_t* n_act) {
+                                 int32_t* act_dst, int32_t* act_id, int32_t* arow_ptr, int32_t* n_act) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e < E && t1_ptr[e + 1] > t1_ptr[e]) { act_list[scan[e]] = (int32_t)e; act_dst[scan[e]] = dst[e]; }
+  if (e < E) {
+    const bool active = t1_ptr[e + 1] > t1_ptr[e];
+    act_id[e] = active ? scan[e] : -1;
+    if (active) { act_list[scan[e]] = (int32_t)e; act_dst[scan[e]] = dst[e]; }
+  }
   if (e <= N) arow_ptr[e] = scan[row_ptr[e]];
   if (e == 0) *n_act = scan[E];
 }
@@ -146,6 +152,10 @@ __global__ void k_tb_windows(int64_t blocks, const int32_t* __restrict__ n_act, 
     w[4] = t2_ptr[ef]; w[5] = t2_ptr[el + 1];
   }
   for (int k = 0; k < 6; ++k) win[6 * b + k] = w[k];
+}
+__global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ table, int32_t* out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) { out[2 * i] = idx[i]; out[2 * i + 1] = table[idx[i]]; }
 }
 __global__ void k_compact_partners(int64_t T, const int32_t* __restrict__ scan, const int32_t* __restrict__ a, const int32_t* __restrict__ b,
                                    int32_t* ac, int32_t* bc) {
@@ -217,9 +227,10 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   hipLaunchKernelGGL(k_active_flags, grid(E + 1), dim3(TPB), 0, s, E, t.t1_ptr, t.act_scan);
   M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, t.act_scan, t.act_scan, (int)(E + 1), s));
   hipLaunchKernelGGL(k_active_scatter, grid(std::max(E, N) + 1), dim3(TPB), 0, s, N, E, t.t1_ptr, t.act_scan, t.row_ptr, t.dst, t.act_list,
-                     t.act_dst, t.arow_ptr, t.n_act);
+                     t.act_dst, t.act_id, t.arow_ptr, t.n_act);
   hipLaunchKernelGGL(k_tb_windows, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t2_ptr,
                      t.tb_win);
+  if (E > 0) hipLaunchKernelGGL(k_pair_with_lookup, grid(E), dim3(TPB), 0, s, E, t.in_edge, t.act_id, t.in_pair);
   if (T > 0) hipLaunchKernelGGL(k_compact_partners, grid(T), dim3(TPB), 0, s, T, t.act_scan, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c);
   M3G_HIP_CHECK(hipGetLastError());
   if (host_flags) {
