@@ -212,7 +212,9 @@ namespace m3g {
 #ifndef M3G_TB_ROWS
 #define M3G_TB_ROWS 128
 #endif
-constexpr int kTbRows = M3G_TB_ROWS;   // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
+constexpr int kTbRows = M3G_TB_ROWS;
+constexpr int kTbCap = kTbRows + 64 < 255 ? kTbRows + 64 : 255;   // staged three-body window: the rows + boundary rows; < 256 so a partner id fits a byte
+   // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
 struct Topo {
   int64_t N, E, T, S;
   int32_t* src;      // [E] centre of each edge
@@ -235,6 +237,8 @@ struct Topo {
   int32_t* arow_ptr;   // [N+1] compacted rows of centre i: arow_ptr[i] .. arow_ptr[i+1]
   int32_t* t1_e2c;     // [T] t1_e2 in compacted ids
   int32_t* t2_e1c;     // [T] t2_e1 in compacted ids
+  uint8_t* t1_b;       // [T] the same partners as byte-sized ids relative to the LDS window of the row's workgroup
+  uint8_t* t2_b;       //     (255: outside the staged window -> the kernels fall back to the int32 list)
   int32_t* act_dst;    // [A] neighbour atom of each active edge (saves a dependent load when staging)
   int32_t* tb_win;     // [6 * blocks] per three-body workgroup: compacted-row window [lo, hi) staged in LDS, then the
                        // ranges [t_lo, t_hi) of its rows' partner lists in t1_e2c and in t2_e1c

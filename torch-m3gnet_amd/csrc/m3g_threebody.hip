@@ -18,8 +18,7 @@
 
 namespace m3g {
 
-constexpr int kTbListCap = 24 * kTbRows;   // staged partner ids (24 partners per row; longer lists continue from global memory)
-constexpr int kTbCap = kTbRows + 64 < 255 ? kTbRows + 64 : 255;   // staged window: the rows + boundary rows (overflow -> global reads); < 256 so a partner id fits a byte
+constexpr int kTbListCap = 32 * kTbRows;   // staged partner ids, one byte each (32 partners per row; longer lists continue from global memory)
 
 // first C floats of a 16-float (64-byte aligned) row as 16-byte loads: a scalar load per element makes every lane of a
 // wave touch its own cache line once per element
@@ -50,6 +49,7 @@ struct TbArgs {
   int64_t E;
   const int32_t *act_list, *act_dst, *tb_win, *n_act;
   const int32_t *t_ptr, *t_other;     // triplets grouped by e1, partners e2 as compacted ids
+  const uint8_t* t_bytes;             // the same partners as window-relative bytes (255: use t_other)
   const float *u, *fc3, *q, *v;       // q: one row per active edge
   float* m;                           // out [A][kCP], one row per active edge
 };
@@ -60,17 +60,17 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   constexpr int C = L * R;
   __shared__ float su[kTbCap * 3];
   __shared__ float sp[kTbCap * C];
-  __shared__ int s_other[kTbListCap];
+  __shared__ unsigned char s_other[kTbListCap];
   // independent first-level loads: A, this workgroup's window, this thread's row
   const int A = *a.n_act;
   const int rb = blockIdx.x * kTbRows;
   if (rb >= A) return;                       // the grid is sized for the worst case A = E
   const int lo = a.tb_win[6 * blockIdx.x], hi_full = a.tb_win[6 * blockIdx.x + 1];
   const int t_lo = a.tb_win[6 * blockIdx.x + 2], t_hi = a.tb_win[6 * blockIdx.x + 3];
-  // the rows' partner lists are one contiguous range of t_other: staged once, coalesced, as window-relative ids --
-  // a global load per triplet inside the loop serialises ~17 L2 round trips per thread
+  // the rows' partner lists are one contiguous range: staged once, coalesced, as window-relative byte ids (precomputed
+  // in the topology) -- a global load per triplet inside the loop serialises ~17 L2 round trips per thread
   const int n_list = (t_hi - t_lo) < kTbListCap ? (t_hi - t_lo) : kTbListCap;
-  for (int k = threadIdx.x; k < n_list; k += kTbRows) s_other[k] = a.t_other[t_lo + k] - lo;
+  for (int k = threadIdx.x; k < n_list; k += kTbRows) s_other[k] = a.t_bytes[t_lo + k];
   const int r = rb + threadIdx.x;
   const bool live = r < A;
   const int64_t e = a.act_list[live ? r : A - 1];
@@ -97,9 +97,10 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   for (int k = 0; k < C; ++k) acc[k] = 0.f;
   for (int t = t0; t < t1; ++t) {
     const int kk = t - t_lo;
-    const int idx = kk < kTbListCap ? s_other[kk] : a.t_other[t] - lo;
+    const int bid = kk < kTbListCap ? s_other[kk] : 255;
+    const int idx = bid != 255 ? bid : a.t_other[t] - lo;
     float vx, vy, vz, pr[C];
-    if (idx >= 0 && idx < n) {
+    if (bid != 255) {
       vx = su[idx * 3]; vy = su[idx * 3 + 1]; vz = su[idx * 3 + 2];
 #pragma unroll
       for (int k = 0; k < C; ++k) pr[k] = sp[idx * C + k];
@@ -138,6 +139,7 @@ struct TbRevArgs {
   int64_t E;
   const int32_t *act_list, *act_dst, *tb_win, *n_act;
   const int32_t *t1_ptr, *t1_other, *t2_ptr, *t2_other;
+  const uint8_t *t1_bytes, *t2_bytes;
   const float *u, *fc3, *fc3p, *q, *qp, *v, *dm;
   float *dd, *du, *dgq;
 };
@@ -164,8 +166,8 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
   const int n1 = (t1_hi - t1_lo) < kTbRevList ? (t1_hi - t1_lo) : kTbRevList;
   const int n2 = (t2_hi - t2_lo) < kTbRevList ? (t2_hi - t2_lo) : kTbRevList;
-  for (int k = threadIdx.x; k < n1; k += kTbRows) { const int d = a.t1_other[t1_lo + k] - lo; s1[k] = (unsigned char)(d >= 0 && d < n && d < 255 ? d : 255); }
-  for (int k = threadIdx.x; k < n2; k += kTbRows) { const int d = a.t2_other[t2_lo + k] - lo; s2[k] = (unsigned char)(d >= 0 && d < n && d < 255 ? d : 255); }
+  for (int k = threadIdx.x; k < n1; k += kTbRows) s1[k] = a.t1_bytes[t1_lo + k];
+  for (int k = threadIdx.x; k < n2; k += kTbRows) s2[k] = a.t2_bytes[t2_lo + k];
   for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
     const int64_t es = a.act_list[lo + idx], ks = a.act_dst[lo + idx];
     su[idx * 3 + 0] = a.u[es * 3];
@@ -283,14 +285,15 @@ static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s) {
   if (t.E == 0) return;
   if (t.T == 0) return;   // no active edge: every consumer reads zeros through act_id < 0
-  TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, w.u, w.fc3, w.q, v, m};
+  TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t1_b, w.u, w.fc3, w.q, v, m};
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }
 
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s) {
   if (t.E == 0) return;
   if (t.T == 0) return;
-  TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, w.u, w.fc3, w.fc3p, w.q, w.qp, v,
+  TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, t.t1_b, t.t2_b, w.u, w.fc3, w.fc3p, w.q,
+              w.qp, v,
               w.dm, w.dd, w.du, w.dg};
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }

@@ -48,6 +48,8 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   t.tb_win = (int32_t*)take(sizeof(int32_t) * 6 * (E / kTbRows + 2));
   t.t1_e2c = (int32_t*)take(sizeof(int32_t) * (T + 1));
   t.t2_e1c = (int32_t*)take(sizeof(int32_t) * (T + 1));
+  t.t1_b = (uint8_t*)take((size_t)T + 16);
+  t.t2_b = (uint8_t*)take((size_t)T + 16);
   t.batch = (int32_t*)take(sizeof(int32_t) * (N + 1));
   t.flags = (int32_t*)take(sizeof(int32_t) * 4);
   t.n_act = t.flags ? t.flags + 2 : nullptr;
@@ -157,6 +159,21 @@ __global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, c
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) { out[2 * i] = idx[i]; out[2 * i + 1] = table[idx[i]]; }
 }
+// byte-sized partner ids: for triplet slot t of list (t_ptr, t_other_c), the row it belongs to (binary search in t_ptr) fixes
+// the workgroup and so the staged window [lo, lo + n); the partner is stored relative to lo, 255 when it falls outside
+__global__ void k_partner_bytes(int64_t E, int64_t T, const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ act_id,
+                                const int32_t* __restrict__ win, const int32_t* __restrict__ t_other_c, uint8_t* out) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  int64_t lo = 0, hi = E;   // last e with t_ptr[e] <= t
+  while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (t_ptr[mid] <= t) lo = mid; else hi = mid - 1; }
+  const int r = act_id[lo];
+  const int blk = (r < 0 ? 0 : r) / kTbRows;
+  const int wlo = win[6 * blk], whi = win[6 * blk + 1];
+  const int n = (whi - wlo) < kTbCap ? (whi - wlo) : kTbCap;
+  const int d = t_other_c[t] - wlo;
+  out[t] = (uint8_t)((r >= 0 && d >= 0 && d < n && d < 255) ? d : 255);
+}
 __global__ void k_compact_partners(int64_t T, const int32_t* __restrict__ scan, const int32_t* __restrict__ a, const int32_t* __restrict__ b,
                                    int32_t* ac, int32_t* bc) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -231,7 +248,11 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   hipLaunchKernelGGL(k_tb_windows, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t2_ptr,
                      t.tb_win);
   if (E > 0) hipLaunchKernelGGL(k_pair_with_lookup, grid(E), dim3(TPB), 0, s, E, t.in_edge, t.act_id, t.in_pair);
-  if (T > 0) hipLaunchKernelGGL(k_compact_partners, grid(T), dim3(TPB), 0, s, T, t.act_scan, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c);
+  if (T > 0) {
+    hipLaunchKernelGGL(k_compact_partners, grid(T), dim3(TPB), 0, s, T, t.act_scan, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c);
+    hipLaunchKernelGGL(k_partner_bytes, grid(T), dim3(TPB), 0, s, E, T, t.t1_ptr, t.act_id, t.tb_win, t.t1_e2c, t.t1_b);
+    hipLaunchKernelGGL(k_partner_bytes, grid(T), dim3(TPB), 0, s, E, T, t.t2_ptr, t.act_id, t.tb_win, t.t2_e1c, t.t2_b);
+  }
   M3G_HIP_CHECK(hipGetLastError());
   if (host_flags) {
     M3G_HIP_CHECK(hipMemcpyAsync(host_flags, t.flags, sizeof(int32_t), hipMemcpyDeviceToHost, s));
