@@ -611,8 +611,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
             M3G_HIP_CHECK(hipMemsetAsync(w.de, 0, sizeof(float) * E * kDP, s));
             M3G_HIP_CHECK(hipMemsetAsync(w.dh, 0, sizeof(float) * E * kRP, s));
           }
-          M3G_HIP_CHECK(hipMemsetAsync(w.dd, 0, sizeof(float) * E, s));
-          M3G_HIP_CHECK(hipMemsetAsync(w.du, 0, sizeof(float) * E * 3, s));
+          // dd / du need no clearing: the first three-body reverse of the step writes its (active) rows, and the geometry
+          // reverse reads active rows only
       }
       if (mfma && fused_rev) {
         M3G_STAGE(ST_EDGE_REV_FUSED);
@@ -630,14 +630,14 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         // side stream beside it, then add the v-gradient share (which needs its dL/dg) once both are done
         M3G_HIP_CHECK(hipEventRecord(plan->ev_fork, s));
         M3G_HIP_CHECK(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
-        launch_threebody_reverse(c, t, w, w.v[b], plan->side_stream);
+        launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, plan->side_stream);
         M3G_HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
         launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*with_v_term=*/false, s);
         M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_join, 0));
         launch_node_reverse_v_term(c, W, wl.blk[b], t, w, w.v[b], dx_alt, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
       } else {
-        { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], s); }
+        { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s); }
         if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
           M3G_STAGE(ST_NODE_REV);
           launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*with_v_term=*/true, s);

@@ -138,10 +138,13 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int
 __global__ void __launch_bounds__(256) k_geometry_reverse(Consts c, int64_t E, const float* __restrict__ u,
                                                           const float* __restrict__ dist, const float* __restrict__ hp,
                                                           const float* __restrict__ dh, int dh_parts, const float* __restrict__ dd,
-                                                          const float* __restrict__ du, float* __restrict__ dr) {
+                                                          const float* __restrict__ du, float* __restrict__ dr,
+                                                          const int32_t* __restrict__ act_id) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= E) return;
-  float g = dd[e];
+  // dd / du (three-body share of dL/dd, dL/du) hold one row per ACTIVE edge; act_id == nullptr: no three-body reverse ran
+  const int ar = act_id ? act_id[e] : -1;
+  float g = ar >= 0 ? dd[ar] : 0.f;
   // dL/dh arrives in `dh_parts` slices (one per reverse kernel that produced a share); summed here, in a fixed order
   float dhs[kRP] = {0.f, 0.f, 0.f, 0.f};
   for (int p = 0; p < dh_parts; ++p) {
@@ -153,7 +156,8 @@ __global__ void __launch_bounds__(256) k_geometry_reverse(Consts c, int64_t E, c
     g += dhs[0] * t.x + dhs[1] * t.y + dhs[2] * t.z + dhs[3] * t.w;
   }
   float ux = u[e * 3], uy = u[e * 3 + 1], uz = u[e * 3 + 2];
-  float ax = du[e * 3], ay = du[e * 3 + 1], az = du[e * 3 + 2];
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  if (ar >= 0) { ax = du[(int64_t)ar * 3]; ay = du[(int64_t)ar * 3 + 1]; az = du[(int64_t)ar * 3 + 2]; }
   float proj = ax * ux + ay * uy + az * uz;
   float inv = 1.f / dist[e];
   dr[e * 3 + 0] = g * ux + (ax - proj * ux) * inv;
@@ -302,7 +306,8 @@ void launch_distance_only(float length_scale, const Topo& t, const float* pos, c
 void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
                              hipStream_t s) {
   if (t.E > 0)
-    hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, c, t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, w.dr);
+    hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, c, t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, w.dr,
+                       (t.T > 0 && c.B > 0) ? t.act_id : nullptr);
   if (t.N > 0)
     hipLaunchKernelGGL(k_force_gather, grid_for(t.N * 16), dim3(256), 0, s, c.length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge,
                        w.dr, forces);

@@ -326,7 +326,7 @@ void launch_copy_strided(const float* in, int in_stride, float* out, int out_str
                          hipStream_t s);
 // threebody.hip
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s);
-void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s);
+void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s);
 // pack_mfma.hip / edge_mfma.hip
 int pack_mfma_images(m3g_plan* plan);
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s);

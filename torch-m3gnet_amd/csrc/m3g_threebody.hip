@@ -141,7 +141,8 @@ struct TbRevArgs {
   const int32_t *t1_ptr, *t1_other, *t2_ptr, *t2_other;
   const uint8_t *t1_bytes, *t2_bytes;
   const float *u, *fc3, *fc3p, *q, *qp, *v, *dm;
-  float *dd, *du, *dgq;
+  float *dd, *du, *dgq;   // dd [A], du [A,3]: geometry gradients of the three-body term, one row per active edge
+  int first;              // first reverse launch of the step (last block): dd/du are written, later launches accumulate
 };
 constexpr int kTbRevList = 32 * kTbRows;   // staged partner ids per list (bytes)
 
@@ -188,7 +189,8 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   const int t10 = a.t1_ptr[e], t11 = a.t1_ptr[e + 1], t20 = a.t2_ptr[e], t21 = a.t2_ptr[e + 1];
   const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
   const float fc = a.fc3[e], fcp = a.fc3p[e];
-  const float dd0 = a.dd[e], du0 = a.du[e * 3], du1 = a.du[e * 3 + 1], du2 = a.du[e * 3 + 2];
+  float dd0 = 0.f, du0 = 0.f, du1 = 0.f, du2 = 0.f;
+  if (!a.first) { dd0 = a.dd[rr]; du0 = a.du[(int64_t)rr * 3]; du1 = a.du[(int64_t)rr * 3 + 1]; du2 = a.du[(int64_t)rr * 3 + 2]; }
   float dmv[C], gv[C], qv[C], qpv[C], vv[C];
   load_row<C>(a.dm + (int64_t)rr * kCP, dmv);
   load_row<C>(a.q + (int64_t)rr * kCP, qv);
@@ -274,10 +276,10 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   }
 #pragma unroll
   for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + (int64_t)r * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
-  a.dd[e] = (dd0 + fcp * dfc) + ddv;
-  a.du[e * 3] = (du0 + fc * a1x) + a2x;
-  a.du[e * 3 + 1] = (du1 + fc * a1y) + a2y;
-  a.du[e * 3 + 2] = (du2 + fc * a1z) + a2z;
+  a.dd[r] = (dd0 + fcp * dfc) + ddv;
+  a.du[(int64_t)r * 3] = (du0 + fc * a1x) + a2x;
+  a.du[(int64_t)r * 3 + 1] = (du1 + fc * a1y) + a2y;
+  a.du[(int64_t)r * 3 + 2] = (du2 + fc * a1z) + a2z;
 }
 
 static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 1) / kTbRows)); }
@@ -289,12 +291,12 @@ void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }
 
-void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, hipStream_t s) {
+void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s) {
   if (t.E == 0) return;
   if (t.T == 0) return;
   TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, t.t1_b, t.t2_b, w.u, w.fc3, w.fc3p, w.q,
               w.qp, v,
-              w.dm, w.dd, w.du, w.dg};
+              w.dm, w.dd, w.du, w.dg, first ? 1 : 0};
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
 }
 
