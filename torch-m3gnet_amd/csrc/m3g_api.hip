@@ -652,8 +652,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
       else launch_embed_reverse(c, W, wl, t, w, s);
     }
     M3G_STAGE(ST_GEOM_REV);
-    if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, fused_rev ? c.B : 2 * c.B + 1, io->forces, s);
-    else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, s);
+    if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, fused_rev ? c.B : 2 * c.B + 1, io->forces, io->stresses, s);
+    else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, io->stresses, s);
     if (io->stresses) {
       if (plan->stress_mode == 1) launch_stress_pair(t, w, io->lattice, io->stresses, s);
       else launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);

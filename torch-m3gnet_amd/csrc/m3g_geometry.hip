@@ -170,8 +170,11 @@ __global__ void __launch_bounds__(256) k_geometry_reverse(Consts c, int64_t E, c
 // atom left 160 waves on the whole chip walking 84 dependent 12-byte gathers each.
 __global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_t N, const int32_t* __restrict__ row_ptr,
                                                       const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_edge,
-                                                      const float* __restrict__ dr, float* __restrict__ forces) {
+                                                      const float* __restrict__ dr, float* __restrict__ forces,
+                                                      float* __restrict__ stresses, int64_t n_stress) {
   const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // the stress kernel that follows accumulates with atomics: its output is cleared here instead of by memset launches
+  if (blockIdx.x == 0) for (int64_t k = threadIdx.x; k < n_stress; k += blockDim.x) stresses[k] = 0.f;
   const int64_t i = gid >> 4;
   const int l = (int)(gid & 15);
   float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -303,26 +306,27 @@ void launch_distance_only(float length_scale, const Topo& t, const float* pos, c
                      u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
+// `stresses` (may be null): cleared by the force-gather kernel for the stress kernel that follows (launch_stress*)
 void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
-                             hipStream_t s) {
+                             float* stresses, hipStream_t s) {
   if (t.E > 0)
     hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, c, t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, w.dr,
                        (t.T > 0 && c.B > 0) ? t.act_id : nullptr);
   if (t.N > 0)
     hipLaunchKernelGGL(k_force_gather, grid_for(t.N * 16), dim3(256), 0, s, c.length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge,
-                       w.dr, forces);
+                       w.dr, forces, stresses, stresses ? 6 * t.S : 0);
+  else if (stresses)
+    (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
 }
 
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s) {
-  (void)c;
-  (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
+  (void)c;   // stresses were cleared by launch_geometry_reverse
   if (t.N > 0) hipLaunchKernelGGL(k_stress, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, pos, lattice, forces, stresses);
 }
 
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s) {
-  (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
-  if (t.N > 0)
+  if (t.N > 0)   // stresses were cleared by launch_geometry_reverse
     hipLaunchKernelGGL(k_stress_pair, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, t.row_ptr, lattice, w.u, w.d, w.dr, stresses);
 }
 

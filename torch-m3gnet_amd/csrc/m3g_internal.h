@@ -294,7 +294,7 @@ Work work_carve(const Consts& c, bool mfma, int64_t N, int64_t E, int64_t T, int
 void launch_geometry(const Consts& c, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
                      const Work& w, hipStream_t s);
 void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
-                             hipStream_t s);
+                             float* stresses, hipStream_t s);
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s);
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s);

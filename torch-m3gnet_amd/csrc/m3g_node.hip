@@ -286,8 +286,10 @@ constexpr int kRA = 4;
 __global__ void __launch_bounds__(256) k_readout(Consts c, int64_t N, const float* __restrict__ W, ReadoutW rw,
                                                  size_t elemental_off, const int64_t* __restrict__ types,
                                                  const float* __restrict__ x, NodeSums ns, float* __restrict__ scaled_atomic,
-                                                 float* __restrict__ dx) {
+                                                 float* __restrict__ dx, float* __restrict__ scaled_total, int64_t S) {
   __shared__ float bufA[4][kRA][kDP], bufB[4][kRA][kDP];
+  // the per-structure sums are accumulated with atomics by the next kernel: cleared here instead of a memset launch
+  if (blockIdx.x == 0) for (int64_t i = threadIdx.x; i < S; i += blockDim.x) scaled_total[i] = 0.f;
   const int wv = threadIdx.x >> 6, o = threadIdx.x & 63;
   const int64_t a0 = ((int64_t)blockIdx.x * 4 + wv) * kRA;
 #pragma unroll
@@ -469,10 +471,10 @@ void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, con
                     const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                     bool want_grad, hipStream_t s) {
   NodeSums ns{x_prev, w.seg_head, w.seg_first, t.row_ptr, x};
-  (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
+  if (t.N == 0) (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
   if (t.N > 0) {
     hipLaunchKernelGGL(k_readout, grid_for(t.N, 4 * kRA), dim3(256), 0, s, c, t.N, W, wl.ro, wl.elemental, types, x, ns, scaled_atomic,
-                       want_grad ? w.dx : nullptr);
+                       want_grad ? w.dx : nullptr, scaled_total, t.S);
     hipLaunchKernelGGL(k_energy_sum, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, scaled_atomic, scaled_total);
   }
   if (t.S > 0) hipLaunchKernelGGL(k_scale, grid_for(t.S), dim3(256), 0, s, t.S, c.energy_scale, scaled_total, total);
