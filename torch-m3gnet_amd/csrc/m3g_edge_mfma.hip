@@ -867,8 +867,8 @@ __global__ void __launch_bounds__(256) k_embed_edges_reverse_soa(int64_t E, int6
 }
 
 // ---------------------------------------------------------------------------------------------- node tables
-// S2 on the matrix pipe: [TA | TB | v]^T (528 rows) = W (528 x 64) . x^T (64 x 16 atoms) per 16-atom tile, exact-fp32
-// v_mfma_f32_16x16x4_f32, the whole weight image (135 KB) resident in LDS.  Replaces the vector-ALU k_node_pre, which
+// S2 on the matrix pipe: [TA | TB | v]^T (528 rows) = W (528 x 64) . x^T (64 x 16 atoms) per 16-atom tile, bf16x3 chains
+// (fp32 accumulate) like the edge kernels', the whole weight image (135 KB) resident in LDS.  Replaces the vector-ALU k_node_pre, which
 // re-read 128 KB of weights from L2 for every 16 atoms.  x^b = x^(b-1) + the per-centre message sums of block b-1 is
 // formed while the tile is loaded (x_prev != nullptr) and written back for the later stages.
 constexpr int kNodeXPitch = 68;   // floats per staged x row: 64 + 4 keeps 16-byte alignment and spreads the 16 rows over the banks
@@ -918,19 +918,18 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
     }
     static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
     // (only this wave reads xs: LDS operations of a wave complete in order)
-    float b[16];
-    static_for<16>([&]<int s>() { b[s] = xs[m * kNodeXPitch + 4 * s + q]; });
+    // x as accumulator-layout blocks: lane (m, q) holds features blk*16 + 4q + {0..3} of atom m
+    f32x4 xb[4];
+    static_for<4>([&]<int blk>() { xb[blk] = *(const f32x4*)(xs + m * kNodeXPitch + blk * 16 + 4 * q); });
     int lv = lane;
     asm volatile("" : "+v"(lv));   // keep the image reads inside the tile loop
-    static_for<kNodeRowBlocks / 3>([&]<int g>() {   // three independent accumulator chains in flight
-      f32x4 acc[3];
-      static_for<3>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (3 * g + j) * 16 + 4 * q); });
-      static_for<16>([&]<int s>() {
-        static_for<3>([&]<int j>() { acc[j] = mfma16(lds[((3 * g + j) * 16 + s) * 64 + lv], b[s], acc[j]); });
-      });
+    static_for<3>([&]<int g>() {   // 11 row blocks per pass: bf16x3 chains like the edge kernels' (fp32 accumulate)
+      f32x4 acc[11];
+      static_for<11>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (11 * g + j) * 16 + 4 * q); });
+      chain<11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv);
       if (live) {
-        static_for<3>([&]<int j>() {
-          constexpr int ob = 3 * g + j;
+        static_for<11>([&]<int j>() {
+          constexpr int ob = 11 * g + j;
           if (ob < 16) *(f32x4*)(TA + atom * (4 * kDP) + ob * 16 + 4 * q) = acc[j];
           else if (ob < 32) *(f32x4*)(TB + atom * (4 * kDP) + (ob - 16) * 16 + 4 * q) = acc[j];
           else {

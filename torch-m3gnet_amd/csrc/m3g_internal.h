@@ -137,8 +137,9 @@ struct MfmaRevFusedLayout {
   int adjp;  // [64][4] plain copy of W_adj for the dL/dh accumulation
   int total;
 };
-// k_node_pre_mfma image: direct fp32 image of the 528 x 64 matrix [W1a (TA columns 0-255) | W1b (TB columns) | W_sigmoid1
-// (v, 16 rows)] -- 33 row blocks x 16 k-steps x 64 lanes -- followed by the 528 row biases (b1 for TA, 0 for TB, b_sigmoid1)
+// k_node_pre_mfma image: the 528 x 64 matrix [W1a (TA columns 0-255) | W1b (TB columns) | W_sigmoid1 (v, 16 rows)] as three
+// bf16x3 chain images of 11 row blocks (hi + lo parts, the size of an fp32 image), followed by the 528 row biases (b1 for
+// TA, 0 for TB, b_sigmoid1)
 constexpr int kNodeRowBlocks = 33;
 constexpr int kNodeImgFloats = kNodeRowBlocks * 16 * 64 + kNodeRowBlocks * 16;
 MfmaFwdLayout mfma_fwd_layout();

@@ -170,7 +170,9 @@ int pack_mfma_images(m3g_plan* plan) {
         const int cidx = row - 512;
         return cidx < C ? ws[(size_t)cidx * D + k] : 0.f;
       };
-      direct_image(ni, kNodeRowBlocks, 16, row_w);
+      // three bf16x3 chain images of 11 row blocks each (the kernel keeps 11 accumulator blocks per pass)
+      for (int g = 0; g < 3; ++g)
+        chain_image(ni + (size_t)g * 11 * 2 * 512, 11, 2, [&](int row, int k) -> float { return row_w(g * 176 + row, k); });
       float* bias = ni + kNodeRowBlocks * 16 * 64;
       for (int row = 0; row < kNodeRowBlocks * 16; ++row) {
         float v = 0.f;
