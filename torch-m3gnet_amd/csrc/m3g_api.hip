@@ -287,6 +287,7 @@ extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (plan->d_mfma_rev) (void)hipFree(plan->d_mfma_rev);
   if (plan->d_mfma_revf) (void)hipFree(plan->d_mfma_revf);
   if (plan->d_node_img) (void)hipFree(plan->d_node_img);
+  if (plan->d_readout_img) (void)hipFree(plan->d_readout_img);
   if (plan->d_stamps) (void)hipFree(plan->d_stamps);
   drop_graphs(plan);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
@@ -584,8 +585,11 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     }
   }
   const bool want_f = io->forces != nullptr;
-  { M3G_STAGE(ST_READOUT); launch_readout(c, W, wl, t, io->atom_types, (mfma && c.B > 0) ? w.x[c.B - 1] : nullptr, w.x[c.B], w, ea, st,
-                                          io->total_energy, want_f, s); }
+  {
+    M3G_STAGE(ST_READOUT);
+    if (mfma) launch_readout_mfma(plan, c, wl, t, io->atom_types, c.B > 0 ? w.x[c.B - 1] : nullptr, w.x[c.B], w, ea, st, io->total_energy, want_f, s);
+    else launch_readout(c, W, wl, t, io->atom_types, nullptr, w.x[c.B], w, ea, st, io->total_energy, want_f, s);
+  }
   StageTimer* st_out = new StageTimer(plan, ST_OUTPUTS, s);
 
   if (io->node_features) launch_copy_strided(w.x[c.B], kDP, io->node_features, c.D, c.D, N, s);

@@ -142,6 +142,21 @@ struct MfmaRevFusedLayout {
 // TA, 0 for TB, b_sigmoid1)
 constexpr int kNodeRowBlocks = 33;
 constexpr int kNodeImgFloats = kNodeRowBlocks * 16 * 64 + kNodeRowBlocks * 16;
+// k_readout_mfma image (floats): exact-fp32 chain images (f32_chain_image) of the readout GatedMLP (nn/readout.py:39-58)
+// and its transposes, then the small vectors
+struct ReadoutImg {
+  static constexpr int w1 = 0;                 // [8 ob][16 k-steps]  rows: dense 0-63 | gate 64-127 first-layer outputs, k: x
+  static constexpr int w2d = w1 + 8 * 2 * 512;   // chain [4][2]
+  static constexpr int w2g = w2d + 4 * 2 * 512;
+  static constexpr int w2dT = w2g + 4 * 2 * 512; // chain [4][2]  rows: hidden input k, cols: second-layer output
+  static constexpr int w2gT = w2dT + 4 * 2 * 512;
+  static constexpr int w1T = w2gT + 4 * 2 * 512; // chain [4][4]  rows: x feature, k: dense 0-63 | gate 64-127
+  static constexpr int b1 = w1T + 4 * 4 * 512;   // [128]
+  static constexpr int b2 = b1 + 128;            // [128] dense | gate
+  static constexpr int w3 = b2 + 128;            // [128] dense | gate final weights
+  static constexpr int b3 = w3 + 128;            // [2] (+2 pad)
+  static constexpr int total = b3 + 4;
+};
 MfmaFwdLayout mfma_fwd_layout();
 MfmaRevLayout mfma_rev_layout();
 MfmaRevFusedLayout mfma_rev_fused_layout();
@@ -159,6 +174,7 @@ struct m3g_plan {
   float* d_mfma_rev = nullptr;   // [num_blocks][MfmaRevLayout.total]
   float* d_mfma_revf = nullptr;  // [num_blocks][MfmaRevFusedLayout.total]
   float* d_node_img = nullptr;   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
+  float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as bf16x3 chain images (k_readout_mfma)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
@@ -312,6 +328,10 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
                      float* v, float* TA, float* TB, hipStream_t s);
 void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
                           float* v, float* TA, float* TB, hipStream_t s);
+void launch_energy_sums(const Consts& c, const Topo& t, const float* scaled_atomic, float* scaled_total, float* total, hipStream_t s);
+void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayout& wl, const Topo& t, const int64_t* types,
+                         const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
+                         bool want_grad, hipStream_t s);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
                          const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool with_v_term, hipStream_t s);
 void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,

@@ -467,6 +467,12 @@ void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& b
                        dx_out, reinterpret_cast<const int2*>(t.in_pair));
 }
 
+// per-structure sums of the scaled atomic energies (atomics into the cleared scaled_total) and total = energy_scale * sum
+void launch_energy_sums(const Consts& c, const Topo& t, const float* scaled_atomic, float* scaled_total, float* total, hipStream_t s) {
+  if (t.N > 0) hipLaunchKernelGGL(k_energy_sum, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, scaled_atomic, scaled_total);
+  if (t.S > 0) hipLaunchKernelGGL(k_scale, grid_for(t.S), dim3(256), 0, s, t.S, c.energy_scale, scaled_total, total);
+}
+
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
                     const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                     bool want_grad, hipStream_t s) {
@@ -475,9 +481,8 @@ void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, con
   if (t.N > 0) {
     hipLaunchKernelGGL(k_readout, grid_for(t.N, 4 * kRA), dim3(256), 0, s, c, t.N, W, wl.ro, wl.elemental, types, x, ns, scaled_atomic,
                        want_grad ? w.dx : nullptr, scaled_total, t.S);
-    hipLaunchKernelGGL(k_energy_sum, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, scaled_atomic, scaled_total);
   }
-  if (t.S > 0) hipLaunchKernelGGL(k_scale, grid_for(t.S), dim3(256), 0, s, t.S, c.energy_scale, scaled_total, total);
+  launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
 }
 
 void launch_gather_rows(const float* table, int64_t n, int width, int table_stride, int table_rows, bool transposed,
