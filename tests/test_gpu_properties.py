@@ -230,6 +230,27 @@ def test_empty_and_ragged_inputs():
     assert float(model(Batch.from_data_list([lone]).to(DEV))[K.FORCES].abs().max()) == 0.0
 
 
+def test_dense_three_body_rows_beyond_the_staged_window():
+    """~100 three-body partners per centre: the rows a three-body workgroup stages in LDS (kTbCap) and its byte-sized
+    partner lists (32 per row) both overflow, so partners are fetched through the global-memory path of
+    csrc/m3g_threebody.hip.  Same tolerances as every other parity case."""
+    from torch_m3gnet.data.material_graph import Batch
+    from oracle import m3gnet_oracle as orc
+
+    K = _K()
+    model = _default_model(seed=2, threebody_cutoff=5.0)
+    dense = random_cell_graph(24, 5.0, 5, cutoff=5.0, tb_cutoff=5.0, dmin=1.2)
+    per_centre = dense[K.NUM_TRIPLETS] / 24
+    assert per_centre > 80 * 79, per_centre
+    for graphs in ([dense], [random_cell_graph(6, 5.5, 1), dense]):
+        g = model(Batch.from_data_list([x.clone() for x in graphs]).to(DEV))
+        p, cfg, c, og = _oracle_inputs(model, g)
+        o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+        assert rel_err(g[K.TOTAL_ENERGY], o["total_energy"]) < 1e-5
+        assert rel_err(g[K.FORCES], o["forces"]) < 1e-4
+        assert rel_err(g[K.STRESSES], o["stresses"]) < 1e-4
+
+
 def test_scales_and_elemental_energies():
     from torch_m3gnet.data.material_graph import Batch
     from oracle import m3gnet_oracle as orc
