@@ -256,7 +256,7 @@ def main():
                             "`achieved` uses the ideal-fusion algorithmic bytes of DESIGN.md section 4, `traffic` is PMC-measured "
                             "HBM bytes per launch, `mfma_view` prices the same launch against the matrix peaks")
         out = {
-            "metric": "atom-steps/sec (energy+forces) on 10k-atom PBC batch", "value": value, "unit": "atom-steps/s",
+            "metric": "atom-steps/sec (energy+forces) on 10k-atom PBC batch, 1/2/4/8 MI355X", "value": value, "unit": "atom-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (dense chains: 3x bf16 split MFMA, fp32 accumulate)", "data": "synthetic",
