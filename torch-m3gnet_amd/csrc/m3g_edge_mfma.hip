@@ -147,6 +147,32 @@ __device__ __forceinline__ SegMasks seg_masks(int ci, int lane) {
   k.first_run = ci == __builtin_amdgcn_readlane(ci, 0);
   return k;
 }
+// One scan step for the 16 values of four accumulator blocks as v_fmac_f32 with a DPP source operand: x += dpp(x) * m in
+// one instruction per value.  The compiler never forms that instruction (it SLP-packs the FMAs into v_pk_fma_f32 behind
+// two v_mov_b32_dpp, 1.5 instructions per value and step).  The 16 independent values keep consecutive steps of one
+// value >= 16 instructions apart, so the only DPP read-after-VALU-write hazard (2 wait states) is at the head of a step,
+// against whatever the compiler scheduled before the statement: the leading s_nop covers it (the hazard recogniser
+// does not look inside inline assembly).
+#define M3G_SCAN_LINE(i, SHR) "v_fmac_f32_dpp %" #i ", %" #i ", %16 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define M3G_SCAN_STEP16(SHR, m)                                                                                            \
+  asm volatile("s_nop 1\n\t" M3G_SCAN_LINE(0, SHR) M3G_SCAN_LINE(1, SHR) M3G_SCAN_LINE(2, SHR) M3G_SCAN_LINE(3, SHR)         \
+                   M3G_SCAN_LINE(4, SHR) M3G_SCAN_LINE(5, SHR) M3G_SCAN_LINE(6, SHR) M3G_SCAN_LINE(7, SHR)                    \
+                       M3G_SCAN_LINE(8, SHR) M3G_SCAN_LINE(9, SHR) M3G_SCAN_LINE(10, SHR) M3G_SCAN_LINE(11, SHR)              \
+                           M3G_SCAN_LINE(12, SHR) M3G_SCAN_LINE(13, SHR) M3G_SCAN_LINE(14, SHR) M3G_SCAN_LINE(15, SHR)        \
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),  \
+                 "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])                     \
+               : "v"(m))
+#ifndef M3G_NO_ASM_SCAN
+__device__ __forceinline__ void seg_scan(f32x4 (&v)[4], const SegMasks& k) {
+  float x[16];
+  static_for<16>([&]<int i>() { x[i] = v[i >> 2][i & 3]; });
+  M3G_SCAN_STEP16(1, k.m1);
+  M3G_SCAN_STEP16(2, k.m2);
+  M3G_SCAN_STEP16(4, k.m4);
+  M3G_SCAN_STEP16(8, k.m8);
+  static_for<16>([&]<int i>() { v[i >> 2][i & 3] = x[i]; });
+}
+#endif
 template <int N>
 __device__ __forceinline__ void seg_scan(f32x4 (&v)[N], const SegMasks& k) {
   static_for<N>([&]<int b>() {
@@ -318,14 +344,24 @@ __global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdL
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
     const int64_t ci = ci_i, cj = cj_i;
+    // Per-lane address parts computed from `lane` are loop-invariant 64-bit VGPR pairs that the compiler hoists and, at
+    // 128 registers, spills: a scratch reload plus s_waitcnt vmcnt(0) in front of each load below.  Taken from the
+    // opaque `lv` they are recomputed per tile (two VALU instructions).  The edge-feature tile pointers of blocks > 0
+    // stay on `lane`: recomputing those costs more spills (of live tile data) than it saves.
+    const int qv = lv >> 4;
+    const int tl_out = FIRST ? lv : lane;
     const float* e_tile = a.e_in + tile * kTileFloats + lane * 4;
-    float* e_otile = a.e_out + tile * kTileFloats + lane * 4;
+    float* e_otile = a.e_out + tile * kTileFloats + tl_out * 4;
     f32x4 x[4];
     if (!FIRST) static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
     float mb[TBS];
     const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
-    static_for<TBS>([&]<int s>() { mb[s] = arow >= 0 ? a.m[(int64_t)arow * kCP + 4 * s + qd] : 0.f; });
-    const float hb = a.h[ec * kRP + qd];
+    static_for<TBS>([&]<int s>() { mb[s] = 0.f; });
+    if (arow >= 0) {                 // one masked region: the TBS loads issue back to back
+      const float* mrow = a.m + (int64_t)arow * kCP + qv;
+      static_for<TBS>([&]<int s>() { mb[s] = mrow[4 * s]; });
+    }
+    const float hb = a.h[ec * kRP + qv];
     if (FIRST) {
       static_for<4>([&]<int blk>() {
         x[blk] = mfma16(lds[L.adj + blk * 64 + lv], hb, f32x4{0.f, 0.f, 0.f, 0.f});
