@@ -53,7 +53,7 @@ EDGE_KERNELS = {
     "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", alg_bytes_per_edge=4 * 256, alg_flops_per_edge=68_224,
                               bf16_mfma_per_tile=204, f32_mfma_per_tile=56),
 }
-PMC_TRAFFIC_FILE = "r01b_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE of this build (tools/pmc_traffic.py)
+PMC_TRAFFIC_FILE = "r01c_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE of this build (tools/pmc_traffic.py)
 
 
 def log(msg):

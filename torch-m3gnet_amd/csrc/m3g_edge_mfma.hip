@@ -34,7 +34,10 @@ namespace m3g {
 constexpr int kFwdLdsFloats = 8 * kTbSteps * 64 + 2 * (8 * 4 * 4 * 64 + 2 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 64) + 4 * 64;
 constexpr int kRevMlpFloats = 8 * 4 * 4 * 64 + 4 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 8 * 4 * 64 + 64 * 4;   // node-MLP reverse image
 constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;                // + three-body images
-constexpr int kWaves = 16;      // forward kernel: 16 waves = 4 per SIMD (<= 128 VGPRs)
+#ifndef M3G_WAVES_FWD
+#define M3G_WAVES_FWD 16        // forward kernel: 16 waves = 4 per SIMD (<= 128 VGPRs)
+#endif
+constexpr int kWaves = M3G_WAVES_FWD;
 #ifndef M3G_WAVES_REV_FUSED
 #define M3G_WAVES_REV_FUSED 8   // 2 waves per SIMD, 256 VGPRs, no spills (12 waves: 168 VGPRs and ~120 spilled, slower)
 #endif
@@ -314,7 +317,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
 // FIRST: block 0 forms its input e0 = SiLU(W_adj h) (nn/featurizer.py:128-132) from the radial basis instead of reading
 // an embedded-edge image that a separate kernel would have to write (256 B/edge) first
 template <int TBS, bool ST = false, bool FIRST = false>
-__global__ void __launch_bounds__(1024, 4) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
+__global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kFwdLdsFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kFwdLdsFloats);
   load_image(lds, a.img, kFwdLdsFloats, q_head);
