@@ -707,8 +707,14 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
     chain_dual_t<4, 2, 64, 4 * half, 0>(lds + (half == 0 ? L.w2d : L.w2g), d2, dp1, lane);
     static_for<4>([&]<int ob>() { dp1[ob] *= p1[4 * half + ob]; });
     if (NEED_DP1 && edge < a.E) {
+#ifndef M3G_DP1_F32
+      // 24-bit rows (pack24): group index = column / 4 = mlp*32 + half*16 + ob*4 + qd
+      unsigned* row = reinterpret_cast<unsigned*>(a.dp1) + edge * kDp1PackedDwords + 3 * (mlp * 32 + half * 16 + qd);
+      static_for<4>([&]<int ob>() { *(u32x3_a4*)(row + 12 * ob) = pack24(dp1[ob]); });
+#else
       float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + half * kDP + 4 * qd;
       static_for<4>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
+#endif
     }
     chain_dual_t<4, 2, 128, 0, 0, 4 * half>(lds + L.w1c, dp1, contrib, lane);   // rows half*64 .. +63 of W1c
     if (NEED_DP1) {

@@ -8,6 +8,7 @@
 namespace m3g {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kDp1Groups = 64;   // a dp1 row is 256 columns = 64 groups of 4 (one accumulator register quad each)
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -54,6 +55,29 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
     lo[4 + j] = (__bf16)(b[j] - (float)hi[4 + j]);
   });
 }
+
+// ---- 24-bit rows for the dp1 hand-over (fused reverse -> node reverse) -------------------------------------------
+// The x_j half of the node reverse gathers one dp1 row per incoming edge, the largest stream of the reverse pass.  The
+// rows are stored with 16 significand bits (sign, exponent and the top 15 mantissa bits, rounded: relative error
+// <= 2^-17, far below the bf16x3 chains' own error) as 3 bytes per value: 4 values -> 3 dwords, 768 B per row instead of
+// 1 KB.  The per-centre sums of the same rows (x_i half) are formed in registers from the unrounded values.
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));   // in memory a group starts at any dword
+__device__ __forceinline__ u32x3 pack24(const f32x4& v) {
+  // (elements copied to scalars first: __builtin_bit_cast of a vector-element lvalue reads element 0)
+  const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+  const unsigned a = __builtin_bit_cast(unsigned, v0) + 0x80u, b = __builtin_bit_cast(unsigned, v1) + 0x80u,
+                 c = __builtin_bit_cast(unsigned, v2) + 0x80u, d = __builtin_bit_cast(unsigned, v3) + 0x80u;
+  // v_perm_b32: selector bytes 0-3 take bytes of the second operand, 4-7 of the first
+  return u32x3{__builtin_amdgcn_perm(b, a, 0x05030201u), __builtin_amdgcn_perm(c, b, 0x06050302u),
+               __builtin_amdgcn_perm(d, c, 0x07060503u)};
+}
+__device__ __forceinline__ f32x4 unpack24(const u32x3& w) {
+  return f32x4{__builtin_bit_cast(float, w[0] << 8), __builtin_bit_cast(float, __builtin_amdgcn_perm(w[1], w[0], 0x0504030cu)),
+               __builtin_bit_cast(float, __builtin_amdgcn_perm(w[2], w[1], 0x0403020cu)),
+               __builtin_bit_cast(float, w[2] & 0xffffff00u)};
+}
+constexpr int kDp1PackedDwords = 3 * kDp1Groups;   // dwords per packed row
 
 template <int N>
 __device__ __forceinline__ void zero(f32x4 (&v)[N]) {

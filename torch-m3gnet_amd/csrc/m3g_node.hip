@@ -5,6 +5,7 @@
 // GatedMLP first layers nn/conv.py:91-97 + nn/core.py:61-62, AtomWiseReadout nn/readout.py:39-58.
 #include "m3g_internal.h"
 #include "m3g_device.h"
+#include "m3g_mfma_common.h"
 
 namespace m3g {
 
@@ -189,6 +190,22 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
         float g[kNrBatch];
 #pragma unroll
         for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_pair[k + j] : make_int2(-1, -1);
+#ifndef M3G_DP1_F32
+        if (seg_head) {   // rows written by the fused reverse kernel: 24-bit values, 12 B per lane (m3g_mfma_common.h: pack24)
+          u32x3 pk[kNrBatch];
+#pragma unroll
+          for (int j = 0; j < kNrBatch; ++j)
+            pk[j] = f[j].x >= 0 ? *reinterpret_cast<const u32x3_a4*>(reinterpret_cast<const unsigned*>(dp1) +
+                                                                   (int64_t)f[j].x * kDp1PackedDwords + 3 * ln)
+                                : u32x3{0u, 0u, 0u};
+#pragma unroll
+          for (int j = 0; j < kNrBatch; ++j) {
+            const f32x4 t = unpack24(pk[j]);
+            u[j] = make_float4(t[0], t[1], t[2], t[3]);
+            g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
+          }
+        } else
+#endif
 #pragma unroll
         for (int j = 0; j < kNrBatch; ++j) {
           u[j] = f[j].x >= 0 ? rows[(int64_t)f[j].x * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
