@@ -113,6 +113,10 @@ struct TileQueue {
   }
 };
 
+// streamed-once tile loads: nontemporal, so they do not evict the node tables the gathers re-use from L2
+// (forward 0.425 -> 0.418 ms, fused reverse 0.892 -> 0.884 per step)
+__device__ __forceinline__ f32x4 load_tile4(const float* p) { return __builtin_nontemporal_load((const f32x4*)p); }
+
 // centre / neighbour atom of this lane's edge in `tile` (clamped for the padding lanes of the last tile)
 __device__ __forceinline__ void load_ends(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t tile, int64_t E,
                                           int lane, int& ci, int& cj) {
@@ -356,7 +360,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
     const float* e_tile = a.e_in + tile * kTileFloats + lane * 4;
     float* e_otile = a.e_out + tile * kTileFloats + tl_out * 4;
     f32x4 x[4];
-    if (!FIRST) static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+    if (!FIRST) static_for<4>([&]<int blk>() { x[blk] = load_tile4(e_tile + blk * 256); });
     float mb[TBS];
     const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
     static_for<TBS>([&]<int s>() { mb[s] = 0.f; });
@@ -770,7 +774,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       // MLP), so nothing of the edge-MLP side has to stay in registers across it.
       f32x4 x2[4];
       const float* e2_tile = a.e2_tile + tile * kTileFloats + lane * 4;
-      static_for<4>([&]<int blk>() { x2[blk] = *(const f32x4*)(e2_tile + blk * 256); });
+      static_for<4>([&]<int blk>() { x2[blk] = load_tile4(e2_tile + blk * 256); });
       // d msg[e] = dx_new[centre(e)]
       f32x4 dmsg[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
@@ -781,7 +785,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     if (a.de_is_zero) {
       static_for<4>([&]<int blk>() { de[blk] = contrib[blk]; });
     } else {
-      static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + contrib[blk]; });
+      static_for<4>([&]<int blk>() { de[blk] = load_tile4(de_tile + blk * 256) + contrib[blk]; });
     }
     // the opaque copy also pins the order: without it the scheduler hoists the e1 computation above the node phase
     asm volatile("" : "+v"(lv));
@@ -793,7 +797,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
         static_for<4>([&]<int r>() { x[blk][r] = fsilu(x[blk][r]); });
       });
     } else {
-      static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+      static_for<4>([&]<int blk>() { x[blk] = load_tile4(e_tile + blk * 256); });
     }
     {  // e1 = e_in + three-body gated update (the edge MLP's input)
       f32x4 p[8];
