@@ -195,8 +195,10 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
           u32x3 pk[kNrBatch];
 #pragma unroll
           for (int j = 0; j < kNrBatch; ++j)
-            pk[j] = f[j].x >= 0 ? *reinterpret_cast<const u32x3_a4*>(reinterpret_cast<const unsigned*>(dp1) +
-                                                                   (int64_t)f[j].x * kDp1PackedDwords + 3 * ln)
+            // nontemporal: every row is read exactly once, and keeping it out of L2 leaves the cache to the weights and
+            // partial rows (node reverse 0.218 -> 0.187 ms per step)
+            pk[j] = f[j].x >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(reinterpret_cast<const unsigned*>(dp1) +
+                                                                   (int64_t)f[j].x * kDp1PackedDwords + 3 * ln))
                                 : u32x3{0u, 0u, 0u};
 #pragma unroll
           for (int j = 0; j < kNrBatch; ++j) {
