@@ -196,6 +196,46 @@ __global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_
   }
 }
 
+// Adds one 6-vector per atom into stresses[structure]: summed inside the wave, then across the workgroup's four waves in LDS,
+// so a workgroup whose atoms share one structure issues 6 float atomics instead of 24 (10k atoms of one structure: every
+// atomic of the launch hits the same cache line and they serialise -- 14 us with one set per wave).  Waves or workgroups
+// spanning several structures fall back to finer-grained atomics.  Must be reached by all 256 threads.
+__device__ __forceinline__ void stress_accumulate(const float (&val)[6], int s, bool live, float* __restrict__ stresses) {
+  __shared__ float part[4][6];
+  __shared__ int part_s[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s0 = __shfl(s, 0);
+  const bool uniform = __all(s == s0 || !live) && s0 >= 0;
+  float red[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float v = val[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    red[k] = v;
+  }
+  if (lane == 0) {
+    part_s[wave] = uniform ? s0 : -2;   // -2: this wave handles its own atomics
+#pragma unroll
+    for (int k = 0; k < 6; ++k) part[wave][k] = red[k];
+  }
+  __syncthreads();
+  // wave w joins the group led by wave 0 when both are uniform in the same structure; others add on their own
+  const int lead = part_s[0];
+  const bool joined = uniform && lead == s0;
+  if (wave == 0 && uniform) {
+    if (lane < 6) {
+      float v = part[0][lane];
+      for (int w = 1; w < 4; ++w) v += part_s[w] == lead ? part[w][lane] : 0.f;
+      atomicAdd(&stresses[(int64_t)s0 * 6 + lane], v);
+    }
+  } else if (uniform && !joined) {
+    if (lane < 6) atomicAdd(&stresses[(int64_t)s0 * 6 + lane], part[wave][lane]);
+  } else if (!uniform && live) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) atomicAdd(&stresses[(int64_t)s * 6 + k], val[k]);
+  }
+}
+
 // virial: sum_a pos_a (x) F_a / V in Voigt order xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62)
 __global__ void __launch_bounds__(256) k_stress(int64_t N, const int32_t* __restrict__ batch, const float* __restrict__ pos,
                                                 const float* __restrict__ lattice, const float* __restrict__ forces,
@@ -213,19 +253,7 @@ __global__ void __launch_bounds__(256) k_stress(int64_t N, const int32_t* __rest
     val[0] = px * fx * inv; val[1] = py * fy * inv; val[2] = pz * fz * inv;
     val[3] = py * fz * inv; val[4] = pz * fx * inv; val[5] = px * fy * inv;
   }
-  int s0 = __shfl(s, 0);
-  bool uniform = __all(s == s0 || !live);
-  if (uniform && s0 >= 0) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      float v = val[k];
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&stresses[(int64_t)s0 * 6 + k], v);
-    }
-  } else if (live) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) atomicAdd(&stresses[(int64_t)s * 6 + k], val[k]);
-  }
+  stress_accumulate(val, s, live, stresses);
 }
 
 // PBC-consistent virial (docs/gradient.md:47-84): with every pair vector r_e = d_e u_e
@@ -255,19 +283,7 @@ __global__ void __launch_bounds__(256) k_stress_pair(int64_t N, const int32_t* _
 #pragma unroll
     for (int k = 0; k < 6; ++k) val[k] *= inv;
   }
-  int s0 = __shfl(s, 0);
-  bool uniform = __all(s == s0 || !live);
-  if (uniform && s0 >= 0) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      float v = val[k];
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&stresses[(int64_t)s0 * 6 + k], v);
-    }
-  } else if (live) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) atomicAdd(&stresses[(int64_t)s * 6 + k], val[k]);
-  }
+  stress_accumulate(val, s, live, stresses);
 }
 
 __global__ void __launch_bounds__(256) k_triplet_angles(int64_t T, const int64_t* __restrict__ tei, const float* __restrict__ u,
