@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
 #endif
 constexpr int kNodesRev = M3G_NODES_REV;
 #ifndef M3G_NR_BATCH
-#define M3G_NR_BATCH 8
+#define M3G_NR_BATCH 4   // with 768-byte nontemporal rows: 4 -> 0.181, 8 -> 0.188, 12 -> 0.198, 16 -> 0.194 ms per step
 #endif
 constexpr int kNrBatch = M3G_NR_BATCH;   // rows in flight per wave in the dp1 gather (multiple of 4)
 __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const float* __restrict__ W, BlockW bw,
