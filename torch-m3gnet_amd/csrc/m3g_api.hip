@@ -561,7 +561,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   {
     M3G_STAGE(ST_EMBED);
     if (mfma) {
-      launch_embed_nodes_only(c, W, wl, t, io->atom_types, w, s);
+      if (c.B == 0) launch_embed_nodes_only(c, W, wl, t, io->atom_types, w, s);   // otherwise block 0's node kernel forms x^0
       if (!fused_rev || c.B == 0) launch_embed_edges_soa(c, W + wl.adj_t, w.h, w.e_blk[0], E, s);   // fused path: block 0 forms e0 in its kernels
     } else {
       launch_embed(c, W, wl, t, io->atom_types, w, s);
@@ -571,7 +571,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     {
       M3G_STAGE(ST_NODE_PRE);
       // MFMA path: block b > 0 forms x^b = x^(b-1) + per-centre message sums of block b-1 while loading it
-      if (mfma) launch_node_pre_mfma(plan, c, t, w, b, b > 0 ? w.x[b - 1] : nullptr, w.x[b], w.v[b], w.TAb[b], w.TBb[b], s);
+      if (mfma) launch_node_pre_mfma(plan, c, t, w, b, b > 0 ? w.x[b - 1] : nullptr, w.x[b], w.v[b], w.TAb[b], w.TBb[b],
+                                     b == 0 ? io->atom_types : nullptr, W + wl.emb, s);
       else launch_node_pre(c, W, wl.blk[b], t, w, nullptr, w.x[b], w.v[b], w.TA, w.TB, s);
     }
     { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }

@@ -924,7 +924,8 @@ constexpr int kNodeXPitch = 68;   // floats per staged x row: 64 + 4 keeps 16-by
 __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
                                                        const float* __restrict__ seg_head, const float* __restrict__ seg_first,
                                                        const int32_t* __restrict__ row_ptr, float* __restrict__ x,
-                                                       float* __restrict__ v, float* __restrict__ TA, float* __restrict__ TB) {
+                                                       float* __restrict__ v, float* __restrict__ TA, float* __restrict__ TB,
+                                                       const int64_t* __restrict__ types, const float* __restrict__ emb, int num_types) {
   __shared__ __attribute__((aligned(16))) float lds[kNodeImgFloats + 4 * 16 * kNodeXPitch];
   {  // image -> LDS, 16 independent 16-byte loads in flight per thread (a load-store-load chain would pay one L2 round trip
      // per 4 KB of the 137 KB image)
@@ -954,7 +955,13 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
     static_for<4>([&]<int j>() { xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; });
     if (live) {
       const float* src = (x_prev ? x_prev : x) + atom * kDP + 16 * q;
+      if (types) {   // block 0: x^0 = atom embedding row (nn/featurizer.py:99-103), formed and stored here
+        int64_t ty = types[atom];
+        ty = ty < 0 ? 0 : (ty >= num_types ? num_types - 1 : ty);
+        src = emb + ty * kDP + 16 * q;
+      }
       static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
+      if (types) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
       if (x_prev) {
         const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
         if (r1 > r0) {
@@ -1184,13 +1191,14 @@ void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayo
   launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
 }
 
+// types != nullptr (block 0): x is formed from the atom embedding `emb` ([num_types][kDP]) instead of being read
 void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
-                          float* v, float* TA, float* TB, hipStream_t s) {
+                          float* v, float* TA, float* TB, const int64_t* types, const float* emb, hipStream_t s) {
   if (t.N == 0) return;
   const int64_t tiles = (t.N + 15) / 16;
   int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
   hipLaunchKernelGGL(k_node_pre_mfma, dim3(wgs), dim3(256), 0, s, c.C, t.N, plan->d_node_img + (size_t)b * kNodeImgFloats, x_prev,
-                     w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB);
+                     w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB, types, emb, c.num_types);
 }
 
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
