@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (run on the GPU box): random small batches x random model shapes (l_max, n_max, blocks,
+cutoffs, scales) against the CPU oracle, with the tolerances of the test-suite (1e-5 energies, 1e-4 forces / stress)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
+    sys.path.insert(0, str(p))
+from helpers import random_cell_graph, rel_err  # noqa: E402
+from oracle import m3gnet_oracle as orc  # noqa: E402
+from test_gpu_properties import _oracle_inputs  # noqa: E402
+from torch_m3gnet.data import MaterialGraphKey as K  # noqa: E402
+from torch_m3gnet.data.material_graph import Batch  # noqa: E402
+from torch_m3gnet.model.build import build_model  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(2024)
+worst = {"E": 0.0, "F": 0.0, "S": 0.0}
+fails = 0
+for case in range(n_cases):
+    l_max, n_max = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    if l_max * n_max > 16:
+        n_max = 16 // l_max
+    blocks = int(rng.integers(1, 5))
+    cutoff = float(rng.uniform(3.5, 6.0))
+    tb = float(rng.uniform(2.5, cutoff))
+    torch.manual_seed(case)
+    model = build_model(cutoff=cutoff, threebody_cutoff=tb, l_max=l_max, n_max=n_max, num_types=95, embedding_dim=64,
+                        num_blocks=blocks, energy_scale=float(rng.uniform(0.5, 3.0)), length_scale=float(rng.uniform(0.8, 1.5)))
+    for m in model.model:
+        if type(m).__name__ == "ThreeBodyInteration":
+            m.nsb.factors = m.nsb.documented_factors()
+    graphs = []
+    for s in range(int(rng.integers(1, 5))):
+        box = float(rng.uniform(4.5, 9.0))
+        n = int(rng.integers(1, max(2, min(40, int(box**3 / 14.0)))))   # keeps the random packing with dmin feasible
+        graphs.append(random_cell_graph(n, box, seed=1000 * case + s, cutoff=cutoff, tb_cutoff=tb, dmin=1.4))
+    g = model(Batch.from_data_list(graphs).to("cuda"))
+    p, cfg, c, og = _oracle_inputs(model, g)
+    o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+    e_err = float(((g[K.TOTAL_ENERGY].cpu() - o["total_energy"]).abs() / o["total_energy"].abs().clamp_min(1e-6)).max())
+    fmax = float(o["forces"].abs().max())
+    f_err = float((g[K.FORCES].cpu() - o["forces"]).abs().max()) / max(fmax, 1e-9)
+    s_err = rel_err(g[K.STRESSES], o["stresses"]) if float(o["stresses"].abs().max()) > 0 else 0.0
+    ok = e_err < 1e-5 and f_err < 1e-4 and s_err < 1e-4
+    fails += 0 if ok else 1
+    worst = {"E": max(worst["E"], e_err), "F": max(worst["F"], f_err), "S": max(worst["S"], s_err)}
+    print(f"case {case:3d} L={l_max} R={n_max} B={blocks} rc={cutoff:.2f} r3={tb:.2f} atoms={g[K.NUM_NODES]} E={g[K.NUM_EDGES]} "
+          f"T={g[K.NUM_TRIPLETS]}: E {e_err:.1e} F {f_err:.1e} S {s_err:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+print("worst", worst, "failures", fails)
