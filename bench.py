@@ -254,9 +254,9 @@ def main():
                             "activation in one fused kernel per block: the kernel is instruction-issue/latency-bound (PMC: VALU "
                             "~59 %, MFMA ~31 % of SIMD cycles at 2 waves/SIMD), below both the HBM and the matrix roofline; "
                             "`achieved` uses the ideal-fusion algorithmic bytes of DESIGN.md section 4, `traffic` is PMC-measured "
-                            "HBM bytes per launch, `mfma_view` prices the same launch against the matrix peaks; the box's practical "
-                            "HBM rates with plain torch kernels are 4.0 TB/s read-only, 4.8 TB/s copy, 6.9 TB/s fill "
-                            "(tools/hbm_bw_probe.py), so the measured traffic rate is ~60 % of what a pure copy reaches")
+                            "HBM bytes per launch, `mfma_view` prices the same launch against the matrix peaks; hand-written streaming "
+                            "kernels on this box reach 5.9-6.5 TB/s read-only and 4.8 TB/s copy (tools/hbm_bw_probe.hip), so the "
+                            "measured read+write traffic rate is ~55 % of what a pure copy reaches")
         out = {
             "metric": "atom-steps/sec (energy+forces) on 10k-atom PBC batch, 1/2/4/8 MI355X", "value": value, "unit": "atom-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
