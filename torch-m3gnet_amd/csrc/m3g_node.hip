@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
 #endif
 constexpr int kNodesRev = M3G_NODES_REV;
 #ifndef M3G_NR_BATCH
-#define M3G_NR_BATCH 4   // with 768-byte nontemporal rows: 4 -> 0.181, 8 -> 0.188, 12 -> 0.198, 16 -> 0.194 ms per step
+#define M3G_NR_BATCH 8   // 768-byte nontemporal rows, index pairs handed out by v_readlane: 4 -> 0.172, 8 -> 0.166, 12 -> 0.171 ms per step
 #endif
 constexpr int kNrBatch = M3G_NR_BATCH;   // rows in flight per wave in the dp1 gather (multiple of 4)
 __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const float* __restrict__ W, BlockW bw,
@@ -184,12 +184,31 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
       const int cq = ln & 15;
       // kNrBatch whole 1-KB rows in flight per wave, the remainder in one guarded batch as well (a row-at-a-time tail
       // is a dependent round trip per row)
+#ifndef M3G_NR_NO_CHUNK
+      // the (edge, three-body row) pairs of up to 64 in-edges arrive in ONE coalesced load, a lane each, and are handed
+      // out by v_readlane: a pair load per batch would put a dependent round trip in front of every batch of row loads
+      const int ks = __builtin_amdgcn_readfirstlane(k), k1s = __builtin_amdgcn_readfirstlane(k1);
+      for (int kc = ks; kc < k1s; kc += 64) {
+        const int cnt = k1s - kc < 64 ? k1s - kc : 64;
+        const int2 mine = ln < cnt ? in_pair[kc + ln] : make_int2(-1, -1);
+      for (int b = 0; b < cnt; b += kNrBatch) {
+        int2 f[kNrBatch];   // (edge id, compact three-body row or -1)
+        float4 u[kNrBatch];
+        float g[kNrBatch];
+#pragma unroll
+        for (int j = 0; j < kNrBatch; ++j) {
+          const int src = b + j < 64 ? b + j : 63;   // lanes >= cnt hold (-1, -1)
+          f[j].x = b + j < 64 ? __builtin_amdgcn_readlane(mine.x, src) : -1;
+          f[j].y = b + j < 64 ? __builtin_amdgcn_readlane(mine.y, src) : -1;
+        }
+#else
       for (; k < k1; k += kNrBatch) {
         int2 f[kNrBatch];   // (edge id, compact three-body row or -1)
         float4 u[kNrBatch];
         float g[kNrBatch];
 #pragma unroll
         for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_pair[k + j] : make_int2(-1, -1);
+#endif
 #ifndef M3G_DP1_F32
         if (seg_head) {   // rows written by the fused reverse kernel: 24-bit values, 12 B per lane (m3g_mfma_common.h: pack24)
           u32x3 pk[kNrBatch];
@@ -223,6 +242,9 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
           dv += (g[j] + g[j + 1]) + (g[j + 2] + g[j + 3]);
         }
       }
+#ifndef M3G_NR_NO_CHUNK
+      }
+#endif
       b0.x += b2.x; b0.y += b2.y; b0.z += b2.z; b0.w += b2.w;
       b1.x += b3.x; b1.y += b3.y; b1.z += b3.z; b1.w += b3.w;
       if (ln < kCP) {
