@@ -74,12 +74,22 @@ __device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f3
   M3G_FWD_CHAIN_PRIO(0);
 }
 
-// bias as one k-step: A = bias image (lanes < 16 carry b[ob*16 + lane]), B = 1 on lane quarter 0
+// bias image: lanes < 16 of block ob carry b[ob*16 + lane] (built as the A operand of a k-step against a constant one).
+// The accumulator registers of lane (m, q) are rows 4q .. 4q+3 of the block, so the same image read as one 16-byte LDS
+// broadcast per block initialises the accumulators directly -- identical values, no MFMA.
+#ifdef M3G_BIAS_MFMA
 template <int OB, int AOFF, int NA>
 __device__ __forceinline__ void bias_step(const float* img, f32x4 (&acc)[NA], int lane) {
   const float one = lane < 16 ? 1.f : 0.f;
   static_for<OB>([&]<int ob>() { acc[AOFF + ob] = mfma16(img[ob * 64 + lane], one, f32x4{0.f, 0.f, 0.f, 0.f}); });
 }
+#else
+template <int OB, int AOFF, int NA>
+__device__ __forceinline__ void bias_step(const float* img, f32x4 (&acc)[NA], int lane) {
+  const int q = lane >> 4;
+  static_for<OB>([&]<int ob>() { acc[AOFF + ob] = *(const f32x4*)(img + ob * 64 + 4 * q); });
+}
+#endif
 
 // Persistent tile queue.  Static over workgroups, dynamic inside one:
 //   * workgroups with the same blockIdx % 8 share an XCD (speed only, never correctness); that label owns one
