@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
 // from the forward pass's output image rather than evaluated a second time).  Against the split
 // kernels this drops the node->edge hand-over buffer (256 B written + read per edge), the second read of the edge
 // features, the second table gather, and one dh slice; block 0 also skips the dp1 rows nobody reads.
-constexpr int kRevFusedFloats = 8 * kTbSteps * 64 + 8 * 4 * 64 + 2 * (128 * 64 + 2 * 64 * 64 + 2 * 4 * 64 + 64 * 4) + 4 * 64 + 64 * 4;
+constexpr int kRevFusedFloats = 8 * kTbSteps * 64 + 8 * 4 * 64 + 2 * (128 * 64 + 2 * 64 * 64 + 2 * 4 * 64 + 64 * 4 + 4 * 64) + 4 * 64 + 64 * 4;
 
 template <bool KEEP_P1>
 __device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlpFused& L, const f32x4 (&x)[4], f32x4 (&p1)[8],
@@ -699,11 +699,15 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
     chain_dual<4, 2, 64, 0, 4 * half>(lds + (half == 0 ? L.w2d : L.w2g), hid, d2, lane);
     M3G_SCHED_FENCE();
   });
+  // W_l h on the matrix pipe (4 small MFMAs, as the forward kernel) instead of a 4-term dot per element on the vector ALU
+  // (64 VALU instructions per MLP; fused reverse 0.904 -> 0.889 ms per step)
+  const float hb_sel = qd == 0 ? hv[0] : qd == 1 ? hv[1] : qd == 2 ? hv[2] : hv[3];
   static_for<4>([&]<int ob>() {
+    const f32x4 sl = mfma16(lds[L.wld + ob * 64 + lane], hb_sel, f32x4{0.f, 0.f, 0.f, 0.f});
     static_for<4>([&]<int r>() {
       const float p2d = d2[ob][r], p2g = d2[4 + ob][r];
       const f32x4 w = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + r) * 4);
-      const float s_lin = w[0] * hv[0] + w[1] * hv[1] + w[2] * hv[2] + w[3] * hv[3];
+      const float s_lin = sl[r];
       const float sg = fsigmoid(p2g), sgd = fsigmoid(p2d), sd = p2d * sgd;
       const float du = d_upd[ob][r];
       const float d_out = du * s_lin, d_s = du * sd * sg;

@@ -128,6 +128,7 @@ struct MfmaMlpFused {
   int w2d, w2g;   // dual images, 64 x 64
   int b2;         // bias images (as the forward kernel's)
   int wl;         // [64][4] plain
+  int wld;        // direct [4 ob][64] image of the same W_l (A operand of the W_l h product)
 };
 struct MfmaRevFusedLayout {
   int tb;    // direct three-body image (forward recompute)

@@ -58,6 +58,7 @@ MfmaRevFusedLayout mfma_rev_fused_layout() {
     L.mlp[m].w2g = take(64 * 64);
     L.mlp[m].b2 = take(2 * 4 * 64);
     L.mlp[m].wl = take(64 * 4);
+    L.mlp[m].wld = take(4 * 64);
   }
   L.adj = take(4 * 64);
   L.adjp = take(64 * 4);
@@ -241,6 +242,7 @@ int pack_mfma_images(m3g_plan* plan) {
       pack_dual_image(rf + Rf.mlp[m].w2g, 64, sq(w2g));
       bias_image(rf + Rf.mlp[m].b2);
       memcpy(rf + Rf.mlp[m].wl, rm + Rv.mlp.wl, sizeof(float) * 64 * 4);
+      direct_image(rf + Rf.mlp[m].wld, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
     }
   }
   if (plan->d_mfma_fwd) { (void)hipFree(plan->d_mfma_fwd); plan->d_mfma_fwd = nullptr; }
