@@ -1,27 +1,44 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: energy + forces of M3GNet (default model, fp32) on the HIP engine.
+"""Benchmark of the hot path: energy + forces of M3GNet (default model) on the HIP engine.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config4] [--precision fp32|bf16x3]
 
-Workload (BASELINE.json configs[2], the "10k-atom PBC batch" the metric is quoted on): one jittered
-fcc-Cu supercell of 10 x 10 x 25 cells = 10,000 atoms per GPU, cutoff 5 A / three-body cutoff 4 A
-(E = 420,000 directed edges, T = 3,060,000 triplets), default model (l_max = n_max = 3, D = 64, 3 blocks,
-95 species), random-init weights (seed 0), synthetic data.  A step = one `model(graph)` call = the fused
-m3g_energy_forces launch sequence (forward + analytic reverse pass + virial), graph tensors resident in HBM.
-With N > 1 each rank owns one independent supercell (structures are independent): weak
-scaling, no data-path collective; the per-structure energies are all-gathered over RCCL every step.
+`--gpus N` (N > 1) without a torch.distributed launcher in the environment starts the N ranks itself (one child
+process per GPU, before anything touches the GPU in the parent) and relays rank 0's JSON line; under
+`python -m torch.distributed.run ... bench.py --gpus N` the ranks come from the launcher.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      HBM roofline (algorithmic bytes) of the dominant kernel, its duration measured live with HIP events in the
-                library; PMC-measured traffic and the matrix-pipe view of the same launch attached
+Workloads
+  config3 (default; BASELINE.json configs[2], the "10k-atom PBC batch" the metric is quoted on): one jittered fcc-Cu
+          supercell of 10 x 10 x 25 cells = 10,000 atoms per GPU, cutoff 5 A / three-body cutoff 4 A (E = 420,000
+          directed edges, T = 3,060,000 triplets).  A single cell does not shard: with N > 1
+          every rank owns one independent supercell -- replicas, weak scaling, no data-path collective; the
+          per-structure energies are all-gathered over RCCL every step.
+  config4 (BASELINE.json configs[3]): 512 x N independent 64-atom random-species cells (seeds 0 .. 512 N - 1)
+          partitioned over the N ranks by `torch_m3gnet.distributed.ShardedBatch` (greedy by triplet/edge cost, priced
+          cooperatively, shard graphs built on the GPU), one RCCL all-gather of the per-structure energies per step.
+          Also measured as a secondary figure (`config4_sharded`) after every default run.
+Model: default M3GNet (l_max = n_max = 3, D = 64, 3 blocks, 95 species), random-init weights (seed 0), synthetic data.
+A step = one `model(graph)` call = the m3g_energy_forces launch sequence (forward + analytic reverse pass + virial),
+graph tensors resident in HBM.
+
+Precision: the headline runs the engine's `fp32` mode (every dense product on v_mfma_f32_16x16x4_f32: exact fp32
+products, fp32 accumulate -- the reference's arithmetic); the `bf16x3` mode (3 bf16 split products per fp32 product,
+~2^-16 relative product error) is timed beside it and reported in `bf16x3`.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      the dominant kernel against the roofline that bounds it (fp32 mode: the fp32 matrix peak; bf16x3: HBM,
+                algorithmic bytes), its duration measured live with HIP events in the library
+  roofline_other_kernels   every other kernel of the step with its bound, algorithmic bytes and achieved rate
   cpu_baseline  the CPU oracle (oracle/m3gnet_oracle.py, a plain-torch port of the reference) timed on the
-                host cores on a bounded sample (2,048-atom Cu supercell), rank 0, N = 1 only
+                host cores on a bounded sample (2,048-atom Cu supercell), rank 0, N = 1 only: all cores and 1 thread
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,26 +51,27 @@ for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-FLOPS_PER_EDGE_BLOCK = 134_144      # a14 65,536+384, a15 65,536+384, a8 MLP 2,304 (forward)
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 matrix peak (no xf32/TF32 on gfx950)
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (about 6.3 TB/s achievable)
-# The fused MFMA edge kernels (m3g_edge_mfma.hip).  Algorithmic figures per edge and launch:
-#   bytes = edge-feature images the kernel must move under ideal fusion (256 B each): forward read e +
-#           write e; reverse read saved e + read and write dL/de;   FLOPs from SURVEY.md 8(d) (backward = 1x forward).
-#   MFMA counts per 16-edge tile: v_mfma_f32_16x16x32_bf16 (16,384 FLOP) / v_mfma_f32_16x16x4_f32 (2,048 FLOP).
+F32_MFMA_FLOP = 2048                # v_mfma_f32_16x16x4_f32
+BF16_MFMA_FLOP = 16384              # v_mfma_f32_16x16x32_bf16
+# Per-kernel algorithmic work.  Edge kernels: bytes = the 256-byte edge-feature rows the kernel must
+# move under ideal fusion; FLOPs = SURVEY.md 8(d)'s 134,144 per edge and block forward, the same again
+# for the input-gradient reverse.  MFMA counts per 16-edge tile by precision mode: (f32 16x16x4, bf16 16x16x32).
 EDGE_KERNELS = {
     "edge_block_fwd": dict(kernel="k_edge_block_mfma", alg_bytes_per_edge=2 * 256, alg_flops_per_edge=134_144,
-                           bf16_mfma_per_tile=192, f32_mfma_per_tile=48),
+                           mfma={"bf16x3": (48, 192), "fp32": (48 + 512, 0)}),
     "edge_rev_fused": dict(kernel="k_edge_rev_fused", alg_bytes_per_edge=3 * 256, alg_flops_per_edge=134_144,
-                           bf16_mfma_per_tile=396, f32_mfma_per_tile=48),
+                           mfma={"bf16x3": (48, 396), "fp32": (48 + 1056, 0)}),
     # split reverse kernels (option rev_kernel = 0)
     "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", alg_bytes_per_edge=2 * 256, alg_flops_per_edge=65_920,
-                              bf16_mfma_per_tile=192, f32_mfma_per_tile=8),
+                              mfma={"bf16x3": (8, 192), "fp32": (8 + 512, 0)}),
     "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", alg_bytes_per_edge=4 * 256, alg_flops_per_edge=68_224,
-                              bf16_mfma_per_tile=204, f32_mfma_per_tile=56),
+                              mfma={"bf16x3": (56, 204), "fp32": (56 + 544, 0)}),
 }
-PMC_TRAFFIC_FILE = "r01c_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE of this build (tools/pmc_traffic.py)
+PMC_TRAFFIC_FILE = "r02_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE of this build (tools/pmc_traffic.py)
+METRIC = "atom-steps/sec (energy+forces) on 10k-atom PBC batch, 1/2/4/8 MI355X"
 
 
 def log(msg):
@@ -83,11 +101,14 @@ def host_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def build_workload(cells, seed, device):
-    from helpers import fcc_cu_graph
-
-    g = fcc_cu_graph(*cells, seed=seed)
-    return g.to(device)
+def cpu_model():
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def default_model(device):
@@ -99,14 +120,12 @@ def default_model(device):
 
 
 def cpu_baseline(sample_cells=(8, 8, 8), steps=3):
-    """Oracle (port of the reference's CPU path) on a bounded sample of the same workload."""
+    """Oracle (port of the reference's CPU path) on a bounded sample of the same workload: all cores, then 1 thread."""
     from helpers import fcc_cu_graph
     from oracle import m3gnet_oracle as orc
     from torch_m3gnet.model.build import build_model
 
     cores = min(host_cores(), 16)  # the GPU box gives 16 cores per GPU
-    torch.set_num_threads(cores)
-    log(f"cpu_baseline: {cores} threads")
     torch.manual_seed(0)
     model = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
     params = {f"model.{k}": v.detach().clone() for k, v in model.model.state_dict().items()}
@@ -115,15 +134,203 @@ def cpu_baseline(sample_cells=(8, 8, 8), steps=3):
     g = fcc_cu_graph(*sample_cells, seed=0)
     graph = {k: g[k] for k in ("pos", "atom_types", "edge_index", "edge_cell_shift", "triplet_edge_index", "lattice", "batch")}
     n = int(g["pos"].size(0))
-    orc.energy_forces(params, cfg, consts, graph)  # warm-up
-    log("cpu_baseline: warm-up done")
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        orc.energy_forces(params, cfg, consts, graph)
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port",
+
+    def run(threads, n_steps):
+        torch.set_num_threads(threads)
+        orc.energy_forces(params, cfg, consts, graph)  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            orc.energy_forces(params, cfg, consts, graph)
+        return (time.perf_counter() - t0) / n_steps
+
+    log(f"cpu_baseline: {cores} threads")
+    dt = run(cores, steps)
+    log(f"cpu_baseline: {dt * 1e3:.0f} ms/step; 1 thread")
+    dt1 = run(1, 1)
+    torch.set_num_threads(cores)
+    return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "threads_1": {"value": n / dt1, "unit": "atom-steps/s", "cores": 1, "ms_per_step": dt1 * 1e3},
             "sample": f"{n}-atom fcc Cu supercell ({'x'.join(map(str, sample_cells))} cells), fp32, {steps} timed steps "
-                      f"after 1 warm-up, {dt * 1e3:.0f} ms/step, torch {torch.__version__} CPU"}
+                      f"after 1 warm-up at {cores} threads ({dt * 1e3:.0f} ms/step), 1 timed step after 1 warm-up at 1 thread "
+                      f"({dt1 * 1e3:.0f} ms/step), torch {torch.__version__} CPU"}
+
+
+# ---------------------------------------------------------------------------------------------- self launch
+def self_launch(args) -> int:
+    """Start one child per rank (before any GPU call in this process) and relay rank 0's output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+# ---------------------------------------------------------------------------------------------- measurement
+class Job:
+    """torch.distributed context of this rank."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.gpus != self.world:
+            raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+        # "gloo": control-flow rehearsal of the N > 1 path on a one-GPU box (several ranks share the GPU)
+        self.backend = os.environ.get("M3G_BENCH_BACKEND", "nccl")
+        dev_index = local_rank if self.backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.device)
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+        self.comm_device = self.device if self.backend == "nccl" else torch.device("cpu")
+
+    def sync_all(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, step, steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; max over ranks (s)."""
+        for _ in range(warmup):
+            step()
+        self.sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.sync_all()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            tmax = torch.tensor([elapsed], device=self.comm_device, dtype=torch.float64)
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def stage_times(model, call, steps):
+    """{stage: (ms per launch, launches per step)} from HIP events recorded on the launch stream inside the library."""
+    eng = model.engine
+    eng.profile(True)
+    for _ in range(steps):
+        call()
+    torch.cuda.synchronize()
+    stages = eng.profile_read()
+    eng.profile(False)
+    return {k: (ms / cnt, cnt / steps) for k, (ms, cnt) in stages.items() if cnt}
+
+
+def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc):
+    """Per-kernel roofline records (DESIGN.md section 4 states every byte / FLOP figure used here)."""
+    tiles = (n_edges + 15) // 16
+    views = {}
+    for stage, spec in EDGE_KERNELS.items():
+        if stage not in per_launch:
+            continue
+        ms = per_launch[stage][0]
+        n_f32, n_bf16 = spec["mfma"][precision]
+        alg_bytes = n_edges * spec["alg_bytes_per_edge"]
+        alg_flops = n_edges * spec["alg_flops_per_edge"]
+        exe_flops = tiles * (n_f32 * F32_MFMA_FLOP + n_bf16 * BF16_MFMA_FLOP)
+        rec = pmc.get(spec["kernel"])
+        traffic = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 if rec else None  # gfx950: FETCH_SIZE x 2
+        hbm_rate = alg_bytes / (ms * 1e-3) / 1e9
+        common = {"kernel": f"{spec['kernel']} (stage {stage})", "avg_launch_ms": ms, "traffic": traffic,
+                  "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": alg_flops,
+                  "executed_mfma_flops_per_launch": exe_flops,
+                  "measured_traffic_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None}
+        if precision == "fp32":
+            # exact-fp32 MFMA chains: matrix-pipe-bound; achieved = executed fp32 MFMA FLOPs (incl. the activations the reverse
+            # kernel recomputes instead of loading) / launch time; the algorithmic rate of SURVEY.md 8(d) beside it
+            t_exe = exe_flops / (ms * 1e-3) / 1e12
+            views[stage] = dict(common, bound="mfma", achieved=t_exe, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                frac=t_exe / PEAK_F32_MFMA_TFLOPS,
+                                algorithmic_tflops=alg_flops / (ms * 1e-3) / 1e12,
+                                hbm_view={"achieved_GBs": hbm_rate, "frac": hbm_rate / PEAK_HBM_GBS})
+        else:
+            views[stage] = dict(common, bound="hbm", achieved=hbm_rate, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_rate / PEAK_HBM_GBS,
+                                mfma_view={"algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12,
+                                           "executed_tflops": exe_flops / (ms * 1e-3) / 1e12,
+                                           "executed_frac_of_bf16_peak": exe_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS})
+    # HBM-bound kernels: bytes the data layout of DESIGN.md section 3 makes each launch move (algorithmic = every array the
+    # kernel must read or write once; gathers from L2/MALL-resident node tables not counted)
+    E, T, N, A = n_edges, n_trip, n_atoms, n_active
+    hbm_kernels = {
+        "geometry_basis": ("k_geometry", E * (8 + 12 + 12 + 4 + 16 + 16) + A * (64 + 64 + 8)),
+        "threebody_fwd": ("k_threebody_fwd", A * (64 + 12 + 4 + 4 + 64) + T * 1),
+        "threebody_rev": ("k_threebody_rev", A * (64 + 64 + 12 + 4 + 4 + 64 + 64 + 16) + 2 * T * 1),
+        "node_rev": ("k_node_reverse", E * (768 + 8) + N * (64 + 256 + 256) * 4),
+        "node_pre": ("k_node_pre_mfma", N * (256 + 2 * 1024 + 64 + 256) + 135 * 1024 * 256),
+        "geometry_rev_forces": ("k_geometry_reverse+k_force_gather+k_stress", E * (16 * 3 + 12 + 4 + 12 + 12 * 2 + 8) + N * 12),
+    }
+    for stage, (kernel, nbytes) in hbm_kernels.items():
+        if stage not in per_launch:
+            continue
+        ms = per_launch[stage][0]
+        rec = pmc.get(kernel)
+        traffic = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 if rec else None
+        rate = nbytes / (ms * 1e-3) / 1e9
+        views[stage] = {"bound": "hbm", "kernel": f"{kernel} (stage {stage})", "achieved": rate, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": rate / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_ms": ms, "launches_per_step": per_launch[stage][1],
+                        "algorithmic_bytes_per_launch": nbytes}
+    return views
+
+
+def measure_config4(job, model, steps, warmup):
+    """BASELINE config 4: 512 x world independent 64-atom cells sharded by ShardedBatch; returns the record."""
+    from helpers import random_cell_arrays
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.distributed import ShardedBatch
+
+    n_structs = 512 * job.world
+    t0 = time.perf_counter()
+    sb = ShardedBatch.from_structures(n_structs, lambda i: random_cell_arrays(64, 9.1, seed=i), 5.0, 4.0, device=job.device)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    evaluate = lambda b: model(b, forces=True, extras=False)   # noqa: E731
+    energies = None
+
+    def step():
+        nonlocal energies
+        energies, _ = sb.evaluate(evaluate)
+
+    step()
+    elapsed = job.timed(step, steps, warmup)
+    n_atoms = sum(sb.sizes)
+    loads = [sum(sb.costs[i] for i in s) for s in sb.shards]
+    return {"workload": f"{n_structs} independent 64-atom random-species cells (L = 9.1 A, seeds 0..{n_structs - 1}), "
+                        f"{512} per GPU, partitioned by ShardedBatch (greedy by triplets + 32 edges), energies all-gathered "
+                        f"({job.backend}) every step",
+            "value": n_atoms * steps / elapsed, "unit": "atom-steps/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "structures": n_structs, "atoms": n_atoms, "local_atoms": sb.n_local_atoms,
+            "local_edges": int(sb.batch[K.NUM_EDGES]), "local_triplets": int(sb.batch[K.NUM_TRIPLETS]),
+            "partition_imbalance": max(loads) / (sum(loads) / len(loads)) - 1.0, "shard_build_s": build_s,
+            "energy_checksum": float(energies.double().sum())}
 
 
 def main():
@@ -131,152 +338,108 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cells", type=int, nargs=3, default=[10, 10, 25], help="fcc cells per axis (4 atoms each)")
+    ap.add_argument("--workload", choices=("config3", "config4"), default="config3")
+    ap.add_argument("--precision", choices=("fp32", "bf16x3"), default="fp32", help="arithmetic of the headline figure")
+    ap.add_argument("--cells", type=int, nargs=3, default=[10, 10, 25], help="config3: fcc cells per axis (4 atoms each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other-precision and config4 secondary figures")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    # one rank per GPU; the modulo only matters for the rehearsal mode below (several ranks sharing one GPU)
-    backend = os.environ.get("M3G_BENCH_BACKEND", "nccl")   # "gloo": control-flow rehearsal of the N > 1 path on a one-GPU box
-    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-
+    job = Job(args)
+    world, rank, device = job.world, job.rank, job.device
     from torch_m3gnet.data import MaterialGraphKey as K
 
     torch.set_num_threads(min(host_cores(), 16))
     model = default_model(device)
+    model.engine.set_precision(args.precision)
+    other = "bf16x3" if args.precision == "fp32" else "fp32"
+    out = {"metric": METRIC, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+           "dtype": "f32" if args.precision == "fp32" else "f32 (dense chains: 3x bf16 split MFMA, fp32 accumulate)"}
+
+    if args.workload == "config4":
+        rec = measure_config4(job, model, args.steps, args.warmup)
+        out.update(value=rec["value"], ms_per_step=rec["ms_per_step"],
+                   config={"workload": rec.pop("workload"), **{k: v for k, v in rec.items() if k not in ("value", "unit", "ms_per_step", "steps")}})
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        job.close()
+        return
+
+    from helpers import fcc_cu_graph
+
     log("building workload graph on the host")
-    graph = build_workload(tuple(args.cells), seed=rank, device=device)
-    log("graph on device")
+    graph = fcc_cu_graph(*args.cells, seed=rank).to(device)
     n_atoms = int(graph[K.POS].size(0))
     n_edges = int(graph[K.EDGE_INDEX].size(1))
     n_trip = int(graph[K.TRIPLET_EDGE_INDEX].size(1))
-    gather_dev = device if backend == "nccl" else torch.device("cpu")
-    energies_all = torch.empty(world, 1, device=gather_dev) if world > 1 else None
+    energies_all = torch.empty(world, 1, device=job.comm_device) if world > 1 else None
 
     def step():
         model(graph, forces=True, extras=False)
         if world > 1:
-            dist.all_gather_into_tensor(energies_all, graph[K.TOTAL_ENERGY].view(1, 1).to(gather_dev))
+            job.dist.all_gather_into_tensor(energies_all, graph[K.TOTAL_ENERGY].view(1, 1).to(job.comm_device))
 
-    t_topo0 = time.perf_counter()
+    t_first = time.perf_counter()
     step()  # first call: plan commit + topology build (index-only, cached on the graph) + workspace allocation
     torch.cuda.synchronize()
-    first_call_s = time.perf_counter() - t_topo0
+    first_call_s = time.perf_counter() - t_first
     log(f"first call {first_call_s:.2f} s")
-    for _ in range(args.warmup):
-        step()
+    elapsed = job.timed(step, args.steps, args.warmup)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n_atoms * args.steps / elapsed
+    log(f"timed region done ({args.precision}): {ms_per_step:.3f} ms/step")
+
     # index-only CSR build (m3g_topology_build), timed on its own: reused while the neighbour list is unchanged
     from torch_m3gnet.nn.modules import _Topology
 
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    _Topology(graph)
+    topo = _Topology(graph)
     torch.cuda.synchronize()
     topo_ms = (time.perf_counter() - t1) * 1e3
+    n_active = topo.n_active()
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    pmc_path = ROOT / "profiles" / PMC_TRAFFIC_FILE
+    pmc_all = json.loads(pmc_path.read_text()) if (pmc_path.exists() and tuple(args.cells) == (10, 10, 25)) else {}
 
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=gather_dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    log(f"timed region done: {ms_per_step:.3f} ms/step")
-    value = world * n_atoms * args.steps / elapsed
+    def record(precision, ms_step):
+        """Roofline objects of one precision mode from live stage timers (the mode must be the engine's current one)."""
+        per_launch = stage_times(model, lambda: model(graph, forces=True, extras=False), args.steps)
+        views = rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc_all.get(precision, {}))
+        edge = {k: v for k, v in views.items() if k in EDGE_KERNELS}
+        dom = max(edge, key=lambda k: edge[k]["avg_launch_ms"] * per_launch[k][1])   # dominant kernel = largest share of the step
+        stage_ms = {k: round(ms * cnt, 4) for k, (ms, cnt) in per_launch.items()}
+        return views[dom], [v for k, v in views.items() if k != dom], stage_ms
 
-    # ---- per-kernel device time: HIP events on the launch stream, recorded inside the library ----
-    eng = model.engine
-    eng.profile(True)
-    for _ in range(args.steps):
-        model(graph, forces=True, extras=False)
-    torch.cuda.synchronize()
-    stages = eng.profile_read()
-    eng.profile(False)
-
-    if rank == 0:
-        per_launch = {k: (ms / max(cnt, 1), cnt) for k, (ms, cnt) in stages.items() if cnt}
-        tiles = (n_edges + 15) // 16
-        pmc_path = ROOT / "profiles" / PMC_TRAFFIC_FILE
-        pmc = json.loads(pmc_path.read_text()) if (pmc_path.exists() and tuple(args.cells) == (10, 10, 25)) else {}
-
-        def kernel_roofline(stage):
-            """Roofline views of one fused edge kernel (each stage timer brackets exactly one launch of it)."""
-            spec = EDGE_KERNELS[stage]
-            ms = per_launch[stage][0]
-            alg_bytes = n_edges * spec["alg_bytes_per_edge"]
-            alg_flops = n_edges * spec["alg_flops_per_edge"]
-            exe_flops = tiles * (spec["bf16_mfma_per_tile"] * 16384 + spec["f32_mfma_per_tile"] * 2048)
-            rec = pmc.get(spec["kernel"])
-            traffic = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 if rec else None  # gfx950: FETCH_SIZE x 2
-            achieved = alg_bytes / (ms * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": f"{spec['kernel']} (stage {stage})", "achieved": achieved, "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_ms": ms,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "measured_traffic_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
-                    "mfma_view": {"algorithmic_flops_per_launch": alg_flops,
-                                  "algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12,
-                                  "executed_flops_per_launch": exe_flops,
-                                  "executed_tflops": exe_flops / (ms * 1e-3) / 1e12,
-                                  "peak_bf16_dense_tflops": PEAK_BF16_MFMA_TFLOPS, "peak_f32_tflops": PEAK_F32_MFMA_TFLOPS,
-                                  "executed_frac_of_bf16_peak": exe_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}}
-
-        views = {st: kernel_roofline(st) for st in EDGE_KERNELS if st in per_launch}
-        dom = max(views, key=lambda k: views[k]["avg_launch_ms"])   # dominant kernel = longest average launch
-        roofline = views[dom]
-        roofline["note"] = ("dense chains run as 3x bf16 split MFMAs (fp32 accumulate) and the reverse pass recomputes every "
-                            "activation in one fused kernel per block: the kernel is instruction-issue/latency-bound (PMC: VALU "
-                            "~59 %, MFMA ~31 % of SIMD cycles at 2 waves/SIMD), below both the HBM and the matrix roofline; "
-                            "`achieved` uses the ideal-fusion algorithmic bytes of DESIGN.md section 4, `traffic` is PMC-measured "
-                            "HBM bytes per launch, `mfma_view` prices the same launch against the matrix peaks; hand-written streaming "
-                            "kernels on this box reach 5.9-6.5 TB/s read-only and 4.8 TB/s copy (tools/hbm_bw_probe.hip), so the "
-                            "measured read+write traffic rate is ~55 % of what a pure copy reaches")
-        out = {
-            "metric": "atom-steps/sec (energy+forces) on 10k-atom PBC batch, 1/2/4/8 MI355X", "value": value, "unit": "atom-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (dense chains: 3x bf16 split MFMA, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"single {n_atoms}-atom fcc Cu PBC supercell per GPU ({'x'.join(map(str, args.cells))} cells, "
+    roofline, others, stage_ms = record(args.precision, ms_per_step)
+    out.update(value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_other_kernels=others,
+               config={"workload": f"single {n_atoms}-atom fcc Cu PBC supercell per GPU ({'x'.join(map(str, args.cells))} cells, "
                                    "a=3.61 A, jitter 0.025 A), r_cut 5 A / 3-body 4 A, default M3GNet (l_max=n_max=3, D=64, "
                                    "3 blocks), energy+forces+stress",
-                       "atoms_per_gpu": n_atoms, "edges_per_gpu": n_edges, "triplets_per_gpu": n_trip,
-                       "first_call_s_incl_topology_build": first_call_s, "topology_build_ms": topo_ms,
-                       "stage_ms_per_step": {k: round(ms / args.steps, 4) for k, (ms, cnt) in stages.items() if cnt}},
-            "roofline": roofline,
-            "roofline_other_kernels": [v for k, v in views.items() if k != dom],
-        }
+                       "precision": args.precision, "atoms_per_gpu": n_atoms, "edges_per_gpu": n_edges, "triplets_per_gpu": n_trip,
+                       "active_edges_per_gpu": n_active, "first_call_s_incl_topology_build": first_call_s,
+                       "topology_build_ms": topo_ms, "stage_ms_per_step": stage_ms,
+                       "multi_gpu": "replicas (a single cell does not shard); config4_sharded below runs the sharded path"})
+    if not args.no_secondary:
+        model.engine.set_precision(other)
+        step()
+        el2 = job.timed(step, args.steps, args.warmup)
+        r2, o2, st2 = record(other, el2 / args.steps * 1e3)
+        out[other] = {"value": world * n_atoms * args.steps / el2, "unit": "atom-steps/s", "ms_per_step": el2 / args.steps * 1e3,
+                      "dtype": "f32" if other == "fp32" else "f32 operands split into 2 bf16 parts, 3 bf16 MFMA products per fp32 product, fp32 accumulate",
+                      "roofline": r2, "stage_ms_per_step": st2}
+        model.engine.set_precision(args.precision)
+        log(f"{other}: {el2 / args.steps * 1e3:.3f} ms/step")
+        out["config4_sharded"] = measure_config4(job, model, max(5, args.steps // 2), 2)
+        log(f"config4_sharded: {out['config4_sharded']['ms_per_step']:.3f} ms/step")
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    job.close()
 
 
 if __name__ == "__main__":

@@ -85,8 +85,14 @@ int m3g_plan_set_param(m3g_plan* plan, const char* key, const float* host_data, 
 int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data, int64_t numel);
 
 /* Engine options (not part of the reference):
+ *   "precision"   = 0 (default) every dense product of the gated MLPs on v_mfma_f32_16x16x4_f32: exact fp32 products, fp32
+ *                   accumulate -- the reference's arithmetic (nn/core.py:61-62, fp32 Linear layers);
+ *                   1 = "bf16x3": each fp32 operand split into two bf16 parts, three v_mfma_f32_16x16x32_bf16 products per fp32
+ *                   product, fp32 accumulate (relative product error ~2^-16; faster, parity within north_star's tolerances);
+ *                   both weight image sets are resident after a commit, switching costs nothing;
  *   "edge_kernel" = 1 fused MFMA edge blocks (default), 0 = vector-ALU baseline kernels (also M3G_EDGE_KERNEL in the env);
- *   "rev_kernel"  = 1 one fused reverse kernel per block (default), 0 = node-MLP + edge-MLP kernel pair (A/B testing);
+ *   "rev_kernel"  = 1 one fused reverse kernel per block (default; bf16x3 mode only -- the fp32 mode always runs the
+ *                   kernel pair), 0 = node-MLP + edge-MLP kernel pair;
  *   "stress_mode" = 0 the reference's sum pos (x) F / V (nn/gradient.py:39-62, default), 1 = pair virial
  *                   -(1/V) sum_e r_e (x) dE/dr_e (docs/gradient.md:47-84), invariant under lattice translations;
  *   "overlap"     = 1 the three-body reverse of a block runs on an internal side stream beside the node reverse's gather
@@ -98,8 +104,10 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *   "stamps"      diagnostic builds with in-kernel cycle stamps (m3g_debug_read_stamps). */
 int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value);
 
-/* Pack and upload everything set so far (synchronous).  Must be called before any compute call
- * and again after parameters/constants change.  Missing keys -> M3G_ERR_STATE. */
+/* Pack and upload everything set so far (synchronous; drains the device first).  Must be called before any compute
+ * call and again after parameters/constants change.  Missing keys -> M3G_ERR_STATE.  The plan's device buffers live on the
+ * HIP device that is current at commit; committing again under another device moves them there, and m3g_energy_forces
+ * under a device other than the plan's returns M3G_ERR_STATE. */
 int m3g_plan_commit(m3g_plan* plan);
 
 /* ---- topology: replaces nothing in the reference nn (which re-gathers by index on every call);
@@ -111,6 +119,11 @@ int m3g_topology_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int
 int m3g_topology_build(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
                        const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
                        void* topo, size_t topo_bytes, int32_t* host_flags, void* stream);
+
+/* Number of ACTIVE edges of a built topology: edges that appear in either column of triplet_edge_index (the three-body
+ * arrays of the workspace hold one row per active edge).  Synchronises the stream. */
+int m3g_topology_active_edges(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
+                              int64_t* host_count, void* stream);
 
 /* ---- the hot call: replaces Gradient.forward over the whole Sequential (nn/gradient.py:25-64,
  * model/build.py:37-81): energies, forces, virial stresses ------------------------------------- */

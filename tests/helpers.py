@@ -65,9 +65,9 @@ def fcc_cu_graph(nx, ny, nz, a=3.61, jitter=0.025, seed=0, cutoff=5.0, tb_cutoff
     return Batch.from_data_list([MaterialGraph.from_arrays(lat, pos, np.full(len(pos), 29), cutoff, tb_cutoff)])
 
 
-def random_cell_graph(n_atoms, box, seed, cutoff=5.0, tb_cutoff=4.0, zmax=94, dmin=1.6):
-    from torch_m3gnet.data.material_graph import MaterialGraph
-
+def random_cell_arrays(n_atoms, box, seed, zmax=94, dmin=1.6):
+    """(lattice, cart_coords, Z) of one cubic cell of side `box` with `n_atoms` atoms placed uniformly under a `dmin`
+    minimum-image rejection rule, species uniform in 1..zmax."""
     rng = np.random.default_rng(seed)
     pos = np.zeros((0, 3))
     while len(pos) < n_atoms:
@@ -76,4 +76,11 @@ def random_cell_graph(n_atoms, box, seed, cutoff=5.0, tb_cutoff=4.0, zmax=94, dm
         dv -= box * np.round(dv / box)
         if len(pos) == 0 or np.sqrt((dv**2).sum(1)).min() >= dmin:
             pos = np.vstack([pos, p])
-    return MaterialGraph.from_arrays(np.eye(3) * box, pos, rng.integers(1, zmax + 1, n_atoms), cutoff, tb_cutoff)
+    return np.eye(3) * box, pos, rng.integers(1, zmax + 1, n_atoms)
+
+
+def random_cell_graph(n_atoms, box, seed, cutoff=5.0, tb_cutoff=4.0, zmax=94, dmin=1.6):
+    from torch_m3gnet.data.material_graph import MaterialGraph
+
+    lat, pos, z = random_cell_arrays(n_atoms, box, seed, zmax=zmax, dmin=dmin)
+    return MaterialGraph.from_arrays(lat, pos, z, cutoff, tb_cutoff)

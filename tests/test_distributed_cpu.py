@@ -44,6 +44,35 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _structure(i):
+    from helpers import random_cell_arrays
+
+    return random_cell_arrays(6 + 2 * (i % 3), 5.5, seed=i)
+
+
+def _worker_structures(rank, world, port, ret):
+    """ShardedBatch.from_structures: cooperative pricing (cost all-gather), shard build, repeated steps."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch_m3gnet.distributed import ShardedBatch
+
+    calls = []
+
+    def fn(i):
+        calls.append(i)
+        return _structure(i)
+
+    sb = ShardedBatch.from_structures(7, fn, 3.5, 3.0, device="cpu")
+    steps = []
+    for _ in range(2):   # the shard batch is built once and re-used
+        e, f = sb.evaluate(_stub_evaluate, gather_forces=True)
+        steps.append((e.numpy().copy(), f.numpy().copy()))
+    e_loc, f_loc = sb.evaluate(_stub_evaluate)
+    ret[rank] = dict(steps=steps, shards=sb.shards, costs=sb.costs, sizes=sb.sizes, calls=sorted(set(calls)),
+                     local=(f_loc.numpy().copy(), dict(sb.local_offsets)))
+    dist.destroy_process_group()
+
+
 def test_partition_is_balanced_and_complete():
     from torch_m3gnet.distributed import partition_structures
 
@@ -72,3 +101,43 @@ def test_two_rank_gloo_energies_match_single_process():
         assert sorted(forces) == list(range(len(graphs)))
         for i, g in enumerate(graphs):
             np.testing.assert_allclose(forces[i], -2 * g[K.POS].numpy(), rtol=1e-6)
+
+
+def test_two_rank_gloo_sharded_batch_from_structures():
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+    from torch_m3gnet.distributed import partition_structures, structure_cost
+
+    graphs = [MaterialGraph.from_arrays(*_structure(i), 3.5, 3.0) for i in range(7)]
+    ref_batch = _stub_evaluate(Batch.from_data_list(graphs))
+    ref_e, ref_f = ref_batch[K.TOTAL_ENERGY].numpy(), ref_batch[K.FORCES].numpy()
+    costs = [structure_cost(g) for g in graphs]
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_structures, args=(2, port, ret), nprocs=2, join=True)
+    for rank in (0, 1):
+        r = ret[rank]
+        assert r["costs"] == costs and r["sizes"] == [int(g[K.NUM_NODES]) for g in graphs]
+        assert r["shards"] == partition_structures(costs, 2)
+        # a rank only ever builds the structures it prices (rank, rank + 2, ...) or owns
+        assert set(r["calls"]) <= set(range(rank, 7, 2)) | set(r["shards"][rank])
+        for e, f in r["steps"]:
+            np.testing.assert_allclose(e, ref_e, rtol=1e-6)
+            np.testing.assert_allclose(f, ref_f, rtol=1e-6)
+        f_loc, offs = r["local"]
+        starts = np.concatenate([[0], np.cumsum(r["sizes"])])
+        for i, off in offs.items():
+            np.testing.assert_allclose(f_loc[off: off + r["sizes"][i]], ref_f[starts[i]: starts[i + 1]], rtol=1e-6)
+
+
+def test_sharded_batch_single_process_matches_plain_batch():
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+    from torch_m3gnet.distributed import ShardedBatch
+
+    sb = ShardedBatch.from_structures(5, _structure, 3.5, 3.0, device="cpu")
+    assert sb.shards == [[0, 1, 2, 3, 4]] and sb.world == 1
+    ref = _stub_evaluate(Batch.from_data_list([MaterialGraph.from_arrays(*_structure(i), 3.5, 3.0) for i in range(5)]))
+    e, f = sb.evaluate(_stub_evaluate, gather_forces=True)
+    np.testing.assert_allclose(e.numpy(), ref[K.TOTAL_ENERGY].numpy(), rtol=1e-6)
+    np.testing.assert_allclose(f.numpy(), ref[K.FORCES].numpy(), rtol=1e-6)

@@ -17,24 +17,28 @@ def _K():
     return K
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case,mode", CASES)
-def test_forces_bitwise_reproducible_on_golden_cases(case, mode):
+def test_forces_bitwise_reproducible_on_golden_cases(case, mode, precision):
     K = _K()
     _, _, _, graph, _ = load_oracle_case(case, mode)
     model, _ = build_engine_model(case, mode)
+    model.engine.set_precision(precision)
     g = engine_graph(graph)
     ref = model(g)[K.FORCES].clone()
     for _ in range(REPS):
         assert torch.equal(model(g)[K.FORCES], ref)
 
 
-def test_forces_bitwise_reproducible_on_a_1500_atom_cell():
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_forces_bitwise_reproducible_on_a_1500_atom_cell(precision):
     """Enough tiles that every workgroup of the persistent kernels is busy and waves overlap in every phase."""
     from torch_m3gnet.model.build import build_model
 
     K = _K()
     torch.manual_seed(0)
     model = build_model(5.0, 4.0, 3, 3, 95, 64, 3).cuda()
+    model.engine.set_precision(precision)
     g = fcc_cu_graph(5, 5, 15).to("cuda")
     out = model(g)
     ref_f, ref_s = out[K.FORCES].clone(), out[K.STRESSES].clone()

@@ -265,6 +265,41 @@ def test_scales_and_elemental_energies():
     assert rel_err(g[K.STRESSES], o["stresses"]) < 1e-4
 
 
+def test_one_sided_and_filtered_triplet_lists():
+    """The reference's gather + scatter_sum (nn/interaction.py:188-217) accepts ANY list of (e1, e2) edge pairs sharing a
+    centre, not only the symmetric list `compute_threebody` emits.  One-sided (e1 < e2 only) and randomly thinned lists
+    contain edges that only ever appear as the partner e2: the engine must keep their rows (they were dropped before the
+    round-2 topology fix, silently corrupting energies and forces)."""
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _default_model(seed=2, energy_scale=2.0)
+    base = Batch.from_data_list([random_cell_graph(20, 6.5, s) for s in (7, 8)])
+    tei = base[K.TRIPLET_EDGE_INDEX]
+    gen = torch.Generator().manual_seed(0)
+    variants = {
+        "one_sided": tei[:, tei[0] < tei[1]],
+        "thinned": tei[:, torch.rand(tei.size(1), generator=gen) < 0.3],
+        "single_pair": tei[:, :1],
+    }
+    for name, sub in variants.items():
+        g = base.clone()
+        g[K.TRIPLET_EDGE_INDEX] = sub.contiguous()
+        g[K.NUM_TRIPLETS] = int(sub.size(1))
+        only_e2 = set(sub[1].tolist()) - set(sub[0].tolist())
+        assert name == "single_pair" or len(only_e2) > 0     # the case the fix is about really occurs
+        out = model(g.to(DEV))
+        p, cfg, c, og = _oracle_inputs(model, out)
+        p = {k: v.double() for k, v in p.items()}
+        c = orc.make_constants(cfg, model.model[1].elemental_energies.cpu(), dtype=torch.float64)
+        c.factors = model.model[6].nsb.factors.double()
+        o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+        assert float(((out[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < 1e-5, name
+        assert rel_err(out[K.FORCES], o["forces"]) < 1e-4, name
+        for b in range(3):
+            assert rel_err(out[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) < 1e-4, (name, b)
+
+
 # ------------------------------------------------------------------ BASELINE.json configurations
 def test_config3_10k_atom_cu_supercell_vs_oracle():
     """10,000-atom Cu supercell (BASELINE config 3): full-size parity against the fp32 CPU oracle plus
@@ -298,23 +333,33 @@ def test_config3_10k_atom_cu_supercell_vs_oracle():
 
 
 def test_config2_batched_random_species_cells():
-    """Batched 64-atom random-species cells (BASELINE config 2; 32 of the 256 cells against the oracle,
-    then all 256 batched == the same cells evaluated in two halves)."""
+    """Batched 64-atom random-species cells (BASELINE config 2): all 256 cells in one batch (graph built on the GPU);
+    the first 32 against the CPU oracle, then the 256 batched == the same cells evaluated in two halves, and no net
+    force on any cell."""
     from oracle import m3gnet_oracle as orc
-    from torch_m3gnet.data.material_graph import Batch
+    from helpers import random_cell_arrays
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
 
     K = _K()
     model = _default_model()
-    cells = [random_cell_graph(64, 9.1, s) for s in range(32)]
-    out = model(Batch.from_data_list(cells).to(DEV))
+    cells = [random_cell_arrays(64, 9.1, s) for s in range(256)]
+    out = model(batch_from_arrays(*zip(*cells), 5.0, 4.0, device=DEV), extras=False)
+    assert out[K.NUM_NODES] == 16_384 and out[K.TOTAL_ENERGY].shape == (256,)
+    e_all, f_all = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone()
+    sub = model(batch_from_arrays(*zip(*cells[:32]), 5.0, 4.0, device=DEV))
     torch.set_num_threads(8)
-    p, cfg, c, og = _oracle_inputs(model, out)
+    p, cfg, c, og = _oracle_inputs(model, sub)
     o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
-    assert float(((out[K.TOTAL_ENERGY].cpu() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < 1e-5
-    assert rel_err(out[K.FORCES], o["forces"]) < 1e-4
-    halves = [model(Batch.from_data_list(cells[a:b]).to(DEV)) for a, b in ((0, 16), (16, 32))]
-    torch.testing.assert_close(out[K.TOTAL_ENERGY], torch.cat([h[K.TOTAL_ENERGY] for h in halves]), rtol=1e-6, atol=1e-6)
-    torch.testing.assert_close(out[K.FORCES], torch.cat([h[K.FORCES] for h in halves]), rtol=1e-5, atol=1e-7)
+    assert float(((e_all[:32].cpu() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < 1e-5
+    assert rel_err(f_all[: 32 * 64], o["forces"]) < 1e-4
+    halves = []
+    for a, b in ((0, 128), (128, 256)):
+        h = model(batch_from_arrays(*zip(*cells[a:b]), 5.0, 4.0, device=DEV), extras=False)
+        halves.append((h[K.TOTAL_ENERGY].clone(), h[K.FORCES].clone()))
+    torch.testing.assert_close(e_all, torch.cat([h[0] for h in halves]), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(f_all, torch.cat([h[1] for h in halves]), rtol=1e-5, atol=1e-7)
+    f = f_all.double().view(256, 64, 3)
+    assert float(f.sum(1).abs().max()) < 1e-3 * float(f.abs().max())
 
 
 def test_config5_high_triplet_density():

@@ -283,11 +283,7 @@ extern "C" int m3g_plan_create(const m3g_config* cfg, m3g_plan** out) {
 extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (!plan) return;
   if (plan->d_weights) (void)hipFree(plan->d_weights);
-  if (plan->d_mfma_fwd) (void)hipFree(plan->d_mfma_fwd);
-  if (plan->d_mfma_rev) (void)hipFree(plan->d_mfma_rev);
-  if (plan->d_mfma_revf) (void)hipFree(plan->d_mfma_revf);
-  if (plan->d_node_img) (void)hipFree(plan->d_node_img);
-  if (plan->d_readout_img) (void)hipFree(plan->d_readout_img);
+  free_mfma_images(plan);
   if (plan->d_stamps) (void)hipFree(plan->d_stamps);
   drop_graphs(plan);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
@@ -324,6 +320,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
   if (strcmp(name, "edge_kernel") == 0) {
     if (value != 0 && value != 1) { set_error("edge_kernel must be 0 (VALU baseline) or 1 (MFMA)"); return M3G_ERR_VALUE; }
     plan->edge_kernel = value;
+    return M3G_OK;
+  }
+  if (strcmp(name, "precision") == 0) {
+    if (value != kPrecF32 && value != kPrecBf16x3) { set_error("precision must be 0 (fp32: exact fp32 MFMA products) or 1 (bf16x3 split products)"); return M3G_ERR_VALUE; }
+    plan->precision = value;   // both image sets are resident: no recommit needed
     return M3G_OK;
   }
   if (strcmp(name, "rev_kernel") == 0) {
@@ -449,6 +450,20 @@ extern "C" int m3g_plan_commit(m3g_plan* plan) {
     blob[r.b3] = plan->params.at(ro + ".dense.4.bias")[0];
     blob[r.b3 + 1] = plan->params.at(ro + ".gate.4.bias")[0];
   }
+  // The plan's buffers live on the device that is current now; a recommit on another device moves them.  Kernels of earlier
+  // calls may still read the old contents on some stream: drain the device(s) before overwriting or freeing.
+  int dev = 0;
+  M3G_HIP_CHECK(hipGetDevice(&dev));
+  if (plan->device >= 0 && plan->device != dev) {
+    M3G_HIP_CHECK(hipSetDevice(plan->device));
+    M3G_HIP_CHECK(hipDeviceSynchronize());
+    if (plan->d_weights) { (void)hipFree(plan->d_weights); plan->d_weights = nullptr; }
+    free_mfma_images(plan);
+    if (plan->d_stamps) { (void)hipFree(plan->d_stamps); plan->d_stamps = nullptr; }
+    M3G_HIP_CHECK(hipSetDevice(dev));
+  }
+  M3G_HIP_CHECK(hipDeviceSynchronize());
+  plan->device = dev;
   if (!plan->d_weights) M3G_HIP_CHECK(hipMalloc((void**)&plan->d_weights, wl.total * sizeof(float)));
   M3G_HIP_CHECK(hipMemcpy(plan->d_weights, blob.data(), wl.total * sizeof(float), hipMemcpyHostToDevice));
   { int rc = pack_mfma_images(plan); if (rc) return rc; }
@@ -506,7 +521,7 @@ static int energy_forces_graph(const m3g_plan* plan, const m3g_io* io, void* wor
   memcpy(k, &workspace, sizeof(void*)); k += sizeof(void*);
   memcpy(k, &s, sizeof(void*)); k += sizeof(void*);
   memcpy(k, &workspace_bytes, sizeof(size_t)); k += sizeof(size_t);
-  const int opts[4] = {plan->edge_kernel, plan->rev_kernel, plan->stress_mode, plan->overlap};
+  const int opts[4] = {plan->edge_kernel, plan->rev_kernel + 2 * plan->precision, plan->stress_mode, plan->overlap};
   memcpy(k, opts, sizeof(opts));
   for (auto& g : plan->graphs)
     if (g.key == key) { M3G_HIP_CHECK(hipGraphLaunch(g.exec, s)); return join(); }
@@ -531,6 +546,14 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
                                  void* stream_) {
   if (!plan || !io) { set_error("m3g_energy_forces: null argument"); return M3G_ERR_VALUE; }
   if (!plan->committed) { set_error("m3g_energy_forces: plan parameters not committed"); return M3G_ERR_STATE; }
+  {
+    int dev = -1;
+    M3G_HIP_CHECK(hipGetDevice(&dev));
+    if (dev != plan->device) {
+      set_error("m3g_energy_forces: the plan was committed on device %d but the current device is %d (commit again on this device)", plan->device, dev);
+      return M3G_ERR_STATE;
+    }
+  }
   if (plan->graph_replay && !plan->capturing && !plan->profile && !plan->overlap)
     return energy_forces_graph(plan, io, workspace, workspace_bytes, (hipStream_t)stream_);
   const int64_t N = io->n_atoms, E = io->n_edges, T = io->n_triplets, S = io->n_structs;
@@ -547,7 +570,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   const float* W = plan->d_weights;
   Topo t = topo_carve(N, E, T, S, const_cast<void*>(io->topo));
   const bool mfma = plan->edge_kernel == 1;
-  const bool fused_rev = mfma && plan->rev_kernel == 1;
+  const bool fused_rev = fused_reverse(plan);
   Work w = work_carve(c, mfma, N, E, T, S, nullptr);
   if (!workspace || workspace_bytes < w.total_bytes) { set_error("workspace too small: %zu < %zu", workspace_bytes, w.total_bytes); return M3G_ERR_SIZE; }
   w = work_carve(c, mfma, N, E, T, S, workspace);

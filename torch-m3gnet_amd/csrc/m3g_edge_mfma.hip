@@ -74,6 +74,32 @@ __device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f3
   M3G_FWD_CHAIN_PRIO(0);
 }
 
+// exact-fp32 chain on v_mfma_f32_16x16x4_f32: acc[AOFF + ob] += W(ob-th row block, :) . x[XOFF .. XOFF + NB) with the
+// accumulator blocks of x as the B operand (k-step blk*4 + r = register r of block blk; image: f32_chain_image).
+// Bitwise a k-ordered fp32 fmaf chain per output element (cdna_hip_programming.md section 3): the reference's arithmetic.
+template <int OB, int NB, int XOFF = 0, int AOFF = 0, int NX, int NA>
+__device__ __forceinline__ void chain_f32(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
+  static_assert(XOFF + NB <= NX && AOFF + OB <= NA, "chain_f32 operand out of range");
+  static_for<NB>([&]<int blk>() {
+    static_for<4>([&]<int r>() {
+      const float b = x[XOFF + blk][r];
+      static_for<OB>([&]<int ob>() { acc[AOFF + ob] = mfma16(img[(ob * (4 * NB) + blk * 4 + r) * 64 + lane], b, acc[AOFF + ob]); });
+    });
+  });
+}
+
+// Precision modes of the dense chains (plan option "precision"):
+//   kPrecF32     every product on v_mfma_f32_16x16x4_f32 -- exact fp32 products, fp32 accumulate (the reference's arithmetic);
+//   kPrecBf16x3  operands split into two bf16 parts, 3 v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32 accumulate
+//                (relative product error ~2^-16).
+// Both read an image of the same size and offsets (an fp32 image is as large as a bf16 hi + lo pair); KS counts 32-wide
+// k-steps, i.e. 2*KS accumulator blocks of x.
+template <int PREC, int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
+__device__ __forceinline__ void chain_p(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
+  if constexpr (PREC == kPrecBf16x3) chain<OB, KS, XOFF, AOFF>(img, x, acc, lane);
+  else chain_f32<OB, 2 * KS, XOFF, AOFF>(img, x, acc, lane);
+}
+
 // bias image: lanes < 16 of block ob carry b[ob*16 + lane] (built as the A operand of a k-step against a constant one).
 // The accumulator registers of lane (m, q) are rows 4q .. 4q+3 of the block, so the same image read as one 16-byte LDS
 // broadcast per block initialises the accumulators directly -- identical values, no MFMA.
@@ -286,10 +312,10 @@ __device__ __forceinline__ void gather_tables(const float* __restrict__ TA, cons
 
 // both layers of one conv GatedMLP from the edge-feature tile x: p1 = layer-1 pre-activations (dense 0..3, gate 4..7),
 // p2 = layer-2 pre-activations.  `w1c/w2d/w2g/b2` are offsets of the forward images inside `lds`.
-template <bool KEEP_P1>
+template <bool KEEP_P1, int PREC>
 __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, int w2g, int b2, const f32x4 (&x)[4], f32x4 (&p1)[8],
                                             f32x4 (&p2)[8], int lane) {
-  chain<8, 2>(lds + w1c, x, p1, lane);
+  chain_p<PREC, 8, 2>(lds + w1c, x, p1, lane);
   bias_step<4, 0>(lds + b2, p2, lane);
   bias_step<4, 4>(lds + b2 + 4 * 64, p2, lane);
   if (KEEP_P1) {
@@ -302,24 +328,24 @@ __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, 
         p1[ob][r] = sg * (1.f + p * (1.f - sg));
       });
     });
-    chain<4, 2, 0, 0>(lds + w2d, hid, p2, lane);
-    chain<4, 2, 4, 4>(lds + w2g, hid, p2, lane);
+    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, hid, p2, lane);
+    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, hid, p2, lane);
   } else {
     static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); }); });
-    chain<4, 2, 0, 0>(lds + w2d, p1, p2, lane);  // hidden dense = p1[0..3]
-    chain<4, 2, 4, 4>(lds + w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
+    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, p1, p2, lane);  // hidden dense = p1[0..3]
+    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
   }
 }
 
 // one conv GatedMLP, forward.  x = edge-feature input tile; out = MLP(x) * (W_l h)
-template <bool ST, int S0>
+template <bool ST, int S0, int PREC>
 __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlpFwd& L, int mlp, const FwdArgs& a, int64_t ci,
                                                  int64_t cj, float hb, const f32x4 (&x)[4], f32x4 (&out)[4], int lane,
                                                  Stamps<ST>& st) {
   f32x4 p1[8], p2[8];
   gather_tables(a.TA, a.TB, mlp, ci, cj, lane >> 4, p1);
   st.template mark<S0>();      // table gather
-  mlp_preacts<false>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane);
+  mlp_preacts<false, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane);
   st.template mark<S0 + 1>();  // both layers
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -330,7 +356,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
 
 // FIRST: block 0 forms its input e0 = SiLU(W_adj h) (nn/featurizer.py:128-132) from the radial basis instead of reading
 // an embedded-edge image that a separate kernel would have to write (256 B/edge) first
-template <int TBS, bool ST = false, bool FIRST = false>
+template <int TBS, bool ST = false, bool FIRST = false, int PREC = kPrecBf16x3>
 __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kFwdLdsFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kFwdLdsFloats);
@@ -393,13 +419,13 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
     }
     st.template mark<1>();  // three-body MLP
     f32x4 out[4];
-    mlp_forward_mfma<ST, 2>(lds, L.mlp[0], 0, a, ci, cj, hb, x, out, lv, st);  // edge update (nn/conv.py:68-75)
+    mlp_forward_mfma<ST, 2, PREC>(lds, L.mlp[0], 0, a, ci, cj, hb, x, out, lv, st);  // edge update (nn/conv.py:68-75)
     static_for<4>([&]<int blk>() {
       x[blk] += out[blk];
       *(f32x4*)(e_otile + blk * 256) = x[blk];
     });
     st.template mark<6>();  // e2 residual + store
-    mlp_forward_mfma<ST, 7>(lds, L.mlp[1], 1, a, ci, cj, hb, x, out, lv, st);  // node message (nn/conv.py:77-89)
+    mlp_forward_mfma<ST, 7, PREC>(lds, L.mlp[1], 1, a, ci, cj, hb, x, out, lv, st);  // node message (nn/conv.py:77-89)
     {  // sum of the messages per centre instead of a [E,64] message array + a node-side pass over it (nn/conv.py:82-88)
       if (edge >= a.E) static_for<4>([&]<int blk>() { out[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; });   // padding lanes of the last tile
       const SegMasks sk = seg_masks((int)ci, lane);
@@ -442,7 +468,7 @@ struct RevArgs {
 
 // reverse of one conv GatedMLP whose edge-feature input tile is x: both layers are recomputed, then
 // d_upd = dL/d(output) is pulled back; returns contrib = W1c^T d_p1 and accumulates dL/dh into dhv.
-template <bool ST>
+template <bool ST, int PREC>
 __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlpRev& L, int mlp, const RevArgs& a, int64_t edge,
                                                  int64_t ci, int64_t cj, const f32x4& hv, const f32x4 (&x)[4],
                                                  const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane,
@@ -451,7 +477,7 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
   f32x4 p1[8], d2[8];  // d2: first p2 dense 0..3 / gate 4..7, then d_p2 in place
   gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
   st.template mark<2>();   // table gather (+ wait for the tile loads)
-  mlp_preacts<true>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, d2, lane);
+  mlp_preacts<true, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, d2, lane);
   st.template mark<3>();   // recompute both layers
   static_for<4>([&]<int ob>() {
     static_for<4>([&]<int r>() {
@@ -472,8 +498,8 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
   st.template mark<4>();   // gating derivatives (VALU)
   f32x4 dp1[8];
   zero(dp1);
-  chain<4, 2, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..3]
-  chain<4, 2, 4, 4>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[4..7]
+  chain_p<PREC, 4, 2, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..3]
+  chain_p<PREC, 4, 2, 4, 4>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[4..7]
   static_for<8>([&]<int ob>() { dp1[ob] *= p1[ob]; });   // p1 holds SiLU'(p1) here (mlp_preacts<true>)
   st.template mark<5>();   // layer-2 transposed chains + SiLU'
   if (edge < a.E) {
@@ -481,7 +507,7 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
     static_for<8>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
   }
   zero(contrib);
-  chain<4, 4>(lds + L.w1cT, dp1, contrib, lane);
+  chain_p<PREC, 4, 4>(lds + L.w1cT, dp1, contrib, lane);
   st.template mark<6>();   // dp1 stores + layer-1 transposed chain
 }
 
@@ -504,6 +530,7 @@ __device__ __forceinline__ void store_dh(float* dh, int64_t edge, int64_t E, f32
 }
 
 // node-message MLP (nn/conv.py:77-89), reverse: d msg[e] = dx_new[centre(e)]
+template <int PREC>
 __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs a, MfmaRevLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kRevMlpFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevMlpFloats);
@@ -538,7 +565,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs
         x[blk] = *(const f32x4*)(e_tile + blk * 256);     // e2: the node MLP's input
       });
       Stamps<false> st0;
-      mlp_reverse_mfma<false>(lds, L.mlp, 1, a, edge, ci, cj, hv, x, dmsg, contrib, dhv, lv, st0);
+      mlp_reverse_mfma<false, PREC>(lds, L.mlp, 1, a, edge, ci, cj, hv, x, dmsg, contrib, dhv, lv, st0);
     }
     static_for<4>([&]<int blk>() { *(f32x4*)(dcn_tile + blk * 256) = contrib[blk]; });
     store_dh(a.dh, edge, a.E, dhv, qd);
@@ -549,7 +576,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs
 }
 
 // edge-update MLP (nn/conv.py:68-75) + three-body gated update (nn/interaction.py:220-221), reverse
-template <int TBS, bool ST = false>
+template <int TBS, bool ST = false, int PREC = kPrecBf16x3>
 __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs a, MfmaRevLayout L) {
   Stamps<ST> st;
   __shared__ __attribute__((aligned(16))) float lds[kRevEdgeFloats + 4];  // + tile-queue head
@@ -595,7 +622,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
       } else {
         static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + *(const f32x4*)(dcn_tile + blk * 256); });
       }
-      mlp_reverse_mfma<ST>(lds, L.mlp, 0, a, edge, ci, cj, hv, x, de, contrib, dhv, lv, st);
+      mlp_reverse_mfma<ST, PREC>(lds, L.mlp, 0, a, edge, ci, cj, hv, x, de, contrib, dhv, lv, st);
     }
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
@@ -613,7 +640,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
     });
     f32x4 dmv[1];
     zero(dmv);
-    chain<1, 4>(lds + L.tbT, d8, dmv, lv);
+    chain_p<PREC, 1, 4>(lds + L.tbT, d8, dmv, lv);
     store_dh(a.dh, edge, a.E, dhv, qd);
     if (edge < a.E && arow >= 0) *(f32x4*)(a.dm + (int64_t)arow * kCP + 4 * qd) = dmv[0];  // rows c = 4*qd + reg
     st.template mark<7>();   // de store + three-body reverse + dm/dh stores
@@ -935,6 +962,7 @@ __global__ void __launch_bounds__(256) k_embed_edges_reverse_soa(int64_t E, int6
 // re-read 128 KB of weights from L2 for every 16 atoms.  x^b = x^(b-1) + the per-centre message sums of block b-1 is
 // formed while the tile is loaded (x_prev != nullptr) and written back for the later stages.
 constexpr int kNodeXPitch = 68;   // floats per staged x row: 64 + 4 keeps 16-byte alignment and spreads the 16 rows over the banks
+template <int PREC>
 __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
                                                        const float* __restrict__ seg_head, const float* __restrict__ seg_first,
                                                        const int32_t* __restrict__ row_ptr, float* __restrict__ x,
@@ -996,7 +1024,7 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
     static_for<3>([&]<int g>() {   // 11 row blocks per pass: bf16x3 chains like the edge kernels' (fp32 accumulate)
       f32x4 acc[11];
       static_for<11>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (11 * g + j) * 16 + 4 * q); });
-      chain<11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv);
+      chain_p<PREC, 11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv);
       if (live) {
         static_for<11>([&]<int j>() {
           constexpr int ob = 11 * g + j;
@@ -1011,19 +1039,6 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
       }
     });
   }
-}
-
-// exact-fp32 chain on v_mfma_f32_16x16x4_f32: acc[AOFF + ob] += W(ob-th row block, :) . x[XOFF .. XOFF + NB) with the
-// accumulator blocks of x as the B operand (k-step blk*4 + r = register r of block blk; image: f32_chain_image)
-template <int OB, int NB, int XOFF = 0, int AOFF = 0, int NX, int NA>
-__device__ __forceinline__ void chain_f32(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
-  static_assert(XOFF + NB <= NX && AOFF + OB <= NA, "chain_f32 operand out of range");
-  static_for<NB>([&]<int blk>() {
-    static_for<4>([&]<int r>() {
-      const float b = x[XOFF + blk][r];
-      static_for<OB>([&]<int ob>() { acc[AOFF + ob] = mfma16(img[(ob * (4 * NB) + blk * 4 + r) * 64 + lane], b, acc[AOFF + ob]); });
-    });
-  });
 }
 
 // ---------------------------------------------------------------------------------------------- readout
@@ -1175,19 +1190,26 @@ void launch_embed_edges_reverse_soa(const float* adj, const float* h, const floa
     default: { constexpr int TBS = 4; CALL; } break; \
   }
 
+#define M3G_PREC_SWITCH(P_, CALL)                                      \
+  if ((P_) == kPrecF32) { constexpr int PREC = kPrecF32; CALL; }       \
+  else { constexpr int PREC = kPrecBf16x3; CALL; }
+
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s) {
   const int64_t tiles = tiles_for(t.E);
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
-    FwdArgs a{t.E, tiles, plan->d_mfma_fwd + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], t.act_id, w.e_blk[b],
-              w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps};
+    FwdArgs a{t.E, tiles, plan->d_mfma_fwd[plan->precision] + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], t.act_id,
+              w.e_blk[b], w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
-    if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3) {  // diagnostic build of the default configuration
-      hipLaunchKernelGGL((k_edge_block_mfma<3, true>), grid, block, 0, s, a, L);
-    } else if (b == 0 && plan->rev_kernel == 1) {   // the fused reverse kernel recomputes e0 as well: no embedded-edge image at all
-      M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS, false, true>), grid, block, 0, s, a, L));
+    const bool first = b == 0 && fused_reverse(plan);   // the fused reverse kernel recomputes e0 as well: no embedded-edge image at all
+    if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3 && plan->precision == kPrecBf16x3) {
+      // diagnostic build of the default configuration (same code path as the shipped kernel, block 0 included)
+      if (first) hipLaunchKernelGGL((k_edge_block_mfma<3, true, true>), grid, block, 0, s, a, L);
+      else hipLaunchKernelGGL((k_edge_block_mfma<3, true, false>), grid, block, 0, s, a, L);
+    } else if (first) {
+      M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS, false, true, PREC>), grid, block, 0, s, a, L)));
     } else {
-      M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS>), grid, block, 0, s, a, L));
+      M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS, false, false, PREC>), grid, block, 0, s, a, L)));
     }
   }
 }
@@ -1211,8 +1233,10 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
   if (t.N == 0) return;
   const int64_t tiles = (t.N + 15) / 16;
   int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
-  hipLaunchKernelGGL(k_node_pre_mfma, dim3(wgs), dim3(256), 0, s, c.C, t.N, plan->d_node_img + (size_t)b * kNodeImgFloats, x_prev,
-                     w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB, types, emb, c.num_types);
+  M3G_PREC_SWITCH(plan->precision,
+                  hipLaunchKernelGGL(k_node_pre_mfma<PREC>, dim3(wgs), dim3(256), 0, s, c.C, t.N,
+                                     plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first,
+                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types));
 }
 
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
@@ -1221,10 +1245,10 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const int64_t tiles = tiles_for(t.E);
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
-  const float* img_n = plan->d_mfma_rev + (size_t)b * L.per_block + L.total_e;
+  const float* img_n = plan->d_mfma_rev[plan->precision] + (size_t)b * L.per_block + L.total_e;
   RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b + 1], nullptr, w.de_soa, w.dcn, 0, w.dm,
              w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(k_edge_rev_node_mlp, dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L);
+  M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL(k_edge_rev_node_mlp<PREC>, dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L));
 }
 
 void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
@@ -1232,15 +1256,15 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const int64_t tiles = tiles_for(t.E);
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
-  const float* img_e = plan->d_mfma_rev + (size_t)b * L.per_block;
+  const float* img_e = plan->d_mfma_rev[plan->precision] + (size_t)b * L.per_block;
   RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], nullptr, w.de_soa, w.dcn,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps, nullptr, nullptr};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
-  if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3) {  // diagnostic build
+  if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3 && plan->precision == kPrecBf16x3) {  // diagnostic build
     hipLaunchKernelGGL((k_edge_rev_edge_mlp<3, true>), grid, block, 0, s, ae, L);
     return;
   }
-  M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS>), grid, block, 0, s, ae, L));
+  M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS, false, PREC>), grid, block, 0, s, ae, L)));
 }
 
 void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,

@@ -18,6 +18,10 @@ constexpr int kRCap = 4;     // n_max <= kRCap
 constexpr int kCP = 16;      // padded l_max*n_max
 constexpr int kRP = 4;       // padded n_max
 constexpr int kMaxBlocks = 8;
+// arithmetic of the dense chains (plan option "precision"; m3g_edge_mfma.hip: chain_p)
+constexpr int kPrecF32 = 0;      // v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate -- the reference's arithmetic (default)
+constexpr int kPrecBf16x3 = 1;   // 3 v_mfma_f32_16x16x32_bf16 products of 2-way bf16 splits per fp32 product, fp32 accumulate
+constexpr int kNumPrec = 2;
 
 void set_error(const char* fmt, ...);
 #define M3G_HIP_CHECK(expr)                                                               \
@@ -171,10 +175,13 @@ struct m3g_plan {
   std::map<std::string, std::vector<float>> params;  // raw state_dict tensors (host)
   std::map<std::string, std::vector<float>> cvals;   // raw constants (host)
   float* d_weights = nullptr;
-  float* d_mfma_fwd = nullptr;   // [num_blocks][MfmaFwdLayout.total]
-  float* d_mfma_rev = nullptr;   // [num_blocks][MfmaRevLayout.total]
-  float* d_mfma_revf = nullptr;  // [num_blocks][MfmaRevFusedLayout.total]
-  float* d_node_img = nullptr;   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
+  // MFMA weight images, one set per precision mode (same layouts and sizes: an fp32 image is as large as a bf16 hi + lo pair)
+  float* d_mfma_fwd[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][MfmaFwdLayout.total]
+  float* d_mfma_rev[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][MfmaRevLayout.total]
+  float* d_mfma_revf = nullptr;  // [num_blocks][MfmaRevFusedLayout.total] (bf16x3 dual-use images)
+  float* d_node_img[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
+  int precision = m3g::kPrecF32; // option "precision"
+  int device = -1;               // HIP device the plan's buffers live on (set by m3g_plan_commit)
   float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as bf16x3 chain images (k_readout_mfma)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
@@ -351,6 +358,9 @@ void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s);
 // pack_mfma.hip / edge_mfma.hip
 int pack_mfma_images(m3g_plan* plan);
+void free_mfma_images(m3g_plan* plan);
+// the fused reverse kernel (dual-use bf16 images) exists for the bf16x3 mode; fp32 runs the node-MLP + edge-MLP kernel pair
+inline bool fused_reverse(const m3g_plan* plan) { return plan->edge_kernel == 1 && plan->rev_kernel == 1 && plan->precision == kPrecBf16x3; }
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s);
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
                               hipStream_t s);

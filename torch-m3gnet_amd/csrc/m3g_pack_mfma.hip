@@ -120,15 +120,37 @@ static void f32_chain_image(float* img, int OB, int S, F get) {
         img[(ob * S + s) * 64 + lane] = get(ob * 16 + (lane & 15), (s >> 2) * 16 + 4 * (lane >> 4) + (s & 3));
 }
 
+// chain image of a layer in the given precision mode: bf16x3 hi/lo pair or exact fp32 (KS 32-wide k-steps = 8*KS fp32 k-steps)
+template <class F>
+static void chain_image_p(int prec, float* img, int OB, int KS, F get) {
+  if (prec == kPrecBf16x3) chain_image(img, OB, KS, get);
+  else f32_chain_image(img, OB, 8 * KS, get);
+}
+
+void free_mfma_images(m3g_plan* plan) {
+  auto drop = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  for (int prec = 0; prec < kNumPrec; ++prec) { drop(plan->d_mfma_fwd[prec]); drop(plan->d_mfma_rev[prec]); drop(plan->d_node_img[prec]); }
+  drop(plan->d_mfma_revf);
+  drop(plan->d_readout_img);
+}
+
+static int upload(float*& dst, const std::vector<float>& host) {
+  if (!dst) M3G_HIP_CHECK(hipMalloc((void**)&dst, host.size() * sizeof(float)));
+  M3G_HIP_CHECK(hipMemcpy(dst, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  return M3G_OK;
+}
+
+// (called by m3g_plan_commit with the device idle; buffers are allocated once per plan and device and overwritten on recommit)
 int pack_mfma_images(m3g_plan* plan) {
   const m3g_config& cfg = plan->cfg;
   const int D = cfg.embedding_dim, R = cfg.n_max, C = cfg.l_max * cfg.n_max, B = cfg.num_blocks;
   const MfmaFwdLayout F = mfma_fwd_layout();
   const MfmaRevLayout Rv = mfma_rev_layout();
   const MfmaRevFusedLayout Rf = mfma_rev_fused_layout();
+  std::vector<float> revf((size_t)std::max(B, 1) * Rf.total, 0.f);
+  for (int prec = 0; prec < kNumPrec; ++prec) {
   std::vector<float> node((size_t)std::max(B, 1) * kNodeImgFloats, 0.f);
-  std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.per_block, 0.f),
-      revf((size_t)std::max(B, 1) * Rf.total, 0.f);
+  std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.per_block, 0.f);
   for (int b = 0; b < B; ++b) {
     float* f = fwd.data() + (size_t)b * F.total;
     float* r = rev.data() + (size_t)b * Rv.per_block;  // [edge-MLP image | node-MLP image]
@@ -146,12 +168,13 @@ int pack_mfma_images(m3g_plan* plan) {
     float* rf = revf.data() + (size_t)b * Rf.total;
     direct_image(rf + Rf.tb, 8, kTbSteps, tbw);
     // reverse three-body: rows = c (16), k = 0..127 over (dense f | gate f)
-    chain_image(r + Rv.tbT, 1, 4, [&](int row, int k) -> float {
+    auto tbT = [&](int row, int k) -> float {
       const float* w = k < 64 ? wd : wg;
       int o = k & 63;
       return (row < C && o < D) ? w[(size_t)o * C + row] : 0.f;
-    });
-    memcpy(rf + Rf.tbT, r + Rv.tbT, sizeof(float) * 8 * 4 * 64);
+    };
+    chain_image_p(prec, r + Rv.tbT, 1, 4, tbT);
+    chain_image(rf + Rf.tbT, 1, 4, tbT);
     {  // edge embedding (nn/featurizer.py:128-132, "model.5.linear.weight" [D,R])
       const float* wadj = plan->params.at("model.5.linear.weight").data();
       auto adj = [&](int row, int k) -> float { return (row < D && k < R) ? wadj[(size_t)row * R + k] : 0.f; };
@@ -184,7 +207,7 @@ int pack_mfma_images(m3g_plan* plan) {
       };
       // three bf16x3 chain images of 11 row blocks each (the kernel keeps 11 accumulator blocks per pass)
       for (int g = 0; g < 3; ++g)
-        chain_image(ni + (size_t)g * 11 * 2 * 512, 11, 2, [&](int row, int k) -> float { return row_w(g * 176 + row, k); });
+        chain_image_p(prec, ni + (size_t)g * 11 * 2 * 512, 11, 2, [&](int row, int k) -> float { return row_w(g * 176 + row, k); });
       float* bias = ni + kNodeRowBlocks * 16 * 64;
       for (int row = 0; row < kNodeRowBlocks * 16; ++row) {
         float v = 0.f;
@@ -220,20 +243,20 @@ int pack_mfma_images(m3g_plan* plan) {
               img[(g * 4 + ob) * 64 + lane] = (lane < 16 && o < D) ? (g == 0 ? b2d[o] : b2g[o]) : 0.f;
             }
       };
-      chain_image(f + F.mlp[m].w1c, 8, 2, w1c);
-      chain_image(f + F.mlp[m].w2d, 4, 2, sq(w2d));
-      chain_image(f + F.mlp[m].w2g, 4, 2, sq(w2g));
+      chain_image_p(prec, f + F.mlp[m].w1c, 8, 2, w1c);
+      chain_image_p(prec, f + F.mlp[m].w2d, 4, 2, sq(w2d));
+      chain_image_p(prec, f + F.mlp[m].w2g, 4, 2, sq(w2g));
       bias_image(f + F.mlp[m].b2);
       direct_image(f + F.mlp[m].wl, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
       // reverse images: m == 0 (edge MLP) at offset 0, m == 1 (node MLP) after the edge image
       float* rm = r + (m == 0 ? 0 : Rv.total_e);
-      chain_image(rm + Rv.mlp.w1c, 8, 2, w1c);
-      chain_image(rm + Rv.mlp.w2d, 4, 2, sq(w2d));
-      chain_image(rm + Rv.mlp.w2g, 4, 2, sq(w2g));
+      chain_image_p(prec, rm + Rv.mlp.w1c, 8, 2, w1c);
+      chain_image_p(prec, rm + Rv.mlp.w2d, 4, 2, sq(w2d));
+      chain_image_p(prec, rm + Rv.mlp.w2g, 4, 2, sq(w2g));
       bias_image(rm + Rv.mlp.b2);
-      chain_image(rm + Rv.mlp.w2dT, 4, 2, sqT(w2d));
-      chain_image(rm + Rv.mlp.w2gT, 4, 2, sqT(w2g));
-      chain_image(rm + Rv.mlp.w1cT, 4, 4, [&](int row, int k) -> float { return w1c(k, row); });
+      chain_image_p(prec, rm + Rv.mlp.w2dT, 4, 2, sqT(w2d));
+      chain_image_p(prec, rm + Rv.mlp.w2gT, 4, 2, sqT(w2g));
+      chain_image_p(prec, rm + Rv.mlp.w1cT, 4, 4, [&](int row, int k) -> float { return w1c(k, row); });
       for (int o = 0; o < 64; ++o)
         for (int rr = 0; rr < 4; ++rr) rm[Rv.mlp.wl + o * 4 + rr] = (o < D && rr < R) ? wl[(size_t)o * R + rr] : 0.f;
       // fused reverse kernel: one dual-use image per matrix
@@ -245,8 +268,10 @@ int pack_mfma_images(m3g_plan* plan) {
       direct_image(rf + Rf.mlp[m].wld, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
     }
   }
-  if (plan->d_mfma_fwd) { (void)hipFree(plan->d_mfma_fwd); plan->d_mfma_fwd = nullptr; }
-  if (plan->d_mfma_rev) { (void)hipFree(plan->d_mfma_rev); plan->d_mfma_rev = nullptr; }
+  { int rc = upload(plan->d_mfma_fwd[prec], fwd); if (rc) return rc; }
+  { int rc = upload(plan->d_mfma_rev[prec], rev); if (rc) return rc; }
+  { int rc = upload(plan->d_node_img[prec], node); if (rc) return rc; }
+  }   // precision modes
   {  // readout MLP ("model.<6+2B>.gated.*") as chain images
     const std::string ro = "model." + std::to_string(6 + 2 * B) + ".gated.";
     const float* w1d = plan->params.at(ro + "dense.0.weight").data();
@@ -277,20 +302,9 @@ int pack_mfma_images(m3g_plan* plan) {
       }
       img[ReadoutImg::b3 + g] = plan->params.at(ro + br[g] + ".4.bias")[0];
     }
-    if (plan->d_readout_img) { (void)hipFree(plan->d_readout_img); plan->d_readout_img = nullptr; }
-    M3G_HIP_CHECK(hipMalloc((void**)&plan->d_readout_img, img.size() * sizeof(float)));
-    M3G_HIP_CHECK(hipMemcpy(plan->d_readout_img, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    { int rc = upload(plan->d_readout_img, img); if (rc) return rc; }
   }
-  if (plan->d_node_img) { (void)hipFree(plan->d_node_img); plan->d_node_img = nullptr; }
-  M3G_HIP_CHECK(hipMalloc((void**)&plan->d_node_img, node.size() * sizeof(float)));
-  M3G_HIP_CHECK(hipMemcpy(plan->d_node_img, node.data(), node.size() * sizeof(float), hipMemcpyHostToDevice));
-  if (plan->d_mfma_revf) { (void)hipFree(plan->d_mfma_revf); plan->d_mfma_revf = nullptr; }
-  M3G_HIP_CHECK(hipMalloc((void**)&plan->d_mfma_revf, revf.size() * sizeof(float)));
-  M3G_HIP_CHECK(hipMemcpy(plan->d_mfma_revf, revf.data(), revf.size() * sizeof(float), hipMemcpyHostToDevice));
-  M3G_HIP_CHECK(hipMalloc((void**)&plan->d_mfma_fwd, fwd.size() * sizeof(float)));
-  M3G_HIP_CHECK(hipMalloc((void**)&plan->d_mfma_rev, rev.size() * sizeof(float)));
-  M3G_HIP_CHECK(hipMemcpy(plan->d_mfma_fwd, fwd.data(), fwd.size() * sizeof(float), hipMemcpyHostToDevice));
-  M3G_HIP_CHECK(hipMemcpy(plan->d_mfma_rev, rev.data(), rev.size() * sizeof(float), hipMemcpyHostToDevice));
+  { int rc = upload(plan->d_mfma_revf, revf); if (rc) return rc; }
   return M3G_OK;
 }
 

@@ -119,17 +119,21 @@ __global__ void k_low_word(int64_t n, const uint64_t* __restrict__ keys, int32_t
   if (i < n) out[i] = (int32_t)(keys[i] & 0xffffffffu);
 }
 
-// active-edge compaction: flag -> exclusive scan -> scatter; compacted row pointers and partner lists
-__global__ void k_active_flags(int64_t E, const int32_t* __restrict__ t1_ptr, int32_t* flag) {
+// active-edge compaction: flag -> exclusive scan -> scatter; compacted row pointers and partner lists.
+// An edge is active when it appears in EITHER column of triplet_edge_index: the reference's gather + scatter_sum
+// (nn/interaction.py:188-217) accepts any list of (e1, e2) pairs, also one-sided or filtered ones in which an edge is
+// only ever a partner e2 -- it then has no aggregate of its own but still needs its row (q, u, dL/dg) in the compacted arrays.
+__global__ void k_active_flags(int64_t E, const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ t2_ptr, int32_t* flag) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e <= E) flag[e] = e < E && t1_ptr[e + 1] > t1_ptr[e] ? 1 : 0;
+  if (e <= E) flag[e] = e < E && (t1_ptr[e + 1] > t1_ptr[e] || t2_ptr[e + 1] > t2_ptr[e]) ? 1 : 0;
 }
-__global__ void k_active_scatter(int64_t N, int64_t E, const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ scan,
+__global__ void k_active_scatter(int64_t N, int64_t E, const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ t2_ptr,
+                                 const int32_t* __restrict__ scan,
                                  const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst, int32_t* act_list,
                                  int32_t* act_dst, int32_t* act_id, int32_t* arow_ptr, int32_t* n_act) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e < E) {
-    const bool active = t1_ptr[e + 1] > t1_ptr[e];
+    const bool active = t1_ptr[e + 1] > t1_ptr[e] || t2_ptr[e + 1] > t2_ptr[e];
     act_id[e] = active ? scan[e] : -1;
     if (active) { act_list[scan[e]] = (int32_t)e; act_dst[scan[e]] = dst[e]; }
   }
@@ -241,9 +245,9 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
     hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, keysB, ptr);
   }
   // compaction of the edges that take part in triplets (act_scan doubles as the flag array before the scan)
-  hipLaunchKernelGGL(k_active_flags, grid(E + 1), dim3(TPB), 0, s, E, t.t1_ptr, t.act_scan);
+  hipLaunchKernelGGL(k_active_flags, grid(E + 1), dim3(TPB), 0, s, E, t.t1_ptr, t.t2_ptr, t.act_scan);
   M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, t.act_scan, t.act_scan, (int)(E + 1), s));
-  hipLaunchKernelGGL(k_active_scatter, grid(std::max(E, N) + 1), dim3(TPB), 0, s, N, E, t.t1_ptr, t.act_scan, t.row_ptr, t.dst, t.act_list,
+  hipLaunchKernelGGL(k_active_scatter, grid(std::max(E, N) + 1), dim3(TPB), 0, s, N, E, t.t1_ptr, t.t2_ptr, t.act_scan, t.row_ptr, t.dst, t.act_list,
                      t.act_dst, t.act_id, t.arow_ptr, t.n_act);
   hipLaunchKernelGGL(k_tb_windows, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t2_ptr,
                      t.tb_win);
@@ -257,5 +261,16 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   if (host_flags) {
     M3G_HIP_CHECK(hipMemcpyAsync(host_flags, t.flags, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   }
+  return M3G_OK;
+}
+
+extern "C" int m3g_topology_active_edges(int64_t N, int64_t E, int64_t T, int64_t S, const void* topo_buf, int64_t* host_count, void* stream_) {
+  if (!topo_buf || !host_count) { set_error("m3g_topology_active_edges: null argument"); return M3G_ERR_VALUE; }
+  hipStream_t s = (hipStream_t)stream_;
+  Topo t = topo_carve(N, E, T, S, const_cast<void*>(topo_buf));
+  int32_t a = 0;
+  M3G_HIP_CHECK(hipMemcpyAsync(&a, t.n_act, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  M3G_HIP_CHECK(hipStreamSynchronize(s));
+  *host_count = a;
   return M3G_OK;
 }

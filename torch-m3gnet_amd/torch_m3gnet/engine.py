@@ -4,6 +4,7 @@ stream only."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -55,6 +56,10 @@ class Engine:
         self.plan = C.c_void_p()
         _lib.check(self.lib.m3g_plan_create(C.byref(self.cfg), C.byref(self.plan)))
         self._sig = None
+        self.precision = "fp32"
+        env_prec = os.environ.get("M3G_PRECISION")   # run a whole test suite in the other mode without touching it
+        if env_prec:
+            self.set_precision(env_prec)
         self._workspace = None
         self._graph_replay = False
         self._out_cache = {}
@@ -68,8 +73,10 @@ class Engine:
             pass
 
     # ---------------------------------------------------------------- parameters
-    def _signature(self):
-        sig = [(p.data_ptr(), p._version) for p in self.seq.parameters()]
+    def _signature(self, dev):
+        # the plan's device buffers live on the device it was committed under: a change of device is a change of plan state
+        sig = [("device", dev.index if dev.index is not None else torch.cuda.current_device())]
+        sig += [(p.data_ptr(), p._version) for p in self.seq.parameters()]
         for m in self.tb[:1]:
             sig.append((m.nsb.factors.data_ptr(), m.nsb.factors._version))
         e = self.atom_ref.elemental_energies
@@ -96,6 +103,16 @@ class Engine:
         for name, arr in consts.items():
             _lib.check(lib.m3g_plan_set_const(plan, name.encode(), arr.ctypes.data, arr.size))
         _lib.check(lib.m3g_plan_commit(plan))
+
+    PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
+    def set_precision(self, name: str) -> None:
+        """Arithmetic of the dense gated-MLP products: "fp32" (default: exact fp32 MFMA products, the reference's arithmetic)
+        or "bf16x3" (three bf16 split products per fp32 product, fp32 accumulate; faster, ~2^-16 product error)."""
+        if name not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}, got {name!r}")
+        self.set_option("precision", self.PRECISIONS[name])
+        self.precision = name
 
     def set_option(self, name: str, value: int) -> None:
         """Engine options, e.g. set_option("edge_kernel", 0) selects the vector-ALU baseline kernels.
@@ -126,7 +143,7 @@ class Engine:
         pos = graph[K.POS]
         M._require_cuda(pos, K.POS)
         dev = pos.device
-        sig = self._signature()
+        sig = self._signature(dev)
         if sig != self._sig:
             with torch.cuda.device(dev):
                 self.commit()

@@ -109,6 +109,13 @@ class _Topology:
         if flags[0] & 4:
             raise ValueError("triplet_edge_index pairs edges that do not share a centre atom")
 
+    def n_active(self) -> int:
+        """Edges that take part in a triplet (rows of the three-body arrays)."""
+        n = C.c_int64()
+        with torch.cuda.device(self.buf.device):
+            _lib.check(_lib.load_library().m3g_topology_active_edges(self.N, self.E, self.T, self.S, _ptr(self.buf), C.byref(n), _stream()))
+        return int(n.value)
+
     @staticmethod
     def signature(graph):
         sig = []
