@@ -17,6 +17,8 @@ from torch_m3gnet.model.build import build_model  # noqa: E402
 torch.manual_seed(0)
 model = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
 g = fcc_cu_graph(10, 10, 25).to("cuda")
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+model.engine.set_precision(prec)
 model(g)
 eng = model.engine
 eng.set_option("stamps", 1)
@@ -26,8 +28,9 @@ torch.cuda.synchronize()
 buf = np.zeros(256 * 16 * 12, dtype=np.uint64)
 _lib.check(eng.lib.m3g_debug_read_stamps(eng.plan, buf.ctypes.data))
 s = buf.reshape(256, 16, 12).astype(np.float64)
-names = ["tile loads", "three-body MLP", "e: table gather", "e: layer-1 chain", "e: P1 store+SiLU", "e: layer-2+gating",
-         "e2 store", "n: table gather", "n: layer-1 chain", "n: P1 store+SiLU", "n: layer-2+gating", "msg store"]
+names = ["tile loads", "three-body MLP", "e: table gather", "e: both layers", "(unused)", "e: gating",
+         "e2 residual+store", "n: table gather", "n: both layers", "(unused)", "n: gating", "message sums"]
+print("precision", prec)
 tot = s.sum(-1)
 print("cycles per wave (mean / min / max over 4096 waves):", tot.mean(), tot.min(), tot.max())
 tiles_per_wave = 26250 / 4096

@@ -14,7 +14,11 @@ import bench  # noqa: E402
 
 model = bench.default_model(torch.device("cuda"))
 cells = tuple(int(v) for v in os.environ.get("M3G_CELLS", "10 10 25").split())
-graph = bench.build_workload(cells, 0, torch.device("cuda"))
+from helpers import fcc_cu_graph  # noqa: E402
+
+graph = fcc_cu_graph(*cells, seed=0).to("cuda")
+if os.environ.get("M3G_PRECISION"):
+    model.engine.set_precision(os.environ["M3G_PRECISION"])
 opt, vals = sys.argv[1], [int(v) for v in sys.argv[2:]]
 model(graph, forces=True, extras=False)
 stream = torch.cuda.Stream() if os.environ.get("M3G_OWN_STREAM") else torch.cuda.current_stream()

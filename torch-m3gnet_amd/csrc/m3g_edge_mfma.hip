@@ -42,9 +42,13 @@ constexpr int kWaves = M3G_WAVES_FWD;
 #define M3G_WAVES_REV_FUSED 8   // 2 waves per SIMD, 256 VGPRs, no spills (12 waves: 168 VGPRs and ~120 spilled, slower)
 #endif
 constexpr int kWavesRevFused = M3G_WAVES_REV_FUSED;
-constexpr int kWavesRev = 12;   // reverse kernels hold layer-1 pre-activations across the recompute: 3 per SIMD (<= 168 VGPRs)
+#ifndef M3G_WAVES_REV
+#define M3G_WAVES_REV 12
+#endif
+constexpr int kWavesRev = M3G_WAVES_REV;   // reverse kernels hold layer-1 pre-activations across the recompute: 3 per SIMD (<= 168 VGPRs)
 constexpr int kTileEdges = 16;
 constexpr int kTileFloats = 4 * 64 * 4;     // one 64-feature tile image: [4 blk][64 lanes][4]
+constexpr int kP1TileFloats = 8 * 64 * 4;   // layer-1 pre-activations of one MLP and tile: [8 blk][64 lanes][4]
 // Nothing is saved for the reverse pass except the per-block edge-feature images and node tables: with the dense
 // chains on bf16x3 the matrix work is cheap, and recomputing both layers of both MLPs in the reverse kernels costs less
 // than streaming 2 KB of pre-activations per edge and block through HBM (measured history: DESIGN.md section 4).
@@ -77,15 +81,26 @@ __device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f3
 // exact-fp32 chain on v_mfma_f32_16x16x4_f32: acc[AOFF + ob] += W(ob-th row block, :) . x[XOFF .. XOFF + NB) with the
 // accumulator blocks of x as the B operand (k-step blk*4 + r = register r of block blk; image: f32_chain_image).
 // Bitwise a k-ordered fp32 fmaf chain per output element (cdna_hip_programming.md section 3): the reference's arithmetic.
+// Wave priority: vector and matrix instructions share a SIMD's issue port and the arbiter serves the oldest wave first, so a
+// vector instruction of an older wave that is ready when the matrix pipe frees delays the next MFMA by its 4 issue cycles
+// (tools/mfma_f32_dep_probe.hip: 36 instead of 32 cycles per MFMA with one v_fma per MFMA in the stream, at 1, 2 and 4 waves
+// per SIMD).  Raised priority inside the chains lets the wave that feeds the matrix pipe win that arbitration.
+#ifndef M3G_NO_F32_CHAIN_PRIO
+#define M3G_F32_CHAIN_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define M3G_F32_CHAIN_PRIO(p) ((void)0)
+#endif
 template <int OB, int NB, int XOFF = 0, int AOFF = 0, int NX, int NA>
 __device__ __forceinline__ void chain_f32(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
   static_assert(XOFF + NB <= NX && AOFF + OB <= NA, "chain_f32 operand out of range");
+  M3G_F32_CHAIN_PRIO(1);
   static_for<NB>([&]<int blk>() {
     static_for<4>([&]<int r>() {
       const float b = x[XOFF + blk][r];
       static_for<OB>([&]<int ob>() { acc[AOFF + ob] = mfma16(img[(ob * (4 * NB) + blk * 4 + r) * 64 + lane], b, acc[AOFF + ob]); });
     });
   });
+  M3G_F32_CHAIN_PRIO(0);
 }
 
 // Precision modes of the dense chains (plan option "precision"):
@@ -290,6 +305,7 @@ struct FwdArgs {
   float* e_out;            // same shape, after this block
   float *seg_head, *seg_first;   // per-centre message sums (see seg_scan)
   unsigned long long* stamps;  // diagnostic build: [gridDim.x][kWaves][12] phase cycle sums
+  float* p1_out;               // fp32 mode: saved layer-1 pre-activations [tiles][2 mlp][8 blk][64 lanes][4], else nullptr
 };
 
 // three-body MLP pre-activations: p[0..3] dense, p[4..7] gate
@@ -312,10 +328,13 @@ __device__ __forceinline__ void gather_tables(const float* __restrict__ TA, cons
 
 // both layers of one conv GatedMLP from the edge-feature tile x: p1 = layer-1 pre-activations (dense 0..3, gate 4..7),
 // p2 = layer-2 pre-activations.  `w1c/w2d/w2g/b2` are offsets of the forward images inside `lds`.
+// p1_out != nullptr: the layer-1 pre-activations (table rows + bias + W1c e) are stored for the reverse pass, which then
+// starts from them instead of gathering the tables and recomputing the layer ([8 blk][64 lanes][4] per tile and MLP)
 template <bool KEEP_P1, int PREC>
 __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, int w2g, int b2, const f32x4 (&x)[4], f32x4 (&p1)[8],
-                                            f32x4 (&p2)[8], int lane) {
+                                            f32x4 (&p2)[8], int lane, float* p1_out = nullptr) {
   chain_p<PREC, 8, 2>(lds + w1c, x, p1, lane);
+  if (p1_out) static_for<8>([&]<int ob>() { *(f32x4*)(p1_out + ob * 256) = p1[ob]; });
   bias_step<4, 0>(lds + b2, p2, lane);
   bias_step<4, 4>(lds + b2 + 4 * 64, p2, lane);
   if (KEEP_P1) {
@@ -341,11 +360,11 @@ __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, 
 template <bool ST, int S0, int PREC>
 __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlpFwd& L, int mlp, const FwdArgs& a, int64_t ci,
                                                  int64_t cj, float hb, const f32x4 (&x)[4], f32x4 (&out)[4], int lane,
-                                                 Stamps<ST>& st) {
+                                                 Stamps<ST>& st, float* p1_out) {
   f32x4 p1[8], p2[8];
   gather_tables(a.TA, a.TB, mlp, ci, cj, lane >> 4, p1);
   st.template mark<S0>();      // table gather
-  mlp_preacts<false, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane);
+  mlp_preacts<false, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane, p1_out);
   st.template mark<S0 + 1>();  // both layers
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -419,13 +438,14 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
     }
     st.template mark<1>();  // three-body MLP
     f32x4 out[4];
-    mlp_forward_mfma<ST, 2, PREC>(lds, L.mlp[0], 0, a, ci, cj, hb, x, out, lv, st);  // edge update (nn/conv.py:68-75)
+    float* p1_tile = a.p1_out ? a.p1_out + tile * (2 * kP1TileFloats) + lane * 4 : nullptr;
+    mlp_forward_mfma<ST, 2, PREC>(lds, L.mlp[0], 0, a, ci, cj, hb, x, out, lv, st, p1_tile);  // edge update (nn/conv.py:68-75)
     static_for<4>([&]<int blk>() {
       x[blk] += out[blk];
       *(f32x4*)(e_otile + blk * 256) = x[blk];
     });
     st.template mark<6>();  // e2 residual + store
-    mlp_forward_mfma<ST, 7, PREC>(lds, L.mlp[1], 1, a, ci, cj, hb, x, out, lv, st);  // node message (nn/conv.py:77-89)
+    mlp_forward_mfma<ST, 7, PREC>(lds, L.mlp[1], 1, a, ci, cj, hb, x, out, lv, st, p1_tile ? p1_tile + kP1TileFloats : nullptr);  // node message (nn/conv.py:77-89)
     {  // sum of the messages per centre instead of a [E,64] message array + a node-side pass over it (nn/conv.py:82-88)
       if (edge >= a.E) static_for<4>([&]<int blk>() { out[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; });   // padding lanes of the last tile
       const SegMasks sk = seg_masks((int)ci, lane);
@@ -464,20 +484,42 @@ struct RevArgs {
   float* dp1;      // [E][256]  each kernel writes its MLP's 128 columns
   unsigned long long* stamps;  // diagnostic build only
   float *seg_head, *seg_first;   // fused kernel: per-centre sums of the dp1 rows (see seg_scan)
+  const float* p1;      // saved layer-1 pre-activations of this block (fp32 mode), else nullptr
 };
 
 // reverse of one conv GatedMLP whose edge-feature input tile is x: both layers are recomputed, then
 // d_upd = dL/d(output) is pulled back; returns contrib = W1c^T d_p1 and accumulates dL/dh into dhv.
-template <bool ST, int PREC>
-__device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlpRev& L, int mlp, const RevArgs& a, int64_t edge,
+// SAVED: the forward kernel stored the layer-1 pre-activations (RevArgs::p1): no table gather, no layer-1 recompute, and
+// the MLP's input tile x is not needed at all (fp32 mode, where the matrix pipe is the bound: a quarter of the reverse
+// kernel's MFMAs for 512 B per edge and MLP of extra traffic each way)
+template <bool ST, int PREC, bool SAVED>
+__device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlpRev& L, int mlp, const RevArgs& a, int64_t edge, int64_t tile,
                                                  int64_t ci, int64_t cj, const f32x4& hv, const f32x4 (&x)[4],
                                                  const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane,
                                                  Stamps<ST>& st) {
   const int qd = lane >> 4;
   f32x4 p1[8], d2[8];  // d2: first p2 dense 0..3 / gate 4..7, then d_p2 in place
-  gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
-  st.template mark<2>();   // table gather (+ wait for the tile loads)
-  mlp_preacts<true, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, d2, lane);
+  if constexpr (SAVED) {
+    const float* src = a.p1 + tile * (2 * kP1TileFloats) + mlp * kP1TileFloats + (threadIdx.x & 63) * 4;
+    static_for<8>([&]<int ob>() { p1[ob] = load_tile4(src + ob * 256); });
+    st.template mark<2>();
+    bias_step<4, 0>(lds + L.b2, d2, lane);
+    bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
+    f32x4 hid[8];
+    static_for<8>([&]<int ob>() {
+      static_for<4>([&]<int r>() {
+        const float p = p1[ob][r], sg = fsigmoid(p);
+        hid[ob][r] = p * sg;
+        p1[ob][r] = sg * (1.f + p * (1.f - sg));
+      });
+    });
+    chain_p<PREC, 4, 2, 0, 0>(lds + L.w2d, hid, d2, lane);
+    chain_p<PREC, 4, 2, 4, 4>(lds + L.w2g, hid, d2, lane);
+  } else {
+    gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
+    st.template mark<2>();   // table gather (+ wait for the tile loads)
+    mlp_preacts<true, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, d2, lane);
+  }
   st.template mark<3>();   // recompute both layers
   static_for<4>([&]<int ob>() {
     static_for<4>([&]<int r>() {
@@ -530,8 +572,8 @@ __device__ __forceinline__ void store_dh(float* dh, int64_t edge, int64_t E, f32
 }
 
 // node-message MLP (nn/conv.py:77-89), reverse: d msg[e] = dx_new[centre(e)]
-template <int PREC>
-__global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs a, MfmaRevLayout L) {
+template <int PREC, bool SAVED = false>
+__global__ void __launch_bounds__(64 * kWavesRev) k_edge_rev_node_mlp(RevArgs a, MfmaRevLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kRevMlpFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevMlpFloats);
   load_image(lds, a.img, kRevMlpFloats, q_head);
@@ -562,10 +604,10 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
       static_for<4>([&]<int blk>() {
         dmsg[blk] = *(const f32x4*)(xrow + blk * 16);
-        x[blk] = *(const f32x4*)(e_tile + blk * 256);     // e2: the node MLP's input
+        if (!SAVED) x[blk] = *(const f32x4*)(e_tile + blk * 256);     // e2: the node MLP's input
       });
       Stamps<false> st0;
-      mlp_reverse_mfma<false, PREC>(lds, L.mlp, 1, a, edge, ci, cj, hv, x, dmsg, contrib, dhv, lv, st0);
+      mlp_reverse_mfma<false, PREC, SAVED>(lds, L.mlp, 1, a, edge, tile, ci, cj, hv, x, dmsg, contrib, dhv, lv, st0);
     }
     static_for<4>([&]<int blk>() { *(f32x4*)(dcn_tile + blk * 256) = contrib[blk]; });
     store_dh(a.dh, edge, a.E, dhv, qd);
@@ -576,8 +618,8 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_node_mlp(RevArgs
 }
 
 // edge-update MLP (nn/conv.py:68-75) + three-body gated update (nn/interaction.py:220-221), reverse
-template <int TBS, bool ST = false, int PREC = kPrecBf16x3>
-__global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs a, MfmaRevLayout L) {
+template <int TBS, bool ST = false, int PREC = kPrecBf16x3, bool SAVED = false>
+__global__ void __launch_bounds__(64 * kWavesRev) k_edge_rev_edge_mlp(RevArgs a, MfmaRevLayout L) {
   Stamps<ST> st;
   __shared__ __attribute__((aligned(16))) float lds[kRevEdgeFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevEdgeFloats);
@@ -609,11 +651,14 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
     static_for<TBS>([&]<int s>() { mb[s] = arow >= 0 ? a.m[(int64_t)arow * kCP + 4 * s + qd] : 0.f; });
     f32x4 de[4], contrib[4];
     {
-      // recompute e1 = e_in + three-body gated update: the edge MLP's input
-      f32x4 x[4], p[8];
-      static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
-      tb_preact<TBS>(lds + L.tb, mb, p, lv);
-      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
+      // recompute e1 = e_in + three-body gated update: the edge MLP's input (not needed when its layer 1 was saved)
+      f32x4 x[4];
+      if constexpr (!SAVED) {
+        f32x4 p[8];
+        static_for<4>([&]<int blk>() { x[blk] = *(const f32x4*)(e_tile + blk * 256); });
+        tb_preact<TBS>(lds + L.tb, mb, p, lv);
+        static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
+      }
       st.template mark<1>();   // tile loads + three-body recompute
       // dL/d e2 = what flows in from later blocks + the node MLP's contribution (both loaded here, at the tile start)
       const float* dcn_tile = a.dcn + tile * kTileFloats + lane * 4;
@@ -622,7 +667,7 @@ __global__ void __launch_bounds__(64 * kWavesRev, 3) k_edge_rev_edge_mlp(RevArgs
       } else {
         static_for<4>([&]<int blk>() { de[blk] = *(const f32x4*)(de_tile + blk * 256) + *(const f32x4*)(dcn_tile + blk * 256); });
       }
-      mlp_reverse_mfma<ST, PREC>(lds, L.mlp, 0, a, edge, ci, cj, hv, x, de, contrib, dhv, lv, st);
+      mlp_reverse_mfma<ST, PREC, SAVED>(lds, L.mlp, 0, a, edge, tile, ci, cj, hv, x, de, contrib, dhv, lv, st);
     }
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
@@ -1199,13 +1244,13 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
     FwdArgs a{t.E, tiles, plan->d_mfma_fwd[plan->precision] + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], t.act_id,
-              w.e_blk[b], w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps};
+              w.e_blk[b], w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps, saves_p1(plan) ? w.p1_blk[b] : nullptr};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
     const bool first = b == 0 && fused_reverse(plan);   // the fused reverse kernel recomputes e0 as well: no embedded-edge image at all
-    if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3 && plan->precision == kPrecBf16x3) {
+    if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3) {
       // diagnostic build of the default configuration (same code path as the shipped kernel, block 0 included)
-      if (first) hipLaunchKernelGGL((k_edge_block_mfma<3, true, true>), grid, block, 0, s, a, L);
-      else hipLaunchKernelGGL((k_edge_block_mfma<3, true, false>), grid, block, 0, s, a, L);
+      if (first) { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_block_mfma<3, true, true, PREC>), grid, block, 0, s, a, L)); }
+      else { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_block_mfma<3, true, false, PREC>), grid, block, 0, s, a, L)); }
     } else if (first) {
       M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS, false, true, PREC>), grid, block, 0, s, a, L)));
     } else {
@@ -1246,9 +1291,11 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   if (tiles == 0) return;
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_n = plan->d_mfma_rev[plan->precision] + (size_t)b * L.per_block + L.total_e;
+  const bool saved = saves_p1(plan);
   RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b + 1], nullptr, w.de_soa, w.dcn, 0, w.dm,
-             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr};
-  M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL(k_edge_rev_node_mlp<PREC>, dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L));
+             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr, saved ? w.p1_blk[b] : nullptr};
+  if (saved) { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_rev_node_mlp<PREC, true>), dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L)); }
+  else { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_rev_node_mlp<PREC, false>), dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L)); }
 }
 
 void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
@@ -1258,13 +1305,15 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const MfmaRevLayout L = mfma_rev_layout();
   const float* img_e = plan->d_mfma_rev[plan->precision] + (size_t)b * L.per_block;
   RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], nullptr, w.de_soa, w.dcn,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps, nullptr, nullptr};
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps, nullptr, nullptr,
+             saves_p1(plan) ? w.p1_blk[b] : nullptr};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
   if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3 && plan->precision == kPrecBf16x3) {  // diagnostic build
     hipLaunchKernelGGL((k_edge_rev_edge_mlp<3, true>), grid, block, 0, s, ae, L);
     return;
   }
-  M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS, false, PREC>), grid, block, 0, s, ae, L)));
+  if (saves_p1(plan)) { M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS, false, PREC, true>), grid, block, 0, s, ae, L))); }
+  else { M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_edge_mlp<TBS, false, PREC, false>), grid, block, 0, s, ae, L))); }
 }
 
 void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
@@ -1274,7 +1323,7 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
   const MfmaRevFusedLayout L = mfma_rev_fused_layout();
   const float* img = plan->d_mfma_revf + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first};
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, nullptr};
   constexpr int WV = kWavesRevFused;
   dim3 grid(grid_for_tiles(tiles)), block(64 * WV);
   if (b > 0) {

@@ -181,6 +181,7 @@ struct m3g_plan {
   float* d_mfma_revf = nullptr;  // [num_blocks][MfmaRevFusedLayout.total] (bf16x3 dual-use images)
   float* d_node_img[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
   int precision = m3g::kPrecF32; // option "precision"
+  int save_p1 = 1;               // option "save_p1" (fp32 mode only): 0 = recompute layer 1 in the reverse kernels (A/B tests)
   int device = -1;               // HIP device the plan's buffers live on (set by m3g_plan_commit)
   float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as bf16x3 chain images (k_readout_mfma)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
@@ -301,6 +302,8 @@ struct Work {
   // MFMA path: tile-SoA images ([tile of 16 edges][4 blk][64 lanes][4]) of the edge features BEFORE each block
   // (e_blk[b]; e_blk[B] = final) and of dL/de, per-block node tables, row-major messages.  No activations saved.
   float* e_blk[kMaxBlocks + 1];
+  float* p1_blk[kMaxBlocks];  // fp32 mode: layer-1 pre-activations of both conv MLPs saved by the forward kernel,
+                              // [tiles][2 mlp][8 blk][64 lanes][4] (the reverse kernels start from them: saves_p1())
   float* TAb[kMaxBlocks];     // [N,4*kDP] per block (the reverse pass recomputes layer 1 from them)
   float* TBb[kMaxBlocks];
   float* de_soa;
@@ -312,7 +315,7 @@ struct Work {
   float* seg_first;           // [N][4*kDP]
   size_t total_bytes;
 };
-Work work_carve(const Consts& c, bool mfma, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
+Work work_carve(const Consts& c, bool mfma, bool save_p1, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
 
 // ---- kernel launchers (each in its own .hip) -----------------------------------------------------------
 // geometry.hip
@@ -360,6 +363,9 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
 int pack_mfma_images(m3g_plan* plan);
 void free_mfma_images(m3g_plan* plan);
 // the fused reverse kernel (dual-use bf16 images) exists for the bf16x3 mode; fp32 runs the node-MLP + edge-MLP kernel pair
+// fp32 mode is bound by the matrix pipe: its forward kernel saves the layer-1 pre-activations of both MLPs (1 KB per edge and
+// block) and the reverse kernels start from them instead of recomputing that layer (a quarter of their MFMAs)
+inline bool saves_p1(const m3g_plan* plan) { return plan->edge_kernel == 1 && plan->precision == kPrecF32 && plan->save_p1 != 0; }
 inline bool fused_reverse(const m3g_plan* plan) { return plan->edge_kernel == 1 && plan->rev_kernel == 1 && plan->precision == kPrecBf16x3; }
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s);
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
