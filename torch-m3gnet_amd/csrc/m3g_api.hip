@@ -649,7 +649,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
       }
       if (mfma && fused_rev) {
         M3G_STAGE(ST_EDGE_REV_FUSED);
-        launch_edge_rev_fused(plan, c, t, w, b, dx_cur, /*de_is_zero=*/b == c.B - 1, s);
+        if (plan->precision == kPrecF32) launch_edge_rev_f32(plan, c, t, w, b, dx_cur, /*de_is_zero=*/b == c.B - 1, s);
+        else launch_edge_rev_fused(plan, c, t, w, b, dx_cur, /*de_is_zero=*/b == c.B - 1, s);
       } else if (mfma) {
         { M3G_STAGE(ST_EDGE_REV_NODE); launch_edge_rev_node_mlp(plan, c, t, w, b, dx_cur, s); }
         M3G_STAGE(ST_EDGE_REV);
@@ -665,7 +666,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         M3G_HIP_CHECK(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
         launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, plan->side_stream);
         M3G_HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
-        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*with_v_term=*/false, s);
+        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*dp1_packed=*/plan->precision == kPrecBf16x3, /*with_v_term=*/false, s);
         M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_join, 0));
         launch_node_reverse_v_term(c, W, wl.blk[b], t, w, w.v[b], dx_alt, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
@@ -673,7 +674,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s); }
         if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
           M3G_STAGE(ST_NODE_REV);
-          launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*with_v_term=*/true, s);
+          launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*dp1_packed=*/fused_rev && plan->precision == kPrecBf16x3,
+                              /*with_v_term=*/true, s);
           float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
         }
       }

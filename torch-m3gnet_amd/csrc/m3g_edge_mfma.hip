@@ -22,310 +22,11 @@
 // (blockIdx % 8) walk a contiguous edge range so their TA/TB rows stay in that XCD's L2.
 // Kernels: k_edge_block_mfma (forward), k_edge_rev_fused (reverse, one launch per block), and the earlier reverse pair
 // k_edge_rev_node_mlp / k_edge_rev_edge_mlp kept behind option rev_kernel = 0 for A/B tests.
-#include <utility>
-
-#include "m3g_device.h"
-#include "m3g_internal.h"
-#include "m3g_dual_chain.h"
-#include "m3g_mfma_common.h"
+#include "m3g_edge_common.h"
 
 namespace m3g {
 
-constexpr int kFwdLdsFloats = 8 * kTbSteps * 64 + 2 * (8 * 4 * 4 * 64 + 2 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 64) + 4 * 64;
-constexpr int kRevMlpFloats = 8 * 4 * 4 * 64 + 4 * (4 * 4 * 4 * 64) + 2 * 4 * 64 + 4 * 8 * 4 * 64 + 64 * 4;   // node-MLP reverse image
-constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;                // + three-body images
-#ifndef M3G_WAVES_FWD
-#define M3G_WAVES_FWD 16        // forward kernel: 16 waves = 4 per SIMD (<= 128 VGPRs)
-#endif
-constexpr int kWaves = M3G_WAVES_FWD;
-#ifndef M3G_WAVES_REV_FUSED
-#define M3G_WAVES_REV_FUSED 8   // 2 waves per SIMD, 256 VGPRs, no spills (12 waves: 168 VGPRs and ~120 spilled, slower)
-#endif
-constexpr int kWavesRevFused = M3G_WAVES_REV_FUSED;
-#ifndef M3G_WAVES_REV
-#define M3G_WAVES_REV 12
-#endif
-constexpr int kWavesRev = M3G_WAVES_REV;   // reverse kernels hold layer-1 pre-activations across the recompute: 3 per SIMD (<= 168 VGPRs)
-constexpr int kTileEdges = 16;
-constexpr int kTileFloats = 4 * 64 * 4;     // one 64-feature tile image: [4 blk][64 lanes][4]
-constexpr int kP1TileFloats = 8 * 64 * 4;   // layer-1 pre-activations of one MLP and tile: [8 blk][64 lanes][4]
-// Nothing is saved for the reverse pass except the per-block edge-feature images and node tables: with the dense
-// chains on bf16x3 the matrix work is cheap, and recomputing both layers of both MLPs in the reverse kernels costs less
-// than streaming 2 KB of pre-activations per edge and block through HBM (measured history: DESIGN.md section 4).
-
-#ifdef M3G_USE_FWD_CHAIN_PRIO
-#define M3G_FWD_CHAIN_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define M3G_FWD_CHAIN_PRIO(p) ((void)0)
-#endif
-// acc[AOFF + ob] += W(ob-th 16-row block, :) . x[XOFF .. XOFF + 2*KS)   (chain image: m3g_pack_mfma.hip)
-template <int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
-__device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
-  static_assert(XOFF + 2 * KS <= NX && AOFF + OB <= NA, "chain operand out of range");
-  const bf16x8* hi_img = reinterpret_cast<const bf16x8*>(img) + lane;
-  const bf16x8* lo_img = hi_img + OB * KS * 64;
-  M3G_FWD_CHAIN_PRIO(1);
-  static_for<KS>([&]<int s>() {
-    bf16x8 bh, bl;
-    split8(x[XOFF + 2 * s], x[XOFF + 2 * s + 1], bh, bl);
-    static_for<OB>([&]<int ob>() {
-      const bf16x8 ah = hi_img[(ob * KS + s) * 64], al = lo_img[(ob * KS + s) * 64];
-      acc[AOFF + ob] = mfma_bf16(ah, bh, acc[AOFF + ob]);
-      acc[AOFF + ob] = mfma_bf16(ah, bl, acc[AOFF + ob]);
-      acc[AOFF + ob] = mfma_bf16(al, bh, acc[AOFF + ob]);
-    });
-  });
-  M3G_FWD_CHAIN_PRIO(0);
-}
-
-// exact-fp32 chain on v_mfma_f32_16x16x4_f32: acc[AOFF + ob] += W(ob-th row block, :) . x[XOFF .. XOFF + NB) with the
-// accumulator blocks of x as the B operand (k-step blk*4 + r = register r of block blk; image: f32_chain_image).
-// Bitwise a k-ordered fp32 fmaf chain per output element (cdna_hip_programming.md section 3): the reference's arithmetic.
-// Wave priority: vector and matrix instructions share a SIMD's issue port and the arbiter serves the oldest wave first, so a
-// vector instruction of an older wave that is ready when the matrix pipe frees delays the next MFMA by its 4 issue cycles
-// (tools/mfma_f32_dep_probe.hip: 36 instead of 32 cycles per MFMA with one v_fma per MFMA in the stream, at 1, 2 and 4 waves
-// per SIMD).  Raised priority inside the chains lets the wave that feeds the matrix pipe win that arbitration.
-#ifndef M3G_NO_F32_CHAIN_PRIO
-#define M3G_F32_CHAIN_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define M3G_F32_CHAIN_PRIO(p) ((void)0)
-#endif
-template <int OB, int NB, int XOFF = 0, int AOFF = 0, int NX, int NA>
-__device__ __forceinline__ void chain_f32(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
-  static_assert(XOFF + NB <= NX && AOFF + OB <= NA, "chain_f32 operand out of range");
-  M3G_F32_CHAIN_PRIO(1);
-  static_for<NB>([&]<int blk>() {
-    static_for<4>([&]<int r>() {
-      const float b = x[XOFF + blk][r];
-      static_for<OB>([&]<int ob>() { acc[AOFF + ob] = mfma16(img[(ob * (4 * NB) + blk * 4 + r) * 64 + lane], b, acc[AOFF + ob]); });
-    });
-  });
-  M3G_F32_CHAIN_PRIO(0);
-}
-
-// Precision modes of the dense chains (plan option "precision"):
-//   kPrecF32     every product on v_mfma_f32_16x16x4_f32 -- exact fp32 products, fp32 accumulate (the reference's arithmetic);
-//   kPrecBf16x3  operands split into two bf16 parts, 3 v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32 accumulate
-//                (relative product error ~2^-16).
-// Both read an image of the same size and offsets (an fp32 image is as large as a bf16 hi + lo pair); KS counts 32-wide
-// k-steps, i.e. 2*KS accumulator blocks of x.
-template <int PREC, int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
-__device__ __forceinline__ void chain_p(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
-  if constexpr (PREC == kPrecBf16x3) chain<OB, KS, XOFF, AOFF>(img, x, acc, lane);
-  else chain_f32<OB, 2 * KS, XOFF, AOFF>(img, x, acc, lane);
-}
-
-// bias image: lanes < 16 of block ob carry b[ob*16 + lane] (built as the A operand of a k-step against a constant one).
-// The accumulator registers of lane (m, q) are rows 4q .. 4q+3 of the block, so the same image read as one 16-byte LDS
-// broadcast per block initialises the accumulators directly -- identical values, no MFMA.
-#ifdef M3G_BIAS_MFMA
-template <int OB, int AOFF, int NA>
-__device__ __forceinline__ void bias_step(const float* img, f32x4 (&acc)[NA], int lane) {
-  const float one = lane < 16 ? 1.f : 0.f;
-  static_for<OB>([&]<int ob>() { acc[AOFF + ob] = mfma16(img[ob * 64 + lane], one, f32x4{0.f, 0.f, 0.f, 0.f}); });
-}
-#else
-template <int OB, int AOFF, int NA>
-__device__ __forceinline__ void bias_step(const float* img, f32x4 (&acc)[NA], int lane) {
-  const int q = lane >> 4;
-  static_for<OB>([&]<int ob>() { acc[AOFF + ob] = *(const f32x4*)(img + ob * 64 + 4 * q); });
-}
-#endif
-
-// Persistent tile queue.  Static over workgroups, dynamic inside one:
-//   * workgroups with the same blockIdx % 8 share an XCD (speed only, never correctness); that label owns one
-//     contiguous eighth of the tiles, cut into equal contiguous chunks, one per workgroup -> the TA/TB rows a
-//     workgroup gathers stay in its L1/L2;
-//   * the 16 waves of a workgroup pull tiles of its chunk from an LDS counter.  A SIMD arbitrates its resident
-//     waves oldest-first, so with equal static shares the old waves finish early and the matrix pipe runs
-//     under-occupied in the tail (measured: waves 0-3 done at 320 k cycles, waves 12-15 at 680 k).
-//     A global atomic head was tried and rejected: its microsecond return sits in front of every tile load on the
-//     in-order vmcnt queue.
-struct TileQueue {
-  int* head;       // LDS counter of this workgroup
-  int64_t base;
-  int count;
-  __device__ TileQueue(int64_t n_tiles, int* lds_head) {
-    const int64_t per_xcd = (n_tiles + 7) / 8;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, wgs = gridDim.x >> 3;
-    const int64_t chunk = (per_xcd + wgs - 1) / wgs;
-    const int64_t lo = (int64_t)xcd * per_xcd + (int64_t)q * chunk;
-    int64_t hi = lo + chunk;
-    const int64_t xcd_end = (int64_t)(xcd + 1) * per_xcd < n_tiles ? (int64_t)(xcd + 1) * per_xcd : n_tiles;
-    if (hi > xcd_end) hi = xcd_end;
-    base = lo;
-    count = hi > lo ? (int)(hi - lo) : 0;
-    head = lds_head;
-  }
-  __device__ __forceinline__ int fetch(int lane) const {
-    int v = 0;
-    if (lane == 0) v = atomicAdd(head, 1);
-    return __builtin_amdgcn_readfirstlane(v);
-  }
-};
-
-// streamed-once tile loads: nontemporal, so they do not evict the node tables the gathers re-use from L2
-// (forward 0.425 -> 0.418 ms, fused reverse 0.892 -> 0.884 per step)
-__device__ __forceinline__ f32x4 load_tile4(const float* p) { return __builtin_nontemporal_load((const f32x4*)p); }
-
-// centre / neighbour atom of this lane's edge in `tile` (clamped for the padding lanes of the last tile)
-__device__ __forceinline__ void load_ends(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t tile, int64_t E,
-                                          int lane, int& ci, int& cj) {
-  const int64_t edge = tile * kTileEdges + (lane & 15);
-  const int64_t ec = edge < E ? edge : E - 1;
-  ci = src[ec];
-  cj = dst ? dst[ec] : 0;
-}
-
-// ---- per-centre sums inside a tile -------------------------------------------------------------------------------
-// The 16 edges of a tile sit on the 16 lanes of a DPP row and edges of one centre are consecutive, so the sum over a
-// centre's edges is a segmented inclusive scan along the row: 4 row_shr steps, each a DPP-sourced FMA with a 0/1 mask
-// (valid because runs are contiguous: equal centres n lanes apart imply equal centres in between).  The last lane of
-// a run then holds the run's sum.
-struct SegMasks {
-  float m1, m2, m4, m8;
-  bool run_end;    // this lane's edge is the last of its run inside the tile
-  bool first_run;  // the run contains the tile's column 0
-};
-template <int N>
-__device__ __forceinline__ int row_shr_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xf, 0xf, false); }
-template <int N>
-__device__ __forceinline__ float row_shr_f(float v) {
-  // bound_ctrl: lanes without a source read 0, which lets the compiler fold the DPP move into the consuming v_fmac
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
-}
-__device__ __forceinline__ SegMasks seg_masks(int ci, int lane) {
-  SegMasks k;
-  k.m1 = row_shr_i<1>(ci, -1) == ci ? 1.f : 0.f;
-  k.m2 = row_shr_i<2>(ci, -1) == ci ? 1.f : 0.f;
-  k.m4 = row_shr_i<4>(ci, -1) == ci ? 1.f : 0.f;
-  k.m8 = row_shr_i<8>(ci, -1) == ci ? 1.f : 0.f;
-  const int next = __builtin_amdgcn_update_dpp(-1, ci, 0x100 + 1, 0xf, 0xf, false);   // row_shl:1 -> lane m+1 (fill -1 at m = 15)
-  k.run_end = next != ci;
-  k.first_run = ci == __builtin_amdgcn_readlane(ci, 0);
-  return k;
-}
-// One scan step for the 16 values of four accumulator blocks as v_fmac_f32 with a DPP source operand: x += dpp(x) * m in
-// one instruction per value.  The compiler never forms that instruction (it SLP-packs the FMAs into v_pk_fma_f32 behind
-// two v_mov_b32_dpp, 1.5 instructions per value and step).  The 16 independent values keep consecutive steps of one
-// value >= 16 instructions apart, so the only DPP read-after-VALU-write hazard (2 wait states) is at the head of a step,
-// against whatever the compiler scheduled before the statement: the leading s_nop covers it (the hazard recogniser
-// does not look inside inline assembly).
-#define M3G_SCAN_LINE(i, SHR) "v_fmac_f32_dpp %" #i ", %" #i ", %16 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#define M3G_SCAN_STEP16(SHR, m)                                                                                            \
-  asm volatile("s_nop 1\n\t" M3G_SCAN_LINE(0, SHR) M3G_SCAN_LINE(1, SHR) M3G_SCAN_LINE(2, SHR) M3G_SCAN_LINE(3, SHR)         \
-                   M3G_SCAN_LINE(4, SHR) M3G_SCAN_LINE(5, SHR) M3G_SCAN_LINE(6, SHR) M3G_SCAN_LINE(7, SHR)                    \
-                       M3G_SCAN_LINE(8, SHR) M3G_SCAN_LINE(9, SHR) M3G_SCAN_LINE(10, SHR) M3G_SCAN_LINE(11, SHR)              \
-                           M3G_SCAN_LINE(12, SHR) M3G_SCAN_LINE(13, SHR) M3G_SCAN_LINE(14, SHR) M3G_SCAN_LINE(15, SHR)        \
-               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),  \
-                 "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])                     \
-               : "v"(m))
-#ifndef M3G_NO_ASM_SCAN
-__device__ __forceinline__ void seg_scan(f32x4 (&v)[4], const SegMasks& k) {
-  float x[16];
-  static_for<16>([&]<int i>() { x[i] = v[i >> 2][i & 3]; });
-  M3G_SCAN_STEP16(1, k.m1);
-  M3G_SCAN_STEP16(2, k.m2);
-  M3G_SCAN_STEP16(4, k.m4);
-  M3G_SCAN_STEP16(8, k.m8);
-  static_for<16>([&]<int i>() { v[i >> 2][i & 3] = x[i]; });
-}
-#endif
-template <int N>
-__device__ __forceinline__ void seg_scan(f32x4 (&v)[N], const SegMasks& k) {
-  static_for<N>([&]<int b>() {
-    static_for<4>([&]<int r>() {
-      float x = v[b][r];
-      x = fmaf(row_shr_f<1>(x), k.m1, x);
-      x = fmaf(row_shr_f<2>(x), k.m2, x);
-      x = fmaf(row_shr_f<4>(x), k.m4, x);
-      x = fmaf(row_shr_f<8>(x), k.m8, x);
-      v[b][r] = x;
-    });
-  });
-}
-// run-end lanes store their run's sum: the tile's first run into seg_head[tile], a run starting mid-tile into
-// seg_first[centre]; row = 4*kDP floats, this call covers blocks [B0, B0+N) of it
-template <int B0, int N>
-__device__ __forceinline__ void seg_store(const f32x4 (&v)[N], const SegMasks& k, float* seg_head, float* seg_first, int64_t tile,
-                                          int64_t ci, int qd) {
-  if (k.run_end) {
-    float* row = (k.first_run ? seg_head + tile * (4 * kDP) : seg_first + ci * (4 * kDP)) + 4 * qd;
-    static_for<N>([&]<int b>() { *(f32x4*)(row + (B0 + b) * 16) = v[b]; });
-  }
-}
-
-// weight image -> LDS with 8 independent 16-byte loads in flight per thread: a plain load-store loop is a chain of
-// dependent L2 round trips (one per blockDim*16 bytes) at the start of every launch
-__device__ __forceinline__ void load_image(float* lds, const float* __restrict__ src, int n_floats, int* lds_head) {
-  constexpr int kBatch = 8;
-  const int n_vec = n_floats >> 2, nt = (int)blockDim.x;
-  for (int base = 0; base < n_vec; base += nt * kBatch) {
-    f32x4 t[kBatch];
-    static_for<kBatch>([&]<int j>() {
-      const int i = base + j * nt + (int)threadIdx.x;
-      t[j] = i < n_vec ? *(const f32x4*)(src + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-    });
-    static_for<kBatch>([&]<int j>() {
-      const int i = base + j * nt + (int)threadIdx.x;
-      if (i < n_vec) *(f32x4*)(lds + 4 * i) = t[j];
-    });
-  }
-  if (threadIdx.x == 0) *lds_head = 0;
-  __syncthreads();
-}
-
-// In-kernel phase stamps (diagnostic build only, never in the shipped kernel): s_memtime deltas summed per
-// wave into a debug buffer that no other code reads (cdna_hip_programming.md section 7, "In-kernel stamps").
-__device__ __forceinline__ unsigned long long stamp_now() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-template <bool ON>
-struct Stamps {
-  unsigned long long last = 0, sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  __device__ __forceinline__ void start() { if (ON) last = stamp_now(); }
-  template <int I>
-  __device__ __forceinline__ void mark() {
-    if (ON) { unsigned long long t = stamp_now(); sum[I] += t - last; last = t; }
-  }
-};
-
 // ---------------------------------------------------------------------------------------------- forward
-struct FwdArgs {
-  int64_t E, tiles;
-  const float* img;        // forward weight image of this block
-  const int32_t *src, *dst;
-  const float *h, *m, *TA, *TB;   // m: three-body aggregate, one row per ACTIVE edge (Topo::act_id)
-  const int32_t* act_id;
-  const float* e_in;       // [tiles][4][64][4] edge features before this block
-  float* e_out;            // same shape, after this block
-  float *seg_head, *seg_first;   // per-centre message sums (see seg_scan)
-  unsigned long long* stamps;  // diagnostic build: [gridDim.x][kWaves][12] phase cycle sums
-  float* p1_out;               // fp32 mode: saved layer-1 pre-activations [tiles][2 mlp][8 blk][64 lanes][4], else nullptr
-};
-
-// three-body MLP pre-activations: p[0..3] dense, p[4..7] gate
-template <int TBS>
-__device__ __forceinline__ void tb_preact(const float* tbimg, const float (&mb)[TBS], f32x4 (&p)[8], int lane) {
-  zero(p);
-  static_for<TBS>([&]<int s>() {
-    const float b = mb[s];
-    static_for<8>([&]<int ob>() { p[ob] = mfma16(tbimg[(ob * kTbSteps + s) * 64 + lane], b, p[ob]); });
-  });
-}
-
-// layer-1 accumulators start from the gathered per-node tables TA[i] + TB[j] (x_i / x_j parts, bias folded)
-__device__ __forceinline__ void gather_tables(const float* __restrict__ TA, const float* __restrict__ TB, int mlp, int64_t ci,
-                                              int64_t cj, int qd, f32x4 (&p1)[8]) {
-  const float* ta = TA + ci * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
-  const float* tb = TB + cj * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
-  static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(ta + ob * 16) + *(const f32x4*)(tb + ob * 16); });
-}
-
 // both layers of one conv GatedMLP from the edge-feature tile x: p1 = layer-1 pre-activations (dense 0..3, gate 4..7),
 // p2 = layer-2 pre-activations.  `w1c/w2d/w2g/b2` are offsets of the forward images inside `lds`.
 // p1_out != nullptr: the layer-1 pre-activations (table rows + bias + W1c e) are stored for the reverse pass, which then
@@ -466,27 +167,6 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
 
 // ---------------------------------------------------------------------------------------------- reverse
 // Two kernels per block (each with its own LDS image): node-MLP reverse, then edge-MLP + three-body reverse.
-struct RevArgs {
-  int64_t E, tiles;
-  const float* img;     // reverse image of this kernel's MLP (edge image also carries the three-body images)
-  const int32_t *src, *dst;
-  const float *h, *m, *dx_new;   // m (and dm below): one row per ACTIVE edge (Topo::act_id)
-  const int32_t* act_id;
-  const float *TA, *TB;   // node tables of this block
-  const float* e_tile;    // node kernel: edge features AFTER the block (input of the node MLP);
-                          // edge / fused kernel: edge features BEFORE the block (three-body update + edge MLP are recomputed)
-  const float* e2_tile;   // fused kernel: edge features AFTER the block
-  float* de_soa;   // edge kernel: in dL/d e after this block (unless de_is_zero), out dL/d e before this block
-  float* dcn;      // node kernel -> edge kernel: the node MLP's contribution to dL/d e2 (tile-SoA)
-  int de_is_zero;  // last block: nothing flows in from later blocks
-  float* dm;       // [E][16]   (edge kernel)
-  float* dh;       // [E][4] slice of this kernel (store only)
-  float* dp1;      // [E][256]  each kernel writes its MLP's 128 columns
-  unsigned long long* stamps;  // diagnostic build only
-  float *seg_head, *seg_first;   // fused kernel: per-centre sums of the dp1 rows (see seg_scan)
-  const float* p1;      // saved layer-1 pre-activations of this block (fp32 mode), else nullptr
-};
-
 // reverse of one conv GatedMLP whose edge-feature input tile is x: both layers are recomputed, then
 // d_upd = dL/d(output) is pulled back; returns contrib = W1c^T d_p1 and accumulates dL/dh into dhv.
 // SAVED: the forward kernel stored the layer-1 pre-activations (RevArgs::p1): no table gather, no layer-1 recompute, and
@@ -551,24 +231,6 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
   zero(contrib);
   chain_p<PREC, 4, 4>(lds + L.w1cT, dp1, contrib, lane);
   st.template mark<6>();   // dp1 stores + layer-1 transposed chain
-}
-
-// x summed over the four lane quarters (lanes l, l^16, l^32, l^48), result in every lane.  v_permlane16/32_swap
-// are VALU moves (gfx950); the ds_bpermute behind __shfl_xor costs an LDS round trip per call.
-__device__ __forceinline__ float sum_lane_quarters(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
-  auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows {1,3} of vdst <-> rows {0,2} of src
-  const float y = __builtin_bit_cast(float, (unsigned)r16[0]) + __builtin_bit_cast(float, (unsigned)r16[1]);
-  const unsigned v = __builtin_bit_cast(unsigned, y);
-  auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // lanes 32-63 of vdst <-> lanes 0-31 of src
-  return __builtin_bit_cast(float, (unsigned)r32[0]) + __builtin_bit_cast(float, (unsigned)r32[1]);
-}
-
-__device__ __forceinline__ void store_dh(float* dh, int64_t edge, int64_t E, f32x4 dhv, int qd) {
-  // the four lane quarters hold disjoint feature sets of the same edge: combine, then quarter 0 owns the edge.
-  // Store-only into this kernel's slice: a read-modify-write here would queue its load behind the dp1 stores.
-  static_for<4>([&]<int rr>() { dhv[rr] = sum_lane_quarters(dhv[rr]); });
-  if (qd == 0 && edge < E) *(f32x4*)(dh + edge * kRP) = dhv;
 }
 
 // node-message MLP (nn/conv.py:77-89), reverse: d msg[e] = dx_new[centre(e)]
@@ -1001,213 +663,6 @@ __global__ void __launch_bounds__(256) k_embed_edges_reverse_soa(int64_t E, int6
   if (qd == 0 && edge < E) *(f32x4*)(dh + edge * kRP) = f32x4{d0, d1, d2, d3};   // this kernel's own slice
 }
 
-// ---------------------------------------------------------------------------------------------- node tables
-// S2 on the matrix pipe: [TA | TB | v]^T (528 rows) = W (528 x 64) . x^T (64 x 16 atoms) per 16-atom tile, bf16x3 chains
-// (fp32 accumulate) like the edge kernels', the whole weight image (135 KB) resident in LDS.  Replaces the vector-ALU k_node_pre, which
-// re-read 128 KB of weights from L2 for every 16 atoms.  x^b = x^(b-1) + the per-centre message sums of block b-1 is
-// formed while the tile is loaded (x_prev != nullptr) and written back for the later stages.
-constexpr int kNodeXPitch = 68;   // floats per staged x row: 64 + 4 keeps 16-byte alignment and spreads the 16 rows over the banks
-template <int PREC>
-__global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
-                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
-                                                       const int32_t* __restrict__ row_ptr, float* __restrict__ x,
-                                                       float* __restrict__ v, float* __restrict__ TA, float* __restrict__ TB,
-                                                       const int64_t* __restrict__ types, const float* __restrict__ emb, int num_types) {
-  __shared__ __attribute__((aligned(16))) float lds[kNodeImgFloats + 4 * 16 * kNodeXPitch];
-  {  // image -> LDS, 16 independent 16-byte loads in flight per thread (a load-store-load chain would pay one L2 round trip
-     // per 4 KB of the 137 KB image)
-    constexpr int kVec = kNodeImgFloats / 4, kBatch = 16;
-    for (int base = 0; base < kVec; base += 256 * kBatch) {
-      f32x4 t[kBatch];
-      static_for<kBatch>([&]<int j>() {
-        const int i = base + j * 256 + (int)threadIdx.x;
-        t[j] = i < kVec ? *(const f32x4*)(img + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      });
-      static_for<kBatch>([&]<int j>() {
-        const int i = base + j * 256 + (int)threadIdx.x;
-        if (i < kVec) *(f32x4*)(lds + 4 * i) = t[j];
-      });
-    }
-  }
-  __syncthreads();
-  const float* bias = lds + kNodeRowBlocks * 16 * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
-  float* xs = lds + kNodeImgFloats + wave * 16 * kNodeXPitch;
-  const int64_t tiles = (N + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    // stage the tile's x rows: lane (m, q) brings features 16q .. 16q+15 of atom m
-    const int64_t atom = tile * 16 + m;
-    const bool live = atom < N;
-    f32x4 xr[4];
-    static_for<4>([&]<int j>() { xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; });
-    if (live) {
-      const float* src = (x_prev ? x_prev : x) + atom * kDP + 16 * q;
-      if (types) {   // block 0: x^0 = atom embedding row (nn/featurizer.py:99-103), formed and stored here
-        int64_t ty = types[atom];
-        ty = ty < 0 ? 0 : (ty >= num_types ? num_types - 1 : ty);
-        src = emb + ty * kDP + 16 * q;
-      }
-      static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
-      if (types) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
-      if (x_prev) {
-        const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
-        if (r1 > r0) {
-          if (r0 & 15) static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_first + atom * (4 * kDP) + 16 * q + 4 * j); });
-          for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
-            static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
-        }
-        static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
-      }
-    }
-    static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
-    // (only this wave reads xs: LDS operations of a wave complete in order)
-    // x as accumulator-layout blocks: lane (m, q) holds features blk*16 + 4q + {0..3} of atom m
-    f32x4 xb[4];
-    static_for<4>([&]<int blk>() { xb[blk] = *(const f32x4*)(xs + m * kNodeXPitch + blk * 16 + 4 * q); });
-    int lv = lane;
-    asm volatile("" : "+v"(lv));   // keep the image reads inside the tile loop
-    static_for<3>([&]<int g>() {   // 11 row blocks per pass: bf16x3 chains like the edge kernels' (fp32 accumulate)
-      f32x4 acc[11];
-      static_for<11>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (11 * g + j) * 16 + 4 * q); });
-      chain_p<PREC, 11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv);
-      if (live) {
-        static_for<11>([&]<int j>() {
-          constexpr int ob = 11 * g + j;
-          if (ob < 16) *(f32x4*)(TA + atom * (4 * kDP) + ob * 16 + 4 * q) = acc[j];
-          else if (ob < 32) *(f32x4*)(TB + atom * (4 * kDP) + (ob - 16) * 16 + 4 * q) = acc[j];
-          else {
-            f32x4 o;
-            static_for<4>([&]<int r>() { o[r] = 4 * q + r < C ? fsigmoid(acc[j][r]) : 0.f; });
-            *(f32x4*)(v + atom * kCP + 4 * q) = o;
-          }
-        });
-      }
-    });
-  }
-}
-
-// ---------------------------------------------------------------------------------------------- readout
-// S5 (nn/readout.py:39-58) and its reverse on the matrix pipe, per 16-atom tile: both layers of the dense and the gate
-// branch as exact-fp32 MFMA chains (this stage seeds the reverse pass), the final 64 -> 1 products as lane-local dots + a lane-quarter sum, then (forces wanted) the
-// transposed chains back to dE/dx.  All seven weight images (130 KB) resident in LDS; x^B = x^(B-1) + per-centre message
-// sums of the last block is formed while the tile is loaded.  Replaces the vector-ALU k_readout on the MFMA path.
-__global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const float* __restrict__ img, const float* __restrict__ elemental,
-                                                      const int64_t* __restrict__ types, const float* __restrict__ x_prev,
-                                                      const float* __restrict__ seg_head, const float* __restrict__ seg_first,
-                                                      const int32_t* __restrict__ row_ptr, float* __restrict__ x,
-                                                      float* __restrict__ scaled_atomic, float* __restrict__ dx,
-                                                      float* __restrict__ scaled_total, int64_t S) {
-  __shared__ __attribute__((aligned(16))) float lds[ReadoutImg::total + 4 * 16 * kNodeXPitch];
-  // the per-structure sums are accumulated with atomics by the next kernel: cleared here instead of a memset launch
-  if (blockIdx.x == 0) for (int64_t i = threadIdx.x; i < S; i += blockDim.x) scaled_total[i] = 0.f;
-  {
-    constexpr int kVec = ReadoutImg::total / 4, kBatch = 16;
-    for (int base = 0; base < kVec; base += 256 * kBatch) {
-      f32x4 t[kBatch];
-      static_for<kBatch>([&]<int j>() {
-        const int i = base + j * 256 + (int)threadIdx.x;
-        t[j] = i < kVec ? *(const f32x4*)(img + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      });
-      static_for<kBatch>([&]<int j>() {
-        const int i = base + j * 256 + (int)threadIdx.x;
-        if (i < kVec) *(f32x4*)(lds + 4 * i) = t[j];
-      });
-    }
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
-  float* xs = lds + ReadoutImg::total + wave * 16 * kNodeXPitch;
-  const int64_t tiles = (N + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t atom = tile * 16 + m;
-    const bool live = atom < N;
-    f32x4 xr[4];
-    static_for<4>([&]<int j>() { xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; });
-    if (live) {
-      const float* src = (x_prev ? x_prev : x) + atom * kDP + 16 * q;
-      static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
-      if (x_prev) {
-        const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
-        if (r1 > r0) {
-          if (r0 & 15) static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_first + atom * (4 * kDP) + 16 * q + 4 * j); });
-          for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
-            static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
-        }
-        static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
-      }
-    }
-    static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
-    f32x4 xb[4];
-    static_for<4>([&]<int blk>() { xb[blk] = *(const f32x4*)(xs + m * kNodeXPitch + blk * 16 + 4 * q); });
-    int lv = lane;
-    asm volatile("" : "+v"(lv));
-    // layer 1 (dense blocks 0-3, gate 4-7): p1 -> hidden, p1 keeps SiLU'
-    f32x4 p1[8], hid[8];
-    static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(lds + ReadoutImg::b1 + ob * 16 + 4 * q); });
-    chain_f32<8, 4>(lds + ReadoutImg::w1, xb, p1, lv);
-    static_for<8>([&]<int ob>() {
-      static_for<4>([&]<int r>() {
-        const float p = p1[ob][r], sg = fsigmoid(p);
-        hid[ob][r] = p * sg;
-        p1[ob][r] = sg * (1.f + p * (1.f - sg));
-      });
-    });
-    // layer 2
-    f32x4 p2[8];
-    static_for<8>([&]<int ob>() { p2[ob] = *(const f32x4*)(lds + ReadoutImg::b2 + ob * 16 + 4 * q); });
-    chain_f32<4, 4, 0, 0>(lds + ReadoutImg::w2d, hid, p2, lv);
-    chain_f32<4, 4, 4, 4>(lds + ReadoutImg::w2g, hid, p2, lv);
-    // final 64 -> 1 of both branches: lane-local dots over this lane's 16 features, then across the four lane quarters
-    float od = 0.f, og = 0.f;
-    f32x4 w3[8];
-    static_for<8>([&]<int ob>() { w3[ob] = *(const f32x4*)(lds + ReadoutImg::w3 + ob * 16 + 4 * q); });
-    static_for<4>([&]<int ob>() {
-      static_for<4>([&]<int r>() {
-        od += w3[ob][r] * fsilu(p2[ob][r]);
-        og += w3[4 + ob][r] * fsilu(p2[4 + ob][r]);
-      });
-    });
-    od = sum_lane_quarters(od) + lds[ReadoutImg::b3];
-    og = sum_lane_quarters(og) + lds[ReadoutImg::b3 + 1];
-    const float sg = fsigmoid(og);
-    if (live && q == 0) {
-      int64_t ty = types[atom];
-      ty = ty < 0 ? 0 : (ty >= c.num_types ? c.num_types - 1 : ty);
-      scaled_atomic[atom] = elemental[ty] / c.energy_scale + od * sg;
-    }
-    if (dx == nullptr) continue;   // uniform
-    // reverse: dL/d eps = energy_scale
-    const float d_od = c.energy_scale * sg, d_og = c.energy_scale * od * sg * (1.f - sg);
-    f32x4 d2[8];
-    static_for<4>([&]<int ob>() {
-      static_for<4>([&]<int r>() {
-        d2[ob][r] = d_od * w3[ob][r] * fdsilu(p2[ob][r]);
-        d2[4 + ob][r] = d_og * w3[4 + ob][r] * fdsilu(p2[4 + ob][r]);
-      });
-    });
-    f32x4 dp1[8];
-    zero(dp1);
-    chain_f32<4, 4, 0, 0>(lds + ReadoutImg::w2dT, d2, dp1, lv);
-    chain_f32<4, 4, 4, 4>(lds + ReadoutImg::w2gT, d2, dp1, lv);
-    static_for<8>([&]<int ob>() { dp1[ob] *= p1[ob]; });
-    f32x4 dxb[4];
-    zero(dxb);
-    chain_f32<4, 8>(lds + ReadoutImg::w1T, dp1, dxb, lv);
-    if (live) static_for<4>([&]<int blk>() { *(f32x4*)(dx + atom * kDP + blk * 16 + 4 * q) = dxb[blk]; });
-  }
-}
-
-static inline int grid_for_tiles(int64_t tiles) {
-  int64_t wgs = (tiles + kWaves - 1) / kWaves;
-  wgs = (wgs + 7) / 8 * 8;
-  if (wgs < 8) wgs = 8;
-  if (wgs > 256) wgs = 256;
-  return (int)wgs;
-}
-
-static inline int tb_steps_for(int C) { return (C + 3) / 4; }
-static inline int64_t tiles_for(int64_t E) { return (E + kTileEdges - 1) / kTileEdges; }
-
 void launch_rows_to_soa(const float* rows, float* soa, int64_t E, hipStream_t s) {
   int64_t tiles = tiles_for(E);
   if (tiles > 0)
@@ -1227,18 +682,6 @@ void launch_embed_edges_reverse_soa(const float* adj, const float* h, const floa
     hipLaunchKernelGGL(k_embed_edges_reverse_soa, dim3((unsigned)((tiles * 64 + 255) / 256)), dim3(256), 0, s, E, tiles, adj, h, de_soa, dh);
 }
 
-#define M3G_TBS_SWITCH(C_, CALL)                     \
-  switch (tb_steps_for(C_)) {                        \
-    case 1: { constexpr int TBS = 1; CALL; } break;  \
-    case 2: { constexpr int TBS = 2; CALL; } break;  \
-    case 3: { constexpr int TBS = 3; CALL; } break;  \
-    default: { constexpr int TBS = 4; CALL; } break; \
-  }
-
-#define M3G_PREC_SWITCH(P_, CALL)                                      \
-  if ((P_) == kPrecF32) { constexpr int PREC = kPrecF32; CALL; }       \
-  else { constexpr int PREC = kPrecBf16x3; CALL; }
-
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s) {
   const int64_t tiles = tiles_for(t.E);
   const MfmaFwdLayout L = mfma_fwd_layout();
@@ -1257,31 +700,6 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
       M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS, false, false, PREC>), grid, block, 0, s, a, L)));
     }
   }
-}
-
-void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayout& wl, const Topo& t, const int64_t* types,
-                         const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
-                         bool want_grad, hipStream_t s) {
-  if (t.N == 0) (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
-  if (t.N > 0) {
-    const int64_t tiles = (t.N + 15) / 16;
-    const int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
-    hipLaunchKernelGGL(k_readout_mfma, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img, plan->d_weights + wl.elemental, types,
-                       x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic, want_grad ? w.dx : nullptr, scaled_total, t.S);
-  }
-  launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
-}
-
-// types != nullptr (block 0): x is formed from the atom embedding `emb` ([num_types][kDP]) instead of being read
-void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
-                          float* v, float* TA, float* TB, const int64_t* types, const float* emb, hipStream_t s) {
-  if (t.N == 0) return;
-  const int64_t tiles = (t.N + 15) / 16;
-  int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
-  M3G_PREC_SWITCH(plan->precision,
-                  hipLaunchKernelGGL(k_node_pre_mfma<PREC>, dim3(wgs), dim3(256), 0, s, c.C, t.N,
-                                     plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first,
-                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types));
 }
 
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,

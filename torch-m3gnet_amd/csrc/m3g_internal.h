@@ -142,6 +142,24 @@ struct MfmaRevFusedLayout {
   int adjp;  // [64][4] plain copy of W_adj for the dL/dh accumulation
   int total;
 };
+// fused fp32 reverse kernel (m3g_edge_rev_f32.hip): it starts from the saved layer-1 pre-activations, so it needs W2 in both
+// orientations (dual-use fp32 images, m3g_dual_f32.h) but W1c only transposed
+struct MfmaMlpRevF32 {
+  int w2d, w2g;   // dual fp32 images [64][64]
+  int w1cT;       // f32 chain image [4 ob][32 k-steps]: rows = edge feature, k = layer-1 outputs (dense 0-63 | gate 64-127)
+  int b2;         // bias images (as the forward kernel's)
+  int wl;         // [64][4] plain
+  int wld;        // direct [4 ob][64] image of W_l
+};
+struct MfmaRevF32Layout {
+  int tb;    // direct three-body image (forward recompute)
+  int tbT;   // f32 chain image [1][32 k-steps] rows: c
+  MfmaMlpRevF32 mlp[2];   // 0: edge update, 1: node message
+  int adj;   // direct edge-embedding image (block 0)
+  int adjp;  // [64][4] plain copy
+  int total;
+};
+MfmaRevF32Layout mfma_rev_f32_layout();
 // k_node_pre_mfma image: the 528 x 64 matrix [W1a (TA columns 0-255) | W1b (TB columns) | W_sigmoid1 (v, 16 rows)] as three
 // bf16x3 chain images of 11 row blocks (hi + lo parts, the size of an fp32 image), followed by the 528 row biases (b1 for
 // TA, 0 for TB, b_sigmoid1)
@@ -179,6 +197,7 @@ struct m3g_plan {
   float* d_mfma_fwd[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][MfmaFwdLayout.total]
   float* d_mfma_rev[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][MfmaRevLayout.total]
   float* d_mfma_revf = nullptr;  // [num_blocks][MfmaRevFusedLayout.total] (bf16x3 dual-use images)
+  float* d_mfma_revf32 = nullptr;  // [num_blocks][MfmaRevF32Layout.total] (fused fp32 reverse kernel)
   float* d_node_img[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
   int precision = m3g::kPrecF32; // option "precision"
   int save_p1 = 1;               // option "save_p1" (fp32 mode only): 0 = recompute layer 1 in the reverse kernels (A/B tests)
@@ -344,7 +363,8 @@ void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayo
                          const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                          bool want_grad, hipStream_t s);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
-                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool with_v_term, hipStream_t s);
+                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool dp1_packed, bool with_v_term,
+                         hipStream_t s);
 void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,
                                 float* dx_out, hipStream_t s);
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
@@ -362,11 +382,14 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
 // pack_mfma.hip / edge_mfma.hip
 int pack_mfma_images(m3g_plan* plan);
 void free_mfma_images(m3g_plan* plan);
-// the fused reverse kernel (dual-use bf16 images) exists for the bf16x3 mode; fp32 runs the node-MLP + edge-MLP kernel pair
+// one fused reverse kernel per block: k_edge_rev_fused (bf16x3, dual-use bf16 images) or k_edge_rev_f32 (fp32, needs the saved
+// layer-1 pre-activations); otherwise the node-MLP + edge-MLP kernel pair
 // fp32 mode is bound by the matrix pipe: its forward kernel saves the layer-1 pre-activations of both MLPs (1 KB per edge and
 // block) and the reverse kernels start from them instead of recomputing that layer (a quarter of their MFMAs)
 inline bool saves_p1(const m3g_plan* plan) { return plan->edge_kernel == 1 && plan->precision == kPrecF32 && plan->save_p1 != 0; }
-inline bool fused_reverse(const m3g_plan* plan) { return plan->edge_kernel == 1 && plan->rev_kernel == 1 && plan->precision == kPrecBf16x3; }
+inline bool fused_reverse(const m3g_plan* plan) {
+  return plan->edge_kernel == 1 && plan->rev_kernel == 1 && (plan->precision == kPrecBf16x3 || saves_p1(plan));
+}
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s);
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
                               hipStream_t s);
@@ -374,6 +397,8 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
                               bool de_is_zero, hipStream_t s);
 void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
                            bool de_is_zero, hipStream_t s);
+void launch_edge_rev_f32(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
+                         bool de_is_zero, hipStream_t s);
 void launch_embed_edges_soa(const Consts& c, const float* adj_t, const float* h, float* soa, int64_t E, hipStream_t s);
 void launch_embed_edges_reverse_soa(const float* adj, const float* h, const float* de_soa, float* dh_slice, int64_t E, hipStream_t s);
 void launch_embed_nodes_only(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,

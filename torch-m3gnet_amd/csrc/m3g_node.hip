@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
                                                       const float* __restrict__ dgq, const float* __restrict__ v,
                                                       const float* __restrict__ dx_new, float* __restrict__ dx_out,
                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
-                                                      int with_v_term, const int2* __restrict__ in_pair) {
+                                                      int with_v_term, const int2* __restrict__ in_pair, int dp1_packed) {
   __shared__ float4 sA[kNodesRev][64], sB[kNodesRev][64];   // row / in-edge sums of dp1, 256 columns as 64 float4
   __shared__ float tv[kNodesRev][kCP];
   __shared__ float part[4][kNodesRev][kDP];
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
         for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_pair[k + j] : make_int2(-1, -1);
 #endif
 #ifndef M3G_DP1_F32
-        if (seg_head) {   // rows written by the fused reverse kernel: 24-bit values, 12 B per lane (m3g_mfma_common.h: pack24)
+        if (dp1_packed) {   // rows written by the fused bf16x3 reverse kernel: 24-bit values, 12 B per lane (m3g_mfma_common.h: pack24)
           u32x3 pk[kNrBatch];
 #pragma unroll
           for (int j = 0; j < kNrBatch; ++j)
@@ -229,7 +229,13 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
 #endif
 #pragma unroll
         for (int j = 0; j < kNrBatch; ++j) {
-          u[j] = f[j].x >= 0 ? rows[(int64_t)f[j].x * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+          // fp32 rows (fp32 mode, split reverse kernels): read once -> nontemporal, like the packed rows
+          if (f[j].x >= 0) {
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dp1) + (int64_t)f[j].x * 64 + ln);
+            u[j] = make_float4(t[0], t[1], t[2], t[3]);
+          } else {
+            u[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
           // dL/dg holds one row per ACTIVE edge; other edges contribute nothing
           g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
         }
@@ -494,11 +500,12 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
 }
 
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
-                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool with_v_term, hipStream_t s) {
+                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool dp1_packed, bool with_v_term,
+                         hipStream_t s) {
   if (t.N > 0)
     hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge,
                        w.dp1, w.dg, v, dx_new, dx_out, row_sums_in_seg ? w.seg_head : nullptr, row_sums_in_seg ? w.seg_first : nullptr,
-                       with_v_term ? 1 : 0, reinterpret_cast<const int2*>(t.in_pair));
+                       with_v_term ? 1 : 0, reinterpret_cast<const int2*>(t.in_pair), dp1_packed ? 1 : 0);
 }
 
 void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,

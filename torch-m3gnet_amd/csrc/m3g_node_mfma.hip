@@ -1,0 +1,228 @@
+// Node-side stages on the matrix pipe: per-node tables TA / TB / v (k_node_pre_mfma, stage S2) and the readout with its
+// reverse (k_readout_mfma, stage S5).  Split from m3g_edge_mfma.hip (shared device code: m3g_edge_common.h).
+#include "m3g_edge_common.h"
+
+namespace m3g {
+
+// ---------------------------------------------------------------------------------------------- node tables
+// S2 on the matrix pipe: [TA | TB | v]^T (528 rows) = W (528 x 64) . x^T (64 x 16 atoms) per 16-atom tile, bf16x3 chains
+// (fp32 accumulate) like the edge kernels', the whole weight image (135 KB) resident in LDS.  Replaces the vector-ALU k_node_pre, which
+// re-read 128 KB of weights from L2 for every 16 atoms.  x^b = x^(b-1) + the per-centre message sums of block b-1 is
+// formed while the tile is loaded (x_prev != nullptr) and written back for the later stages.
+constexpr int kNodeXPitch = 68;   // floats per staged x row: 64 + 4 keeps 16-byte alignment and spreads the 16 rows over the banks
+template <int PREC>
+__global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
+                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
+                                                       const int32_t* __restrict__ row_ptr, float* __restrict__ x,
+                                                       float* __restrict__ v, float* __restrict__ TA, float* __restrict__ TB,
+                                                       const int64_t* __restrict__ types, const float* __restrict__ emb, int num_types) {
+  __shared__ __attribute__((aligned(16))) float lds[kNodeImgFloats + 4 * 16 * kNodeXPitch];
+  {  // image -> LDS, 16 independent 16-byte loads in flight per thread (a load-store-load chain would pay one L2 round trip
+     // per 4 KB of the 137 KB image)
+    constexpr int kVec = kNodeImgFloats / 4, kBatch = 16;
+    for (int base = 0; base < kVec; base += 256 * kBatch) {
+      f32x4 t[kBatch];
+      static_for<kBatch>([&]<int j>() {
+        const int i = base + j * 256 + (int)threadIdx.x;
+        t[j] = i < kVec ? *(const f32x4*)(img + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      });
+      static_for<kBatch>([&]<int j>() {
+        const int i = base + j * 256 + (int)threadIdx.x;
+        if (i < kVec) *(f32x4*)(lds + 4 * i) = t[j];
+      });
+    }
+  }
+  __syncthreads();
+  const float* bias = lds + kNodeRowBlocks * 16 * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
+  float* xs = lds + kNodeImgFloats + wave * 16 * kNodeXPitch;
+  const int64_t tiles = (N + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    // stage the tile's x rows: lane (m, q) brings features 16q .. 16q+15 of atom m
+    const int64_t atom = tile * 16 + m;
+    const bool live = atom < N;
+    f32x4 xr[4];
+    static_for<4>([&]<int j>() { xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+    if (live) {
+      const float* src = (x_prev ? x_prev : x) + atom * kDP + 16 * q;
+      if (types) {   // block 0: x^0 = atom embedding row (nn/featurizer.py:99-103), formed and stored here
+        int64_t ty = types[atom];
+        ty = ty < 0 ? 0 : (ty >= num_types ? num_types - 1 : ty);
+        src = emb + ty * kDP + 16 * q;
+      }
+      static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
+      if (types) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+      if (x_prev) {
+        const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
+        if (r1 > r0) {
+          if (r0 & 15) static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_first + atom * (4 * kDP) + 16 * q + 4 * j); });
+          for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
+            static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
+        }
+        static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+      }
+    }
+    static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
+    // (only this wave reads xs: LDS operations of a wave complete in order)
+    // x as accumulator-layout blocks: lane (m, q) holds features blk*16 + 4q + {0..3} of atom m
+    f32x4 xb[4];
+    static_for<4>([&]<int blk>() { xb[blk] = *(const f32x4*)(xs + m * kNodeXPitch + blk * 16 + 4 * q); });
+    int lv = lane;
+    asm volatile("" : "+v"(lv));   // keep the image reads inside the tile loop
+    static_for<3>([&]<int g>() {   // 11 row blocks per pass: bf16x3 chains like the edge kernels' (fp32 accumulate)
+      f32x4 acc[11];
+      static_for<11>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (11 * g + j) * 16 + 4 * q); });
+      chain_p<PREC, 11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv);
+      if (live) {
+        static_for<11>([&]<int j>() {
+          constexpr int ob = 11 * g + j;
+          if (ob < 16) *(f32x4*)(TA + atom * (4 * kDP) + ob * 16 + 4 * q) = acc[j];
+          else if (ob < 32) *(f32x4*)(TB + atom * (4 * kDP) + (ob - 16) * 16 + 4 * q) = acc[j];
+          else {
+            f32x4 o;
+            static_for<4>([&]<int r>() { o[r] = 4 * q + r < C ? fsigmoid(acc[j][r]) : 0.f; });
+            *(f32x4*)(v + atom * kCP + 4 * q) = o;
+          }
+        });
+      }
+    });
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- readout
+// S5 (nn/readout.py:39-58) and its reverse on the matrix pipe, per 16-atom tile: both layers of the dense and the gate
+// branch as exact-fp32 MFMA chains (this stage seeds the reverse pass), the final 64 -> 1 products as lane-local dots + a lane-quarter sum, then (forces wanted) the
+// transposed chains back to dE/dx.  All seven weight images (130 KB) resident in LDS; x^B = x^(B-1) + per-centre message
+// sums of the last block is formed while the tile is loaded.  Replaces the vector-ALU k_readout on the MFMA path.
+__global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const float* __restrict__ img, const float* __restrict__ elemental,
+                                                      const int64_t* __restrict__ types, const float* __restrict__ x_prev,
+                                                      const float* __restrict__ seg_head, const float* __restrict__ seg_first,
+                                                      const int32_t* __restrict__ row_ptr, float* __restrict__ x,
+                                                      float* __restrict__ scaled_atomic, float* __restrict__ dx,
+                                                      float* __restrict__ scaled_total, int64_t S) {
+  __shared__ __attribute__((aligned(16))) float lds[ReadoutImg::total + 4 * 16 * kNodeXPitch];
+  // the per-structure sums are accumulated with atomics by the next kernel: cleared here instead of a memset launch
+  if (blockIdx.x == 0) for (int64_t i = threadIdx.x; i < S; i += blockDim.x) scaled_total[i] = 0.f;
+  {
+    constexpr int kVec = ReadoutImg::total / 4, kBatch = 16;
+    for (int base = 0; base < kVec; base += 256 * kBatch) {
+      f32x4 t[kBatch];
+      static_for<kBatch>([&]<int j>() {
+        const int i = base + j * 256 + (int)threadIdx.x;
+        t[j] = i < kVec ? *(const f32x4*)(img + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      });
+      static_for<kBatch>([&]<int j>() {
+        const int i = base + j * 256 + (int)threadIdx.x;
+        if (i < kVec) *(f32x4*)(lds + 4 * i) = t[j];
+      });
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
+  float* xs = lds + ReadoutImg::total + wave * 16 * kNodeXPitch;
+  const int64_t tiles = (N + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t atom = tile * 16 + m;
+    const bool live = atom < N;
+    f32x4 xr[4];
+    static_for<4>([&]<int j>() { xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+    if (live) {
+      const float* src = (x_prev ? x_prev : x) + atom * kDP + 16 * q;
+      static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
+      if (x_prev) {
+        const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
+        if (r1 > r0) {
+          if (r0 & 15) static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_first + atom * (4 * kDP) + 16 * q + 4 * j); });
+          for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
+            static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
+        }
+        static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+      }
+    }
+    static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
+    f32x4 xb[4];
+    static_for<4>([&]<int blk>() { xb[blk] = *(const f32x4*)(xs + m * kNodeXPitch + blk * 16 + 4 * q); });
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    // layer 1 (dense blocks 0-3, gate 4-7): p1 -> hidden, p1 keeps SiLU'
+    f32x4 p1[8], hid[8];
+    static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(lds + ReadoutImg::b1 + ob * 16 + 4 * q); });
+    chain_f32<8, 4>(lds + ReadoutImg::w1, xb, p1, lv);
+    static_for<8>([&]<int ob>() {
+      static_for<4>([&]<int r>() {
+        const float p = p1[ob][r], sg = fsigmoid(p);
+        hid[ob][r] = p * sg;
+        p1[ob][r] = sg * (1.f + p * (1.f - sg));
+      });
+    });
+    // layer 2
+    f32x4 p2[8];
+    static_for<8>([&]<int ob>() { p2[ob] = *(const f32x4*)(lds + ReadoutImg::b2 + ob * 16 + 4 * q); });
+    chain_f32<4, 4, 0, 0>(lds + ReadoutImg::w2d, hid, p2, lv);
+    chain_f32<4, 4, 4, 4>(lds + ReadoutImg::w2g, hid, p2, lv);
+    // final 64 -> 1 of both branches: lane-local dots over this lane's 16 features, then across the four lane quarters
+    float od = 0.f, og = 0.f;
+    f32x4 w3[8];
+    static_for<8>([&]<int ob>() { w3[ob] = *(const f32x4*)(lds + ReadoutImg::w3 + ob * 16 + 4 * q); });
+    static_for<4>([&]<int ob>() {
+      static_for<4>([&]<int r>() {
+        od += w3[ob][r] * fsilu(p2[ob][r]);
+        og += w3[4 + ob][r] * fsilu(p2[4 + ob][r]);
+      });
+    });
+    od = sum_lane_quarters(od) + lds[ReadoutImg::b3];
+    og = sum_lane_quarters(og) + lds[ReadoutImg::b3 + 1];
+    const float sg = fsigmoid(og);
+    if (live && q == 0) {
+      int64_t ty = types[atom];
+      ty = ty < 0 ? 0 : (ty >= c.num_types ? c.num_types - 1 : ty);
+      scaled_atomic[atom] = elemental[ty] / c.energy_scale + od * sg;
+    }
+    if (dx == nullptr) continue;   // uniform
+    // reverse: dL/d eps = energy_scale
+    const float d_od = c.energy_scale * sg, d_og = c.energy_scale * od * sg * (1.f - sg);
+    f32x4 d2[8];
+    static_for<4>([&]<int ob>() {
+      static_for<4>([&]<int r>() {
+        d2[ob][r] = d_od * w3[ob][r] * fdsilu(p2[ob][r]);
+        d2[4 + ob][r] = d_og * w3[4 + ob][r] * fdsilu(p2[4 + ob][r]);
+      });
+    });
+    f32x4 dp1[8];
+    zero(dp1);
+    chain_f32<4, 4, 0, 0>(lds + ReadoutImg::w2dT, d2, dp1, lv);
+    chain_f32<4, 4, 4, 4>(lds + ReadoutImg::w2gT, d2, dp1, lv);
+    static_for<8>([&]<int ob>() { dp1[ob] *= p1[ob]; });
+    f32x4 dxb[4];
+    zero(dxb);
+    chain_f32<4, 8>(lds + ReadoutImg::w1T, dp1, dxb, lv);
+    if (live) static_for<4>([&]<int blk>() { *(f32x4*)(dx + atom * kDP + blk * 16 + 4 * q) = dxb[blk]; });
+  }
+}
+
+void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayout& wl, const Topo& t, const int64_t* types,
+                         const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
+                         bool want_grad, hipStream_t s) {
+  if (t.N == 0) (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
+  if (t.N > 0) {
+    const int64_t tiles = (t.N + 15) / 16;
+    const int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
+    hipLaunchKernelGGL(k_readout_mfma, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img, plan->d_weights + wl.elemental, types,
+                       x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic, want_grad ? w.dx : nullptr, scaled_total, t.S);
+  }
+  launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
+}
+
+// types != nullptr (block 0): x is formed from the atom embedding `emb` ([num_types][kDP]) instead of being read
+void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
+                          float* v, float* TA, float* TB, const int64_t* types, const float* emb, hipStream_t s) {
+  if (t.N == 0) return;
+  const int64_t tiles = (t.N + 15) / 16;
+  int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
+  M3G_PREC_SWITCH(plan->precision,
+                  hipLaunchKernelGGL(k_node_pre_mfma<PREC>, dim3(wgs), dim3(256), 0, s, c.C, t.N,
+                                     plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first,
+                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types));
+}
+
+}  // namespace m3g

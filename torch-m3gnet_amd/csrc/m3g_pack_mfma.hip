@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "m3g_dual_chain.h"
+#include "m3g_dual_f32.h"
 #include "m3g_internal.h"
 
 namespace m3g {
@@ -131,6 +132,7 @@ void free_mfma_images(m3g_plan* plan) {
   auto drop = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   for (int prec = 0; prec < kNumPrec; ++prec) { drop(plan->d_mfma_fwd[prec]); drop(plan->d_mfma_rev[prec]); drop(plan->d_node_img[prec]); }
   drop(plan->d_mfma_revf);
+  drop(plan->d_mfma_revf32);
   drop(plan->d_readout_img);
 }
 
@@ -147,7 +149,8 @@ int pack_mfma_images(m3g_plan* plan) {
   const MfmaFwdLayout F = mfma_fwd_layout();
   const MfmaRevLayout Rv = mfma_rev_layout();
   const MfmaRevFusedLayout Rf = mfma_rev_fused_layout();
-  std::vector<float> revf((size_t)std::max(B, 1) * Rf.total, 0.f);
+  const MfmaRevF32Layout R32 = mfma_rev_f32_layout();
+  std::vector<float> revf((size_t)std::max(B, 1) * Rf.total, 0.f), revf32((size_t)std::max(B, 1) * R32.total, 0.f);
   for (int prec = 0; prec < kNumPrec; ++prec) {
   std::vector<float> node((size_t)std::max(B, 1) * kNodeImgFloats, 0.f);
   std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.per_block, 0.f);
@@ -175,13 +178,17 @@ int pack_mfma_images(m3g_plan* plan) {
     };
     chain_image_p(prec, r + Rv.tbT, 1, 4, tbT);
     chain_image(rf + Rf.tbT, 1, 4, tbT);
+    float* r32 = revf32.data() + (size_t)b * R32.total;   // fused fp32 reverse kernel
+    direct_image(r32 + R32.tb, 8, kTbSteps, tbw);
+    f32_chain_image(r32 + R32.tbT, 1, 32, tbT);
     {  // edge embedding (nn/featurizer.py:128-132, "model.5.linear.weight" [D,R])
       const float* wadj = plan->params.at("model.5.linear.weight").data();
       auto adj = [&](int row, int k) -> float { return (row < D && k < R) ? wadj[(size_t)row * R + k] : 0.f; };
       direct_image(f + F.adj, 4, 1, adj);
       direct_image(rf + Rf.adj, 4, 1, adj);
+      direct_image(r32 + R32.adj, 4, 1, adj);
       for (int o = 0; o < 64; ++o)
-        for (int rr = 0; rr < 4; ++rr) rf[Rf.adjp + o * 4 + rr] = adj(o, rr);
+        for (int rr = 0; rr < 4; ++rr) rf[Rf.adjp + o * 4 + rr] = r32[R32.adjp + o * 4 + rr] = adj(o, rr);
     }
     {  // node tables on the matrix pipe (k_node_pre_mfma): rows = table columns, k = node feature
       float* ni = node.data() + (size_t)b * kNodeImgFloats;
@@ -266,6 +273,13 @@ int pack_mfma_images(m3g_plan* plan) {
       bias_image(rf + Rf.mlp[m].b2);
       memcpy(rf + Rf.mlp[m].wl, rm + Rv.mlp.wl, sizeof(float) * 64 * 4);
       direct_image(rf + Rf.mlp[m].wld, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
+      // fused fp32 reverse kernel: W2 as dual-use fp32 images, W1c transposed only
+      pack_dual32_image(r32 + R32.mlp[m].w2d, 64, sq(w2d));
+      pack_dual32_image(r32 + R32.mlp[m].w2g, 64, sq(w2g));
+      f32_chain_image(r32 + R32.mlp[m].w1cT, 4, 32, [&](int row, int k) -> float { return w1c(k, row); });
+      bias_image(r32 + R32.mlp[m].b2);
+      memcpy(r32 + R32.mlp[m].wl, rm + Rv.mlp.wl, sizeof(float) * 64 * 4);
+      memcpy(r32 + R32.mlp[m].wld, rf + Rf.mlp[m].wld, sizeof(float) * 4 * 64);
     }
   }
   { int rc = upload(plan->d_mfma_fwd[prec], fwd); if (rc) return rc; }
@@ -305,6 +319,7 @@ int pack_mfma_images(m3g_plan* plan) {
     { int rc = upload(plan->d_readout_img, img); if (rc) return rc; }
   }
   { int rc = upload(plan->d_mfma_revf, revf); if (rc) return rc; }
+  { int rc = upload(plan->d_mfma_revf32, revf32); if (rc) return rc; }
   return M3G_OK;
 }
 
