@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate golden vectors by RUNNING THE REFERENCE's own nn code (build container only).
 
-    python tests/golden/generate_golden.py          # writes tests/golden/*.npz
+    python tests/golden/generate_golden.py                       # writes tests/golden/*.npz
+    python tests/golden/generate_golden.py --out DIR --cases cu32  # regenerate some cases elsewhere (tests/test_golden_pin.py)
 
 The reference (`/root/reference/src/torch_m3gnet`) imports four third-party packages that are
 absent from this image (torch_scatter, torchtyping, torch_geometric, pymatgen).  The tiny stand-ins
@@ -22,6 +23,7 @@ Each case is stored in two `factors` modes:
 """
 from __future__ import annotations
 
+import argparse
 import importlib.util
 import math
 import sys
@@ -210,6 +212,12 @@ def save_model(path, model, cfg):
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", type=Path, default=HERE, help="directory the .npz files are written to")
+    ap.add_argument("--cases", nargs="*", default=["cu32", "tio", "alna", "mix"], help="cases to (re)generate")
+    args = ap.parse_args()
+    out_dir, cases = args.out, set(args.cases)
+    out_dir.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(1)  # deterministic reduction order
     out = {}
 
@@ -224,13 +232,15 @@ def main():
 
     for mode in ("ref", "doc"):
         m = make(cfg_default, 0)
-        if mode == "ref":
-            save_model(HERE / "model_default_seed0.npz", m, cfg_default)
-        lat, pos, z = fcc_cu(2, 2, 2)
-        run_case("cu32", m, [single_graph(lat, pos, z, 5.0, 4.0)], mode, out)
-        m = make(cfg_default, 0)
-        lat, pos, z = ti8o24()
-        run_case("tio", m, [single_graph(lat, pos, z, 5.0, 4.0)], mode, out)
+        if mode == "ref" and cases & {"cu32", "tio"}:
+            save_model(out_dir / "model_default_seed0.npz", m, cfg_default)
+        if "cu32" in cases:
+            lat, pos, z = fcc_cu(2, 2, 2)
+            run_case("cu32", m, [single_graph(lat, pos, z, 5.0, 4.0)], mode, out)
+        if "tio" in cases:
+            m = make(cfg_default, 0)
+            lat, pos, z = ti8o24()
+            run_case("tio", m, [single_graph(lat, pos, z, 5.0, 4.0)], mode, out)
 
     # small test model of the reference's conftest
     structs, rc = al_na()
@@ -244,9 +254,11 @@ def main():
         gr["pos"] = (pos + 1e-1 * (rng.random(pos.shape) - 0.5)).astype(np.float32)
         graphs.append(gr)
     for mode in ("ref", "doc"):
+        if "alna" not in cases:
+            break
         m = make(cfg_small, 0)
         if mode == "ref":
-            save_model(HERE / "model_small_seed0.npz", m, cfg_small)
+            save_model(out_dir / "model_small_seed0.npz", m, cfg_small)
         run_case("alna", m, graphs, mode, out)
 
     # scales / elemental energies / mixed species batch
@@ -258,13 +270,15 @@ def main():
         lat, pos, z = random_cell(n_at, 7.3 if seed == 0 else 6.1, seed)
         graphs.append(single_graph(lat, pos, z, 5.0, 4.0))
     for mode in ("ref", "doc"):
+        if "mix" not in cases:
+            break
         m = make(cfg_mix, 3, elemental)
         if mode == "ref":
-            save_model(HERE / "model_mix_seed3.npz", m, cfg_mix)
+            save_model(out_dir / "model_mix_seed3.npz", m, cfg_mix)
         run_case("mix", m, graphs, mode, out)
 
     for name, d in out.items():
-        np.savez_compressed(HERE / f"case_{name}.npz", **d)
+        np.savez_compressed(out_dir / f"case_{name}.npz", **d)
         e = d["out_total_energy"]
         f = d["out_forces"]
         print(f"{name:10s} N={len(d['in_pos']):4d} E={d['in_edge_index'].shape[1]:6d} T={d['in_triplet_edge_index'].shape[1]:7d} "

@@ -84,9 +84,9 @@ def test_reference_fixture_counts():
     assert tei.shape[1] == graph["triplet_edge_index"].shape[1] == 640
     np.testing.assert_allclose(d, 3.0, atol=1e-9)
 
-    def keyset(ei_, sh_):   # the fixture predates the canonical order: compare as sets
-        return sorted(map(tuple, np.concatenate([ei_.T, sh_], 1).tolist()))
-    assert keyset(ei, sh) == keyset(graph["edge_index"].numpy(), graph["edge_cell_shift"].numpy())
+    # the fixture carries the canonical order (centre, image lexicographic, neighbour): element by element
+    np.testing.assert_array_equal(ei, graph["edge_index"].numpy())
+    np.testing.assert_array_equal(sh, graph["edge_cell_shift"].numpy())
     np.testing.assert_array_equal(nti, np.bincount(graph["edge_index"][0].numpy()[graph["triplet_edge_index"][0].numpy()], minlength=6))
 
 

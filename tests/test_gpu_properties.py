@@ -171,10 +171,10 @@ def test_standalone_distance_angle_and_featurizers():
     ang = g[K.TRIPLET_ANGLES]
     assert (ang <= 1).all() and (ang >= -1).all()
     theta_sum = float(torch.arccos(ang.double()).sum()) / np.pi
-    # reference tests/test_invariance.py:69-82.  arccos is ill-conditioned at +-1 (perfectly collinear lattice
-    # triplets): a 1e-7 difference in cos moves one angle by ~4e-4 rad, so the bound is 5e-3 (the cosines
-    # themselves are checked against the reference to 2e-6 in test_gpu_parity.py).
-    assert abs(theta_sum - round(theta_sum)) < 5e-3
+    # reference tests/test_invariance.py:69-82, same bound (atol 1e-4 in units of pi): the reported cosines of collinear
+    # triplets are snapped to exactly +-1 (k_triplet_angles), as the reference's clamp does for the half of them that land
+    # outside [-1, 1]
+    assert abs(theta_sum - round(theta_sum)) < 1e-4
     torch.testing.assert_close(g[K.EDGE_DISTANCES], torch.full_like(g[K.EDGE_DISTANCES], 3.0), rtol=1e-5, atol=1e-5)
     assert g[K.EDGE_WEIGHTS].shape[1] == 3 and torch.isfinite(g[K.EDGE_WEIGHTS]).all()
     # oracle cross-check of the standalone stage outputs
@@ -263,6 +263,29 @@ def test_scales_and_elemental_energies():
     assert rel_err(g[K.TOTAL_ENERGY], o["total_energy"]) < 1e-5
     assert rel_err(g[K.FORCES], o["forces"]) < 1e-4
     assert rel_err(g[K.STRESSES], o["stresses"]) < 1e-4
+
+
+def test_out_of_range_species_raise_and_leading_module_keys_are_published():
+    """The reference raises IndexError from `elemental_energies[atom_types]` (nn/atom_ref.py:27) for a species index outside
+    the model's table; the kernels would otherwise clamp it silently.  With `extras` the fused call also leaves the keys of
+    the leading modules on the graph (scaled_pos, scaled_lattice: nn/scale.py:24-29; elemental_energies: nn/atom_ref.py)."""
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _default_model(num_types=30, length_scale=1.7, elemental_energies=torch.linspace(-1, 1, 30))
+    g = Batch.from_data_list([random_cell_graph(12, 6.0, 3, zmax=30)]).to(DEV)
+    out = model(g)
+    torch.testing.assert_close(out[K.SCALED_POS], g[K.POS] / 1.7)
+    torch.testing.assert_close(out[K.SCALED_LATTICE], g[K.LATTICE] / 1.7)
+    torch.testing.assert_close(out[K.ELEMENTAL_ENERGIES], torch.linspace(-1, 1, 30, device=DEV)[g[K.ATOM_TYPES]])
+    bad = g.clone()
+    bad[K.ATOM_TYPES] = bad[K.ATOM_TYPES].clone()
+    bad[K.ATOM_TYPES][3] = 30
+    with pytest.raises(IndexError):
+        model(bad)
+    bad[K.ATOM_TYPES][3] = -1
+    with pytest.raises(IndexError):
+        model(bad)
 
 
 def test_one_sided_and_filtered_triplet_lists():

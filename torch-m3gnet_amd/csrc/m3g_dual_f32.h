@@ -14,7 +14,9 @@ namespace m3g {
 __host__ __device__ inline int dual32_f(int m) { return (m & 3) | (((m >> 2) & 1) << 4) | (((m >> 3) & 1) << 3); }
 __host__ __device__ inline int dual32_index(int row, int col) { return row * 64 + (col ^ dual32_f(row & 15)); }
 
-#ifndef M3G_NO_F32_CHAIN_PRIO
+#if defined(M3G_F32_STAGGER_PRIO)
+#define M3G_DUAL32_PRIO(p) do { if (p) { const int cls = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)); if (cls == 0) __builtin_amdgcn_s_setprio(3); else if (cls == 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); } else __builtin_amdgcn_s_setprio(0); } while (0)
+#elif !defined(M3G_NO_F32_CHAIN_PRIO)
 #define M3G_DUAL32_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #else
 #define M3G_DUAL32_PRIO(p) ((void)0)

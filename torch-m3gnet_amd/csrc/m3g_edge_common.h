@@ -66,7 +66,17 @@ __device__ __forceinline__ void chain(const float* img, const f32x4 (&x)[NX], f3
 // vector instruction of an older wave that is ready when the matrix pipe frees delays the next MFMA by its 4 issue cycles
 // (tools/mfma_f32_dep_probe.hip: 36 instead of 32 cycles per MFMA with one v_fma per MFMA in the stream, at 1, 2 and 4 waves
 // per SIMD).  Raised priority inside the chains lets the wave that feeds the matrix pipe win that arbitration.
-#ifndef M3G_NO_F32_CHAIN_PRIO
+#if defined(M3G_F32_STAGGER_PRIO)
+// experiment: the waves that share a SIMD (wave ids w, w+4, w+8, ...) enter their chains at different priorities, so two
+// co-running chains do not split the matrix pipe evenly and leave it at the same moment
+__device__ __forceinline__ void f32_chain_prio_on() {
+  const int cls = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  if (cls == 0) __builtin_amdgcn_s_setprio(3);
+  else if (cls == 1) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(1);
+}
+#define M3G_F32_CHAIN_PRIO(p) do { if (p) f32_chain_prio_on(); else __builtin_amdgcn_s_setprio(0); } while (0)
+#elif !defined(M3G_NO_F32_CHAIN_PRIO)
 #define M3G_F32_CHAIN_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #else
 #define M3G_F32_CHAIN_PRIO(p) ((void)0)

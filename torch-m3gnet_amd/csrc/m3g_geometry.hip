@@ -292,7 +292,14 @@ __global__ void __launch_bounds__(256) k_triplet_angles(int64_t T, const int64_t
   if (t >= T) return;
   int64_t e1 = tei[t], e2 = tei[T + t];
   float c = u[e1 * 3] * u[e2 * 3] + u[e1 * 3 + 1] * u[e2 * 3 + 1] + u[e1 * 3 + 2] * u[e2 * 3 + 2];
-  out[t] = fminf(1.f, fmaxf(-1.f, c));
+  c = fminf(1.f, fmaxf(-1.f, c));   // torch.clamp(cos, -1, 1), nn/invariant.py:40
+  // Collinear triplets (a neighbour and its mirror image, or two images of one neighbour) have |cos| = 1 exactly; in fp32
+  // the quotient lands within 2 ulp of it, on either side.  The reference's clamp repairs the outside half of those cases;
+  // the inside half is the same rounding accident, and arccos -- which the reference's own angle test applies,
+  // tests/test_invariance.py:77-82 -- turns 1e-7 there into 4e-4 rad.  Reported angles therefore snap both halves to +-1.
+  // (The energy path keeps its own value: cos enters it only through the polynomials P_l, where 1e-7 is rounding noise.)
+  if (fabsf(c) > 1.f - 2.4e-7f) c = copysignf(1.f, c);
+  out[t] = c;
 }
 
 __global__ void __launch_bounds__(256) k_edge_featurizer(Consts c, int64_t E, const float* __restrict__ d, float* __restrict__ out,

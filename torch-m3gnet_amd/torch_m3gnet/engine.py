@@ -154,6 +154,7 @@ class Engine:
             D, R, Cc, B = self.cfg.embedding_dim, self.cfg.n_max, self.cfg.l_max * self.cfg.n_max, self.num_blocks
             pos_c = pos.detach().contiguous().float()
             types = graph[K.ATOM_TYPES].contiguous().long()
+            self._check_species(graph, types)
             shift = graph[K.EDGE_CELL_SHIFT].contiguous().to(torch.int32)
             lat = graph[K.LATTICE].contiguous().float()
             nbytes = C.c_size_t()
@@ -193,4 +194,24 @@ class Engine:
             _lib.check(self.lib.m3g_energy_forces(self.plan, C.byref(io), p(self._workspace), self._workspace.numel(), M._stream()))
         for key, val in out.items():
             graph[key] = val
+        if extras:
+            # the remaining keys the reference's leading modules leave on the graph (nn/scale.py:24-29, nn/atom_ref.py:25-29)
+            self.scale(graph)
+            self.atom_ref(graph)
         return graph
+
+    def _check_species(self, graph, types: torch.Tensor) -> None:
+        """The reference fails on a species index outside the model's table (`elemental_energies[atom_types]`,
+        nn/atom_ref.py:27, raises IndexError; one_hot raises after it).  Checked once per atom_types tensor (one host
+        synchronisation), cached on the graph like the topology."""
+        sig = (types.data_ptr(), types._version, int(types.numel()), int(self.cfg.num_types))
+        if isinstance(graph, dict) and graph.get("_m3g_species_ok") == sig:
+            return
+        if types.numel():
+            lo, hi = torch.aminmax(types)
+            lo, hi = int(lo), int(hi)
+            if lo < 0 or hi >= self.cfg.num_types:
+                raise IndexError(f"atom_types must lie in [0, {self.cfg.num_types - 1}] (num_types = {self.cfg.num_types}); "
+                                 f"got values in [{lo}, {hi}]")
+        if isinstance(graph, dict):
+            dict.__setitem__(graph, "_m3g_species_ok", sig)
