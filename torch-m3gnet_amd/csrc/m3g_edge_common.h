@@ -199,13 +199,18 @@ __device__ __forceinline__ SegMasks seg_masks(int ci, int lane) {
 }
 // One scan step for the 16 values of four accumulator blocks as v_fmac_f32 with a DPP source operand: x += dpp(x) * m in
 // one instruction per value.  The compiler never forms that instruction (it SLP-packs the FMAs into v_pk_fma_f32 behind
-// two v_mov_b32_dpp, 1.5 instructions per value and step).  The 16 independent values keep consecutive steps of one
-// value >= 16 instructions apart, so the only DPP read-after-VALU-write hazard (2 wait states) is at the head of a step,
-// against whatever the compiler scheduled before the statement: the leading s_nop covers it (the hazard recogniser
-// does not look inside inline assembly).
+// two v_mov_b32_dpp, 1.5 instructions per value and step).
+// Hazards (the recogniser does not look inside inline assembly; at an asm boundary it pads only the dst_sel-forwarding and
+// 12-dword-store cases, LLVM GCNHazardRecognizer::checkInlineAsmHazards): the consumer is a DPP instruction, so the
+// software-managed producers are a VALU write of a DPP-read VGPR (2 wait states), a transcendental or dst_sel write of a
+// VGPR the block reads (1) and a VALU write of EXEC (5).  The block opens with `s_nop 4` = 5 wait states, the worst case of
+// that table, so it is safe whatever the compiler schedules in front of it; inside, the 16 independent values keep
+// consecutive steps of one value 16 instructions apart.  (An MFMA result never feeds the block directly: every input passes
+// through a vector multiply first.)  tools/asm_hazard_audit.py checks a listing against the same table: margins >= 2 wait
+// states in every kept listing of round 1, the rejected vectorised-activation variants included.
 #define M3G_SCAN_LINE(i, SHR) "v_fmac_f32_dpp %" #i ", %" #i ", %16 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define M3G_SCAN_STEP16(SHR, m)                                                                                            \
-  asm volatile("s_nop 1\n\t" M3G_SCAN_LINE(0, SHR) M3G_SCAN_LINE(1, SHR) M3G_SCAN_LINE(2, SHR) M3G_SCAN_LINE(3, SHR)         \
+  asm volatile("s_nop 4\n\t" M3G_SCAN_LINE(0, SHR) M3G_SCAN_LINE(1, SHR) M3G_SCAN_LINE(2, SHR) M3G_SCAN_LINE(3, SHR)         \
                    M3G_SCAN_LINE(4, SHR) M3G_SCAN_LINE(5, SHR) M3G_SCAN_LINE(6, SHR) M3G_SCAN_LINE(7, SHR)                    \
                        M3G_SCAN_LINE(8, SHR) M3G_SCAN_LINE(9, SHR) M3G_SCAN_LINE(10, SHR) M3G_SCAN_LINE(11, SHR)              \
                            M3G_SCAN_LINE(12, SHR) M3G_SCAN_LINE(13, SHR) M3G_SCAN_LINE(14, SHR) M3G_SCAN_LINE(15, SHR)        \
