@@ -407,6 +407,35 @@ def test_config5_high_triplet_density():
     assert rel_err(out[K.MID_EDGE_FEATURES][2], o["mid_edge_features_2"]) < 1e-4
 
 
+def test_config5_full_size_through_properties():
+    """BASELINE config 5 at full size: 2,000 atoms, r_cut = r_3 = 6 A (~60 neighbours, ~3,500 triplets per atom, 7.0 M
+    triplets: the long-partner-list instantiation of the three-body kernels and their global-memory fallback are active).
+    Too large for the CPU oracle in test time, so checked through size-independent properties: no net force, translation
+    invariance, and the cell batched with a second structure == the cell on its own."""
+    from helpers import random_cell_arrays
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+
+    K = _K()
+    model = _default_model(cutoff=6.0, threebody_cutoff=6.0)
+    big = random_cell_arrays(2000, 31.1, seed=0)
+    small = random_cell_arrays(40, 8.5, seed=1)
+    g = batch_from_arrays(*zip(big), 6.0, 6.0, device=DEV)
+    assert g[K.NUM_NODES] == 2000 and g[K.NUM_TRIPLETS] > 3000 * 2000
+    out = model(g, extras=False)
+    e1, f1 = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone()
+    assert torch.isfinite(e1).all() and torch.isfinite(f1).all()
+    assert float(f1.double().sum(0).abs().max()) < 1e-3 * float(f1.abs().max())
+    moved = (big[0], big[1] + np.array([0.7, -2.3, 1.9]), big[2])
+    out2 = model(batch_from_arrays(*zip(moved), 6.0, 6.0, device=DEV), extras=False)
+    assert rel_err(out2[K.TOTAL_ENERGY], e1) < 1e-5
+    assert rel_err(out2[K.FORCES], f1) < 1e-3
+    both = model(batch_from_arrays(*zip(big, small), 6.0, 6.0, device=DEV), extras=False)
+    torch.testing.assert_close(both[K.TOTAL_ENERGY][:1], e1, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(both[K.FORCES][:2000], f1, rtol=1e-5, atol=1e-7)
+    alone = model(batch_from_arrays(*zip(small), 6.0, 6.0, device=DEV), extras=False)
+    torch.testing.assert_close(both[K.TOTAL_ENERGY][1:], alone[K.TOTAL_ENERGY], rtol=1e-6, atol=1e-6)
+
+
 # ------------------------------------------------------------------ hyper-parameter sweep (padding paths, template variants)
 @pytest.mark.parametrize("l_max,n_max,dim,blocks,cut,tb_cut", [
     (1, 1, 8, 1, 4.0, 3.0),     # smallest everything: C = 1, one three-body k-step

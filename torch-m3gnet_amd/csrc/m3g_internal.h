@@ -258,7 +258,18 @@ namespace m3g {
 #define M3G_TB_ROWS 128
 #endif
 constexpr int kTbRows = M3G_TB_ROWS;
-constexpr int kTbCap = kTbRows + 64 < 255 ? kTbRows + 64 : 255;   // staged three-body window: the rows + boundary rows; < 256 so a partner id fits a byte
+#ifndef M3G_TB_CAP
+#define M3G_TB_CAP 255
+#endif
+constexpr int kTbCap = M3G_TB_CAP;   // staged three-body window: the rows of the workgroup + the other rows of the centres they belong to;
+                                     // < 256 so a window-relative partner id fits a byte (rows beyond it are read from global memory)
+// staged partner ids per row and list (one byte each; longer lists continue from global memory).  Two instantiations of the
+// three-body kernels: the short lists of the usual 3-body cutoff (r_3 = 4 A: ~17 partners per active edge) and the long ones of
+// dense neighbourhoods (BASELINE config 5, r_3 = 6 A: ~58 per edge) -- sweep in profiles/r02_config5_sweep.txt: staging 96
+// ids per row takes the dense case from 61 to 24 us (forward) and 137 to 86 us (reverse) per launch, but costs the 10k-atom
+// Cu cell 25 % of its three-body reverse (LDS footprint -> fewer resident workgroups), hence the choice per launch.
+constexpr int kTbListShort = 32, kTbListLong = 96;
+constexpr int kTbCapShort = kTbRows + 64 < kTbCap ? kTbRows + 64 : kTbCap;   // window rows the short-list instantiation stages
    // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
 struct Topo {
   int64_t N, E, T, S;

@@ -18,7 +18,6 @@
 
 namespace m3g {
 
-constexpr int kTbListCap = 32 * kTbRows;   // staged partner ids, one byte each (32 partners per row; longer lists continue from global memory)
 
 // first C floats of a 16-float (64-byte aligned) row as 16-byte loads: a scalar load per element makes every lane of a
 // wave touch its own cache line once per element
@@ -55,11 +54,14 @@ struct TbArgs {
 };
 
 // Forward: m[e1,:] = fc(d_e1) sum_t Y_l(cos_t) g[e2(t),:]
-template <int L, int R>
+template <int L, int R, int LIST, int CAP>
 __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   constexpr int C = L * R;
-  __shared__ float su[kTbCap * 3];
-  __shared__ float sp[kTbCap * C];
+  constexpr int kTbListCap = LIST * kTbRows;   // staged partner ids, one byte each
+  // CAP <= kTbCap rows of the window are staged; the topology's byte ids count from the window start up to kTbCap, ids at or
+  // beyond CAP take the global-memory path like the 255 marker
+  __shared__ float su[CAP * 3];
+  __shared__ float sp[CAP * C];
   __shared__ unsigned char s_other[kTbListCap];
   // independent first-level loads: A, this workgroup's window, this thread's row
   const int A = *a.n_act;
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   const int r = rb + threadIdx.x;
   const bool live = r < A;
   const int64_t e = a.act_list[live ? r : A - 1];
-  const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
+  const int n = (hi_full - lo) < CAP ? (hi_full - lo) : CAP;
   for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
     const int64_t es = a.act_list[lo + idx], ks = a.act_dst[lo + idx];
     su[idx * 3 + 0] = a.u[es * 3];
@@ -98,9 +100,9 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   for (int t = t0; t < t1; ++t) {
     const int kk = t - t_lo;
     const int bid = kk < kTbListCap ? s_other[kk] : 255;
-    const int idx = bid != 255 ? bid : a.t_other[t] - lo;
+    const int idx = bid < CAP ? bid : a.t_other[t] - lo;
     float vx, vy, vz, pr[C];
-    if (bid != 255) {
+    if (bid < CAP) {
       vx = su[idx * 3]; vy = su[idx * 3 + 1]; vz = su[idx * 3 + 2];
 #pragma unroll
       for (int k = 0; k < C; ++k) pr[k] = sp[idx * C + k];
@@ -144,14 +146,14 @@ struct TbRevArgs {
   float *dd, *du, *dgq;   // dd [A], du [A,3]: geometry gradients of the three-body term, one row per active edge
   int first;              // first reverse launch of the step (last block): dd/du are written, later launches accumulate
 };
-constexpr int kTbRevList = 32 * kTbRows;   // staged partner ids per list (bytes)
 
-template <int L, int R>
+template <int L, int R, int LIST, int CAP>
 __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a) {
   constexpr int C = L * R;
-  __shared__ float su[kTbCap * 3];
-  __shared__ float sg[kTbCap * C];
-  __shared__ float ss[kTbCap * C];
+  constexpr int kTbRevList = LIST * kTbRows;   // staged partner ids per list (bytes)
+  __shared__ float su[CAP * 3];
+  __shared__ float sg[CAP * C];
+  __shared__ float ss[CAP * C];
   __shared__ unsigned char s1[kTbRevList], s2[kTbRevList];
   const int A = *a.n_act;
   const int rb = blockIdx.x * kTbRows;
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   const int rr = live ? r : A - 1;           // compact row of this thread
   const int64_t e = a.act_list[rr];
   const int64_t kd = a.act_dst[rr];
-  const int n = (hi_full - lo) < kTbCap ? (hi_full - lo) : kTbCap;
+  const int n = (hi_full - lo) < CAP ? (hi_full - lo) : CAP;
   const int n1 = (t1_hi - t1_lo) < kTbRevList ? (t1_hi - t1_lo) : kTbRevList;
   const int n2 = (t2_hi - t2_lo) < kTbRevList ? (t2_hi - t2_lo) : kTbRevList;
   for (int k = threadIdx.x; k < n1; k += kTbRows) s1[k] = a.t1_bytes[t1_lo + k];
@@ -202,7 +204,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   if (!live) return;
   // partner (window-relative id, or the global fallback) -> unit vector and payload row
   auto fetch = [&](int id, const int32_t* list, int t, const float* sp, bool want_s, float& vx, float& vy, float& vz, float* pr) {
-    if (id != 255) {
+    if (id < CAP) {
       vx = su[id * 3]; vy = su[id * 3 + 1]; vz = su[id * 3 + 2];
 #pragma unroll
       for (int k = 0; k < C; ++k) pr[k] = sp[id * C + k];
@@ -283,12 +285,16 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
 }
 
 static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 1) / kTbRows)); }
+// Long partner lists?  Triplets per edge is a host-side lower bound of triplets per ACTIVE edge (the number of active edges
+// lives on the device); either choice is correct, the wrong one only costs time (global-memory fallback or LDS footprint).
+static inline bool long_lists(const Topo& t) { return t.T > 24 * t.E; }
 
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s) {
   if (t.E == 0) return;
   if (t.T == 0) return;   // no active edge: every consumer reads zeros through act_id < 0
   TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t1_b, w.u, w.fc3, w.q, v, m};
-  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
+  if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListLong, kTbCap>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a)); }
+  else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListShort, kTbCapShort>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a)); }
 }
 
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s) {
@@ -297,7 +303,8 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
   TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, t.t1_b, t.t2_b, w.u, w.fc3, w.fc3p, w.q,
               w.qp, v,
               w.dm, w.dd, w.du, w.dg, first ? 1 : 0};
-  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a));
+  if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R, kTbListLong, kTbCap>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a)); }
+  else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R, kTbListShort, kTbCapShort>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a)); }
 }
 
 }  // namespace m3g
