@@ -56,19 +56,25 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (about 6.3 TB/s achievable)
 F32_MFMA_FLOP = 2048                # v_mfma_f32_16x16x4_f32
 BF16_MFMA_FLOP = 16384              # v_mfma_f32_16x16x32_bf16
-# Per-kernel algorithmic work.  Edge kernels: bytes = the 256-byte edge-feature rows the kernel must
-# move under ideal fusion; FLOPs = SURVEY.md 8(d)'s 134,144 per edge and block forward, the same again
-# for the input-gradient reverse.  MFMA counts per 16-edge tile by precision mode: (f32 16x16x4, bf16 16x16x32).
+# Per-kernel algorithmic work, per precision mode.  bytes = what the kernel must move per edge and launch:
+# the 256-byte edge-feature rows under ideal fusion and, in the fp32 mode, the activations it saves for /
+# reads back in the reverse pass (SiLU'(p1) and p2 of both MLPs, 1 KB each) and the fp32 dL/dp1 rows (1 KB; blocks > 0 only:
+# averaged over the 3 launches of a step).  FLOPs = SURVEY.md 8(d)'s 134,144 per edge and block forward, the same again for
+# the input-gradient reverse.  MFMA counts per 16-edge tile: (f32 16x16x4, bf16 16x16x32).
 EDGE_KERNELS = {
-    "edge_block_fwd": dict(kernel="k_edge_block_mfma", alg_bytes_per_edge=2 * 256, alg_flops_per_edge=134_144,
-                           mfma={"bf16x3": (48, 192), "fp32": (48 + 512, 0)}),
-    "edge_rev_fused": dict(kernel="k_edge_rev_fused", alg_bytes_per_edge=3 * 256, alg_flops_per_edge=134_144,
-                           mfma={"bf16x3": (48, 396), "fp32": (48 + 1056, 0)}),
-    # split reverse kernels (option rev_kernel = 0)
-    "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", alg_bytes_per_edge=2 * 256, alg_flops_per_edge=65_920,
-                              mfma={"bf16x3": (8, 192), "fp32": (8 + 512, 0)}),
-    "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", alg_bytes_per_edge=4 * 256, alg_flops_per_edge=68_224,
-                              mfma={"bf16x3": (56, 204), "fp32": (56 + 544, 0)}),
+    "edge_block_fwd": dict(kernel="k_edge_block_mfma", alg_flops_per_edge=134_144,
+                           alg_bytes_per_edge={"bf16x3": 2 * 256, "fp32": 2 * 256 + 2048},
+                           mfma={"bf16x3": (48, 192), "fp32": (545, 0)}),
+    "edge_rev_fused": dict(kernel={"bf16x3": "k_edge_rev_fused", "fp32": "k_edge_rev_f32"}, alg_flops_per_edge=134_144,
+                           alg_bytes_per_edge={"bf16x3": 3 * 256, "fp32": 2048 + (2 * (512 + 1024) + 256) / 3},
+                           mfma={"bf16x3": (48, 396), "fp32": (577, 0)}),
+    # split reverse kernels (option rev_kernel = 0; fp32: layer 1 saved, layer 2 recomputed)
+    "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", alg_flops_per_edge=65_920,
+                              alg_bytes_per_edge={"bf16x3": 2 * 256, "fp32": 512 + 256 + 512},
+                              mfma={"bf16x3": (8, 192), "fp32": (388, 0)}),
+    "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", alg_flops_per_edge=68_224,
+                              alg_bytes_per_edge={"bf16x3": 4 * 256, "fp32": 512 + 3 * 256 + 512},
+                              mfma={"bf16x3": (56, 204), "fp32": (444, 0)}),
 }
 PMC_TRAFFIC_FILE = "r02_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE of this build (tools/pmc_traffic.py)
 METRIC = "atom-steps/sec (energy+forces) on 10k-atom PBC batch, 1/2/4/8 MI355X"
@@ -254,29 +260,31 @@ def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc):
             continue
         ms = per_launch[stage][0]
         n_f32, n_bf16 = spec["mfma"][precision]
-        alg_bytes = n_edges * spec["alg_bytes_per_edge"]
+        kname = spec["kernel"][precision] if isinstance(spec["kernel"], dict) else spec["kernel"]
+        alg_bytes = n_edges * spec["alg_bytes_per_edge"][precision]
         alg_flops = n_edges * spec["alg_flops_per_edge"]
         exe_flops = tiles * (n_f32 * F32_MFMA_FLOP + n_bf16 * BF16_MFMA_FLOP)
-        rec = pmc.get(spec["kernel"])
+        rec = pmc.get(kname)
         traffic = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 if rec else None  # gfx950: FETCH_SIZE x 2
         hbm_rate = alg_bytes / (ms * 1e-3) / 1e9
-        common = {"kernel": f"{spec['kernel']} (stage {stage})", "avg_launch_ms": ms, "traffic": traffic,
+        t_exe = exe_flops / (ms * 1e-3) / 1e12
+        common = {"kernel": f"{kname} (stage {stage})", "avg_launch_ms": ms, "launches_per_step": per_launch[stage][1], "traffic": traffic,
                   "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": alg_flops,
                   "executed_mfma_flops_per_launch": exe_flops,
                   "measured_traffic_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None}
+        hbm_view = {"bound": "hbm", "achieved": hbm_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_rate / PEAK_HBM_GBS}
         if precision == "fp32":
-            # exact-fp32 MFMA chains: matrix-pipe-bound; achieved = executed fp32 MFMA FLOPs (incl. the activations the reverse
-            # kernel recomputes instead of loading) / launch time; the algorithmic rate of SURVEY.md 8(d) beside it
-            t_exe = exe_flops / (ms * 1e-3) / 1e12
-            views[stage] = dict(common, bound="mfma", achieved=t_exe, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                                frac=t_exe / PEAK_F32_MFMA_TFLOPS,
-                                algorithmic_tflops=alg_flops / (ms * 1e-3) / 1e12,
-                                hbm_view={"achieved_GBs": hbm_rate, "frac": hbm_rate / PEAK_HBM_GBS})
+            # exact-fp32 MFMA chains: every MFMA the kernel issues is algorithmic work (nothing is recomputed in this mode), so
+            # the matrix view prices executed fp32 MFMA FLOPs against the fp32 matrix peak; the byte view prices the rows
+            # above against HBM.  The kernel's bound is the view with the larger fraction.
+            mfma_view = {"bound": "mfma", "achieved": t_exe, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": t_exe / PEAK_F32_MFMA_TFLOPS,
+                         "algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12}
+            first, second = (mfma_view, hbm_view) if mfma_view["frac"] >= hbm_view["frac"] else (hbm_view, mfma_view)
+            views[stage] = dict(common, **first, other_view=second)
         else:
-            views[stage] = dict(common, bound="hbm", achieved=hbm_rate, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_rate / PEAK_HBM_GBS,
-                                mfma_view={"algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12,
-                                           "executed_tflops": exe_flops / (ms * 1e-3) / 1e12,
-                                           "executed_frac_of_bf16_peak": exe_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS})
+            views[stage] = dict(common, **hbm_view,
+                                mfma_view={"algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12, "executed_tflops": t_exe,
+                                           "executed_frac_of_bf16_peak": t_exe / PEAK_BF16_MFMA_TFLOPS})
     # HBM-bound kernels: bytes the data layout of DESIGN.md section 3 makes each launch move (algorithmic = every array the
     # kernel must read or write once; gathers from L2/MALL-resident node tables not counted)
     E, T, N, A = n_edges, n_trip, n_atoms, n_active

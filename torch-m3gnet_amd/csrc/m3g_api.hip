@@ -139,7 +139,7 @@ static void pack_mlp(std::vector<float>& blob, const MlpW& m, const m3g_plan& p,
   put_n(blob, m.wl, kRP, wl, D, R, 0, R);
 }
 
-Work work_carve(const Consts& c, bool mfma, bool save_p1, int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
+Work work_carve(const Consts& c, bool mfma, int save_acts, int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   (void)T;
   Work w{};
   char* p = (char*)base;
@@ -158,7 +158,8 @@ Work work_carve(const Consts& c, bool mfma, bool save_p1, int64_t N, int64_t E, 
   if (mfma) {
     // fused MFMA path: per-block edge-feature images and node tables; the reverse pass recomputes every activation
     for (int b = 0; b <= c.B; ++b) w.e_blk[b] = take(tiles16 * 1024);
-    if (save_p1) for (int b = 0; b < c.B; ++b) w.p1_blk[b] = take(tiles16 * 2 * 2048);
+    if (save_acts >= 1) for (int b = 0; b < c.B; ++b) w.p1_blk[b] = take(tiles16 * 2 * 2048);
+    if (save_acts >= 2) for (int b = 0; b < c.B; ++b) w.p2_blk[b] = take(tiles16 * 2 * 2048);
     for (int b = 0; b < c.B; ++b) { w.TAb[b] = take(n * 4 * kDP); w.TBb[b] = take(n * 4 * kDP); }
     w.de_soa = take(tiles16 * 1024);
     w.dcn = take(tiles16 * 1024);
@@ -332,6 +333,10 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->save_p1 = value != 0;
     return M3G_OK;
   }
+  if (strcmp(name, "save_p2") == 0) {
+    plan->save_p2 = value != 0;
+    return M3G_OK;
+  }
   if (strcmp(name, "rev_kernel") == 0) {
     if (value != 0 && value != 1) { set_error("rev_kernel must be 0 (node-MLP + edge-MLP kernel pair) or 1 (fused)"); return M3G_ERR_VALUE; }
     plan->rev_kernel = value;
@@ -480,7 +485,7 @@ extern "C" int m3g_workspace_bytes(const m3g_plan* plan, int64_t N, int64_t E, i
   if (!plan || !bytes || N < 0 || E < 0 || T < 0 || S < 0) { set_error("m3g_workspace_bytes: bad argument"); return M3G_ERR_VALUE; }
   Consts c{};
   c.B = plan->cfg.num_blocks;
-  *bytes = work_carve(c, plan->edge_kernel == 1, saves_p1(plan), N, E, T, S, nullptr).total_bytes;
+  *bytes = work_carve(c, plan->edge_kernel == 1, saved_activations(plan), N, E, T, S, nullptr).total_bytes;
   return M3G_OK;
 }
 
@@ -526,7 +531,7 @@ static int energy_forces_graph(const m3g_plan* plan, const m3g_io* io, void* wor
   memcpy(k, &workspace, sizeof(void*)); k += sizeof(void*);
   memcpy(k, &s, sizeof(void*)); k += sizeof(void*);
   memcpy(k, &workspace_bytes, sizeof(size_t)); k += sizeof(size_t);
-  const int opts[4] = {plan->edge_kernel, plan->rev_kernel + 2 * plan->precision + 4 * plan->save_p1, plan->stress_mode, plan->overlap};
+  const int opts[4] = {plan->edge_kernel, plan->rev_kernel + 2 * plan->precision + 4 * plan->save_p1 + 8 * plan->save_p2, plan->stress_mode, plan->overlap};
   memcpy(k, opts, sizeof(opts));
   for (auto& g : plan->graphs)
     if (g.key == key) { M3G_HIP_CHECK(hipGraphLaunch(g.exec, s)); return join(); }
@@ -576,9 +581,9 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   Topo t = topo_carve(N, E, T, S, const_cast<void*>(io->topo));
   const bool mfma = plan->edge_kernel == 1;
   const bool fused_rev = fused_reverse(plan);
-  Work w = work_carve(c, mfma, saves_p1(plan), N, E, T, S, nullptr);
+  Work w = work_carve(c, mfma, saved_activations(plan), N, E, T, S, nullptr);
   if (!workspace || workspace_bytes < w.total_bytes) { set_error("workspace too small: %zu < %zu", workspace_bytes, w.total_bytes); return M3G_ERR_SIZE; }
-  w = work_carve(c, mfma, saves_p1(plan), N, E, T, S, workspace);
+  w = work_carve(c, mfma, saved_activations(plan), N, E, T, S, workspace);
   // tail scratch: per-atom energies + per-structure sums when the caller does not want them
   float* tail = (float*)((char*)workspace + w.total_bytes - align_up(((size_t)N + (size_t)S * 2 + 64) * sizeof(float)));
   float* ea = io->scaled_atomic_energies ? io->scaled_atomic_energies : tail;

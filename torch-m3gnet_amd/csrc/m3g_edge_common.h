@@ -303,6 +303,7 @@ struct FwdArgs {
   float *seg_head, *seg_first;   // per-centre message sums (see seg_scan)
   unsigned long long* stamps;  // diagnostic build: [gridDim.x][kWaves][12] phase cycle sums
   float* p1_out;               // fp32 mode: saved layer-1 pre-activations [tiles][2 mlp][8 blk][64 lanes][4], else nullptr
+  float* p2_out;               // fp32 mode, saves_p2: layer-2 pre-activations, same shape (p1_out then holds SiLU'(p1)), else nullptr
 };
 
 // three-body MLP pre-activations: p[0..3] dense, p[4..7] gate
@@ -341,7 +342,8 @@ struct RevArgs {
   float* dp1;      // [E][256]  each kernel writes its MLP's 128 columns
   unsigned long long* stamps;  // diagnostic build only
   float *seg_head, *seg_first;   // fused kernel: per-centre sums of the dp1 rows (see seg_scan)
-  const float* p1;      // saved layer-1 pre-activations of this block (fp32 mode), else nullptr
+  const float* p1;      // saved layer-1 pre-activations of this block (fp32 mode; SiLU'(p1) when p2 is saved too), else nullptr
+  const float* p2;      // saved layer-2 pre-activations (fp32 mode, saves_p2), else nullptr
 };
 
 // x summed over the four lane quarters (lanes l, l^16, l^32, l^48), result in every lane.  v_permlane16/32_swap

@@ -31,13 +31,38 @@ namespace m3g {
 // p2 = layer-2 pre-activations.  `w1c/w2d/w2g/b2` are offsets of the forward images inside `lds`.
 // p1_out != nullptr: the layer-1 pre-activations (table rows + bias + W1c e) are stored for the reverse pass, which then
 // starts from them instead of gathering the tables and recomputing the layer ([8 blk][64 lanes][4] per tile and MLP)
-template <bool KEEP_P1, int PREC>
+// saved activations are written once and read once, a whole reverse pass later: streaming stores keep them out of L2
+#ifndef M3G_SAVE_PLAIN_STORE
+#define M3G_SAVE_STORE(ptr, val) __builtin_nontemporal_store((val), (f32x4*)(ptr))
+#else
+#define M3G_SAVE_STORE(ptr, val) (*(f32x4*)(ptr) = (val))
+#endif
+// SAVE (compile time: a run-time choice doubles the code paths and spills): 0 nothing saved, 1 p1 -> p1_out, 2 SiLU'(p1) ->
+// p1_out and p2 -> p2_out
+template <bool KEEP_P1, int PREC, int SAVE = 0>
 __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, int w2g, int b2, const f32x4 (&x)[4], f32x4 (&p1)[8],
-                                            f32x4 (&p2)[8], int lane, float* p1_out = nullptr) {
+                                            f32x4 (&p2)[8], int lane, float* p1_out = nullptr, float* p2_out = nullptr) {
   chain_p<PREC, 8, 2>(lds + w1c, x, p1, lane);
-  if (p1_out) static_for<8>([&]<int ob>() { *(f32x4*)(p1_out + ob * 256) = p1[ob]; });
+  if constexpr (SAVE == 1) static_for<8>([&]<int ob>() { *(f32x4*)(p1_out + ob * 256) = p1[ob]; });
   bias_step<4, 0>(lds + b2, p2, lane);
   bias_step<4, 4>(lds + b2 + 4 * 64, p2, lane);
+  if constexpr (!KEEP_P1 && SAVE == 2) {
+    // fp32 mode with both layers saved (saves_p2): the reverse kernel needs layer 1 only as SiLU'(p1) and layer 2 as its
+    // pre-activations -- SiLU' costs three more vector instructions here, next to the sigmoid SiLU evaluates anyway
+    static_for<8>([&]<int ob>() {
+      f32x4 ds;
+      static_for<4>([&]<int r>() {
+        const float p = p1[ob][r], sg = fsigmoid(p);
+        p1[ob][r] = p * sg;
+        ds[r] = sg * (1.f + p * (1.f - sg));
+      });
+      M3G_SAVE_STORE(p1_out + ob * 256, ds);
+    });
+    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, p1, p2, lane);
+    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, p1, p2, lane);
+    static_for<8>([&]<int ob>() { M3G_SAVE_STORE(p2_out + ob * 256, p2[ob]); });
+    return;
+  }
   if (KEEP_P1) {
     // reverse pass: p1 is only needed again as SiLU'(p1) -- leave that in p1 (one sigmoid evaluation for both)
     f32x4 hid[8];
@@ -58,14 +83,14 @@ __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, 
 }
 
 // one conv GatedMLP, forward.  x = edge-feature input tile; out = MLP(x) * (W_l h)
-template <bool ST, int S0, int PREC>
+template <bool ST, int S0, int PREC, int SAVE>
 __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlpFwd& L, int mlp, const FwdArgs& a, int64_t ci,
                                                  int64_t cj, float hb, const f32x4 (&x)[4], f32x4 (&out)[4], int lane,
-                                                 Stamps<ST>& st, float* p1_out) {
+                                                 Stamps<ST>& st, float* p1_out, float* p2_out) {
   f32x4 p1[8], p2[8];
   gather_tables(a.TA, a.TB, mlp, ci, cj, lane >> 4, p1);
   st.template mark<S0>();      // table gather
-  mlp_preacts<false, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane, p1_out);
+  mlp_preacts<false, PREC, SAVE>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane, p1_out, p2_out);
   st.template mark<S0 + 1>();  // both layers
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -76,7 +101,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
 
 // FIRST: block 0 forms its input e0 = SiLU(W_adj h) (nn/featurizer.py:128-132) from the radial basis instead of reading
 // an embedded-edge image that a separate kernel would have to write (256 B/edge) first
-template <int TBS, bool ST = false, bool FIRST = false, int PREC = kPrecBf16x3>
+template <int TBS, bool ST = false, bool FIRST = false, int PREC = kPrecBf16x3, int SAVE = 0>
 __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kFwdLdsFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kFwdLdsFloats);
@@ -139,14 +164,16 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
     }
     st.template mark<1>();  // three-body MLP
     f32x4 out[4];
-    float* p1_tile = a.p1_out ? a.p1_out + tile * (2 * kP1TileFloats) + lane * 4 : nullptr;
-    mlp_forward_mfma<ST, 2, PREC>(lds, L.mlp[0], 0, a, ci, cj, hb, x, out, lv, st, p1_tile);  // edge update (nn/conv.py:68-75)
+    float* p1_tile = SAVE >= 1 ? a.p1_out + tile * (2 * kP1TileFloats) + lane * 4 : nullptr;
+    float* p2_tile = SAVE >= 2 ? a.p2_out + tile * (2 * kP1TileFloats) + lane * 4 : nullptr;
+    mlp_forward_mfma<ST, 2, PREC, SAVE>(lds, L.mlp[0], 0, a, ci, cj, hb, x, out, lv, st, p1_tile, p2_tile);  // edge update (nn/conv.py:68-75)
     static_for<4>([&]<int blk>() {
       x[blk] += out[blk];
       *(f32x4*)(e_otile + blk * 256) = x[blk];
     });
     st.template mark<6>();  // e2 residual + store
-    mlp_forward_mfma<ST, 7, PREC>(lds, L.mlp[1], 1, a, ci, cj, hb, x, out, lv, st, p1_tile ? p1_tile + kP1TileFloats : nullptr);  // node message (nn/conv.py:77-89)
+    mlp_forward_mfma<ST, 7, PREC, SAVE>(lds, L.mlp[1], 1, a, ci, cj, hb, x, out, lv, st, SAVE >= 1 ? p1_tile + kP1TileFloats : nullptr,
+                                        SAVE >= 2 ? p2_tile + kP1TileFloats : nullptr);  // node message (nn/conv.py:77-89)
     {  // sum of the messages per centre instead of a [E,64] message array + a node-side pass over it (nn/conv.py:82-88)
       if (edge >= a.E) static_for<4>([&]<int blk>() { out[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; });   // padding lanes of the last tile
       const SegMasks sk = seg_masks((int)ci, lane);
@@ -687,18 +714,28 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
     FwdArgs a{t.E, tiles, plan->d_mfma_fwd[plan->precision] + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], t.act_id,
-              w.e_blk[b], w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps, saves_p1(plan) ? w.p1_blk[b] : nullptr};
+              w.e_blk[b], w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps, saves_p1(plan) ? w.p1_blk[b] : nullptr,
+              saves_p2(plan) ? w.p2_blk[b] : nullptr};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
     const bool first = b == 0 && fused_reverse(plan);   // the fused reverse kernel recomputes e0 as well: no embedded-edge image at all
+    const int save = saved_activations(plan);   // fp32 mode only (saves_p1 / saves_p2)
+#define M3G_FWD_LAUNCH(ST_, FIRST_, PREC_, SAVE_) hipLaunchKernelGGL((k_edge_block_mfma<TBS, ST_, FIRST_, PREC_, SAVE_>), grid, block, 0, s, a, L)
+#define M3G_FWD_BY_MODE(ST_, FIRST_)                                                               \
+  if (plan->precision == kPrecBf16x3) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecBf16x3, 0); }             \
+  else if (save == 2) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecF32, 2); }                                \
+  else if (save == 1) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecF32, 1); }                                \
+  else { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecF32, 0); }
     if (plan->d_stamps && plan->stamp_target == 0 && tb_steps_for(c.C) == 3) {
       // diagnostic build of the default configuration (same code path as the shipped kernel, block 0 included)
-      if (first) { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_block_mfma<3, true, true, PREC>), grid, block, 0, s, a, L)); }
-      else { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_block_mfma<3, true, false, PREC>), grid, block, 0, s, a, L)); }
+      constexpr int TBS = 3;
+      if (first) { M3G_FWD_BY_MODE(true, true); } else { M3G_FWD_BY_MODE(true, false); }
     } else if (first) {
-      M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS, false, true, PREC>), grid, block, 0, s, a, L)));
+      M3G_TBS_SWITCH(c.C, M3G_FWD_BY_MODE(false, true));
     } else {
-      M3G_PREC_SWITCH(plan->precision, M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_block_mfma<TBS, false, false, PREC>), grid, block, 0, s, a, L)));
+      M3G_TBS_SWITCH(c.C, M3G_FWD_BY_MODE(false, false));
     }
+#undef M3G_FWD_BY_MODE
+#undef M3G_FWD_LAUNCH
   }
 }
 
@@ -711,7 +748,7 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const float* img_n = plan->d_mfma_rev[plan->precision] + (size_t)b * L.per_block + L.total_e;
   const bool saved = saves_p1(plan);
   RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b + 1], nullptr, w.de_soa, w.dcn, 0, w.dm,
-             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr, saved ? w.p1_blk[b] : nullptr};
+             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr, saved ? w.p1_blk[b] : nullptr, nullptr};
   if (saved) { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_rev_node_mlp<PREC, true>), dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L)); }
   else { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_rev_node_mlp<PREC, false>), dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L)); }
 }
@@ -724,7 +761,7 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const float* img_e = plan->d_mfma_rev[plan->precision] + (size_t)b * L.per_block;
   RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], nullptr, w.de_soa, w.dcn,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps, nullptr, nullptr,
-             saves_p1(plan) ? w.p1_blk[b] : nullptr};
+             saves_p1(plan) ? w.p1_blk[b] : nullptr, nullptr};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
   if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3 && plan->precision == kPrecBf16x3) {  // diagnostic build
     hipLaunchKernelGGL((k_edge_rev_edge_mlp<3, true>), grid, block, 0, s, ae, L);
@@ -741,7 +778,7 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
   const MfmaRevFusedLayout L = mfma_rev_fused_layout();
   const float* img = plan->d_mfma_revf + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, nullptr};
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, nullptr, nullptr};
   constexpr int WV = kWavesRevFused;
   dim3 grid(grid_for_tiles(tiles)), block(64 * WV);
   if (b > 0) {

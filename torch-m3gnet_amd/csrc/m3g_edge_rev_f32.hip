@@ -53,30 +53,35 @@ constexpr int kWavesRevF32 = M3G_WAVES_REV_F32;
 // reverse of one conv GatedMLP from its saved layer-1 pre-activations: d_upd = dL/d(output) is pulled back; returns
 // contrib = W1c^T dL/dp1 and accumulates dL/dh into dhv; NEED_DP1: stores the dL/dp1 rows (x_j half of the node reverse) and
 // their per-centre sums (x_i half)
-template <bool NEED_DP1, int MLP>
+// SAVED_P2: the forward kernel also stored the layer-2 pre-activations (RevArgs::p2) and SiLU'(p1) in place of p1: no recompute
+// at all, and SiLU'(p1) is loaded half by half where it is used
+template <bool NEED_DP1, int MLP, bool SAVED_P2>
 __device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpRevF32& L, const RevArgs& a, int64_t edge, int64_t tile,
                                                 int64_t ci, const SegMasks& sk, const f32x4& hv, const f32x4 (&d_upd)[4],
                                                 f32x4 (&contrib)[4], f32x4& dhv, int lane) {
   const int qd = lane >> 4;
-  f32x4 p1[8], d2[8];
-  {
-    const float* src = a.p1 + tile * (2 * kP1TileFloats) + MLP * kP1TileFloats + (threadIdx.x & 63) * 4;
-    static_for<8>([&]<int ob>() { p1[ob] = load_tile4(src + ob * 256); });
-  }
-  bias_step<4, 0>(lds + L.b2, d2, lane);
-  bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
-  static_for<2>([&]<int half>() {   // 0: dense branch (p1[0..3] -> d2[0..3]), 1: gate branch
-    f32x4 hid[4];
-    static_for<4>([&]<int ob>() {
-      static_for<4>([&]<int r>() {
-        const float p = p1[4 * half + ob][r], sg = fsigmoid(p);
-        hid[ob][r] = p * sg;
-        p1[4 * half + ob][r] = sg * (1.f + p * (1.f - sg));   // p1 is only needed again as SiLU'(p1)
+  f32x4 p1[SAVED_P2 ? 1 : 8], d2[8];
+  const float* p1_src = a.p1 + tile * (2 * kP1TileFloats) + MLP * kP1TileFloats + (threadIdx.x & 63) * 4;
+  if constexpr (SAVED_P2) {
+    const float* src = a.p2 + tile * (2 * kP1TileFloats) + MLP * kP1TileFloats + (threadIdx.x & 63) * 4;
+    static_for<8>([&]<int ob>() { d2[ob] = load_tile4(src + ob * 256); });
+  } else {
+    static_for<8>([&]<int ob>() { p1[ob] = load_tile4(p1_src + ob * 256); });
+    bias_step<4, 0>(lds + L.b2, d2, lane);
+    bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
+    static_for<2>([&]<int half>() {   // 0: dense branch (p1[0..3] -> d2[0..3]), 1: gate branch
+      f32x4 hid[4];
+      static_for<4>([&]<int ob>() {
+        static_for<4>([&]<int r>() {
+          const float p = p1[4 * half + ob][r], sg = fsigmoid(p);
+          hid[ob][r] = p * sg;
+          p1[4 * half + ob][r] = sg * (1.f + p * (1.f - sg));   // p1 is only needed again as SiLU'(p1)
+        });
       });
+      chain_dual32<4, 0, 4 * half>(lds + (half == 0 ? L.w2d : L.w2g), hid, d2, lane);
+      M3G_F32_FENCE();
     });
-    chain_dual32<4, 0, 4 * half>(lds + (half == 0 ? L.w2d : L.w2g), hid, d2, lane);
-    M3G_F32_FENCE();
-  });
+  }
   // gating derivatives; W_l h on the matrix pipe (4 small MFMAs), dL/dh on the vector ALU
   const float hb_sel = qd == 0 ? hv[0] : qd == 1 ? hv[1] : qd == 2 ? hv[2] : hv[3];
   static_for<4>([&]<int ob>() {
@@ -101,8 +106,11 @@ __device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpR
   static_for<2>([&]<int half>() {
     f32x4 dp1[4];
     zero(dp1);
+    f32x4 ds1[4];   // SiLU'(p1) of this half
+    if constexpr (SAVED_P2) static_for<4>([&]<int ob>() { ds1[ob] = load_tile4(p1_src + (4 * half + ob) * 256); });
     chain_dual32_t<4, 4 * half, 0>(lds + (half == 0 ? L.w2d : L.w2g), d2, dp1, lane);
-    static_for<4>([&]<int ob>() { dp1[ob] *= p1[4 * half + ob]; });
+    if constexpr (SAVED_P2) static_for<4>([&]<int ob>() { dp1[ob] *= ds1[ob]; });
+    else static_for<4>([&]<int ob>() { dp1[ob] *= p1[4 * half + ob]; });
     if (NEED_DP1 && edge < a.E) {
       float* row = a.dp1 + edge * (4 * kDP) + MLP * (2 * kDP) + half * kDP + 4 * qd;
       static_for<4>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
@@ -117,7 +125,7 @@ __device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpR
   });
 }
 
-template <int TBS, bool NEED_DP1, int WAVES>
+template <int TBS, bool NEED_DP1, int WAVES, bool SAVED_P2>
 __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF32Layout L) {
   __shared__ __attribute__((aligned(16))) float lds[kRevF32Floats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevF32Floats);
@@ -153,7 +161,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
       f32x4 dmsg[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
       static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
-      mlp_reverse_f32<NEED_DP1, 1>(lds, L.mlp[1], a, edge, tile, ci, sk, hv, dmsg, contrib, dhv, lv);
+      mlp_reverse_f32<NEED_DP1, 1, SAVED_P2>(lds, L.mlp[1], a, edge, tile, ci, sk, hv, dmsg, contrib, dhv, lv);
     }
     // dL/d e2 = what flows in from later blocks + the node MLP's contribution
     if (a.de_is_zero) {
@@ -164,7 +172,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
     asm volatile("" : "+v"(lv));
     M3G_F32_FENCE();
     // edge-update MLP (nn/conv.py:68-75)
-    mlp_reverse_f32<NEED_DP1, 0>(lds, L.mlp[0], a, edge, tile, ci, sk, hv, de, contrib, dhv, lv);
+    mlp_reverse_f32<NEED_DP1, 0, SAVED_P2>(lds, L.mlp[0], a, edge, tile, ci, sk, hv, de, contrib, dhv, lv);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
       if (!FIRST) *(f32x4*)(de_tile + blk * 256) = de[blk];
@@ -210,17 +218,19 @@ void launch_edge_rev_f32(const m3g_plan* plan, const Consts& c, const Topo& t, c
   static_assert(kRevF32Floats * 4 + 16 <= 160 * 1024, "fused fp32 reverse image exceeds the LDS");
   const float* img = plan->d_mfma_revf32 + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, nullptr, nullptr, nullptr, nullptr, w.de_soa, nullptr,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, w.p1_blk[b]};
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, w.p1_blk[b],
+             saves_p2(plan) ? w.p2_blk[b] : nullptr};
   constexpr int WV = kWavesRevF32;
   int64_t wgs = (tiles + WV - 1) / WV;
   wgs = (wgs + 7) / 8 * 8;
   wgs = wgs < 8 ? 8 : (wgs > 256 ? 256 : wgs);
   dim3 grid((unsigned)wgs), block(64 * WV);
-  if (b > 0) {
-    M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_f32<TBS, true, WV>), grid, block, 0, s, ar, L));
-  } else {   // x^0 has no position dependence: nobody reads block 0's dp1 rows
-    M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_f32<TBS, false, WV>), grid, block, 0, s, ar, L));
-  }
+  const bool p2 = saves_p2(plan);
+  // (block 0: x^0 has no position dependence, nobody reads its dp1 rows)
+#define M3G_REV_F32_LAUNCH(NEED, P2) M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_f32<TBS, NEED, WV, P2>), grid, block, 0, s, ar, L))
+  if (b > 0) { if (p2) { M3G_REV_F32_LAUNCH(true, true); } else { M3G_REV_F32_LAUNCH(true, false); } }
+  else { if (p2) { M3G_REV_F32_LAUNCH(false, true); } else { M3G_REV_F32_LAUNCH(false, false); } }
+#undef M3G_REV_F32_LAUNCH
 }
 
 }  // namespace m3g

@@ -201,6 +201,7 @@ struct m3g_plan {
   float* d_node_img[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
   int precision = m3g::kPrecF32; // option "precision"
   int save_p1 = 1;               // option "save_p1" (fp32 mode only): 0 = recompute layer 1 in the reverse kernels (A/B tests)
+  int save_p2 = 1;               // option "save_p2" (fp32 mode, fused reverse): 0 = recompute layer 2 in the reverse kernel
   int device = -1;               // HIP device the plan's buffers live on (set by m3g_plan_commit)
   float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as bf16x3 chain images (k_readout_mfma)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
@@ -332,6 +333,7 @@ struct Work {
   // MFMA path: tile-SoA images ([tile of 16 edges][4 blk][64 lanes][4]) of the edge features BEFORE each block
   // (e_blk[b]; e_blk[B] = final) and of dL/de, per-block node tables, row-major messages.  No activations saved.
   float* e_blk[kMaxBlocks + 1];
+  float* p2_blk[kMaxBlocks];  // fp32 mode, saves_p2(): layer-2 pre-activations, same shape; p1_blk then holds SiLU'(p1)
   float* p1_blk[kMaxBlocks];  // fp32 mode: layer-1 pre-activations of both conv MLPs saved by the forward kernel,
                               // [tiles][2 mlp][8 blk][64 lanes][4] (the reverse kernels start from them: saves_p1())
   float* TAb[kMaxBlocks];     // [N,4*kDP] per block (the reverse pass recomputes layer 1 from them)
@@ -345,7 +347,7 @@ struct Work {
   float* seg_first;           // [N][4*kDP]
   size_t total_bytes;
 };
-Work work_carve(const Consts& c, bool mfma, bool save_p1, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
+Work work_carve(const Consts& c, bool mfma, int save_acts /* 0 none, 1 p1, 2 p1 + p2 */, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
 
 // ---- kernel launchers (each in its own .hip) -----------------------------------------------------------
 // geometry.hip
@@ -398,6 +400,10 @@ void free_mfma_images(m3g_plan* plan);
 // fp32 mode is bound by the matrix pipe: its forward kernel saves the layer-1 pre-activations of both MLPs (1 KB per edge and
 // block) and the reverse kernels start from them instead of recomputing that layer (a quarter of their MFMAs)
 inline bool saves_p1(const m3g_plan* plan) { return plan->edge_kernel == 1 && plan->precision == kPrecF32 && plan->save_p1 != 0; }
+// ... and, with the fused fp32 reverse kernel, the layer-2 pre-activations as well (another 1 KB per edge and block): the
+// reverse kernel then issues no recompute MFMA at all (576 instead of 832 per tile)
+inline bool saves_p2(const m3g_plan* plan) { return saves_p1(plan) && plan->rev_kernel == 1 && plan->save_p2 != 0; }
+inline int saved_activations(const m3g_plan* plan) { return saves_p2(plan) ? 2 : saves_p1(plan) ? 1 : 0; }
 inline bool fused_reverse(const m3g_plan* plan) {
   return plan->edge_kernel == 1 && plan->rev_kernel == 1 && (plan->precision == kPrecBf16x3 || saves_p1(plan));
 }
