@@ -443,6 +443,12 @@ def test_config5_full_size_through_properties():
     (4, 4, 64, 2, 5.0, 3.5),    # largest supported bases: C = 16
     (3, 4, 48, 1, 4.2, 4.0),    # n_max = 4, C = 12
     (4, 1, 16, 3, 5.0, 4.0),    # C = 4
+    # beyond the MFMA kernels' tiles: the any-size path (csrc/m3g_generic.hip) takes over
+    (3, 3, 96, 2, 4.5, 4.0),    # embedding_dim 96
+    (3, 3, 128, 1, 4.5, 4.0),   # embedding_dim 128
+    (5, 5, 32, 2, 4.5, 4.0),    # l_max = n_max = 5, C = 25
+    (9, 10, 24, 1, 4.0, 3.5),   # the reference's Bessel-root table used to its limits: C = 90
+    (2, 3, 20, 10, 4.0, 3.5),   # more than 8 blocks
 ])
 def test_hyperparameter_sweep_against_oracle(l_max, n_max, dim, blocks, cut, tb_cut):
     from oracle import m3gnet_oracle as orc
@@ -456,7 +462,8 @@ def test_hyperparameter_sweep_against_oracle(l_max, n_max, dim, blocks, cut, tb_
         if type(m).__name__ == "ThreeBodyInteration":
             m.nsb.factors = m.nsb.documented_factors()
     cells = [random_cell_graph(14 + 3 * s, 6.0 + 0.3 * s, 20 + s, cutoff=cut, tb_cutoff=tb_cut, zmax=59) for s in range(3)]
-    for kern in (1, 0):
+    big = l_max > 4 or n_max > 4 or dim > 64 or blocks > 8
+    for kern in ((2,) if big else (1, 0, 2)):   # 1: MFMA kernels, 0: vector-ALU baseline, 2: any-size path
         model.engine.set_option("edge_kernel", kern)
         out = model(Batch.from_data_list([c.clone() for c in cells]).to(DEV))
         p, cfg, c, og = _oracle_inputs(model, out)

@@ -269,15 +269,16 @@ extern "C" int m3g_plan_create(const m3g_config* cfg, m3g_plan** out) {
     set_error("Three body cutoff raidus should be smaller than two body.");
     return M3G_ERR_VALUE;
   }
-  if (cfg->l_max > kLCap || cfg->n_max > kRCap || cfg->embedding_dim > kDP || cfg->num_blocks > kMaxBlocks) {
-    set_error("unsupported size: this build handles l_max<=%d, n_max<=%d, embedding_dim<=%d, num_blocks<=%d", kLCap, kRCap,
-              kDP, kMaxBlocks);
+  if (cfg->num_blocks > 32 || cfg->embedding_dim > 4096) {
+    set_error("unsupported size: this build handles num_blocks <= 32 and embedding_dim <= 4096");
     return M3G_ERR_UNSUPPORTED;
   }
   m3g_plan* p = new m3g_plan();
   p->cfg = *cfg;
+  // sizes beyond the tiles of the MFMA kernels run on the any-size path (m3g_generic.hip)
+  p->generic = cfg->l_max > kLCap || cfg->n_max > kRCap || cfg->embedding_dim > kDP || cfg->num_blocks > kMaxBlocks;
   if (const char* env = getenv("M3G_EDGE_KERNEL")) p->edge_kernel = atoi(env) != 0 ? 1 : 0;
-  p->wl = make_layout(*cfg);
+  if (!p->generic) p->wl = make_layout(*cfg);
   *out = p;
   return M3G_OK;
 }
@@ -286,6 +287,7 @@ extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (!plan) return;
   if (plan->d_weights) (void)hipFree(plan->d_weights);
   free_mfma_images(plan);
+  generic_free(plan);
   if (plan->d_stamps) (void)hipFree(plan->d_stamps);
   drop_graphs(plan);
   for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
@@ -320,7 +322,8 @@ extern "C" int m3g_plan_set_const(m3g_plan* plan, const char* name, const float*
 extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value) {
   if (!plan || !name) { set_error("m3g_plan_set_option: null argument"); return M3G_ERR_VALUE; }
   if (strcmp(name, "edge_kernel") == 0) {
-    if (value != 0 && value != 1) { set_error("edge_kernel must be 0 (VALU baseline) or 1 (MFMA)"); return M3G_ERR_VALUE; }
+    if (value < 0 || value > 2) { set_error("edge_kernel must be 0 (VALU baseline), 1 (MFMA) or 2 (any-size path)"); return M3G_ERR_VALUE; }
+    if (plan->generic && value != 2) { set_error("this model size only runs on the any-size path (edge_kernel = 2)"); return M3G_ERR_UNSUPPORTED; }
     plan->edge_kernel = value;
     return M3G_OK;
   }
@@ -386,6 +389,27 @@ extern "C" int m3g_plan_commit(m3g_plan* plan) {
   for (auto& kv : expected_consts(cfg))
     if (!plan->cvals.count(kv.first)) { set_error("constant '%s' was never set", kv.first.c_str()); return M3G_ERR_STATE; }
   const int D = cfg.embedding_dim, R = cfg.n_max, L = cfg.l_max, C = L * R, B = cfg.num_blocks;
+  {
+    int dev = 0;
+    M3G_HIP_CHECK(hipGetDevice(&dev));
+    if (plan->device >= 0 && plan->device != dev) {   // the plan moves to the current device
+      M3G_HIP_CHECK(hipSetDevice(plan->device));
+      M3G_HIP_CHECK(hipDeviceSynchronize());
+      if (plan->d_weights) { (void)hipFree(plan->d_weights); plan->d_weights = nullptr; }
+      free_mfma_images(plan);
+      generic_free(plan);
+      if (plan->d_stamps) { (void)hipFree(plan->d_stamps); plan->d_stamps = nullptr; }
+      M3G_HIP_CHECK(hipSetDevice(dev));
+    }
+    M3G_HIP_CHECK(hipDeviceSynchronize());   // kernels of earlier calls may still read the buffers this call overwrites
+    plan->device = dev;
+  }
+  { int rc = generic_commit(plan); if (rc) return rc; }
+  if (plan->generic) {   // no padded blob, no MFMA images: the any-size path reads the raw tensors
+    plan->edge_kernel = 2;
+    plan->committed = true;
+    return M3G_OK;
+  }
 
   // ---- constants (fp32 arithmetic in the reference's order; see oracle make_constants/radial_basis) ----
   Consts& c = plan->consts;
@@ -460,20 +484,6 @@ extern "C" int m3g_plan_commit(m3g_plan* plan) {
     blob[r.b3] = plan->params.at(ro + ".dense.4.bias")[0];
     blob[r.b3 + 1] = plan->params.at(ro + ".gate.4.bias")[0];
   }
-  // The plan's buffers live on the device that is current now; a recommit on another device moves them.  Kernels of earlier
-  // calls may still read the old contents on some stream: drain the device(s) before overwriting or freeing.
-  int dev = 0;
-  M3G_HIP_CHECK(hipGetDevice(&dev));
-  if (plan->device >= 0 && plan->device != dev) {
-    M3G_HIP_CHECK(hipSetDevice(plan->device));
-    M3G_HIP_CHECK(hipDeviceSynchronize());
-    if (plan->d_weights) { (void)hipFree(plan->d_weights); plan->d_weights = nullptr; }
-    free_mfma_images(plan);
-    if (plan->d_stamps) { (void)hipFree(plan->d_stamps); plan->d_stamps = nullptr; }
-    M3G_HIP_CHECK(hipSetDevice(dev));
-  }
-  M3G_HIP_CHECK(hipDeviceSynchronize());
-  plan->device = dev;
   if (!plan->d_weights) M3G_HIP_CHECK(hipMalloc((void**)&plan->d_weights, wl.total * sizeof(float)));
   M3G_HIP_CHECK(hipMemcpy(plan->d_weights, blob.data(), wl.total * sizeof(float), hipMemcpyHostToDevice));
   { int rc = pack_mfma_images(plan); if (rc) return rc; }
@@ -483,6 +493,7 @@ extern "C" int m3g_plan_commit(m3g_plan* plan) {
 
 extern "C" int m3g_workspace_bytes(const m3g_plan* plan, int64_t N, int64_t E, int64_t T, int64_t S, size_t* bytes) {
   if (!plan || !bytes || N < 0 || E < 0 || T < 0 || S < 0) { set_error("m3g_workspace_bytes: bad argument"); return M3G_ERR_VALUE; }
+  if (plan->edge_kernel == 2) { *bytes = generic_workspace_bytes(plan, N, E, T, S); return M3G_OK; }
   Consts c{};
   c.B = plan->cfg.num_blocks;
   *bytes = work_carve(c, plan->edge_kernel == 1, saved_activations(plan), N, E, T, S, nullptr).total_bytes;
@@ -575,6 +586,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   }
   if (io->triplet_angles && T > 0 && !io->triplet_edge_index) { set_error("triplet_angles requires triplet_edge_index"); return M3G_ERR_VALUE; }
   hipStream_t s = (hipStream_t)stream_;
+  if (plan->edge_kernel == 2) return generic_energy_forces(plan, io, workspace, workspace_bytes, s);
   const Consts& c = plan->consts;
   const WeightLayout& wl = plan->wl;
   const float* W = plan->d_weights;

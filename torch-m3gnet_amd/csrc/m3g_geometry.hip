@@ -342,6 +342,15 @@ void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, cons
     (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
 }
 
+// force gather on its own (generic path, m3g_generic.hip): F = -(d E / d r) summed through both CSR lists, / length_scale
+void launch_force_gather(float length_scale, const Topo& t, const float* dr, float* forces, float* stresses, hipStream_t s) {
+  if (t.N > 0)
+    hipLaunchKernelGGL(k_force_gather, grid_for(t.N * 16), dim3(256), 0, s, length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge, dr, forces,
+                       stresses, stresses ? 6 * t.S : 0);
+  else if (stresses)
+    (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
+}
+
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s) {
   (void)c;   // stresses were cleared by launch_geometry_reverse

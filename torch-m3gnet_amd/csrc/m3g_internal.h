@@ -203,6 +203,10 @@ struct m3g_plan {
   int save_p1 = 1;               // option "save_p1" (fp32 mode only): 0 = recompute layer 1 in the reverse kernels (A/B tests)
   int save_p2 = 1;               // option "save_p2" (fp32 mode, fused reverse): 0 = recompute layer 2 in the reverse kernel
   int device = -1;               // HIP device the plan's buffers live on (set by m3g_plan_commit)
+  // generic path (m3g_generic.hip): raw state_dict tensors, unpadded, in one device blob; offsets by key
+  bool generic = false;          // sizes beyond the MFMA kernels' tiles (or option "edge_kernel" = 2)
+  float* d_generic = nullptr;
+  std::map<std::string, size_t> generic_off;
   float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as bf16x3 chain images (k_readout_mfma)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
@@ -358,6 +362,12 @@ void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, cons
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s);
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s);
+void launch_force_gather(float length_scale, const Topo& t, const float* dr, float* forces, float* stresses, hipStream_t s);
+// generic.hip: any-size path (embedding_dim, l_max, n_max beyond the MFMA kernels' tiles)
+size_t generic_workspace_bytes(const m3g_plan* plan, int64_t N, int64_t E, int64_t T, int64_t S);
+int generic_commit(m3g_plan* plan);
+void generic_free(m3g_plan* plan);
+int generic_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes, hipStream_t s);
 void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s);
 void launch_distance_only(float length_scale, const Topo& t, const float* pos, const float* lattice,
                           const int32_t* shift, float* u, float* d, hipStream_t s);
