@@ -90,7 +90,11 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *                   1 = "bf16x3": each fp32 operand split into two bf16 parts, three v_mfma_f32_16x16x32_bf16 products per fp32
  *                   product, fp32 accumulate (relative product error ~2^-16; faster, parity within north_star's tolerances);
  *                   both weight image sets are resident after a commit, switching costs nothing;
- *   "edge_kernel" = 1 fused MFMA edge blocks (default), 0 = vector-ALU baseline kernels (also M3G_EDGE_KERNEL in the env);
+ *   "edge_kernel" = 1 fused MFMA edge blocks (default), 0 = vector-ALU baseline kernels (also M3G_EDGE_KERNEL in the env),
+ *                   2 = the any-size path (run-time-sized fp32 kernels; chosen automatically for embedding_dim > 64,
+ *                   l_max or n_max > 4, more than 8 blocks -- up to the reference's own limits l_max <= 9, n_max <= 10);
+ *   "save_p1" / "save_p2" (fp32 mode, default 1): the forward kernel saves SiLU'(p1) / the layer-2 pre-activations of both conv
+ *                   MLPs for the reverse kernel (no recompute MFMAs) -- 0 for A/B measurements;
  *   "rev_kernel"  = 1 one fused reverse kernel per block (default; bf16x3 mode only -- the fp32 mode always runs the
  *                   kernel pair), 0 = node-MLP + edge-MLP kernel pair;
  *   "stress_mode" = 0 the reference's sum pos (x) F / V (nn/gradient.py:39-62, default), 1 = pair virial
@@ -172,6 +176,36 @@ int m3g_atom_featurizer(int32_t num_types, int32_t dim, const float* weight, int
 /* AtomRef.forward (nn/atom_ref.py:25-29) */
 int m3g_atom_ref(int32_t num_types, const float* elemental_energies, int64_t n_atoms, const int64_t* atom_types,
                  float* out, void* stream);
+
+/* ---- stand-alone forward of the block modules (any size; run-time-sized fp32 kernels, csrc/m3g_generic.hip).  The reference's
+ * modules can be called one by one (tests/test_model.py:14-38 runs the bare Sequential); these are their kernels. -------------- */
+/* torch.nn.Linear + activation: Y = act(X W^T + b); act 0 none, 1 SiLU, 2 sigmoid (nn/core.py:31-59, nn/featurizer.py:128-132) */
+int m3g_linear(int64_t n, int32_t in_features, int32_t out_features, const float* x, const float* weight, const float* bias /* or NULL */,
+               int32_t act, float* y, void* stream);
+/* y = a * b: the dense(x) * gate(x) of GatedMLP.forward (nn/core.py:61-62) */
+int m3g_multiply(int64_t n, const float* a, const float* b, float* y, void* stream);
+/* NormalizedSphericalBessel.forward (nn/interaction.py:268-281): out [l_max, n_max, n]; host_zeros / host_factors HOST [l_max*n_max] */
+int m3g_bessel_basis(int32_t l_max, int32_t n_max, double cutoff, const float* host_zeros, const float* host_factors, int64_t n,
+                     const float* rs, float* out, void* stream);
+/* ThreeBodyInteration.forward (nn/interaction.py:187-223): edge_attr [E,D] updated in place from the graph's edge_distances,
+ * triplet_angles and node features; scratch (N*C + E*C + 2*E*D) floats, C = l_max*n_max; mid (or NULL) receives the aggregate [E,C] */
+int m3g_three_body(int32_t l_max, int32_t n_max, int32_t embedding_dim, double scaled_cutoff, double scaled_threebody_cutoff,
+                   const float* host_zeros, const float* host_factors, int64_t n_atoms, int64_t n_edges, int64_t n_triplets,
+                   const int64_t* edge_index, const int64_t* triplet_edge_index, const float* edge_distances, const float* triplet_angles,
+                   const float* x, const float* w_sigmoid, const float* b_sigmoid, const float* w_dense, const float* w_gate, float* scratch,
+                   float* edge_attr, float* mid, void* stream);
+/* M3GNetConv.forward (nn/conv.py:63-97): x [N,D] and edge_attr [E,D] updated in place.  host_params: HOST array of 18 DEVICE pointers,
+ * edge MLP {dense.0.weight, gate.0.weight, dense.0.bias, gate.0.bias, dense.2.weight, gate.2.weight, dense.2.bias, gate.2.bias,
+ * edge_linear.weight}, then the node MLP likewise (node_linear.weight last) */
+int m3g_conv_block_scratch_bytes(int32_t embedding_dim, int64_t n_edges, size_t* bytes);
+int m3g_conv_block(int32_t embedding_dim, int32_t n_max, int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
+                   const void* topo, const float* const* host_params, const float* edge_weights, float* x, float* edge_attr, float* scratch,
+                   size_t scratch_bytes, void* stream);
+/* AtomWiseReadout.forward (nn/readout.py:39-58).  host_params: HOST array of 12 DEVICE pointers {dense.0.weight, dense.0.bias,
+ * dense.2.weight, dense.2.bias, dense.4.weight, dense.4.bias, gate.0.weight, ...}; scratch (6*N*D + 2*N) floats */
+int m3g_readout(int32_t embedding_dim, int64_t n_atoms, int64_t n_structs, const float* const* host_params, double energy_scale,
+                const float* x, const float* elemental_energies_per_atom, const int64_t* batch, float* scaled_atomic_energies,
+                float* scaled_total_energy, float* total_energy, float* scratch, void* stream);
 
 /* ---- graph construction on the GPU -------------------------------------
  * Periodic neighbour list: replaces get_all_neighbors_with_cell_shifts (data/material_graph.py:168-193, pymatgen

@@ -1,0 +1,104 @@
+"""GPU: stand-alone `forward` of the block modules (EdgeAdjustor, GatedMLP, NormalizedSphericalBessel, ThreeBodyInteration,
+M3GNetConv, AtomWiseReadout) -- the reference calls the bare Sequential in tests/test_model.py:14-38.  Each module runs its own
+C-ABI stage kernel; checked against the fused engine call, against plain torch fp32 on the CPU (single ops), and through the
+reference's triplet-permutation property."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+from test_gpu_properties import _al_na, _default_model, _oracle_inputs, _small_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _K():
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    return K
+
+
+@pytest.mark.parametrize("which", ["small", "default", "wide"])
+def test_bare_sequential_matches_the_fused_call_and_the_oracle(which):
+    from oracle import m3gnet_oracle as orc
+    from helpers import random_cell_graph
+    from torch_m3gnet.data.material_graph import Batch
+    from torch_m3gnet.model.build import build_model
+
+    K = _K()
+    if which == "small":
+        model, cells = _small_model(), _al_na(True)
+    elif which == "default":
+        model = _default_model(energy_scale=2.0, elemental_energies=torch.linspace(-1, 1, 95))
+        cells = [random_cell_graph(18, 6.2, s) for s in (4, 5)]
+    else:   # sizes only the any-size kernels handle
+        torch.manual_seed(3)
+        model = build_model(4.5, 4.0, 5, 4, 40, 96, 2)
+        for m in model.model:
+            if type(m).__name__ == "ThreeBodyInteration":
+                m.nsb.factors = m.nsb.documented_factors()
+        cells = [random_cell_graph(15, 6.0, 9, cutoff=4.5, tb_cutoff=4.0, zmax=39)]
+    model = model.to(DEV)
+    g = Batch.from_data_list(cells).to(DEV)
+    fused = model(g.clone())
+    bare = model.model(g.clone())             # module by module, as reference tests/test_model.py:14-18 does
+    for key in (K.NODE_FEATURES, K.EDGE_ATTR, K.SCALED_ATOMIC_ENERGIES):
+        assert torch.isfinite(bare[key]).all(), key
+    assert rel_err(bare[K.NODE_FEATURES], fused[K.NODE_FEATURES]) < 1e-5
+    assert rel_err(bare[K.EDGE_ATTR], fused[K.EDGE_ATTR]) < 1e-5
+    assert rel_err(bare[K.EDGE_DISTANCES], fused[K.EDGE_DISTANCES]) < 1e-6
+    assert rel_err(bare[K.SCALED_ATOMIC_ENERGIES], fused[K.SCALED_ATOMIC_ENERGIES]) < 1e-5
+    assert float(((bare[K.TOTAL_ENERGY] - fused[K.TOTAL_ENERGY]).abs() / fused[K.TOTAL_ENERGY].abs()).max()) < 1e-5
+    p, cfg, c, og = _oracle_inputs(model, fused)
+    o = orc.energy_forces(p, cfg, c, og, want_forces=False)
+    assert float(((bare[K.TOTAL_ENERGY].cpu() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < 1e-5
+    n_blocks = (len(model.model) - 7) // 2
+    if which != "small":   # (the Al/Na neighbours sit exactly on the three-body cutoff: their aggregate is ~1e-18, pure rounding)
+        assert rel_err(bare[K.MID_EDGE_FEATURES], o[f"mid_edge_features_{n_blocks - 1}"]) < 1e-4
+
+
+def test_edge_features_invariant_under_triplet_permutation():
+    """reference tests/test_model.py:21-38, on the stand-alone modules."""
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _small_model().to(DEV)
+    g = Batch.from_data_list(_al_na(True)).to(DEV)
+    a = model.model(g.clone())[K.EDGE_ATTR]
+    g2 = g.clone()
+    perm = torch.randperm(g2[K.TRIPLET_EDGE_INDEX].size(1), generator=torch.Generator().manual_seed(0)).to(DEV)
+    g2[K.TRIPLET_EDGE_INDEX] = g2[K.TRIPLET_EDGE_INDEX][:, perm].contiguous()
+    b = model.model(g2)[K.EDGE_ATTR]
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("in_features,dims,is_output,use_bias", [(9, [64], False, False), (192, [64, 64], False, True), (17, [33, 5, 1], True, True)])
+def test_gated_mlp_forward_against_plain_torch(in_features, dims, is_output, use_bias):
+    """GatedMLP.forward on its own (reference nn/core.py:61-62) against the same layers evaluated by plain torch fp32 on the CPU."""
+    from torch_m3gnet.nn.core import GatedMLP
+
+    torch.manual_seed(1)
+    mlp = GatedMLP(in_features, dims, is_output=is_output, use_bias=use_bias)
+    x = torch.randn(37, in_features)
+    ref = torch.nn.Sequential(*mlp.dense)(x) * torch.nn.Sequential(*mlp.gate)(x)
+    out = mlp.to(DEV)(x.to(DEV))
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_normalized_spherical_bessel_forward():
+    from torch_m3gnet.nn.interaction import NormalizedSphericalBessel
+    from torch_m3gnet.nn.modules import spherical_bessel
+
+    nsb = NormalizedSphericalBessel(cutoff=4.2, l_max=4, n_max=5)
+    nsb.factors = nsb.documented_factors()
+    rs = torch.linspace(0.0, 4.2, 57)
+    out = nsb(rs.to(DEV)).cpu()
+    assert out.shape == (4, 5, 57)
+    z = nsb.spherical_bessel_zeros[:4, :5]
+    for l in range(4):
+        # the reference's arithmetic: the fp32 upward recurrence (ill-conditioned at small arguments for l >= 2: ~5e-6 absolute
+        # away from the fp64 value there, in the reference as well)
+        ref = spherical_bessel(z[l][:, None] * rs[None, :] / 4.2, l) / nsb.factors[l][:, None]
+        assert float((out[l] - ref).abs().max()) < 1e-5 * float(ref.abs().max())

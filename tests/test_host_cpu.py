@@ -197,8 +197,16 @@ def test_c_abi_plan_error_codes():
     assert lib.m3g_plan_create(C.byref(bad), C.byref(plan)) == _lib.M3G_ERR_VALUE
     with pytest.raises(ValueError, match="Too large l_max"):
         _lib.check(_lib.M3G_ERR_VALUE)
-    big = _lib.M3GConfig(5.0, 4.0, 1.0, 1.0, 3, 3, 95, 256, 3, 0)
-    assert lib.m3g_plan_create(C.byref(big), C.byref(plan)) == _lib.M3G_ERR_UNSUPPORTED
+    # sizes beyond the MFMA kernels' tiles are accepted (any-size path); only absurd ones are refused
+    big = _lib.M3GConfig(5.0, 4.0, 1.0, 1.0, 9, 10, 95, 256, 12, 0)
+    assert lib.m3g_plan_create(C.byref(big), C.byref(plan)) == _lib.M3G_OK
+    assert lib.m3g_plan_set_option(plan, b"edge_kernel", 1) == _lib.M3G_ERR_UNSUPPORTED   # such a model cannot run on the MFMA kernels
+    lib.m3g_plan_destroy(plan)
+    huge = _lib.M3GConfig(5.0, 4.0, 1.0, 1.0, 3, 3, 95, 64, 33, 0)
+    assert lib.m3g_plan_create(C.byref(huge), C.byref(plan)) == _lib.M3G_ERR_UNSUPPORTED
+    too_many_n = _lib.M3GConfig(5.0, 4.0, 1.0, 1.0, 3, 11, 95, 64, 3, 0)
+    assert lib.m3g_plan_create(C.byref(too_many_n), C.byref(plan)) == _lib.M3G_ERR_VALUE
+    assert b"Too large n_max" in lib.m3g_last_error()
     tb = _lib.M3GConfig(4.0, 5.0, 1.0, 1.0, 3, 3, 95, 64, 3, 0)
     assert lib.m3g_plan_create(C.byref(tb), C.byref(plan)) == _lib.M3G_ERR_VALUE
 
@@ -219,8 +227,14 @@ def test_no_cpu_fallback():
         torch.nn.Sequential(ScaleLength(1.0), DistanceAndAngle())(g)
     with pytest.raises(RuntimeError, match="GPU tensor"):
         AtomFeaturizer(15, 8)(g)
-    with pytest.raises(RuntimeError, match="fused"):
+    g["x"] = torch.zeros(6, 17)
+    g["edge_attr"] = torch.zeros(int(g["edge_index"].size(1)), 17)
+    with pytest.raises(RuntimeError, match="GPU tensor"):   # the stand-alone block modules have no host path either
         model.model[7](g)
+    from torch_m3gnet.nn.core import GatedMLP
+
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        GatedMLP(4, [3])(torch.zeros(2, 4))
 
 
 def test_unfused_layout_is_rejected():

@@ -661,3 +661,206 @@ int generic_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspac
 }
 
 }  // namespace m3g
+
+// ---------------------------------------------------------------------------------------------- stand-alone stages
+// The reference's block modules are usable on their own (tests/test_model.py:14-38 calls the bare Sequential; nn/core.py,
+// nn/featurizer.py, nn/interaction.py, nn/conv.py, nn/readout.py each define a forward).  These entry points run one module
+// forward on plain row-major device tensors of any size, on the same run-time-sized kernels as the any-size path.
+namespace m3g {
+namespace {
+__global__ void __launch_bounds__(256) g_mul(int64_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y) {
+  GEN_IDX(n);
+  y[gid] = a[gid] * b[gid];
+}
+// chi[l, n, t] = j_l(z_ln r_t / rc) / factors[l, n]   (NormalizedSphericalBessel.forward, nn/interaction.py:268-281)
+__global__ void __launch_bounds__(256) g_bessel_basis(GenConsts c, int64_t n, const float* __restrict__ rs, float* __restrict__ out) {
+  GEN_IDX(n * c.C);
+  const int64_t t = gid % n;
+  const int cc = (int)(gid / n), l = cc / c.R, k = cc % c.R;
+  float jl[kGL], djl[kGL];
+  g_bessel(c.L, c.zeros[l][k] * rs[t] / c.rc, jl, djl);
+  out[gid] = jl[l] / c.factors[l][k];
+}
+// per triplet and order l: m[e1, l*R+n] += chi_ln(d_ik) Y_l(cos) fc(d_ij) fc(d_ik) v[k, l*R+n]   (nn/interaction.py:188-217; the
+// module takes cos(theta) and the distances from the graph, so the sum runs over the caller's triplet list: float atomics)
+__global__ void __launch_bounds__(256) g_threebody_standalone(GenConsts c, int64_t T, int64_t E, const int64_t* __restrict__ ei,
+                                                              const int64_t* __restrict__ tei, const float* __restrict__ dist,
+                                                              const float* __restrict__ angles, const float* __restrict__ v, float* __restrict__ m) {
+  GEN_IDX(T * c.L);
+  const int64_t t = gid / c.L;
+  const int l = (int)(gid % c.L);
+  const int64_t e1 = tei[t], e2 = tei[T + t];
+  const float d1 = dist[e1], d2 = dist[e2];
+  auto fc = [&](float d) {
+    const float rho = d / c.rc3;
+    if (rho > 1.f) return 0.f;
+    const float r2 = rho * rho, r3 = r2 * rho;
+    return 1.f - 6.f * r3 * r2 + 15.f * r2 * r2 - 10.f * r3;
+  };
+  const float f = fc(d1) * fc(d2);
+  float P[kGL], dP[kGL];
+  g_legendre(c.L, angles[t], P, dP);
+  const float y = c.ynorm[l] * P[l] * f;
+  const int64_t k = ei[E + e2];
+  for (int n = 0; n < c.R; ++n) {
+    float jl[kGL], djl[kGL];
+    g_bessel(c.L, c.zeros[l][n] * d2 / c.rc, jl, djl);
+    atomicAdd(&m[e1 * c.C + l * c.R + n], jl[l] / c.factors[l][n] * y * v[k * c.C + l * c.R + n]);
+  }
+}
+__global__ void __launch_bounds__(256) g_atomic_energy_standalone(int64_t N, float energy_scale, const float* __restrict__ elemental_per_atom,
+                                                                  const float* __restrict__ od, const float* __restrict__ og,
+                                                                  const int64_t* __restrict__ batch, float* __restrict__ ea,
+                                                                  float* __restrict__ scaled_total) {
+  GEN_IDX(N);
+  const float v = elemental_per_atom[gid] / energy_scale + od[gid] * sigmoid_f(og[gid]);
+  ea[gid] = v;
+  atomicAdd(&scaled_total[batch[gid]], v);
+}
+__global__ void __launch_bounds__(256) g_scale(int64_t n, float a, const float* __restrict__ x, float* __restrict__ y) {
+  GEN_IDX(n);
+  y[gid] = a * x[gid];
+}
+static GenConsts basis_consts(int l_max, int n_max, double rc, double rc3, const float* zeros, const float* factors) {
+  GenConsts c{};
+  c.L = l_max; c.R = n_max; c.C = l_max * n_max; c.rc = (float)rc; c.rc3 = (float)rc3;
+  for (int l = 0; l < l_max; ++l) {
+    c.ynorm[l] = (float)std::sqrt((2 * l + 1) / (4.0 * M_PI));
+    for (int n = 0; n < n_max; ++n) { c.zeros[l][n] = zeros[l * n_max + n]; c.factors[l][n] = factors[l * n_max + n]; }
+  }
+  return c;
+}
+}  // namespace
+}  // namespace m3g
+
+using namespace m3g;
+
+// torch.nn.Linear (+ activation): Y = act(X W^T + b); act 0 none, 1 SiLU, 2 sigmoid.  X [n,in], W [out,in], Y [n,out].
+extern "C" int m3g_linear(int64_t n, int32_t in, int32_t out, const float* X, const float* W, const float* b, int32_t act, float* Y, void* stream_) {
+  if (n < 0 || in < 1 || out < 1 || (n > 0 && (!X || !W || !Y)) || act < 0 || act > 2) { set_error("m3g_linear: bad argument"); return M3G_ERR_VALUE; }
+  hipStream_t s = (hipStream_t)stream_;
+  linear(s, n, out, in, X, in, W, b, Y, out);
+  if (act == 1) map(s, n * out, OP_SILU, Y, Y);
+  if (act == 2) map(s, n * out, OP_SIGMOID, Y, Y);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+// y = a * b elementwise (the final dense(x) * gate(x) of GatedMLP.forward, nn/core.py:61-62)
+extern "C" int m3g_multiply(int64_t n, const float* a, const float* b, float* y, void* stream_) {
+  if (n < 0 || (n > 0 && (!a || !b || !y))) { set_error("m3g_multiply: bad argument"); return M3G_ERR_VALUE; }
+  if (n > 0) hipLaunchKernelGGL(g_mul, grid1(n), dim3(256), 0, (hipStream_t)stream_, n, a, b, y);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+// NormalizedSphericalBessel.forward (nn/interaction.py:268-281): out [l_max, n_max, n]
+extern "C" int m3g_bessel_basis(int32_t l_max, int32_t n_max, double cutoff, const float* host_zeros, const float* host_factors, int64_t n,
+                                const float* rs, float* out, void* stream_) {
+  if (l_max < 1 || l_max > kGL || n_max < 1 || n_max > kGR || !host_zeros || !host_factors || (n > 0 && (!rs || !out))) {
+    set_error("m3g_bessel_basis: bad argument");
+    return M3G_ERR_VALUE;
+  }
+  const GenConsts c = basis_consts(l_max, n_max, cutoff, cutoff, host_zeros, host_factors);
+  if (n > 0) hipLaunchKernelGGL(g_bessel_basis, grid1(n * c.C), dim3(256), 0, (hipStream_t)stream_, c, n, rs, out);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+// ThreeBodyInteration.forward (nn/interaction.py:187-223): edge_attr += GatedMLP(m), m from the graph's distances, angles and x.
+// scratch: (N*C + E*C + 2*E*D) floats.  mid (optional) receives m [E,C].
+extern "C" int m3g_three_body(int32_t l_max, int32_t n_max, int32_t D, double scaled_cutoff, double scaled_threebody_cutoff,
+                              const float* host_zeros, const float* host_factors, int64_t N, int64_t E, int64_t T, const int64_t* edge_index,
+                              const int64_t* triplet_edge_index, const float* edge_distances, const float* triplet_angles, const float* x,
+                              const float* w_sigmoid, const float* b_sigmoid, const float* w_dense, const float* w_gate, float* scratch,
+                              float* edge_attr, float* mid, void* stream_) {
+  if (l_max < 1 || l_max > kGL || n_max < 1 || n_max > kGR || D < 1 || !host_zeros || !host_factors || !scratch) {
+    set_error("m3g_three_body: bad argument");
+    return M3G_ERR_VALUE;
+  }
+  hipStream_t s = (hipStream_t)stream_;
+  const GenConsts c = basis_consts(l_max, n_max, scaled_cutoff, scaled_threebody_cutoff, host_zeros, host_factors);
+  const int C = c.C;
+  float* v = scratch;
+  float* m = v + (size_t)N * C;
+  float* pd = m + (size_t)E * C;
+  float* pg = pd + (size_t)E * D;
+  linear(s, N, C, D, x, D, w_sigmoid, b_sigmoid, v, C);
+  map(s, N * C, OP_SIGMOID, v, v);
+  M3G_HIP_CHECK(hipMemsetAsync(m, 0, sizeof(float) * E * C, s));
+  if (T > 0) hipLaunchKernelGGL(g_threebody_standalone, grid1(T * c.L), dim3(256), 0, s, c, T, E, edge_index, triplet_edge_index, edge_distances,
+                                triplet_angles, v, m);
+  linear(s, E, D, C, m, C, w_dense, nullptr, pd, D);
+  linear(s, E, D, C, m, C, w_gate, nullptr, pg, D);
+  gated(s, E * D, pd, pg, nullptr, edge_attr, edge_attr);
+  if (mid && E > 0) M3G_HIP_CHECK(hipMemcpyAsync(mid, m, sizeof(float) * E * C, hipMemcpyDeviceToDevice, s));
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+// M3GNetConv.forward (nn/conv.py:63-97): edge update, then node update with centre aggregation.  host_params: 18 DEVICE pointers in
+// the order edge {dense.0.weight, gate.0.weight, dense.0.bias, gate.0.bias, dense.2.weight, gate.2.weight, dense.2.bias, gate.2.bias,
+// edge_linear.weight}, node {the same with node_linear.weight}.  scratch: m3g_conv_block_scratch_bytes.
+extern "C" int m3g_conv_block_scratch_bytes(int32_t D, int64_t E, size_t* bytes) {
+  if (!bytes || D < 1 || E < 0) { set_error("m3g_conv_block_scratch_bytes: bad argument"); return M3G_ERR_VALUE; }
+  *bytes = ((size_t)E * D * (3 + 5 + 3) + 1024) * sizeof(float);
+  return M3G_OK;
+}
+extern "C" int m3g_conv_block(int32_t D, int32_t R, int64_t N, int64_t E, int64_t T, int64_t S, const void* topo, const float* const* host_params,
+                              const float* edge_weights, float* x, float* edge_attr, float* scratch, size_t scratch_bytes, void* stream_) {
+  size_t need = 0;
+  if (m3g_conv_block_scratch_bytes(D, E, &need) != M3G_OK || !host_params || !topo || !scratch || scratch_bytes < need) {
+    set_error("m3g_conv_block: bad argument or scratch too small");
+    return M3G_ERR_VALUE;
+  }
+  hipStream_t s = (hipStream_t)stream_;
+  Topo t = topo_carve(N, E, T, S, const_cast<void*>(topo));
+  GenWork w{};
+  GenWork::Blk k{};
+  float* p = scratch;
+  auto take = [&](size_t n) { float* r = p; p += n; return r; };
+  const size_t ed = (size_t)E * D;
+  w.cat = take(3 * ed); w.hd = take(ed); w.hg = take(ed); w.msg = take(ed);
+  w.h = const_cast<float*>(edge_weights);
+  k.p1d[0] = k.p1d[1] = take(ed); k.p1g[0] = k.p1g[1] = take(ed); k.p2d[0] = k.p2d[1] = take(ed); k.p2g[0] = k.p2g[1] = take(ed);
+  k.lin[0] = k.lin[1] = take(ed);
+  GenBlockW::Mlp q[2];
+  for (int m = 0; m < 2; ++m) {
+    const float* const* a = host_params + 9 * m;
+    q[m] = GenBlockW::Mlp{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
+  }
+  if (E > 0) hipLaunchKernelGGL(g_concat, grid1(E * 3 * D), dim3(256), 0, s, E, D, t.src, t.dst, x, edge_attr, w.cat);
+  gen_mlp_forward(s, E, D, R, q[0], w, k, 0, edge_attr, edge_attr);   // e += GatedMLP(concat) * (W_e h)
+  if (E > 0) hipLaunchKernelGGL(g_concat, grid1(E * 3 * D), dim3(256), 0, s, E, D, t.src, t.dst, x, edge_attr, w.cat);
+  gen_mlp_forward(s, E, D, R, q[1], w, k, 1, nullptr, w.msg);
+  if (N > 0) hipLaunchKernelGGL(g_segsum, grid1(N * D), dim3(256), 0, s, N, D, t.row_ptr, nullptr, w.msg, (int64_t)D, x, (int64_t)D, 1);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+// AtomWiseReadout.forward (nn/readout.py:39-58).  host_params: 12 DEVICE pointers {dense.0.w, dense.0.b, dense.2.w, dense.2.b,
+// dense.4.w, dense.4.b, gate.0.w, ...}; elemental_per_atom = graph["elemental_energies"] [N].  scratch: (6*N*D + 2*N) floats.
+extern "C" int m3g_readout(int32_t D, int64_t N, int64_t S, const float* const* host_params, double energy_scale, const float* x,
+                           const float* elemental_per_atom, const int64_t* batch, float* scaled_atomic, float* scaled_total, float* total,
+                           float* scratch, void* stream_) {
+  if (D < 1 || N < 0 || S < 0 || !host_params || !scaled_total || !total || (N > 0 && (!x || !elemental_per_atom || !batch || !scaled_atomic || !scratch))) {
+    set_error("m3g_readout: bad argument");
+    return M3G_ERR_VALUE;
+  }
+  hipStream_t s = (hipStream_t)stream_;
+  const size_t nd = (size_t)N * D;
+  float* hd = scratch; float* hg = hd + nd; float* t0 = hg + nd; float* t1 = t0 + nd; float* od = t1 + nd; float* og = od + N;
+  const float* const* dp = host_params;
+  const float* const* gp = host_params + 6;
+  linear(s, N, D, D, x, D, dp[0], dp[1], hd, D);
+  linear(s, N, D, D, x, D, gp[0], gp[1], hg, D);
+  map(s, N * D, OP_SILU, hd, hd);
+  map(s, N * D, OP_SILU, hg, hg);
+  linear(s, N, D, D, hd, D, dp[2], dp[3], t0, D);
+  linear(s, N, D, D, hg, D, gp[2], gp[3], t1, D);
+  map(s, N * D, OP_SILU, t0, t0);
+  map(s, N * D, OP_SILU, t1, t1);
+  linear(s, N, 1, D, t0, D, dp[4], dp[5], od, 1);
+  linear(s, N, 1, D, t1, D, gp[4], gp[5], og, 1);
+  M3G_HIP_CHECK(hipMemsetAsync(scaled_total, 0, sizeof(float) * S, s));
+  if (N > 0) hipLaunchKernelGGL(g_atomic_energy_standalone, grid1(N), dim3(256), 0, s, N, (float)energy_scale, elemental_per_atom, od, og, batch,
+                                scaled_atomic, scaled_total);
+  if (S > 0) hipLaunchKernelGGL(g_scale, grid1(S), dim3(256), 0, s, S, (float)energy_scale, scaled_total, total);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}

@@ -5,8 +5,10 @@ Every module keeps the reference protocol `forward(graph) -> graph` (mutates and
 container).  `Gradient(Sequential(...))` as assembled by `build_model` runs the whole path as ONE
 fused engine call (m3g_energy_forces).  The cheap leading modules (ScaleLength, AtomRef,
 DistanceAndAngle, AtomFeaturizer, EdgeFeaturizer) can also run on their own through the C-ABI
-stage entry points, as the reference's unit tests use them.  The block modules (EdgeAdjustor,
-ThreeBodyInteration, M3GNetConv, AtomWiseReadout, GatedMLP) only run fused.
+stage entry points, as the reference's unit tests use them, and so can the block modules (EdgeAdjustor,
+GatedMLP, NormalizedSphericalBessel, ThreeBodyInteration, M3GNetConv, AtomWiseReadout: m3g_linear, m3g_three_body,
+m3g_conv_block, m3g_readout -- run-time-sized fp32 kernels, forward only): the bare `Sequential` is callable like
+the reference's (tests/test_model.py:14-38).
 
 Parameter creation order follows the reference so that a given `torch.manual_seed` yields the same
 initial weights; constants (`em`, `dm`, `coeff`, `factors`) are built with the same fp32 torch
@@ -253,11 +255,27 @@ class EdgeFeaturizer(torch.nn.Module):
         return graph
 
 
-def _fused_only(name: str):
-    raise RuntimeError(
-        f"torch_m3gnet (MI355X build): {name} runs only inside the fused model returned by build_model(...) "
-        "(Gradient(Sequential(...))); it has no standalone kernel entry point yet"
-    )
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().contiguous().float()
+
+
+def _param_ptr_array(tensors):
+    """HOST array of DEVICE pointers (the `host_params` argument of m3g_conv_block / m3g_readout); returns (array, keep-alive)."""
+    keep = [_f32(t) for t in tensors]
+    arr = (C.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+    return arr, keep
+
+
+def _linear(x: torch.Tensor, lin: torch.nn.Linear, act: int) -> torch.Tensor:
+    """act(x W^T + b) through m3g_linear (act 0 none, 1 SiLU, 2 sigmoid)."""
+    _require_cuda(x, "input")
+    x2 = _f32(x).reshape(-1, lin.in_features)
+    w = _f32(lin.weight).to(x2.device)
+    b = _f32(lin.bias).to(x2.device) if lin.bias is not None else None
+    y = torch.empty(x2.size(0), lin.out_features, dtype=torch.float, device=x2.device)
+    with torch.cuda.device(x2.device):
+        _lib.check(_lib.load_library().m3g_linear(x2.size(0), lin.in_features, lin.out_features, _ptr(x2), _ptr(w), _ptr(b), act, _ptr(y), _stream()))
+    return y.reshape(*x.shape[:-1], lin.out_features)
 
 
 class EdgeAdjustor(torch.nn.Module):
@@ -270,7 +288,8 @@ class EdgeAdjustor(torch.nn.Module):
         self.swish = torch.nn.SiLU()
 
     def forward(self, graph):
-        _fused_only("EdgeAdjustor")
+        graph[K.EDGE_ATTR] = _linear(graph[K.EDGE_WEIGHTS], self.linear, act=1)   # SiLU(W edge_weights)
+        return graph
 
 
 class GatedMLP(torch.nn.Module):
@@ -291,8 +310,25 @@ class GatedMLP(torch.nn.Module):
             self.gate.append(torch.nn.Linear(widths[i], widths[i + 1], bias=use_bias, device=device))
             self.gate.append(torch.nn.Sigmoid() if i == last else torch.nn.SiLU())
 
+    @staticmethod
+    def _branch(seq: torch.nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            lin = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            act = 1 if isinstance(nxt, torch.nn.SiLU) else 2 if isinstance(nxt, torch.nn.Sigmoid) else 0
+            x = _linear(x, lin, act)
+            i += 2 if act else 1
+        return x
+
     def forward(self, x):
-        _fused_only("GatedMLP")
+        """dense(x) * gate(x) for any layer widths (m3g_linear per layer, m3g_multiply for the product)."""
+        d, g = self._branch(self.dense, x), self._branch(self.gate, x)
+        out = torch.empty_like(d)
+        with torch.cuda.device(d.device):
+            _lib.check(_lib.load_library().m3g_multiply(d.numel(), _ptr(d), _ptr(g), _ptr(out), _stream()))
+        return out
 
 
 class NormalizedSphericalBessel(torch.nn.Module):
@@ -322,8 +358,21 @@ class NormalizedSphericalBessel(torch.nn.Module):
         rows = [scale / torch.abs(spherical_bessel(z[l, : self.n_max], l + 1)) for l in range(self.l_max)]
         return (1.0 / torch.stack(rows)).to(torch.float)
 
+    def _host_tables(self):
+        z = np.ascontiguousarray(self.spherical_bessel_zeros[: self.l_max, : self.n_max].detach().cpu().numpy(), dtype=np.float32)
+        f = np.ascontiguousarray(self.factors.detach().cpu().numpy(), dtype=np.float32)
+        return z, f
+
     def forward(self, rs):
-        _fused_only("NormalizedSphericalBessel")
+        """chi [l_max, n_max, len(rs)] (reference nn/interaction.py:268-281)."""
+        _require_cuda(rs, "rs")
+        r = _f32(rs).reshape(-1)
+        z, f = self._host_tables()
+        out = torch.empty(self.l_max, self.n_max, r.numel(), dtype=torch.float, device=r.device)
+        with torch.cuda.device(r.device):
+            _lib.check(_lib.load_library().m3g_bessel_basis(self.l_max, self.n_max, float(self.cutoff), z.ctypes.data, f.ctypes.data, r.numel(),
+                                                             _ptr(r), _ptr(out), _stream()))
+        return out
 
 
 class ThreeBodyInteration(torch.nn.Module):
@@ -340,7 +389,26 @@ class ThreeBodyInteration(torch.nn.Module):
         self.gated_mlp = GatedMLP(self.degree, [num_edge_features], use_bias=False, device=device)
 
     def forward(self, graph):
-        _fused_only("ThreeBodyInteration")
+        """edge_attr += GatedMLP(three-body aggregate) from the graph's edge_distances / triplet_angles / x (m3g_three_body)."""
+        x, e = graph[K.NODE_FEATURES], graph[K.EDGE_ATTR]
+        _require_cuda(x, K.NODE_FEATURES)
+        dev = x.device
+        x, e_new = _f32(x), _f32(e).clone()
+        ei, tei = graph[K.EDGE_INDEX].contiguous().long(), graph[K.TRIPLET_EDGE_INDEX].contiguous().long()
+        d, ang = _f32(graph[K.EDGE_DISTANCES]), _f32(graph[K.TRIPLET_ANGLES])
+        N, E, T, D, Cc = x.size(0), ei.size(1), tei.size(1), x.size(1), self.degree
+        z, f = self.nsb._host_tables()
+        scratch = torch.empty(N * Cc + E * Cc + 2 * E * D + 16, dtype=torch.float, device=dev)
+        mid = torch.empty(E, Cc, dtype=torch.float, device=dev)
+        ws, bs = _f32(self.linear_sigmoid1.weight).to(dev), _f32(self.linear_sigmoid1.bias).to(dev)
+        wd, wg = _f32(self.gated_mlp.dense[0].weight).to(dev), _f32(self.gated_mlp.gate[0].weight).to(dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load_library().m3g_three_body(
+                self.l_max, self.n_max, D, float(self.cutoff), float(self.threebody_cutoff), z.ctypes.data, f.ctypes.data, N, E, T, _ptr(ei),
+                _ptr(tei), _ptr(d), _ptr(ang), _ptr(x), _ptr(ws), _ptr(bs), _ptr(wd), _ptr(wg), _ptr(scratch), _ptr(e_new), _ptr(mid), _stream()))
+        graph[K.EDGE_ATTR] = e_new
+        graph[K.MID_EDGE_FEATURES] = mid
+        return graph
 
 
 class M3GNetConv(torch.nn.Module):
@@ -356,7 +424,28 @@ class M3GNetConv(torch.nn.Module):
         self.node_linear = torch.nn.Linear(degree, num_node_features, bias=False, device=device)
 
     def forward(self, graph):
-        _fused_only("M3GNetConv")
+        """Gated edge update, then gated node update aggregated onto the centre atoms (m3g_conv_block)."""
+        x, e = graph[K.NODE_FEATURES], graph[K.EDGE_ATTR]
+        _require_cuda(x, K.NODE_FEATURES)
+        dev = x.device
+        topo = _Topology.of(graph)
+        x_new, e_new, h = _f32(x).clone(), _f32(e).clone(), _f32(graph[K.EDGE_WEIGHTS])
+        D = x_new.size(1)
+        tensors = []
+        for mlp, lin in ((self.concat_edge_update, self.edge_linear), (self.concat_node_update, self.node_linear)):
+            tensors += [mlp.dense[0].weight, mlp.gate[0].weight, mlp.dense[0].bias, mlp.gate[0].bias,
+                        mlp.dense[2].weight, mlp.gate[2].weight, mlp.dense[2].bias, mlp.gate[2].bias, lin.weight]
+        params, keep = _param_ptr_array([t.to(dev) for t in tensors])
+        lib = _lib.load_library()
+        nbytes = C.c_size_t()
+        _lib.check(lib.m3g_conv_block_scratch_bytes(D, topo.E, C.byref(nbytes)))
+        scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.m3g_conv_block(D, self.degree, topo.N, topo.E, topo.T, topo.S, _ptr(topo.buf), params, _ptr(h), _ptr(x_new), _ptr(e_new),
+                                          _ptr(scratch), nbytes.value, _stream()))
+            torch.cuda.current_stream().synchronize()   # `keep` and `scratch` are released when this returns
+        graph[K.NODE_FEATURES], graph[K.EDGE_ATTR] = x_new, e_new
+        return graph
 
 
 class AtomWiseReadout(torch.nn.Module):
@@ -368,7 +457,29 @@ class AtomWiseReadout(torch.nn.Module):
         self.gated = GatedMLP(in_features, [in_features] * (num_layers - 1) + [1], is_output=True, device=device)
 
     def forward(self, graph):
-        _fused_only("AtomWiseReadout")
+        """Per-atom gated MLP, elemental reference added, per-structure sums (m3g_readout)."""
+        x = graph[K.NODE_FEATURES]
+        _require_cuda(x, K.NODE_FEATURES)
+        dev = x.device
+        x = _f32(x)
+        N, D = x.shape
+        batch = graph[K.BATCH].contiguous().long()
+        S = int(graph[K.LATTICE].size(0))
+        elem = _f32(graph[K.ELEMENTAL_ENERGIES])
+        tensors = []
+        for seq in (self.gated.dense, self.gated.gate):
+            for i in (0, 2, 4):
+                tensors += [seq[i].weight, seq[i].bias]
+        params, keep = _param_ptr_array([t.to(dev) for t in tensors])
+        ea = torch.empty(N, dtype=torch.float, device=dev)
+        st, tot = torch.empty(S, dtype=torch.float, device=dev), torch.empty(S, dtype=torch.float, device=dev)
+        scratch = torch.empty(6 * N * D + 2 * N + 16, dtype=torch.float, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load_library().m3g_readout(D, N, S, params, float(self.scale), _ptr(x), _ptr(elem), _ptr(batch), _ptr(ea), _ptr(st),
+                                                       _ptr(tot), _ptr(scratch), _stream()))
+            torch.cuda.current_stream().synchronize()
+        graph[K.SCALED_ATOMIC_ENERGIES], graph[K.SCALED_TOTAL_ENERGY], graph[K.TOTAL_ENERGY] = ea, st, tot
+        return graph
 
 
 class Gradient(torch.nn.Module):
