@@ -96,9 +96,13 @@ def test_normalized_spherical_bessel_forward():
     rs = torch.linspace(0.0, 4.2, 57)
     out = nsb(rs.to(DEV)).cpu()
     assert out.shape == (4, 5, 57)
-    z = nsb.spherical_bessel_zeros[:4, :5]
+    z = nsb.spherical_bessel_zeros[:4, :5].double()
+    well = rs >= 0.6
     for l in range(4):
-        # the reference's arithmetic: the fp32 upward recurrence (ill-conditioned at small arguments for l >= 2: ~5e-6 absolute
-        # away from the fp64 value there, in the reference as well)
-        ref = spherical_bessel(z[l][:, None] * rs[None, :] / 4.2, l) / nsb.factors[l][:, None]
-        assert float((out[l] - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+        # The reference's fp32 upward recurrence (nn/interaction.py:293-318) is ill-conditioned at small arguments for l >= 2:
+        # on the CPU it is itself 1e-4 away from the fp64 value there (l = 3), so the exact comparison covers r >= 0.6, where
+        # it is good to 4e-7, and the small-argument region is held to that noise level.
+        ref = spherical_bessel(z[l][:, None] * rs.double()[None, :] / 4.2, l) / nsb.factors[l].double()[:, None]
+        err = (out[l].double() - ref).abs()
+        assert float(err[:, well].max()) < 3e-6 * float(ref.abs().max())
+        assert float(err.max()) < 1e-3 * float(ref.abs().max())
