@@ -82,8 +82,8 @@ def test_model_outputs_finite():
 
 def test_three_body_interaction_invariant_to_triplet_order():
     """reference tests/test_model.py:21-38.  The topology build canonicalises the triplet order, so the
-    three-body aggregate itself is bitwise identical; later blocks see float-atomic node sums whose order is
-    not fixed, hence assert_close (as the reference does) for the rest."""
+    three-body aggregate itself is bitwise identical and so is everything on the force path (no atomics there); only the
+    per-structure energy sums and the virial use float atomics, hence assert_close (as the reference does) over all keys."""
     from torch_m3gnet.data.material_graph import Batch
 
     K = _K()
