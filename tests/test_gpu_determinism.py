@@ -25,9 +25,13 @@ def test_forces_bitwise_reproducible_on_golden_cases(case, mode, precision):
     model, _ = build_engine_model(case, mode)
     model.engine.set_precision(precision)
     g = engine_graph(graph)
-    ref = model(g)[K.FORCES].clone()
+    first = model(g)
+    ref, ref_e, ref_s = first[K.FORCES].clone(), first[K.TOTAL_ENERGY].clone(), first[K.STRESSES].clone()
     for _ in range(REPS):
-        assert torch.equal(model(g)[K.FORCES], ref)
+        out = model(g)
+        assert torch.equal(out[K.FORCES], ref)
+        # per-structure sums run without atomics too (sorted batch): energies and stresses are bit-reproducible as well
+        assert torch.equal(out[K.TOTAL_ENERGY], ref_e) and torch.equal(out[K.STRESSES], ref_s)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
@@ -45,5 +49,4 @@ def test_forces_bitwise_reproducible_on_a_1500_atom_cell(precision):
     for _ in range(REPS):
         out = model(g)
         assert torch.equal(out[K.FORCES], ref_f)
-        # the virial is summed with float atomics: reproducible to rounding only
-        torch.testing.assert_close(out[K.STRESSES], ref_s, rtol=1e-4, atol=1e-9)
+        assert torch.equal(out[K.STRESSES], ref_s)   # fixed-order per-structure sums

@@ -288,6 +288,38 @@ def test_out_of_range_species_raise_and_leading_module_keys_are_published():
         model(bad)
 
 
+def test_unsorted_batch_vector_gives_the_same_energies_and_forces():
+    """The reference's scatter_sum accepts any `batch` vector (nn/readout.py:49-53, nn/gradient.py:41); its own batching always
+    emits a sorted one, which is what the atomics-free per-structure sums rely on.  With the atoms of two structures interleaved
+    the float-atomic fallback kernels take over (topology flag): same energies, same forces up to the relabelling."""
+    from torch_m3gnet.data.material_graph import Batch
+
+    K = _K()
+    model = _default_model(seed=1, energy_scale=1.5)
+    g = Batch.from_data_list([random_cell_graph(13, 6.0, 11), random_cell_graph(17, 6.4, 12)])
+    ref = model(g.clone().to(DEV))
+    n = int(g[K.NUM_NODES])
+    new_index = torch.randperm(n, generator=torch.Generator().manual_seed(3))     # new label of old atom a
+    src, dst = new_index[g[K.EDGE_INDEX][0]], new_index[g[K.EDGE_INDEX][1]]
+    order = torch.argsort(src, stable=True)                                        # edges stay sorted by (new) centre
+    inv_order = torch.empty_like(order)
+    inv_order[order] = torch.arange(order.numel())
+    h = g.clone()
+    for key in (K.POS, K.ATOM_TYPES, K.BATCH, K.NUM_TRIPLET_I):
+        out = torch.empty_like(g[key])
+        out[new_index] = g[key]
+        h[key] = out
+    h[K.EDGE_INDEX] = torch.stack([src[order], dst[order]])
+    h[K.EDGE_CELL_SHIFT] = g[K.EDGE_CELL_SHIFT][order]
+    h[K.NUM_TRIPLET_IJ] = g[K.NUM_TRIPLET_IJ][order]
+    h[K.TRIPLET_EDGE_INDEX] = inv_order[g[K.TRIPLET_EDGE_INDEX]]
+    assert not bool((h[K.BATCH][1:] >= h[K.BATCH][:-1]).all())                      # really unsorted
+    out = model(h.to(DEV))
+    torch.testing.assert_close(out[K.TOTAL_ENERGY], ref[K.TOTAL_ENERGY], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out[K.FORCES], ref[K.FORCES][torch.argsort(new_index).to(DEV)], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(out[K.STRESSES], ref[K.STRESSES], rtol=1e-4, atol=1e-8)
+
+
 def test_one_sided_and_filtered_triplet_lists():
     """The reference's gather + scatter_sum (nn/interaction.py:188-217) accepts ANY list of (e1, e2) edge pairs sharing a
     centre, not only the symmetric list `compute_threebody` emits.  One-sided (e1 < e2 only) and randomly thinned lists

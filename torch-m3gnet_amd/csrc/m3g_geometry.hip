@@ -236,10 +236,84 @@ __device__ __forceinline__ void stress_accumulate(const float (&val)[6], int s, 
   }
 }
 
-// virial: sum_a pos_a (x) F_a / V in Voigt order xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62)
+// Per-structure sums without atomics: the atoms of a structure are contiguous when `batch` is sorted (as the reference's
+// batching produces it), so one workgroup per structure adds its atoms in a fixed order -- strided private sums, then a
+// fixed LDS tree: energies and stresses are then bit-reproducible like the forces.  An unsorted `batch` (flags[3] != 0)
+// takes the float-atomic kernels instead; both kinds are launched and the wrong one returns at once.
+template <int W, class F>
+__device__ __forceinline__ void struct_reduce(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags, float* __restrict__ out,
+                                              F per_atom) {
+  __shared__ float part[256][W];
+  if (flags[3] != 0) return;
+  const int s = blockIdx.x;
+  float acc[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) acc[k] = 0.f;
+  for (int a = struct_ptr[s] + (int)threadIdx.x; a < struct_ptr[s + 1]; a += 256) {
+    float v[W];
+    per_atom(a, s, v);
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < W; ++k) part[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+#pragma unroll
+      for (int k = 0; k < W; ++k) part[threadIdx.x][k] += part[threadIdx.x + off][k];
+    __syncthreads();
+  }
+  if (threadIdx.x < W) out[(int64_t)s * W + threadIdx.x] = part[0][threadIdx.x];
+}
+__device__ __forceinline__ float inv_volume(const float* __restrict__ L) {
+  const float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
+  return 1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
+}
+__global__ void __launch_bounds__(256) k_struct_stress(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
+                                                       const float* __restrict__ pos, const float* __restrict__ lattice,
+                                                       const float* __restrict__ forces, float* __restrict__ stresses) {
+  struct_reduce<6>(struct_ptr, flags, stresses, [&](int a, int s, float* v) {
+    const float inv = inv_volume(lattice + (int64_t)s * 9);
+    const float px = pos[a * 3], py = pos[a * 3 + 1], pz = pos[a * 3 + 2];
+    const float fx = forces[a * 3], fy = forces[a * 3 + 1], fz = forces[a * 3 + 2];
+    v[0] = px * fx * inv; v[1] = py * fy * inv; v[2] = pz * fz * inv;
+    v[3] = py * fz * inv; v[4] = pz * fx * inv; v[5] = px * fy * inv;
+  });
+}
+__global__ void __launch_bounds__(256) k_struct_stress_pair(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
+                                                            const int32_t* __restrict__ row_ptr, const float* __restrict__ lattice,
+                                                            const float* __restrict__ u, const float* __restrict__ dist,
+                                                            const float* __restrict__ dr, float* __restrict__ stresses) {
+  struct_reduce<6>(struct_ptr, flags, stresses, [&](int a, int s, float* v) {
+    const float inv = -inv_volume(lattice + (int64_t)s * 9);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = 0.f;
+    for (int e = row_ptr[a]; e < row_ptr[a + 1]; ++e) {
+      const float d = dist[e];
+      const float rx = d * u[e * 3], ry = d * u[e * 3 + 1], rz = d * u[e * 3 + 2];
+      const float gx = dr[e * 3], gy = dr[e * 3 + 1], gz = dr[e * 3 + 2];
+      v[0] += rx * gx; v[1] += ry * gy; v[2] += rz * gz;
+      v[3] += 0.5f * (ry * gz + rz * gy); v[4] += 0.5f * (rz * gx + rx * gz); v[5] += 0.5f * (rx * gy + ry * gx);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] *= inv;
+  });
+}
+// scaled_total[s] = sum of the structure's scaled atomic energies (nn/readout.py:49-53), total = energy_scale * that
+__global__ void __launch_bounds__(256) k_struct_energy(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
+                                                       const float* __restrict__ ea, float* __restrict__ scaled_total) {
+  struct_reduce<1>(struct_ptr, flags, scaled_total, [&](int a, int, float* v) { v[0] = ea[a]; });
+}
+void launch_struct_energy(const Topo& t, const float* ea, float* scaled_total, hipStream_t s) {
+  if (t.S > 0) hipLaunchKernelGGL(k_struct_energy, dim3((unsigned)t.S), dim3(256), 0, s, t.struct_ptr, t.flags, ea, scaled_total);
+}
+
+// virial: sum_a pos_a (x) F_a / V in Voigt order xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62)  [float-atomic fallback: unsorted batch]
 __global__ void __launch_bounds__(256) k_stress(int64_t N, const int32_t* __restrict__ batch, const float* __restrict__ pos,
                                                 const float* __restrict__ lattice, const float* __restrict__ forces,
-                                                float* __restrict__ stresses) {
+                                                float* __restrict__ stresses, const int32_t* __restrict__ flags) {
+  if (flags[3] == 0) return;   // sorted batch: k_struct_stress does the sums
   int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   bool live = a < N;
   int s = live ? batch[a] : -1;
@@ -264,7 +338,8 @@ __global__ void __launch_bounds__(256) k_stress(int64_t N, const int32_t* __rest
 __global__ void __launch_bounds__(256) k_stress_pair(int64_t N, const int32_t* __restrict__ batch, const int32_t* __restrict__ row_ptr,
                                                      const float* __restrict__ lattice, const float* __restrict__ u,
                                                      const float* __restrict__ dist, const float* __restrict__ dr,
-                                                     float* __restrict__ stresses) {
+                                                     float* __restrict__ stresses, const int32_t* __restrict__ flags) {
+  if (flags[3] == 0) return;   // sorted batch: k_struct_stress_pair does the sums
   int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   bool live = a < N;
   int s = live ? batch[a] : -1;
@@ -354,12 +429,15 @@ void launch_force_gather(float length_scale, const Topo& t, const float* dr, flo
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s) {
   (void)c;   // stresses were cleared by launch_geometry_reverse
-  if (t.N > 0) hipLaunchKernelGGL(k_stress, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, pos, lattice, forces, stresses);
+  if (t.N > 0) hipLaunchKernelGGL(k_stress, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, pos, lattice, forces, stresses, t.flags);
+  if (t.S > 0) hipLaunchKernelGGL(k_struct_stress, dim3((unsigned)t.S), dim3(256), 0, s, t.struct_ptr, t.flags, pos, lattice, forces, stresses);
 }
 
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s) {
   if (t.N > 0)   // stresses were cleared by launch_geometry_reverse
-    hipLaunchKernelGGL(k_stress_pair, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, t.row_ptr, lattice, w.u, w.d, w.dr, stresses);
+    hipLaunchKernelGGL(k_stress_pair, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, t.row_ptr, lattice, w.u, w.d, w.dr, stresses, t.flags);
+  if (t.S > 0)
+    hipLaunchKernelGGL(k_struct_stress_pair, dim3((unsigned)t.S), dim3(256), 0, s, t.struct_ptr, t.flags, t.row_ptr, lattice, w.u, w.d, w.dr, stresses);
 }
 
 void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s) {

@@ -305,7 +305,8 @@ struct Topo {
                        // ranges [t_lo, t_hi) of its rows' partner lists in t1_e2c and in t2_e1c
   int32_t* n_act;      // device scalar A (= flags + 2)
   int32_t* batch;    // [N]
-  int32_t* flags;    // [4] malformed-graph flags; [2] = A
+  int32_t* struct_ptr;  // [S+1] atoms of structure s: struct_ptr[s] .. struct_ptr[s+1] (valid when `batch` is non-decreasing, flags[3] == 0)
+  int32_t* flags;    // [4] [0] malformed-graph bits; [2] = A; [3] != 0: `batch` is not sorted (per-structure sums then use atomics)
   void* sort_tmp;    // scratch for the radix sorts
   size_t sort_tmp_bytes;
   size_t total_bytes;
@@ -362,6 +363,7 @@ void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, cons
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s);
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s);
+void launch_struct_energy(const Topo& t, const float* ea, float* scaled_total, hipStream_t s);
 void launch_force_gather(float length_scale, const Topo& t, const float* dr, float* forces, float* stresses, hipStream_t s);
 // generic.hip: any-size path (embedding_dim, l_max, n_max beyond the MFMA kernels' tiles)
 size_t generic_workspace_bytes(const m3g_plan* plan, int64_t N, int64_t E, int64_t T, int64_t S);

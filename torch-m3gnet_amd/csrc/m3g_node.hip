@@ -420,7 +420,8 @@ __global__ void __launch_bounds__(256) k_readout(Consts c, int64_t N, const floa
 
 // per-structure energy sum: wave-level pre-reduction when the wave's atoms share a structure
 __global__ void __launch_bounds__(256) k_energy_sum(int64_t N, const int32_t* __restrict__ batch, const float* __restrict__ ea,
-                                                    float* __restrict__ scaled_total) {
+                                                    float* __restrict__ scaled_total, const int32_t* __restrict__ flags) {
+  if (flags[3] == 0) return;   // sorted batch: k_struct_energy (m3g_geometry.hip) sums without atomics
   int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   bool live = a < N;
   int s = live ? batch[a] : -1;
@@ -517,7 +518,8 @@ void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& b
 
 // per-structure sums of the scaled atomic energies (atomics into the cleared scaled_total) and total = energy_scale * sum
 void launch_energy_sums(const Consts& c, const Topo& t, const float* scaled_atomic, float* scaled_total, float* total, hipStream_t s) {
-  if (t.N > 0) hipLaunchKernelGGL(k_energy_sum, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, scaled_atomic, scaled_total);
+  if (t.N > 0) hipLaunchKernelGGL(k_energy_sum, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, scaled_atomic, scaled_total, t.flags);
+  launch_struct_energy(t, scaled_atomic, scaled_total, s);
   if (t.S > 0) hipLaunchKernelGGL(k_scale, grid_for(t.S), dim3(256), 0, s, t.S, c.energy_scale, scaled_total, total);
 }
 

@@ -51,6 +51,7 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   t.t1_b = (uint8_t*)take((size_t)T + 16);
   t.t2_b = (uint8_t*)take((size_t)T + 16);
   t.batch = (int32_t*)take(sizeof(int32_t) * (N + 1));
+  t.struct_ptr = (int32_t*)take(sizeof(int32_t) * (S + 2));
   t.flags = (int32_t*)take(sizeof(int32_t) * 4);
   t.n_act = t.flags ? t.flags + 2 : nullptr;
   t.sort_tmp_bytes = topo_sort_tmp_bytes(E, T);
@@ -78,6 +79,7 @@ __global__ void k_convert_batch(int64_t N, int64_t S, const int64_t* __restrict_
   if (a >= N) return;
   int64_t b = batch[a];
   if (b < 0 || b >= S) { atomicOr(flags, 2); b = 0; }
+  if (a > 0 && batch[a - 1] > batch[a]) atomicOr(flags + 3, 1);   // not sorted: per-structure sums fall back to atomics
   out[a] = (int32_t)b;
 }
 
@@ -233,6 +235,7 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
     hipLaunchKernelGGL(k_low_word, grid(E), dim3(TPB), 0, s, E, keysB, t.in_edge);
   }
   hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, t.src, t.row_ptr);
+  hipLaunchKernelGGL(k_lower_bound32, grid(S + 1), dim3(TPB), 0, s, S, N, t.batch, t.struct_ptr);
   hipLaunchKernelGGL(k_lower_bound64, grid(N + 1), dim3(TPB), 0, s, N, E, keysB, t.in_ptr);
   for (int which = 0; which < 2; ++which) {
     int32_t* ptr = which == 0 ? t.t1_ptr : t.t2_ptr;
