@@ -11,21 +11,26 @@ from test_gpu_properties import _oracle_inputs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(20))
 def test_random_model_shape_and_batch_vs_oracle(case):
+    """cases 0-11: shapes of the fast (MFMA) kernels; 12-19: any shape the reference accepts (widths up to 160, l_max up to 9,
+    n_max up to 10, up to 10 blocks) -- the any-size path."""
     from torch_m3gnet.data import MaterialGraphKey as K
     from torch_m3gnet.data.material_graph import Batch
     from torch_m3gnet.model.build import build_model
 
     rng = np.random.default_rng(7000 + case)
-    l_max, n_max = int(rng.integers(1, 5)), int(rng.integers(1, 5))
-    if l_max * n_max > 16:
-        n_max = 16 // l_max
+    if case < 12:
+        l_max, n_max, dim, max_blocks = int(rng.integers(1, 5)), int(rng.integers(1, 5)), 64, 5
+        if l_max * n_max > 16:
+            n_max = 16 // l_max
+    else:
+        l_max, n_max, dim, max_blocks = int(rng.integers(1, 10)), int(rng.integers(1, 11)), int(rng.integers(8, 161)), 11
     cutoff = float(rng.uniform(3.5, 6.0))
     tb = float(rng.uniform(2.5, cutoff))
     torch.manual_seed(case)
-    model = build_model(cutoff=cutoff, threebody_cutoff=tb, l_max=l_max, n_max=n_max, num_types=95, embedding_dim=64,
-                        num_blocks=int(rng.integers(1, 5)), energy_scale=float(rng.uniform(0.5, 3.0)),
+    model = build_model(cutoff=cutoff, threebody_cutoff=tb, l_max=l_max, n_max=n_max, num_types=95, embedding_dim=dim,
+                        num_blocks=int(rng.integers(1, max_blocks)), energy_scale=float(rng.uniform(0.5, 3.0)),
                         length_scale=float(rng.uniform(0.8, 1.5)))
     for m in model.model:  # documented chi so the three-body path carries weight
         if type(m).__name__ == "ThreeBodyInteration":

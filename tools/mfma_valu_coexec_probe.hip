@@ -13,10 +13,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kIters = 4000;
 
-template <int M, int V, int ROLES>   // ROLES bit 0: matrix waves run, bit 1: vector waves run
+// PRIO: 0 both roles at priority 0; 1: matrix waves at s_setprio 1; 2: vector waves at s_setprio 1
+template <int M, int V, int ROLES, int PRIO = 0>   // ROLES bit 0: matrix waves run, bit 1: vector waves run
 __global__ void __launch_bounds__(512) probe(float* out, unsigned long long* cycles, float seed) {
   const int wave = threadIdx.x >> 6;
   const bool matrix = wave < 4;
+  if (PRIO == 1 && matrix) __builtin_amdgcn_s_setprio(1);
+  if (PRIO == 2 && !matrix) __builtin_amdgcn_s_setprio(1);
   unsigned long long t0 = 0, t1 = 0;
   float res = 0.f;
   if (matrix && (ROLES & 1)) {
@@ -54,10 +57,10 @@ __global__ void __launch_bounds__(512) probe(float* out, unsigned long long* cyc
   if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int M, int V, int ROLES>
+template <int M, int V, int ROLES, int PRIO = 0>
 static void run(const char* label, float* out, unsigned long long* cyc) {
-  hipLaunchKernelGGL((probe<M, V, ROLES>), dim3(256), dim3(512), 0, 0, out, cyc, 1.0f);   // warm-up
-  hipLaunchKernelGGL((probe<M, V, ROLES>), dim3(256), dim3(512), 0, 0, out, cyc, 1.0f);
+  hipLaunchKernelGGL((probe<M, V, ROLES, PRIO>), dim3(256), dim3(512), 0, 0, out, cyc, 1.0f);   // warm-up
+  hipLaunchKernelGGL((probe<M, V, ROLES, PRIO>), dim3(256), dim3(512), 0, 0, out, cyc, 1.0f);
   hipDeviceSynchronize();
   unsigned long long h[8];
   hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
@@ -75,6 +78,9 @@ int main() {
   run<0, 1, 2>("v_exp_f32 alone", out, cyc);
   run<0, 0, 3>("f32 MFMA + v_fma_f32 on the same SIMD", out, cyc);
   run<0, 1, 3>("f32 MFMA + v_exp_f32 on the same SIMD", out, cyc);
+  run<0, 0, 3, 1>("f32 MFMA (prio 1) + v_fma_f32 (prio 0)", out, cyc);
+  run<0, 1, 3, 1>("f32 MFMA (prio 1) + v_exp_f32 (prio 0)", out, cyc);
+  run<0, 0, 3, 2>("f32 MFMA (prio 0) + v_fma_f32 (prio 1)", out, cyc);
   run<1, 0, 1>("bf16 MFMA alone", out, cyc);
   run<1, 0, 3>("bf16 MFMA + v_fma_f32 on the same SIMD", out, cyc);
   run<1, 1, 3>("bf16 MFMA + v_exp_f32 on the same SIMD", out, cyc);

@@ -58,13 +58,12 @@ constexpr int kWavesRevF32 = M3G_WAVES_REV_F32;
 template <bool NEED_DP1, int MLP, bool SAVED_P2>
 __device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpRevF32& L, const RevArgs& a, int64_t edge, int64_t tile,
                                                 int64_t ci, const SegMasks& sk, const f32x4& hv, const f32x4 (&d_upd)[4],
-                                                f32x4 (&contrib)[4], f32x4& dhv, int lane) {
+                                                f32x4 (&contrib)[4], f32x4& dhv, int lane, f32x4 (&d2)[8]) {
   const int qd = lane >> 4;
-  f32x4 p1[SAVED_P2 ? 1 : 8], d2[8];
+  f32x4 p1[SAVED_P2 ? 1 : 8];
   const float* p1_src = a.p1 + tile * (2 * kP1TileFloats) + MLP * kP1TileFloats + (threadIdx.x & 63) * 4;
   if constexpr (SAVED_P2) {
-    const float* src = a.p2 + tile * (2 * kP1TileFloats) + MLP * kP1TileFloats + (threadIdx.x & 63) * 4;
-    static_for<8>([&]<int ob>() { d2[ob] = load_tile4(src + ob * 256); });
+    // d2 arrives loaded with the saved layer-2 pre-activations (load_p2: requested by the caller ahead of their use)
   } else {
     static_for<8>([&]<int ob>() { p1[ob] = load_tile4(p1_src + ob * 256); });
     bias_step<4, 0>(lds + L.b2, d2, lane);
@@ -125,6 +124,12 @@ __device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpR
   });
 }
 
+// saved layer-2 pre-activations of MLP `mlp` of this tile (8 x 1 KB per wave, streaming loads)
+__device__ __forceinline__ void load_p2(const RevArgs& a, int64_t tile, int mlp, f32x4 (&d2)[8]) {
+  const float* src = a.p2 + tile * (2 * kP1TileFloats) + mlp * kP1TileFloats + (threadIdx.x & 63) * 4;
+  static_for<8>([&]<int ob>() { d2[ob] = load_tile4(src + ob * 256); });
+}
+
 template <int TBS, bool NEED_DP1, int WAVES, bool SAVED_P2>
 __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF32Layout L) {
   __shared__ __attribute__((aligned(16))) float lds[kRevF32Floats + 4];  // + tile-queue head
@@ -132,6 +137,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
   load_image(lds, a.img, kRevF32Floats, q_head);
   const int lane = threadIdx.x & 63, qd = lane >> 4;
   TileQueue queue(a.tiles, q_head);
+#ifdef M3G_REV_F32_STAGGER
+  // experiment: the second wave of each SIMD (waves WAVES/2 ..) starts late, so the two do not run their chains in lockstep
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 32 * WAVES)
+    for (int i = 0; i < M3G_REV_F32_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   int ticket = queue.fetch(lane);
   if (ticket >= queue.count) return;
   int ci_i, cj_i;
@@ -155,13 +165,19 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
     float mb[TBS];
     const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
     static_for<TBS>([&]<int s>() { mb[s] = arow >= 0 ? a.m[(int64_t)arow * kCP + 4 * s + qd] : 0.f; });
-    f32x4 de[4], contrib[4];
+    f32x4 de[4], contrib[4], d2e[8];
     {
       // node-message MLP (nn/conv.py:77-89): d msg[e] = dx_new[centre(e)]
       f32x4 dmsg[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
       static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
-      mlp_reverse_f32<NEED_DP1, 1, SAVED_P2>(lds, L.mlp[1], a, edge, tile, ci, sk, hv, dmsg, contrib, dhv, lv);
+      f32x4 d2n[8];
+      if constexpr (SAVED_P2) load_p2(a, tile, 1, d2n);
+#ifdef M3G_P2_PREFETCH   // measured: no effect (1.011 vs 1.003 ms per step), the SIMD's other wave already covers that latency
+      // the edge MLP's saved rows are requested now, a whole MLP reverse ahead of their use (32 registers; the kernel has them)
+      if constexpr (SAVED_P2) load_p2(a, tile, 0, d2e);
+#endif
+      mlp_reverse_f32<NEED_DP1, 1, SAVED_P2>(lds, L.mlp[1], a, edge, tile, ci, sk, hv, dmsg, contrib, dhv, lv, d2n);
     }
     // dL/d e2 = what flows in from later blocks + the node MLP's contribution
     if (a.de_is_zero) {
@@ -172,7 +188,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
     asm volatile("" : "+v"(lv));
     M3G_F32_FENCE();
     // edge-update MLP (nn/conv.py:68-75)
-    mlp_reverse_f32<NEED_DP1, 0, SAVED_P2>(lds, L.mlp[0], a, edge, tile, ci, sk, hv, de, contrib, dhv, lv);
+#ifndef M3G_P2_PREFETCH
+    if constexpr (SAVED_P2) load_p2(a, tile, 0, d2e);
+#endif
+    mlp_reverse_f32<NEED_DP1, 0, SAVED_P2>(lds, L.mlp[0], a, edge, tile, ci, sk, hv, de, contrib, dhv, lv, d2e);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
       if (!FIRST) *(f32x4*)(de_tile + blk * 256) = de[blk];
