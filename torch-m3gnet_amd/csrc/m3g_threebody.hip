@@ -54,9 +54,25 @@ struct TbArgs {
 };
 
 // Forward: m[e1,:] = fc(d_e1) sum_t Y_l(cos_t) g[e2(t),:]
-template <int L, int R, int LIST, int CAP>
-__global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
+// LPR lanes share one row: each walks every LPR-th partner of the row's list and the partial sums are combined inside the lane
+// group (fixed order: deterministic).  The kernels are latency-bound -- a dependent LDS id read, then the partner's unit vector
+// and payload row, then the Legendre recurrence, per partner -- so the serial chain per row shrinks LPR-fold.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+  if (LPR >= 2) x += __shfl_xor(x, 1);
+  if (LPR >= 4) x += __shfl_xor(x, 2);
+  if (LPR >= 8) x += __shfl_xor(x, 4);
+  return x;
+}
+// lanes per row, measured (profiles/r02_config5_sweep.txt): 10k-atom Cu cell (17 partners per row) three-body forward / reverse
+// 0.054 / 0.108 ms per step at 1 lane, 0.047 / 0.102 at 2, 0.052 / 0.130 at 4, 0.066 / 0.198 at 8; dense cell (58 partners per
+// row) 24 / 86 us per launch at 1, 20 / 53 at 2, 19 / 50 at 4, 23 / 70 at 8
+constexpr int kTbLprShort = 2, kTbLprLong = 4;
+
+template <int L, int R, int LIST, int CAP, int LPR>
+__global__ void __launch_bounds__(kTbRows * LPR) k_threebody_fwd(Consts c, TbArgs a) {
   constexpr int C = L * R;
+  constexpr int kThreads = kTbRows * LPR;
   constexpr int kTbListCap = LIST * kTbRows;   // staged partner ids, one byte each
   // CAP <= kTbCap rows of the window are staged; the topology's byte ids count from the window start up to kTbCap, ids at or
   // beyond CAP take the global-memory path like the 255 marker
@@ -72,12 +88,13 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   // the rows' partner lists are one contiguous range: staged once, coalesced, as window-relative byte ids (precomputed
   // in the topology) -- a global load per triplet inside the loop serialises ~17 L2 round trips per thread
   const int n_list = (t_hi - t_lo) < kTbListCap ? (t_hi - t_lo) : kTbListCap;
-  for (int k = threadIdx.x; k < n_list; k += kTbRows) s_other[k] = a.t_bytes[t_lo + k];
-  const int r = rb + threadIdx.x;
+  for (int k = threadIdx.x; k < n_list; k += kThreads) s_other[k] = a.t_bytes[t_lo + k];
+  const int sub = threadIdx.x % LPR;
+  const int r = rb + (int)threadIdx.x / LPR;
   const bool live = r < A;
   const int64_t e = a.act_list[live ? r : A - 1];
   const int n = (hi_full - lo) < CAP ? (hi_full - lo) : CAP;
-  for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
+  for (int idx = threadIdx.x; idx < n; idx += kThreads) {
     const int64_t es = a.act_list[lo + idx], ks = a.act_dst[lo + idx];
     su[idx * 3 + 0] = a.u[es * 3];
     su[idx * 3 + 1] = a.u[es * 3 + 1];
@@ -97,7 +114,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
   float acc[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) acc[k] = 0.f;
-  for (int t = t0; t < t1; ++t) {
+  for (int t = t0 + sub; t < t1; t += LPR) {
     const int kk = t - t_lo;
     const int bid = kk < kTbListCap ? s_other[kk] : 255;
     const int idx = bid < CAP ? bid : a.t_other[t] - lo;
@@ -123,6 +140,9 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_fwd(Consts c, TbArgs a) {
     }
   }
 #pragma unroll
+  for (int k = 0; k < C; ++k) acc[k] = group_sum<LPR>(acc[k]);
+  if (sub != 0) return;
+#pragma unroll
   for (int k = 0; k < kCP; k += 4) {
     float4 o;
     o.x = k + 0 < C ? fc * acc[k + 0 < C ? k + 0 : 0] : 0.f;
@@ -147,9 +167,10 @@ struct TbRevArgs {
   int first;              // first reverse launch of the step (last block): dd/du are written, later launches accumulate
 };
 
-template <int L, int R, int LIST, int CAP>
-__global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a) {
+template <int L, int R, int LIST, int CAP, int LPR>
+__global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRevArgs a) {
   constexpr int C = L * R;
+  constexpr int kThreads = kTbRows * LPR;
   constexpr int kTbRevList = LIST * kTbRows;   // staged partner ids per list (bytes)
   __shared__ float su[CAP * 3];
   __shared__ float sg[CAP * C];
@@ -161,7 +182,8 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   const int lo = a.tb_win[6 * blockIdx.x], hi_full = a.tb_win[6 * blockIdx.x + 1];
   const int t1_lo = a.tb_win[6 * blockIdx.x + 2], t1_hi = a.tb_win[6 * blockIdx.x + 3];
   const int t2_lo = a.tb_win[6 * blockIdx.x + 4], t2_hi = a.tb_win[6 * blockIdx.x + 5];
-  const int r = rb + threadIdx.x;
+  const int sub = threadIdx.x % LPR;
+  const int r = rb + (int)threadIdx.x / LPR;
   const bool live = r < A;
   const int rr = live ? r : A - 1;           // compact row of this thread
   const int64_t e = a.act_list[rr];
@@ -169,9 +191,9 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
   const int n = (hi_full - lo) < CAP ? (hi_full - lo) : CAP;
   const int n1 = (t1_hi - t1_lo) < kTbRevList ? (t1_hi - t1_lo) : kTbRevList;
   const int n2 = (t2_hi - t2_lo) < kTbRevList ? (t2_hi - t2_lo) : kTbRevList;
-  for (int k = threadIdx.x; k < n1; k += kTbRows) s1[k] = a.t1_bytes[t1_lo + k];
-  for (int k = threadIdx.x; k < n2; k += kTbRows) s2[k] = a.t2_bytes[t2_lo + k];
-  for (int idx = threadIdx.x; idx < n; idx += kTbRows) {
+  for (int k = threadIdx.x; k < n1; k += kThreads) s1[k] = a.t1_bytes[t1_lo + k];
+  for (int k = threadIdx.x; k < n2; k += kThreads) s2[k] = a.t2_bytes[t2_lo + k];
+  for (int idx = threadIdx.x; idx < n; idx += kThreads) {
     const int64_t es = a.act_list[lo + idx], ks = a.act_dst[lo + idx];
     su[idx * 3 + 0] = a.u[es * 3];
     su[idx * 3 + 1] = a.u[es * 3 + 1];
@@ -221,7 +243,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
 #pragma unroll
   for (int k = 0; k < C; ++k) { S[k] = 0.f; dg[k] = 0.f; }
   float a1x = 0.f, a1y = 0.f, a1z = 0.f, a2x = 0.f, a2y = 0.f, a2z = 0.f;
-  for (int t = t10; t < t11; ++t) {      // this edge as e1: S += Y g[e2], d cos += dm1 dY g[e2]
+  for (int t = t10 + sub; t < t11; t += LPR) {      // this edge as e1: S += Y g[e2], d cos += dm1 dY g[e2]
     const int kk = t - t1_lo;
     float vx, vy, vz, pr[C];
     fetch(kk < kTbRevList ? s1[kk] : 255, a.t1_other, t, sg, false, vx, vy, vz, pr);
@@ -243,7 +265,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
     dcos = (raw >= -1.f && raw <= 1.f) ? dcos : 0.f;   // torch.clamp passes the gradient only inside [-1, 1]
     a1x += dcos * vx; a1y += dcos * vy; a1z += dcos * vz;
   }
-  for (int t = t20; t < t21; ++t) {      // this edge as e2: dg += dS[e1] Y, d cos += dS[e1] dY g_own
+  for (int t = t20 + sub; t < t21; t += LPR) {      // this edge as e2: dg += dS[e1] Y, d cos += dS[e1] dY g_own
     const int kk = t - t2_lo;
     float vx, vy, vz, pr[C];
     fetch(kk < kTbRevList ? s2[kk] : 255, a.t2_other, t, ss, true, vx, vy, vz, pr);
@@ -265,13 +287,20 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_rev(Consts c, TbRevArgs a
     dcos = (raw >= -1.f && raw <= 1.f) ? dcos : 0.f;
     a2x += dcos * vx; a2y += dcos * vy; a2z += dcos * vz;
   }
-  float dfc = 0.f, ddv = 0.f, val[kCP];
+  // combine the lane group's partial sums (S enters only through dfc = sum_k dm_k S_k, which is linear: reduce that scalar)
+  float dfc = 0.f;
+#pragma unroll
+  for (int k = 0; k < C; ++k) { dfc += dmv[k] * S[k]; dg[k] = group_sum<LPR>(dg[k]); }
+  dfc = group_sum<LPR>(dfc);
+  a1x = group_sum<LPR>(a1x); a1y = group_sum<LPR>(a1y); a1z = group_sum<LPR>(a1z);
+  a2x = group_sum<LPR>(a2x); a2y = group_sum<LPR>(a2y); a2z = group_sum<LPR>(a2z);
+  if (sub != 0) return;
+  float ddv = 0.f, val[kCP];
 #pragma unroll
   for (int k = 0; k < kCP; ++k) {
     val[k] = 0.f;
     if (k < C) {
       const int kc = k < C ? k : 0;
-      dfc += dmv[kc] * S[kc];
       ddv += dg[kc] * vv[kc] * qpv[kc];
       val[k] = dg[kc] * qv[kc];
     }
@@ -293,8 +322,8 @@ void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float
   if (t.E == 0) return;
   if (t.T == 0) return;   // no active edge: every consumer reads zeros through act_id < 0
   TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t1_b, w.u, w.fc3, w.q, v, m};
-  if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListLong, kTbCap>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a)); }
-  else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListShort, kTbCapShort>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a)); }
+  if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListLong, kTbCap, kTbLprLong>), grid_rows(t.E), dim3(kTbRows * kTbLprLong), 0, s, c, a)); }
+  else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListShort, kTbCapShort, kTbLprShort>), grid_rows(t.E), dim3(kTbRows * kTbLprShort), 0, s, c, a)); }
 }
 
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s) {
@@ -303,8 +332,8 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
   TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, t.t1_b, t.t2_b, w.u, w.fc3, w.fc3p, w.q,
               w.qp, v,
               w.dm, w.dd, w.du, w.dg, first ? 1 : 0};
-  if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R, kTbListLong, kTbCap>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a)); }
-  else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R, kTbListShort, kTbCapShort>), grid_rows(t.E), dim3(kTbRows), 0, s, c, a)); }
+  if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R, kTbListLong, kTbCap, kTbLprLong>), grid_rows(t.E), dim3(kTbRows * kTbLprLong), 0, s, c, a)); }
+  else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R, kTbListShort, kTbCapShort, kTbLprShort>), grid_rows(t.E), dim3(kTbRows * kTbLprShort), 0, s, c, a)); }
 }
 
 }  // namespace m3g
