@@ -137,11 +137,6 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
   load_image(lds, a.img, kRevF32Floats, q_head);
   const int lane = threadIdx.x & 63, qd = lane >> 4;
   TileQueue queue(a.tiles, q_head);
-#ifdef M3G_REV_F32_STAGGER
-  // experiment: the second wave of each SIMD (waves WAVES/2 ..) starts late, so the two do not run their chains in lockstep
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 32 * WAVES)
-    for (int i = 0; i < M3G_REV_F32_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
   int ticket = queue.fetch(lane);
   if (ticket >= queue.count) return;
   int ci_i, cj_i;
