@@ -83,8 +83,9 @@ __global__ void k_convert_batch(int64_t N, int64_t S, const int64_t* __restrict_
   out[a] = (int32_t)b;
 }
 
+// `order` (which == 0 only): order[0] != 0 when the (e1, e2) keys are not already in ascending order
 __global__ void k_convert_triplets(int64_t E, int64_t T, const int64_t* __restrict__ tei, const int32_t* __restrict__ src,
-                                   uint64_t* keys, int which, int32_t* flags) {
+                                   uint64_t* keys, int which, int32_t* flags, int32_t* order) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= T) return;
   int64_t e1 = tei[t], e2 = tei[T + t];
@@ -93,6 +94,22 @@ __global__ void k_convert_triplets(int64_t E, int64_t T, const int64_t* __restri
   else if (src[e1] != src[e2]) bad |= 4;
   keys[t] = which == 0 ? (((uint64_t)e1 << 32) | (uint64_t)e2) : (((uint64_t)e2 << 32) | (uint64_t)e1);
   if (bad) atomicOr(flags, bad);
+  if (which == 0 && t > 0) {
+    const int64_t p1 = tei[t - 1], p2 = tei[T + t - 1];
+    if (p1 > e1 || (p1 == e1 && p2 > e2)) atomicOr(order, 1);
+  }
+}
+// order[0] != 0 when some triplet (e1, e2) has no mirror (e2, e1) in the SORTED key list (binary search): the list is one-sided
+__global__ void k_check_symmetric(int64_t T, const uint64_t* __restrict__ sorted_keys, int32_t* order) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const uint64_t k = sorted_keys[t], want = (k << 32) | (k >> 32);
+  int64_t lo = 0, hi = T;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted_keys[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= T || sorted_keys[lo] != want) atomicOr(order, 1);
 }
 
 // ptr[r] = first position whose key (high word of keys64, or keys32[pos]) >= r, for r = 0..rows
@@ -237,15 +254,43 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, t.src, t.row_ptr);
   hipLaunchKernelGGL(k_lower_bound32, grid(S + 1), dim3(TPB), 0, s, S, N, t.batch, t.struct_ptr);
   hipLaunchKernelGGL(k_lower_bound64, grid(N + 1), dim3(TPB), 0, s, N, E, keysB, t.in_ptr);
-  for (int which = 0; which < 2; ++which) {
-    int32_t* ptr = which == 0 ? t.t1_ptr : t.t2_ptr;
-    int32_t* lst = which == 0 ? t.t1_e2 : t.t2_e1;
-    if (T > 0) {
-      hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, which, t.flags);
+  // Triplet lists grouped by first edge (t1) and by second edge (t2), each in canonical (sorted) order.  The list the graph
+  // builders emit (compute_threebody's order, data/material_graph.py:239-248) is already sorted by (e1, e2) and symmetric
+  // (every ordered pair of a centre's edges): then t1 needs no sort and t2 IS t1.  Both properties are checked on the device
+  // (one small host read-back); any other list -- permuted, one-sided, filtered -- takes the radix sorts.
+  int32_t* order = t.flags + 1;   // flags[1] (otherwise unused): first "not sorted", then "not symmetric"
+  if (T > 0) {
+    hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, 0, t.flags, order);
+    int32_t unsorted = 0;
+    M3G_HIP_CHECK(hipMemcpyAsync(&unsorted, order, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    M3G_HIP_CHECK(hipStreamSynchronize(s));
+    uint64_t* sorted = keysA;
+    if (unsorted) {
       M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)T, 0, 32 + bits_for(E + 1), s));
-      hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, keysB, lst);
+      sorted = keysB;
     }
-    hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, keysB, ptr);
+    hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, sorted, t.t1_e2);
+    hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, sorted, t.t1_ptr);
+    M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, sorted, order);
+    int32_t asym = 0;
+    M3G_HIP_CHECK(hipMemcpyAsync(&asym, order, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    M3G_HIP_CHECK(hipStreamSynchronize(s));
+    M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
+    if (!asym) {   // symmetric: the partners of e as second edge are its partners as first edge
+      M3G_HIP_CHECK(hipMemcpyAsync(t.t2_ptr, t.t1_ptr, sizeof(int32_t) * (E + 1), hipMemcpyDeviceToDevice, s));
+      M3G_HIP_CHECK(hipMemcpyAsync(t.t2_e1, t.t1_e2, sizeof(int32_t) * T, hipMemcpyDeviceToDevice, s));
+    } else {
+      uint64_t* other = sorted == keysA ? keysB : keysA;   // the t1 keys are no longer needed
+      hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, other, 1, t.flags, order);
+      uint64_t* out = other == keysA ? keysB : keysA;
+      M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, other, out, (int)T, 0, 32 + bits_for(E + 1), s));
+      hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, out, t.t2_e1);
+      hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, out, t.t2_ptr);
+    }
+  } else {
+    M3G_HIP_CHECK(hipMemsetAsync(t.t1_ptr, 0, sizeof(int32_t) * (E + 1), s));
+    M3G_HIP_CHECK(hipMemsetAsync(t.t2_ptr, 0, sizeof(int32_t) * (E + 1), s));
   }
   // compaction of the edges that take part in triplets (act_scan doubles as the flag array before the scan)
   hipLaunchKernelGGL(k_active_flags, grid(E + 1), dim3(TPB), 0, s, E, t.t1_ptr, t.t2_ptr, t.act_scan);
