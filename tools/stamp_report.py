@@ -25,15 +25,17 @@ eng.set_option("stamps", 1)
 for _ in range(3):
     model(g, extras=False)
 torch.cuda.synchronize()
+import os
+W = int(os.environ.get("STAMP_WAVES", "16"))   # waves per workgroup of the build under test (M3G_WAVES_FWD)
 buf = np.zeros(256 * 16 * 12, dtype=np.uint64)
 _lib.check(eng.lib.m3g_debug_read_stamps(eng.plan, buf.ctypes.data))
-s = buf.reshape(256, 16, 12).astype(np.float64)
+s = buf[:256 * W * 12].reshape(256, W, 12).astype(np.float64)
 names = ["tile loads", "three-body MLP", "e: table gather", "e: both layers", "(unused)", "e: gating",
          "e2 residual+store", "n: table gather", "n: both layers", "(unused)", "n: gating", "message sums"]
 print("precision", prec)
 tot = s.sum(-1)
-print("cycles per wave (mean / min / max over 4096 waves):", tot.mean(), tot.min(), tot.max())
-tiles_per_wave = 26250 / 4096
+print("cycles per wave (mean / min / max over all waves):", tot.mean(), tot.min(), tot.max())
+tiles_per_wave = 26250 / (256 * W)
 for i, n in enumerate(names):
     print(f"{n:22s} {s[..., i].mean() / tiles_per_wave:10.0f} cyc/tile  {100 * s[..., i].sum() / tot.sum():5.1f} %")
 wg = tot.max(1)          # a workgroup ends with its slowest wave

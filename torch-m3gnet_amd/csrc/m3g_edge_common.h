@@ -76,6 +76,9 @@ __device__ __forceinline__ void f32_chain_prio_on() {
   else __builtin_amdgcn_s_setprio(1);
 }
 #define M3G_F32_CHAIN_PRIO(p) do { if (p) f32_chain_prio_on(); else __builtin_amdgcn_s_setprio(0); } while (0)
+#elif defined(M3G_F32_INVERSE_PRIO)
+// experiment: the vector phases run at raised priority, the chains at 0
+#define M3G_F32_CHAIN_PRIO(p) __builtin_amdgcn_s_setprio((p) ? 0 : M3G_F32_INVERSE_PRIO)
 #elif !defined(M3G_NO_F32_CHAIN_PRIO)
 #define M3G_F32_CHAIN_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #else
@@ -319,6 +322,10 @@ __device__ __forceinline__ void tb_preact(const float* tbimg, const float (&mb)[
 // layer-1 accumulators start from the gathered per-node tables TA[i] + TB[j] (x_i / x_j parts, bias folded)
 __device__ __forceinline__ void gather_tables(const float* __restrict__ TA, const float* __restrict__ TB, int mlp, int64_t ci,
                                               int64_t cj, int qd, f32x4 (&p1)[8]) {
+#ifdef M3G_DIAG_NO_GATHER   // timing diagnostic only (wrong results): what the table gathers cost
+  static_for<8>([&]<int ob>() { p1[ob] = f32x4{0.1f, 0.2f, 0.3f, 0.4f}; });
+  return;
+#endif
   const float* ta = TA + ci * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
   const float* tb = TB + cj * (4 * kDP) + mlp * (2 * kDP) + 4 * qd;
   static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(ta + ob * 16) + *(const f32x4*)(tb + ob * 16); });

@@ -21,12 +21,20 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+#ifdef M3G_DIAG_CHEAP_ACT   // timing diagnostic only (wrong results): activations without transcendentals
+__device__ __forceinline__ float fsigmoid(float p) { return p * 0.25f + 0.5f; }
+#else
 __device__ __forceinline__ float fsigmoid(float p) { return __builtin_amdgcn_rcpf(1.f + __expf(-p)); }
+#endif
 __device__ __forceinline__ float fsilu(float p) { return p * fsigmoid(p); }
 // SiLU(p) * sigmoid(g) = p / ((1 + e^-p)(1 + e^-g)): one reciprocal for the gated product instead of two sigmoids
 // (each factor is >= 1, an overflowing exponential gives inf -> rcp 0, the correct limit)
 __device__ __forceinline__ float fgated(float p, float g) {
+#ifdef M3G_DIAG_CHEAP_ACT
+  return p * (g * 0.25f + 0.5f);
+#else
   return p * __builtin_amdgcn_rcpf((1.f + __expf(-p)) * (1.f + __expf(-g)));
+#endif
 }
 __device__ __forceinline__ float fdsilu(float p) {
   float s = fsigmoid(p);
