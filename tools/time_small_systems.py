@@ -1,0 +1,30 @@
+"""Step latency of small systems (fcc Cu supercells of n x n x n conventional cells, cutoff 5 / 4): a small system's step is
+the serial latency of its ~36 kernels, not throughput.  Usage: python tools/time_small_systems.py [fp32|bf16x3] [n ...]"""
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
+    sys.path.insert(0, str(p))
+from helpers import fcc_cu_graph  # noqa: E402
+from torch_m3gnet.model.build import build_model  # noqa: E402
+
+torch.manual_seed(0)
+model = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
+model.engine.set_precision(sys.argv[1] if len(sys.argv) > 1 else "fp32")
+for n in ([int(v) for v in sys.argv[2:]] or (2, 3, 4, 6, 8, 10)):
+    g = fcc_cu_graph(n, n, n).to("cuda")
+    for _ in range(5):
+        model(g, forces=True, extras=False)
+    torch.cuda.synchronize()
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        model(g, forces=True, extras=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    atoms = 4 * n ** 3
+    print(f"{atoms:6d} atoms  {int(g['edge_index'].shape[1]):8d} edges: {ms:.3f} ms/step = {atoms / ms * 1e3 / 1e6:.3f} M atom-steps/s", flush=True)

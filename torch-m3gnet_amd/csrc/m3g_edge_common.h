@@ -371,8 +371,15 @@ __device__ __forceinline__ void store_dh(float* dh, int64_t edge, int64_t E, f32
   if (qd == 0 && edge < E) *(f32x4*)(dh + edge * kRP) = dhv;
 }
 
-inline int grid_for_tiles(int64_t tiles) {
+// One workgroup per CU for large problems.  Small ones are spread one tile per workgroup over as many CUs as there are tiles
+// instead of filling the 16 wave slots of a few CUs: a wave alone on its SIMD finishes a tile about three times sooner than
+// four waves sharing the SIMD finish theirs, and a small system's step is the serial latency of its kernels.
+inline int grid_for_tiles(int64_t tiles, int /*waves*/ = kWaves) {
+#ifdef M3G_GRID_PACKED   // round-1 rule: fill the wave slots of ceil(tiles / waves) CUs
   int64_t wgs = (tiles + kWaves - 1) / kWaves;
+#else
+  int64_t wgs = tiles;
+#endif
   wgs = (wgs + 7) / 8 * 8;
   if (wgs < 8) wgs = 8;
   if (wgs > 256) wgs = 256;

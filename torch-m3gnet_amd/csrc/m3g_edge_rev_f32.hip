@@ -235,10 +235,7 @@ void launch_edge_rev_f32(const m3g_plan* plan, const Consts& c, const Topo& t, c
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, w.p1_blk[b],
              saves_p2(plan) ? w.p2_blk[b] : nullptr};
   constexpr int WV = kWavesRevF32;
-  int64_t wgs = (tiles + WV - 1) / WV;
-  wgs = (wgs + 7) / 8 * 8;
-  wgs = wgs < 8 ? 8 : (wgs > 256 ? 256 : wgs);
-  dim3 grid((unsigned)wgs), block(64 * WV);
+  dim3 grid(grid_for_tiles(tiles, WV)), block(64 * WV);
   const bool p2 = saves_p2(plan);
   // (block 0: x^0 has no position dependence, nobody reads its dp1 rows)
 #define M3G_REV_F32_LAUNCH(NEED, P2) M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_f32<TBS, NEED, WV, P2>), grid, block, 0, s, ar, L))
