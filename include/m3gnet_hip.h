@@ -118,7 +118,8 @@ int m3g_plan_commit(m3g_plan* plan);
  * it converts MaterialGraph index tensors into the receiver-sorted CSR form the kernels use.
  * Depends on the index tensors only -- reusable across calls while they are unchanged. ---------- */
 int m3g_topology_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, size_t* bytes);
-/* On return (after stream sync) host_flags[0] != 0 means the graph is malformed:
+/* The call waits for the stream once (it reads back whether the triplet list is sorted and symmetric, which decides the
+ * sorts); on return host_flags[0] != 0 means the graph is malformed (the remaining kernels of the build may still be running):
  *   bit 0: edge_index[0] not sorted; bit 1: index out of range; bit 2: triplet edges with different centres. */
 int m3g_topology_build(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
                        const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,

@@ -466,6 +466,17 @@ def test_config5_full_size_through_properties():
     torch.testing.assert_close(both[K.FORCES][:2000], f1, rtol=1e-5, atol=1e-7)
     alone = model(batch_from_arrays(*zip(small), 6.0, 6.0, device=DEV), extras=False)
     torch.testing.assert_close(both[K.TOTAL_ENERGY][1:], alone[K.TOTAL_ENERGY], rtol=1e-6, atol=1e-6)
+    # the two precision modes share nothing in their dense chains (exact-fp32 MFMAs / 3 split bf16 MFMAs): at ~60 neighbours
+    # per atom, where per-centre sums are longest, they must still agree within the bf16x3 mode's error budget
+    current = model.engine.precision
+    other = "bf16x3" if current == "fp32" else "fp32"
+    model.engine.set_precision(other)
+    try:
+        out3 = model(g, extras=False)
+        assert rel_err(out3[K.TOTAL_ENERGY], e1) < 1e-5, (other, rel_err(out3[K.TOTAL_ENERGY], e1))
+        assert rel_err(out3[K.FORCES], f1) < 1e-4, (other, rel_err(out3[K.FORCES], f1))
+    finally:
+        model.engine.set_precision(current)
 
 
 # ------------------------------------------------------------------ hyper-parameter sweep (padding paths, template variants)

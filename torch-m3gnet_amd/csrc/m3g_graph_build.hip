@@ -9,8 +9,8 @@
 // (sx, sy, sz) lexicographic, then neighbour index -- the same order torch_m3gnet/data/neighbors.py produces, so
 // both builders can be compared element by element.
 // Geometry in fp64 like pymatgen (inclusion d <= cutoff is decided in double; the stored tensors are narrowed by
-// the caller).  Linked cells: atoms are radix-sorted (hipCUB) into bins at least one cutoff wide, and one thread per
-// (atom, periodic image) tests only the bins of that image within reach -- O(N) pair tests for large cells, and
+// the caller).  Linked cells: atoms are radix-sorted (hipCUB) into bins at least one cutoff wide, and one wave per atom
+// walks its periodic images, testing only the bins of an image within reach -- O(N) pair tests for large cells, and
 // the plain all-images x all-atoms search when the cell is smaller than the cutoff (one bin).  Integer/byte work,
 // L2-bound.  Count -> exclusive scan (hipCUB) -> fill, so no atomics and a deterministic result.
 #include <hipcub/hipcub.hpp>
@@ -161,10 +161,41 @@ __global__ void k_bin_ranges(int64_t N, int64_t S, const int64_t* __restrict__ b
   bin_start[g] = (int32_t)lo;
 }
 
-// One thread per (atom i, image).  The thread walks the bins of that image that can hold a neighbour (at most
-// 3x3x3, or the single bin of a small cell for every image), counting (FILL = false) or writing (FILL = true)
-// its matches into the slot range the exclusive scan assigned; the fill pass then orders its own short segment
-// by neighbour index so the result is canonical and independent of the bin traversal.
+// One wave per atom i.  The wave walks the atom's periodic images in order; for an image it visits the bins that can hold a
+// neighbour (at most 3x3x3, or the single bin of a small cell for every image) with its 64 lanes striding over the bin-sorted
+// candidates, and counts (FILL = false) or writes (FILL = true) the matches into the slot range the exclusive scan assigned to
+// (atom, image).  A segment must come out ordered by neighbour index (canonical order, independent of the bin traversal): the
+// matches are staged in LDS and every lane places its match by counting the smaller indices (a neighbour occurs once per image);
+// a segment longer than the staging buffer is written and insertion-sorted by one lane in global memory.
+// (Round 1 ran one THREAD per (atom, image): in a large cell only the home image of an atom has work, ~290 fp64 pair tests on
+// 2-3 lanes of every wave: count + fill 0.46 ms on the 10,000-atom cell.)
+constexpr int kNbStage = 512;   // staged matches per wave (one (atom, image) segment)
+
+struct NbImage {
+  int sh[3], lo[3], hi[3];
+  bool any;
+  double ox, oy, oz;
+};
+__device__ __forceinline__ NbImage nb_image(const StructInfo& si, int img, const int32_t* binc_i, const double* pos_w_i) {
+  NbImage im;
+  const int ny = 2 * si.reps[1] + 1, nz = 2 * si.reps[2] + 1;
+  im.sh[0] = img / (ny * nz) - si.reps[0];
+  im.sh[1] = (img / nz) % ny - si.reps[1];
+  im.sh[2] = img % nz - si.reps[2];
+  im.any = true;
+  for (int p = 0; p < 3; ++p) {   // bins b' of the image whose unwrapped coordinate b' + s nb is within reach of this atom's bin
+    const int b = binc_i[p];
+    im.lo[p] = max(0, b - si.reach[p] - im.sh[p] * si.nb[p]);
+    im.hi[p] = min(si.nb[p] - 1, b + si.reach[p] - im.sh[p] * si.nb[p]);
+    im.any = im.any && im.lo[p] <= im.hi[p];
+  }
+  // image displacement minus this atom's wrapped position: |pos_w[j] + o| is the pair distance
+  im.ox = im.sh[0] * si.lat[0] + im.sh[1] * si.lat[3] + im.sh[2] * si.lat[6] - pos_w_i[0];
+  im.oy = im.sh[0] * si.lat[1] + im.sh[1] * si.lat[4] + im.sh[2] * si.lat[7] - pos_w_i[1];
+  im.oz = im.sh[0] * si.lat[2] + im.sh[1] * si.lat[5] + im.sh[2] * si.lat[8] - pos_w_i[2];
+  return im;
+}
+
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const int64_t* __restrict__ batch,
                                                    const StructInfo* __restrict__ info, const int64_t* __restrict__ bin_off,
@@ -173,59 +204,100 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
                                                    const int32_t* __restrict__ binc, const int32_t* __restrict__ wrap, double cutoff,
                                                    int64_t* __restrict__ counts, int64_t E, int64_t* __restrict__ edge_index,
                                                    int32_t* __restrict__ shift, double* __restrict__ dist) {
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= N * M) return;
-  const int64_t i = t / M;
-  const int img = (int)(t % M);
+  __shared__ int32_t stage_j[FILL ? 4 * kNbStage : 1];
+  __shared__ double stage_d[FILL ? 4 * kNbStage : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + wave;   // wave-uniform
+  if (i >= N) return;
   const int s = (int)batch[i];
   const StructInfo& si = info[s];
-  if (img >= si.n_img) { if (!FILL) counts[t] = 0; return; }
-  const int ny = 2 * si.reps[1] + 1, nz = 2 * si.reps[2] + 1;
-  const int sh[3] = {img / (ny * nz) - si.reps[0], (img / nz) % ny - si.reps[1], img % nz - si.reps[2]};
-  int lo[3], hi[3];
-  bool any = true;
-  for (int p = 0; p < 3; ++p) {   // bins b' of the image whose unwrapped coordinate b' + s nb is within reach of this atom's bin
-    const int b = binc[i * 3 + p];
-    lo[p] = max(0, b - si.reach[p] - sh[p] * si.nb[p]);
-    hi[p] = min(si.nb[p] - 1, b + si.reach[p] - sh[p] * si.nb[p]);
-    any = any && lo[p] <= hi[p];
-  }
-  // image displacement minus this atom's wrapped position: |pos_w[j] + o| is the pair distance
-  const double ox = sh[0] * si.lat[0] + sh[1] * si.lat[3] + sh[2] * si.lat[6] - pos_w[i * 3];
-  const double oy = sh[0] * si.lat[1] + sh[1] * si.lat[4] + sh[2] * si.lat[7] - pos_w[i * 3 + 1];
-  const double oz = sh[0] * si.lat[2] + sh[1] * si.lat[5] + sh[2] * si.lat[8] - pos_w[i * 3 + 2];
   const double c2 = (cutoff + 1e-8) * (cutoff + 1e-8);
-  const int64_t begin = FILL ? counts[t] : 0;
-  int64_t out = begin;
-  if (any) {
-    const int64_t b0 = bin_off[s];
-    for (int bx = lo[0]; bx <= hi[0]; ++bx)
-      for (int by = lo[1]; by <= hi[1]; ++by) {
-        const int64_t g0 = b0 + ((int64_t)bx * si.nb[1] + by) * si.nb[2];
-        const int k0 = bin_start[g0 + lo[2]], k1 = bin_start[g0 + hi[2] + 1];   // bins along z are consecutive slots
-        for (int k = k0; k < k1; ++k) {
-          const double dx = pos_s[(int64_t)k * 3] + ox, dy = pos_s[(int64_t)k * 3 + 1] + oy, dz = pos_s[(int64_t)k * 3 + 2] + oz;
-          const double d2 = dx * dx + dy * dy + dz * dz;
-          if (d2 <= c2 && d2 > 1e-16) {
-            if (FILL && out < E) { edge_index[E + out] = perm[k]; dist[out] = sqrt(d2); }
-            ++out;
+  const int64_t b0 = bin_off[s];
+  // A cell smaller than the cutoff is one bin and has many images with at most `count` candidates each: the wave then works
+  // on G = 64 / W images at a time, W lanes per image.
+  const bool one_bin = si.nb[0] == 1 && si.nb[1] == 1 && si.nb[2] == 1;
+  const int logw = !one_bin || si.count > 32 ? 6 : si.count > 16 ? 5 : si.count > 8 ? 4 : 3;
+  const int W = 1 << logw, G = 64 >> logw, g = lane >> logw, gl = lane & (W - 1);
+  const unsigned long long group_bits = W == 64 ? ~0ull : ((1ull << W) - 1ull);
+  const int cap = kNbStage >> (6 - logw);   // staged matches per group
+  int32_t* sj = stage_j + (FILL ? wave * kNbStage + g * cap : 0);
+  double* sd = stage_d + (FILL ? wave * kNbStage + g * cap : 0);
+  if (!FILL) for (int64_t img = si.n_img + lane; img < M; img += 64) counts[i * M + img] = 0;   // images this structure does not have
+  for (int img0 = 0; img0 < si.n_img; img0 += G) {
+    const int img = img0 + g;
+    const bool valid = img < si.n_img;
+    NbImage im = nb_image(si, valid ? img : 0, binc + i * 3, pos_w + i * 3);
+    if (!valid) im.any = false;
+    const int64_t begin = FILL && valid ? counts[i * M + img] : 0;
+    int n = 0;   // matches of this image so far (uniform over the group)
+    if (im.any) {
+      for (int bx = im.lo[0]; bx <= im.hi[0]; ++bx)
+        for (int by = im.lo[1]; by <= im.hi[1]; ++by) {
+          const int64_t g0 = b0 + ((int64_t)bx * si.nb[1] + by) * si.nb[2];
+          const int k0 = bin_start[g0 + im.lo[2]], k1 = bin_start[g0 + im.hi[2] + 1];   // bins along z are consecutive slots
+          for (int kb = k0; kb < k1; kb += W) {
+            const int k = kb + gl;
+            bool hit = false;
+            double d2 = 0.0;
+            if (k < k1) {
+              const double dx = pos_s[(int64_t)k * 3] + im.ox, dy = pos_s[(int64_t)k * 3 + 1] + im.oy, dz = pos_s[(int64_t)k * 3 + 2] + im.oz;
+              d2 = dx * dx + dy * dy + dz * dz;
+              hit = d2 <= c2 && d2 > 1e-16;
+            }
+            const unsigned long long m = (__ballot(hit) >> (g * W)) & group_bits;   // this group's lanes (all in this iteration together)
+            if (FILL && hit) {
+              const int at = n + __popcll(m & ((1ull << gl) - 1ull));
+              if (at < cap) { sj[at] = perm[k]; sd[at] = sqrt(d2); }
+            }
+            n += __popcll(m);
           }
         }
+    }
+    if (!FILL) { if (valid && gl == 0) counts[i * M + img] = n; continue; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the staged matches of the other lanes (same wave: LDS keeps program order)
+    if (n > 0 && n <= cap) {
+      for (int e = gl; e < n; e += W) {
+        const int32_t j = sj[e];
+        int rank = 0;
+        for (int f = 0; f < n; ++f) rank += sj[f] < j ? 1 : 0;
+        const int64_t a = begin + rank;
+        if (a < E) {
+          edge_index[a] = i;
+          edge_index[E + a] = j;
+          dist[a] = sd[e];
+          for (int p = 0; p < 3; ++p) shift[a * 3 + p] = im.sh[p] - wrap[(int64_t)j * 3 + p] + wrap[i * 3 + p];
+        }
       }
-  }
-  if (!FILL) { counts[t] = out; return; }
-  const int64_t end = out < E ? out : E;
-  for (int64_t a = begin + 1; a < end; ++a) {   // insertion sort of this (atom, image) segment by neighbour index
-    const int64_t j = edge_index[E + a];
-    const double d = dist[a];
-    int64_t b = a;
-    while (b > begin && edge_index[E + b - 1] > j) { edge_index[E + b] = edge_index[E + b - 1]; dist[b] = dist[b - 1]; --b; }
-    edge_index[E + b] = j; dist[b] = d;
-  }
-  for (int64_t a = begin; a < end; ++a) {
-    const int64_t j = edge_index[E + a];
-    edge_index[a] = i;
-    for (int p = 0; p < 3; ++p) shift[a * 3 + p] = sh[p] - wrap[j * 3 + p] + wrap[i * 3 + p];
+    } else if (n > cap && gl == 0) {   // oversized segment: one lane, in place
+      int64_t out = begin;
+      for (int bx = im.lo[0]; bx <= im.hi[0]; ++bx)
+        for (int by = im.lo[1]; by <= im.hi[1]; ++by) {
+          const int64_t g0 = b0 + ((int64_t)bx * si.nb[1] + by) * si.nb[2];
+          const int k0 = bin_start[g0 + im.lo[2]], k1 = bin_start[g0 + im.hi[2] + 1];
+          for (int k = k0; k < k1; ++k) {
+            const double dx = pos_s[(int64_t)k * 3] + im.ox, dy = pos_s[(int64_t)k * 3 + 1] + im.oy, dz = pos_s[(int64_t)k * 3 + 2] + im.oz;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 <= c2 && d2 > 1e-16) {
+              if (out < E) { edge_index[E + out] = perm[k]; dist[out] = sqrt(d2); }
+              ++out;
+            }
+          }
+        }
+      const int64_t end = out < E ? out : E;
+      for (int64_t a = begin + 1; a < end; ++a) {   // insertion sort by neighbour index
+        const int64_t j = edge_index[E + a];
+        const double d = dist[a];
+        int64_t b = a;
+        while (b > begin && edge_index[E + b - 1] > j) { edge_index[E + b] = edge_index[E + b - 1]; dist[b] = dist[b - 1]; --b; }
+        edge_index[E + b] = j; dist[b] = d;
+      }
+      for (int64_t a = begin; a < end; ++a) {
+        const int64_t j = edge_index[E + a];
+        edge_index[a] = i;
+        for (int p = 0; p < 3; ++p) shift[a * 3 + p] = im.sh[p] - wrap[j * 3 + p] + wrap[i * 3 + p];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // before the next image overwrites the stage
   }
 }
 
@@ -265,34 +337,76 @@ __global__ void k_rows_from_sorted(int64_t N, int64_t E, const int64_t* __restri
   if (r < N && lo < E && lo > 0 && src[lo - 1] > src[lo]) atomicOr(flags, 1);
 }
 
-// one thread per centre: rank its valid edges (d <= threebody_cutoff, decided on the fp32 distances like the reference)
-__global__ void k_rank_valid(int64_t N, const int32_t* __restrict__ row_ptr, const float* __restrict__ dist, float tb_cutoff,
-                             int32_t* rank, int32_t* deg, int64_t* counts) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+// One wave per centre: rank its valid edges (d <= threebody_cutoff, decided on the fp32 distances like the reference) with a
+// ballot prefix count, 64 edges of the row per pass.
+__global__ void __launch_bounds__(256) k_rank_valid(int64_t N, const int32_t* __restrict__ row_ptr, const float* __restrict__ dist,
+                                                    float tb_cutoff, int32_t* rank, int32_t* deg, int64_t* counts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
+  const int r0 = row_ptr[i], r1 = row_ptr[i + 1];
   int d = 0;
-  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) rank[e] = dist[e] <= tb_cutoff ? d++ : -1;
-  deg[i] = d;
-  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) counts[e] = rank[e] >= 0 ? d - 1 : 0;
+  for (int base = r0; base < r1; base += 64) {
+    const int e = base + lane;
+    const bool v = e < r1 && dist[e] <= tb_cutoff;
+    const unsigned long long m = __ballot(v);
+    if (e < r1) rank[e] = v ? d + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    d += __popcll(m);
+  }
+  if (lane == 0) deg[i] = d;
+  for (int base = r0; base < r1; base += 64) {
+    const int e = base + lane;
+    if (e < r1) counts[e] = dist[e] <= tb_cutoff ? d - 1 : 0;
+  }
 }
 
-// one thread per edge: write its deg-1 triplets in the reference's order (partners in edge order, itself skipped)
-__global__ void k_fill_triplets(int64_t N, int64_t E, int64_t T, const int64_t* __restrict__ src, const int32_t* __restrict__ row_ptr,
-                                const int32_t* __restrict__ rank, const int32_t* __restrict__ deg,
-                                const int64_t* __restrict__ offsets, int64_t* __restrict__ tei, int64_t* __restrict__ num_triplet_i,
-                                int32_t* __restrict__ num_triplet_ij) {
-  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e < N && num_triplet_i) { int64_t d = deg[e]; num_triplet_i[e] = d * (d - 1); }
-  if (e >= E) return;
-  const int64_t i = src[e];
-  const bool valid = rank[e] >= 0;
-  if (num_triplet_ij) num_triplet_ij[e] = valid ? deg[i] - 1 : 0;
-  if (!valid) return;
-  int64_t out = offsets[e];
-  for (int f = row_ptr[i]; f < row_ptr[i + 1]; ++f) {
-    if (f == e || rank[f] < 0) continue;
-    if (out < T) { tei[out] = e; tei[T + out] = f; }
-    ++out;
+// One wave per centre: its d (d - 1) triplets in the reference's order (first edge in edge order; partners in edge order, itself
+// skipped) occupy one contiguous range of the output, which the lanes write side by side: slot q -> first edge of rank
+// q / (d - 1), partner of rank k or k + 1 with k = q % (d - 1).  The centre's valid edges are listed by rank in LDS; a centre
+// with more than kTripletList of them falls back to one lane per first edge.
+constexpr int kTripletList = 256;
+__global__ void __launch_bounds__(256) k_fill_triplets(int64_t N, int64_t E, int64_t T, const int32_t* __restrict__ row_ptr,
+                                                       const int32_t* __restrict__ rank, const int32_t* __restrict__ deg,
+                                                       const int64_t* __restrict__ offsets, int64_t* __restrict__ tei,
+                                                       int64_t* __restrict__ num_triplet_i, int32_t* __restrict__ num_triplet_ij) {
+  __shared__ int32_t vlist_all[4 * kTripletList];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + wave;
+  if (i >= N) return;
+  int32_t* vlist = vlist_all + wave * kTripletList;
+  const int r0 = row_ptr[i], r1 = row_ptr[i + 1];
+  const int d = deg[i];
+  if (lane == 0 && num_triplet_i) num_triplet_i[i] = (int64_t)d * (d - 1);
+  int first = -1;   // the centre's first valid edge: its offset is the centre's output base
+  for (int base = r0; base < r1; base += 64) {
+    const int e = base + lane;
+    const int rk = e < r1 ? rank[e] : -1;
+    if (e < r1 && num_triplet_ij) num_triplet_ij[e] = rk >= 0 ? d - 1 : 0;
+    if (rk >= 0 && rk < kTripletList) vlist[rk] = e;
+    if (rk == 0) first = e;
+  }
+  if (d < 2) return;
+  first = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, first));
+  const int64_t out0 = offsets[first];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // vlist entries written by other lanes of this wave
+  if (d <= kTripletList) {
+    const int n = d * (d - 1);
+    for (int q = lane; q < n; q += 64) {
+      const int a = q / (d - 1), k = q - a * (d - 1);
+      const int64_t o = out0 + q;
+      if (o < T) { tei[o] = vlist[a]; tei[T + o] = vlist[k < a ? k : k + 1]; }
+    }
+  } else {   // very long rows: one lane per first edge, partners found by walking the row
+    for (int base = r0; base < r1; base += 64) {
+      const int e = base + lane;
+      if (e >= r1 || rank[e] < 0) continue;
+      int64_t o = offsets[e];
+      for (int f = r0; f < r1; ++f) {
+        if (f == e || rank[f] < 0) continue;
+        if (o < T) { tei[o] = e; tei[T + o] = f; }
+        ++o;
+      }
+    }
   }
 }
 
@@ -328,10 +442,12 @@ extern "C" int m3g_neighbor_count(int64_t N, int64_t S, int64_t max_images, cons
   M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, w.bin_off, w.bin_off, (int)(S + 1), s));
   hipLaunchKernelGGL(k_wrap_positions, g_for(N), dim3(256), 0, s, N, S, pos, batch, w.info, w.bin_off, w.pos_w, w.wrap, w.binc, w.bin_key,
                      w.iota, flags);
-  M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w.tmp, w.tmp_bytes, w.bin_key, w.bin_key_s, w.iota, w.perm, (int)N, 0, 32, s));
+  int key_bits = 1;   // bin ids are < max_bins
+  while ((int64_t(1) << key_bits) <= w.max_bins) ++key_bits;
+  M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w.tmp, w.tmp_bytes, w.bin_key, w.bin_key_s, w.iota, w.perm, (int)N, 0, key_bits, s));
   hipLaunchKernelGGL(k_bin_ranges, g_for(w.max_bins + 1), dim3(256), 0, s, N, S, w.bin_off, w.bin_key_s, w.perm, w.pos_w, w.bin_start, w.pos_s);
   const int64_t NM = N * max_images;
-  hipLaunchKernelGGL((k_neighbors<false>), g_for(NM), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm, w.pos_s,
+  hipLaunchKernelGGL((k_neighbors<false>), g_for(N * 64), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm, w.pos_s,
                      w.pos_w, w.binc, w.wrap, cutoff, w.counts, (int64_t)0, nullptr, nullptr, nullptr);
   M3G_HIP_CHECK(hipMemsetAsync(w.counts + NM, 0, sizeof(int64_t), s));
   M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, w.counts, w.counts, (int)(NM + 1), s));
@@ -351,7 +467,7 @@ extern "C" int m3g_neighbor_fill(int64_t N, int64_t S, int64_t max_images, const
   if (n_edges == 0 || N == 0) return M3G_OK;
   if (!scratch || !edge_index || !edge_cell_shift || !distances) { set_error("m3g_neighbor_fill: null argument"); return M3G_ERR_VALUE; }
   NbScratch w = nb_carve(N, S, max_images, scratch);
-  hipLaunchKernelGGL((k_neighbors<true>), g_for(N * max_images), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm,
+  hipLaunchKernelGGL((k_neighbors<true>), g_for(N * 64), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm,
                      w.pos_s, w.pos_w, w.binc, w.wrap, cutoff, w.counts, n_edges, edge_index, edge_cell_shift, distances);
   M3G_HIP_CHECK(hipGetLastError());
   return M3G_OK;
@@ -377,7 +493,7 @@ extern "C" int m3g_threebody_count(int64_t N, int64_t E, const int64_t* edge_ind
   int* flags = (int*)((char*)scratch + w.total);
   M3G_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int), s));
   hipLaunchKernelGGL(k_rows_from_sorted, g_for(N + 1), dim3(256), 0, s, N, E, edge_index, w.row_ptr, flags);
-  hipLaunchKernelGGL(k_rank_valid, g_for(N), dim3(256), 0, s, N, w.row_ptr, distances, threebody_cutoff, w.rank, w.deg, w.counts);
+  hipLaunchKernelGGL(k_rank_valid, g_for(N * 64), dim3(256), 0, s, N, w.row_ptr, distances, threebody_cutoff, w.rank, w.deg, w.counts);
   M3G_HIP_CHECK(hipMemsetAsync(w.counts + E, 0, sizeof(int64_t), s));
   M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, w.scan_tmp_bytes, w.counts, w.counts, (int)(E + 1), s));
   int h_flags = 0;
@@ -394,8 +510,8 @@ extern "C" int m3g_threebody_fill(int64_t N, int64_t E, const int64_t* edge_inde
   if (N == 0) return M3G_OK;
   if (!scratch || (n_triplets > 0 && !triplet_edge_index)) { set_error("m3g_threebody_fill: null argument"); return M3G_ERR_VALUE; }
   TbScratch w = tb_carve(N, E, scratch);
-  hipLaunchKernelGGL(k_fill_triplets, g_for(std::max(E, N)), dim3(256), 0, s, N, E, n_triplets, edge_index, w.row_ptr, w.rank, w.deg,
-                     w.counts, triplet_edge_index, num_triplet_i, num_triplet_ij);
+  hipLaunchKernelGGL(k_fill_triplets, g_for(N * 64), dim3(256), 0, s, N, E, n_triplets, w.row_ptr, w.rank, w.deg, w.counts, triplet_edge_index,
+                     num_triplet_i, num_triplet_ij);
   M3G_HIP_CHECK(hipGetLastError());
   return M3G_OK;
 }

@@ -99,17 +99,20 @@ __global__ void k_convert_triplets(int64_t E, int64_t T, const int64_t* __restri
     if (p1 > e1 || (p1 == e1 && p2 > e2)) atomicOr(order, 1);
   }
 }
-// order[0] != 0 when some triplet (e1, e2) has no mirror (e2, e1) in the SORTED key list (binary search): the list is one-sided
-__global__ void k_check_symmetric(int64_t T, const uint64_t* __restrict__ sorted_keys, int32_t* order) {
+// order[0] |= 2 when some triplet (e1, e2) has no mirror (e2, e1) in the SORTED key list: the list is one-sided.  The mirror can
+// only sit in the row of e2, rows[e2] .. rows[e2 + 1] (a handful of slots), so the search stays inside that row.
+__global__ void k_check_symmetric(int64_t T, const uint64_t* __restrict__ sorted_keys, const int32_t* __restrict__ rows, int32_t* order) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= T) return;
   const uint64_t k = sorted_keys[t], want = (k << 32) | (k >> 32);
-  int64_t lo = 0, hi = T;
+  const int64_t e2 = (int64_t)(k & 0xffffffffu);
+  int64_t lo = rows[e2], hi = rows[e2 + 1];
+  const int64_t end = hi;
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
     if (sorted_keys[mid] < want) lo = mid + 1; else hi = mid;
   }
-  if (lo >= T || sorted_keys[lo] != want) atomicOr(order, 1);
+  if (lo >= end || sorted_keys[lo] != want) atomicOr(order, 2);
 }
 
 // ptr[r] = first position whose key (high word of keys64, or keys32[pos]) >= r, for r = 0..rows
@@ -182,14 +185,22 @@ __global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, c
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) { out[2 * i] = idx[i]; out[2 * i + 1] = table[idx[i]]; }
 }
-// byte-sized partner ids: for triplet slot t of list (t_ptr, t_other_c), the row it belongs to (binary search in t_ptr) fixes
-// the workgroup and so the staged window [lo, lo + n); the partner is stored relative to lo, 255 when it falls outside
-__global__ void k_partner_bytes(int64_t E, int64_t T, const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ act_id,
-                                const int32_t* __restrict__ win, const int32_t* __restrict__ t_other_c, uint8_t* out) {
+// byte-sized partner ids: for triplet slot t of list (t_ptr, t_other_c), the row it belongs to fixes the workgroup and so the
+// staged window [lo, lo + n); the partner is stored relative to lo, 255 when it falls outside.  The row is the high word of the
+// slot's sorted key when the keys are still at hand (KEYS), otherwise a binary search in t_ptr.
+template <bool KEYS>
+__global__ void k_partner_bytes(int64_t E, int64_t T, const int32_t* __restrict__ t_ptr, const uint64_t* __restrict__ sorted_keys,
+                                const int32_t* __restrict__ act_id, const int32_t* __restrict__ win, const int32_t* __restrict__ t_other_c,
+                                uint8_t* out) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= T) return;
-  int64_t lo = 0, hi = E;   // last e with t_ptr[e] <= t
-  while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (t_ptr[mid] <= t) lo = mid; else hi = mid - 1; }
+  int64_t lo = 0;
+  if (KEYS) {
+    lo = (int64_t)(sorted_keys[t] >> 32);
+  } else {
+    int64_t hi = E;   // last e with t_ptr[e] <= t
+    while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (t_ptr[mid] <= t) lo = mid; else hi = mid - 1; }
+  }
   const int r = act_id[lo];
   const int blk = (r < 0 ? 0 : r) / kTbRows;
   const int wlo = win[6 * blk], whi = win[6 * blk + 1];
@@ -258,28 +269,36 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   // builders emit (compute_threebody's order, data/material_graph.py:239-248) is already sorted by (e1, e2) and symmetric
   // (every ordered pair of a centre's edges): then t1 needs no sort and t2 IS t1.  Both properties are checked on the device
   // (one small host read-back); any other list -- permuted, one-sided, filtered -- takes the radix sorts.
-  int32_t* order = t.flags + 1;   // flags[1] (otherwise unused): first "not sorted", then "not symmetric"
+  int32_t* order = t.flags + 1;   // flags[1] (otherwise unused): bit 0 "not sorted", bit 1 "not symmetric"
+  bool symmetric = false, flags_read = false;
+  const uint64_t* t1_keys = nullptr;   // sorted (e1, e2) keys while they are still in the sort buffers
+  int32_t h[2] = {0, 0};               // flags[0] (malformed graph), flags[1] (order)
   if (T > 0) {
+    // optimistic pass: rows and partners as if the list were sorted, and the mirror check on it -- ONE host read-back decides
     hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, 0, t.flags, order);
-    int32_t unsorted = 0;
-    M3G_HIP_CHECK(hipMemcpyAsync(&unsorted, order, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, keysA, t.t1_e2);
+    hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, keysA, t.t1_ptr);
+    hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, keysA, t.t1_ptr, order);
+    M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     M3G_HIP_CHECK(hipStreamSynchronize(s));
+    flags_read = true;   // every kernel that can flag a malformed graph has run
     uint64_t* sorted = keysA;
-    if (unsorted) {
+    if (h[1] & 1) {      // not sorted: radix sort, then rows, partners and the mirror check again
       M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)T, 0, 32 + bits_for(E + 1), s));
       sorted = keysB;
+      hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, sorted, t.t1_e2);
+      hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, sorted, t.t1_ptr);
+      M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
+      hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, sorted, t.t1_ptr, order);
+      M3G_HIP_CHECK(hipMemcpyAsync(h + 1, order, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      M3G_HIP_CHECK(hipStreamSynchronize(s));
     }
-    hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, sorted, t.t1_e2);
-    hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, sorted, t.t1_ptr);
     M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, sorted, order);
-    int32_t asym = 0;
-    M3G_HIP_CHECK(hipMemcpyAsync(&asym, order, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    M3G_HIP_CHECK(hipStreamSynchronize(s));
-    M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
-    if (!asym) {   // symmetric: the partners of e as second edge are its partners as first edge
+    symmetric = !(h[1] & 2);
+    if (symmetric) {   // the partners of e as second edge are its partners as first edge
       M3G_HIP_CHECK(hipMemcpyAsync(t.t2_ptr, t.t1_ptr, sizeof(int32_t) * (E + 1), hipMemcpyDeviceToDevice, s));
       M3G_HIP_CHECK(hipMemcpyAsync(t.t2_e1, t.t1_e2, sizeof(int32_t) * T, hipMemcpyDeviceToDevice, s));
+      t1_keys = sorted;
     } else {
       uint64_t* other = sorted == keysA ? keysB : keysA;   // the t1 keys are no longer needed
       hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, other, 1, t.flags, order);
@@ -302,12 +321,21 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   if (E > 0) hipLaunchKernelGGL(k_pair_with_lookup, grid(E), dim3(TPB), 0, s, E, t.in_edge, t.act_id, t.in_pair);
   if (T > 0) {
     hipLaunchKernelGGL(k_compact_partners, grid(T), dim3(TPB), 0, s, T, t.act_scan, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c);
-    hipLaunchKernelGGL(k_partner_bytes, grid(T), dim3(TPB), 0, s, E, T, t.t1_ptr, t.act_id, t.tb_win, t.t1_e2c, t.t1_b);
-    hipLaunchKernelGGL(k_partner_bytes, grid(T), dim3(TPB), 0, s, E, T, t.t2_ptr, t.act_id, t.tb_win, t.t2_e1c, t.t2_b);
+    if (symmetric) {   // one list serves both roles
+      hipLaunchKernelGGL(k_partner_bytes<true>, grid(T), dim3(TPB), 0, s, E, T, t.t1_ptr, t1_keys, t.act_id, t.tb_win, t.t1_e2c, t.t1_b);
+      M3G_HIP_CHECK(hipMemcpyAsync(t.t2_b, t.t1_b, (size_t)T, hipMemcpyDeviceToDevice, s));
+    } else {
+      hipLaunchKernelGGL(k_partner_bytes<false>, grid(T), dim3(TPB), 0, s, E, T, t.t1_ptr, nullptr, t.act_id, t.tb_win, t.t1_e2c, t.t1_b);
+      hipLaunchKernelGGL(k_partner_bytes<false>, grid(T), dim3(TPB), 0, s, E, T, t.t2_ptr, nullptr, t.act_id, t.tb_win, t.t2_e1c, t.t2_b);
+    }
   }
   M3G_HIP_CHECK(hipGetLastError());
   if (host_flags) {
-    M3G_HIP_CHECK(hipMemcpyAsync(host_flags, t.flags, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!flags_read) {   // no triplets: nothing above waited for the device
+      M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      M3G_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    host_flags[0] = h[0];
   }
   return M3G_OK;
 }

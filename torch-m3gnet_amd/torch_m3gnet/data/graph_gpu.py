@@ -33,8 +33,9 @@ def max_images(lattices: np.ndarray, cutoff: float) -> int:
     return int(n.max()) if len(n) else 1
 
 
-def neighbor_list_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Tensor, cutoff: float):
-    """lattice [S,3,3] f64, pos [N,3] f64, batch [N] i64 (sorted), all on the GPU.
+def neighbor_list_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Tensor, cutoff: float, host_lattice=None):
+    """lattice [S,3,3] f64, pos [N,3] f64, batch [N] i64 (sorted), all on the GPU; host_lattice: the same lattices as a host
+    array when the caller has them (saves the device read-back that sizes the image loop).
     Returns edge_index [2,E] i64, edge_cell_shift [E,3] i32, distances [E] f64 (device tensors)."""
     lib = _lib.load_library()
     dev = pos.device
@@ -42,7 +43,7 @@ def neighbor_list_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Ten
     pos = pos.to(torch.float64).contiguous()
     batch = batch.to(torch.int64).contiguous()
     N, S = int(pos.size(0)), int(lattice.size(0))
-    M = max_images(lattice.cpu().numpy(), cutoff)
+    M = max_images(lattice.cpu().numpy() if host_lattice is None else np.asarray(host_lattice, dtype=np.float64).reshape(-1, 3, 3), cutoff)
     nbytes = C.c_size_t()
     _lib.check(lib.m3g_neighbor_scratch_bytes(N, S, M, C.byref(nbytes)))
     scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
@@ -55,7 +56,8 @@ def neighbor_list_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Ten
         shift = torch.empty(E, 3, dtype=torch.int32, device=dev)
         dist = torch.empty(E, dtype=torch.float64, device=dev)
         _lib.check(lib.m3g_neighbor_fill(N, S, M, _ptr(batch), float(cutoff), _ptr(scratch), E, _ptr(ei), _ptr(shift), _ptr(dist), _stream()))
-        torch.cuda.current_stream().synchronize()   # scratch is released when this function returns
+    # no wait here: `scratch` goes back to torch's caching allocator, which hands a block out again only to work queued on the
+    # same stream behind the fill kernel
     return ei, shift, dist
 
 
@@ -79,8 +81,7 @@ def threebody_index_gpu(num_nodes: int, edge_index: torch.Tensor, distances: tor
         nti = torch.empty(N, dtype=torch.int64, device=dev)
         ntij = torch.empty(E, dtype=torch.int32, device=dev)
         _lib.check(lib.m3g_threebody_fill(N, E, _ptr(ei), _ptr(scratch), T, _ptr(tei), _ptr(nti), _ptr(ntij), _stream()))
-        torch.cuda.current_stream().synchronize()
-    return tei, nti, ntij
+    return tei, nti, ntij   # (no wait: see neighbor_list_gpu)
 
 
 def batch_from_arrays(lattices: Sequence, cart_coords: Sequence, atomic_numbers: Sequence, cutoff: float, threebody_cutoff: float,
@@ -98,7 +99,7 @@ def batch_from_arrays(lattices: Sequence, cart_coords: Sequence, atomic_numbers:
     lat_d = torch.tensor(lat, device=dev)
     pos_d = torch.tensor(pos, device=dev)
     batch_d = torch.tensor(batch, dtype=torch.int64, device=dev)
-    ei, shift, dist = neighbor_list_gpu(lat_d, pos_d, batch_d, cutoff)
+    ei, shift, dist = neighbor_list_gpu(lat_d, pos_d, batch_d, cutoff, host_lattice=lat)
     tei, nti, ntij = threebody_index_gpu(len(pos), ei, dist, threebody_cutoff)
     g = Batch.__new__(Batch)
     dict.__init__(g)

@@ -103,7 +103,7 @@ class _Topology:
         flags = (C.c_int32 * 1)(0)
         _lib.check(lib.m3g_topology_build(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
                                           _ptr(self.buf), nbytes.value, flags, _stream()))
-        torch.cuda.current_stream().synchronize()
+        # (the build waits for the stream itself, once, and the flags are final on return: include/m3gnet_hip.h)
         if flags[0] & 1:
             raise ValueError("edge_index must be sorted by centre atom (row 0), as MaterialGraph builds it")
         if flags[0] & 2:
