@@ -62,6 +62,7 @@ class Engine:
             self.set_precision(env_prec)
         self._workspace = None
         self._graph_replay = False
+        self._species_host = None   # pinned [min, max] of the last species check
         self._out_cache = {}
 
     def __del__(self):
@@ -149,12 +150,13 @@ class Engine:
                 self.commit()
             self._sig = sig
         with torch.cuda.device(dev):
+            types = graph[K.ATOM_TYPES].contiguous().long()
+            probe = self._species_probe(graph, types)   # queued before the topology build, read after it (no extra wait)
             topo = M._Topology.of(graph)
             N, E, T, S = topo.N, topo.E, topo.T, topo.S
             D, R, Cc, B = self.cfg.embedding_dim, self.cfg.n_max, self.cfg.l_max * self.cfg.n_max, self.num_blocks
             pos_c = pos.detach().contiguous().float()
-            types = graph[K.ATOM_TYPES].contiguous().long()
-            self._check_species(graph, types)
+            self._check_species(graph, probe)
             shift = graph[K.EDGE_CELL_SHIFT].contiguous().to(torch.int32)
             lat = graph[K.LATTICE].contiguous().float()
             nbytes = C.c_size_t()
@@ -200,16 +202,31 @@ class Engine:
             self.atom_ref(graph)
         return graph
 
-    def _check_species(self, graph, types: torch.Tensor) -> None:
+    def _species_probe(self, graph, types: torch.Tensor):
         """The reference fails on a species index outside the model's table (`elemental_energies[atom_types]`,
-        nn/atom_ref.py:27, raises IndexError; one_hot raises after it).  Checked once per atom_types tensor (one host
-        synchronisation), cached on the graph like the topology."""
+        nn/atom_ref.py:27, raises IndexError; one_hot raises after it).  Checked once per atom_types tensor and cached on the
+        graph like the topology.  The min/max reduction and its copy to pinned host memory are queued here; `_check_species`
+        reads them after the topology build, whose own wait for the stream (new graph) has then already covered them."""
         sig = (types.data_ptr(), types._version, int(types.numel()), int(self.cfg.num_types))
         if isinstance(graph, dict) and graph.get("_m3g_species_ok") == sig:
+            return None
+        if not types.numel():
+            return (sig, None, None)
+        if self._species_host is None:
+            self._species_host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        lo, hi = torch.aminmax(types)
+        self._species_host.copy_(torch.stack((lo, hi)), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return (sig, self._species_host, done)
+
+    def _check_species(self, graph, probe) -> None:
+        if probe is None:
             return
-        if types.numel():
-            lo, hi = torch.aminmax(types)
-            lo, hi = int(lo), int(hi)
+        sig, host, done = probe
+        if host is not None:
+            done.synchronize()
+            lo, hi = int(host[0]), int(host[1])
             if lo < 0 or hi >= self.cfg.num_types:
                 raise IndexError(f"atom_types must lie in [0, {self.cfg.num_types - 1}] (num_types = {self.cfg.num_types}); "
                                  f"got values in [{lo}, {hi}]")
