@@ -240,16 +240,17 @@ __device__ __forceinline__ void stress_accumulate(const float (&val)[6], int s, 
 // batching produces it), so one workgroup per structure adds its atoms in a fixed order -- strided private sums, then a
 // fixed LDS tree: energies and stresses are then bit-reproducible like the forces.  An unsorted `batch` (flags[3] != 0)
 // takes the float-atomic kernels instead; both kinds are launched and the wrong one returns at once.
+constexpr int kStructThreads = 1024;   // one large cell is ONE workgroup: 1,024 threads keep its strided loop at ~10 trips for 10k atoms
 template <int W, class F>
 __device__ __forceinline__ void struct_reduce(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags, float* __restrict__ out,
                                               F per_atom) {
-  __shared__ float part[256][W];
+  __shared__ float part[kStructThreads][W];
   if (flags[3] != 0) return;
   const int s = blockIdx.x;
   float acc[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) acc[k] = 0.f;
-  for (int a = struct_ptr[s] + (int)threadIdx.x; a < struct_ptr[s + 1]; a += 256) {
+  for (int a = struct_ptr[s] + (int)threadIdx.x; a < struct_ptr[s + 1]; a += kStructThreads) {
     float v[W];
     per_atom(a, s, v);
 #pragma unroll
@@ -258,7 +259,7 @@ __device__ __forceinline__ void struct_reduce(const int32_t* __restrict__ struct
 #pragma unroll
   for (int k = 0; k < W; ++k) part[threadIdx.x][k] = acc[k];
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = kStructThreads / 2; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off)
 #pragma unroll
       for (int k = 0; k < W; ++k) part[threadIdx.x][k] += part[threadIdx.x + off][k];
@@ -270,7 +271,7 @@ __device__ __forceinline__ float inv_volume(const float* __restrict__ L) {
   const float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
   return 1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
 }
-__global__ void __launch_bounds__(256) k_struct_stress(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
+__global__ void __launch_bounds__(kStructThreads) k_struct_stress(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
                                                        const float* __restrict__ pos, const float* __restrict__ lattice,
                                                        const float* __restrict__ forces, float* __restrict__ stresses) {
   struct_reduce<6>(struct_ptr, flags, stresses, [&](int a, int s, float* v) {
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(256) k_struct_stress(const int32_t* __restrict
     v[3] = py * fz * inv; v[4] = pz * fx * inv; v[5] = px * fy * inv;
   });
 }
-__global__ void __launch_bounds__(256) k_struct_stress_pair(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
+__global__ void __launch_bounds__(kStructThreads) k_struct_stress_pair(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
                                                             const int32_t* __restrict__ row_ptr, const float* __restrict__ lattice,
                                                             const float* __restrict__ u, const float* __restrict__ dist,
                                                             const float* __restrict__ dr, float* __restrict__ stresses) {
@@ -301,12 +302,12 @@ __global__ void __launch_bounds__(256) k_struct_stress_pair(const int32_t* __res
   });
 }
 // scaled_total[s] = sum of the structure's scaled atomic energies (nn/readout.py:49-53), total = energy_scale * that
-__global__ void __launch_bounds__(256) k_struct_energy(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
+__global__ void __launch_bounds__(kStructThreads) k_struct_energy(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
                                                        const float* __restrict__ ea, float* __restrict__ scaled_total) {
   struct_reduce<1>(struct_ptr, flags, scaled_total, [&](int a, int, float* v) { v[0] = ea[a]; });
 }
 void launch_struct_energy(const Topo& t, const float* ea, float* scaled_total, hipStream_t s) {
-  if (t.S > 0) hipLaunchKernelGGL(k_struct_energy, dim3((unsigned)t.S), dim3(256), 0, s, t.struct_ptr, t.flags, ea, scaled_total);
+  if (t.S > 0) hipLaunchKernelGGL(k_struct_energy, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, ea, scaled_total);
 }
 
 // virial: sum_a pos_a (x) F_a / V in Voigt order xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62)  [float-atomic fallback: unsorted batch]
@@ -430,14 +431,14 @@ void launch_stress(const Consts& c, const Topo& t, const float* pos, const float
                    float* stresses, hipStream_t s) {
   (void)c;   // stresses were cleared by launch_geometry_reverse
   if (t.N > 0) hipLaunchKernelGGL(k_stress, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, pos, lattice, forces, stresses, t.flags);
-  if (t.S > 0) hipLaunchKernelGGL(k_struct_stress, dim3((unsigned)t.S), dim3(256), 0, s, t.struct_ptr, t.flags, pos, lattice, forces, stresses);
+  if (t.S > 0) hipLaunchKernelGGL(k_struct_stress, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, pos, lattice, forces, stresses);
 }
 
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s) {
   if (t.N > 0)   // stresses were cleared by launch_geometry_reverse
     hipLaunchKernelGGL(k_stress_pair, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, t.row_ptr, lattice, w.u, w.d, w.dr, stresses, t.flags);
   if (t.S > 0)
-    hipLaunchKernelGGL(k_struct_stress_pair, dim3((unsigned)t.S), dim3(256), 0, s, t.struct_ptr, t.flags, t.row_ptr, lattice, w.u, w.d, w.dr, stresses);
+    hipLaunchKernelGGL(k_struct_stress_pair, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, t.row_ptr, lattice, w.u, w.d, w.dr, stresses);
 }
 
 void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s) {
