@@ -19,9 +19,12 @@ static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a
 size_t topo_sort_tmp_bytes(int64_t E, int64_t T) {
   size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
   size_t cub = 0, scan = 0;
+  size_t pairs = 0;
   (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)m, 0, 64, 0);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, pairs, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                           (int)std::max<int64_t>(E, 1), 0, 32, 0);
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(E + 1));
-  return align_up(std::max(cub, scan)) + 2 * align_up(m * sizeof(uint64_t));
+  return align_up(std::max(std::max(cub, pairs), scan)) + 2 * align_up(m * sizeof(uint64_t));
 }
 
 Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
@@ -61,7 +64,7 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
 }
 
 __global__ void k_convert_edges(int64_t N, int64_t E, const int64_t* __restrict__ ei, int32_t* src, int32_t* dst,
-                                uint64_t* in_keys, int32_t* flags) {
+                                int32_t* edge_ids, int32_t* flags) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= E) return;
   int64_t i = ei[e], j = ei[E + e];
@@ -70,7 +73,7 @@ __global__ void k_convert_edges(int64_t N, int64_t E, const int64_t* __restrict_
   if (e > 0 && ei[e - 1] > i) bad |= 1;
   src[e] = (int32_t)i;
   dst[e] = (int32_t)j;
-  in_keys[e] = ((uint64_t)j << 32) | (uint64_t)e;
+  edge_ids[e] = (int32_t)e;
   if (bad) atomicOr(flags, bad);
 }
 
@@ -257,14 +260,17 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   size_t cub_bytes = t.sort_tmp_bytes - 2 * align_up(m * sizeof(uint64_t));
 
   if (N > 0) hipLaunchKernelGGL(k_convert_batch, grid(N), dim3(TPB), 0, s, N, S, batch, t.batch, t.flags);
+  // incoming-edge lists: edges ordered by (neighbour atom, edge id) = a STABLE sort of the edge ids on the neighbour index alone
+  // (bits_for(N) key bits: 2 radix passes for 10k atoms, where sorting the 64-bit (neighbour, edge) keys took 6)
+  int32_t* dst_sorted = (int32_t*)keysA;
+  int32_t* edge_ids = (int32_t*)keysB;
   if (E > 0) {
-    hipLaunchKernelGGL(k_convert_edges, grid(E), dim3(TPB), 0, s, N, E, edge_index, t.src, t.dst, keysA, t.flags);
-    M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)E, 0, 32 + bits_for(N + 1), s));
-    hipLaunchKernelGGL(k_low_word, grid(E), dim3(TPB), 0, s, E, keysB, t.in_edge);
+    hipLaunchKernelGGL(k_convert_edges, grid(E), dim3(TPB), 0, s, N, E, edge_index, t.src, t.dst, edge_ids, t.flags);
+    M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, t.dst, dst_sorted, edge_ids, t.in_edge, (int)E, 0, bits_for(N + 1), s));
   }
   hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, t.src, t.row_ptr);
   hipLaunchKernelGGL(k_lower_bound32, grid(S + 1), dim3(TPB), 0, s, S, N, t.batch, t.struct_ptr);
-  hipLaunchKernelGGL(k_lower_bound64, grid(N + 1), dim3(TPB), 0, s, N, E, keysB, t.in_ptr);
+  hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, dst_sorted, t.in_ptr);
   // Triplet lists grouped by first edge (t1) and by second edge (t2), each in canonical (sorted) order.  The list the graph
   // builders emit (compute_threebody's order, data/material_graph.py:239-248) is already sorted by (e1, e2) and symmetric
   // (every ordered pair of a centre's edges): then t1 needs no sort and t2 IS t1.  Both properties are checked on the device
