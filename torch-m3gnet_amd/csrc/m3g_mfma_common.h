@@ -67,7 +67,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
 // ---- 24-bit rows for the dp1 hand-over (fused reverse -> node reverse) -------------------------------------------
 // The x_j half of the node reverse gathers one dp1 row per incoming edge, the largest stream of the reverse pass.  The
 // rows are stored with 16 significand bits (sign, exponent and the top 15 mantissa bits, rounded: relative error
-// <= 2^-17, far below the bf16x3 chains' own error) as 3 bytes per value: 4 values -> 3 dwords, 768 B per row instead of
+// <= 2^-17, the size of one split product's error in the bf16x3 chains; the fp32 mode keeps fp32 rows) as 3 bytes per value: 4 values -> 3 dwords, 768 B per row instead of
 // 1 KB.  The per-centre sums of the same rows (x_i half) are formed in registers from the unrounded values.
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));   // in memory a group starts at any dword
