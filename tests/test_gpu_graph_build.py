@@ -152,3 +152,25 @@ def test_large_supercell_counts_and_properties():
     tei = gr["triplet_edge_index"]
     assert bool((ei[0][tei[0]] == ei[0][tei[1]]).all()) and bool((tei[0] != tei[1]).all())
     assert int(gr["num_triplet_ij"].sum()) == gr["num_triplets"] == int(gr["num_triplet_i"].sum())
+
+
+def test_long_segments_take_the_fallback_paths():
+    """Both wave-per-atom kernels stage one segment in LDS and fall back to a single lane when it does not fit: more than 512
+    neighbours of an atom inside ONE periodic image (dense cell, 12 A cutoff, two bins per axis), and more than 256 edges of a
+    centre inside the three-body cutoff.  Same element-by-element comparison with the host builder."""
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    rng = np.random.default_rng(9)
+    grid = np.stack(np.meshgrid(*[np.arange(7)] * 3, indexing="ij"), -1).reshape(-1, 1, 3)
+    pos = (grid + base[None]).reshape(-1, 3) * a + rng.uniform(-0.03, 0.03, (4 * 343, 3))
+    lat = np.eye(3) * 7 * a
+    host = _host(lat, pos, 12.0, 3.0)
+    per_image = np.unique(np.concatenate([host[0][:1].T, host[1]], axis=1), axis=0, return_counts=True)[1]
+    assert per_image.max() > 512, per_image.max()     # the neighbour kernel's oversized-segment path is exercised
+    _assert_same(host, _gpu([lat], [pos], 12.0, 3.0))
+    grid = np.stack(np.meshgrid(*[np.arange(3)] * 3, indexing="ij"), -1).reshape(-1, 1, 3)
+    pos = (grid + base[None]).reshape(-1, 3) * a + rng.uniform(-0.03, 0.03, (108, 3))
+    lat = np.eye(3) * 3 * a
+    host = _host(lat, pos, 10.0, 10.0)
+    assert host[4].max() > 256 * 255, host[4].max()   # a centre with more than 256 valid edges: the triplet kernel's long-row path
+    _assert_same(host, _gpu([lat], [pos], 10.0, 10.0))
