@@ -174,3 +174,22 @@ def test_long_segments_take_the_fallback_paths():
     host = _host(lat, pos, 10.0, 10.0)
     assert host[4].max() > 256 * 255, host[4].max()   # a centre with more than 256 valid edges: the triplet kernel's long-row path
     _assert_same(host, _gpu([lat], [pos], 10.0, 10.0))
+
+
+def test_random_cells_match_host_builder():
+    """60 random batches (tools/fuzz_graph_build.py: cubic to sheared and left-handed lattices of 2-25 A, 1-120 atoms, cutoffs
+    2.5-9 A, 1-6 structures per call) -- the sub-wave image groups of small cells, multi-bin cells and mixed batches."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+
+    path = Path(__file__).resolve().parent.parent / "tools" / "fuzz_graph_build.py"
+    spec = importlib.util.spec_from_file_location("fuzz_graph_build", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = [str(path), "60", "7"]
+    try:
+        mod.main()
+    finally:
+        sys.argv = argv
