@@ -29,6 +29,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   roofline      the dominant kernel against the roofline that bounds it (fp32 mode: the fp32 matrix peak; bf16x3: HBM,
                 algorithmic bytes), its duration measured live with HIP events in the library
   roofline_other_kernels   every other kernel of the step with its bound, algorithmic bytes and achieved rate
+  beside        (n_gpus = 1, default run) step latency of the 32-atom Cu cell of BASELINE configs[0] and one MD-style iteration on
+                the headline cell: GPU neighbour list + triplets + topology + step from fresh positions
   cpu_baseline  the CPU oracle (oracle/m3gnet_oracle.py, a plain-torch port of the reference) timed on the
                 host cores on a bounded sample (2,048-atom Cu supercell), rank 0, N = 1 only: all cores and 1 thread
 """
@@ -341,6 +343,58 @@ def measure_config4(job, model, steps, warmup):
             "energy_checksum": float(energies.double().sum())}
 
 
+def measure_beside(model, device):
+    """Two figures beside the throughput headline (n_gpus = 1 only): the step latency of BASELINE configs[0]'s 32-atom Cu cell and
+    one MD-style iteration on the headline cell -- fresh positions -> GPU neighbour list + triplets -> topology -> energies and
+    forces (tools/time_small_systems.py, tools/profile_graph_build.py)."""
+    import numpy as np
+    from helpers import fcc_cu_graph
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+
+    def per_call(fn, reps, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    small = fcc_cu_graph(2, 2, 2).to(device)
+    rec = {"step_ms_32_atom_cu_cell": per_call(lambda: model(small, forces=True, extras=False), 50, warm=5)}
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    gi = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(25), indexing="ij"), -1)
+    pos0 = (gi.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a
+    lat = np.diag([10 * a, 10 * a, 25 * a]).astype(float)
+    z = np.full(len(pos0), 29)
+    rng = np.random.default_rng(0)
+    t_build = [0.0]
+
+    def iteration():
+        pos = pos0 + rng.uniform(-0.025, 0.025, pos0.shape)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g = batch_from_arrays([lat], [pos], [z], 5.0, 4.0, device=device)
+        torch.cuda.synchronize()
+        t_build[0] += time.perf_counter() - t0
+        model(g, forces=True, extras=False)
+
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    t_build[0] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(10):
+        iteration()
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t0) / 10 * 1e3
+    rec["md_iteration_ms_10k_atom_cell"] = {"graph_build_from_host_positions": t_build[0] / 10 * 1e3,
+                                            "topology_and_step": total - t_build[0] / 10 * 1e3, "total_incl_position_jitter_on_host": total}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -443,6 +497,9 @@ def main():
         log(f"{other}: {el2 / args.steps * 1e3:.3f} ms/step")
         out["config4_sharded"] = measure_config4(job, model, max(5, args.steps // 2), 2)
         log(f"config4_sharded: {out['config4_sharded']['ms_per_step']:.3f} ms/step")
+        if world == 1 and tuple(args.cells) == (10, 10, 25):
+            out["beside"] = measure_beside(model, device)
+            log(f"beside: {out['beside']}")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
