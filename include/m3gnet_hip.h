@@ -218,6 +218,12 @@ int m3g_neighbor_scratch_bytes(int64_t n_atoms, int64_t n_structs, int64_t max_i
 int m3g_neighbor_count(int64_t n_atoms, int64_t n_structs, int64_t max_images, const double* pos, const double* lattice,
                        const int64_t* batch, double cutoff, void* scratch, size_t scratch_bytes, int64_t* host_n_edges,
                        void* stream);
+/* m3g_neighbor_count that also returns, from the same pass and the same wait, the number of triplets the list will have under
+ * `threebody_cutoff` (valid edges: fp32 length <= it, as compute_threebody thresholds them): a caller building both lists sizes
+ * every tensor after ONE wait for the device and follows up with m3g_neighbor_fill + m3g_threebody_build. */
+int m3g_neighbor_count_triplets(int64_t n_atoms, int64_t n_structs, int64_t max_images, const double* pos, const double* lattice,
+                                const int64_t* batch, double cutoff, float threebody_cutoff, void* scratch, size_t scratch_bytes,
+                                int64_t* host_n_edges, int64_t* host_n_triplets, void* stream);
 int m3g_neighbor_fill(int64_t n_atoms, int64_t n_structs, int64_t max_images, const int64_t* batch, double cutoff,
                       void* scratch, int64_t n_edges, int64_t* edge_index /* [2,E] */, int32_t* edge_cell_shift /* [E,3] */,
                       double* distances /* [E] */, void* stream);
@@ -229,6 +235,11 @@ int m3g_threebody_count(int64_t n_atoms, int64_t n_edges, const int64_t* edge_in
 int m3g_threebody_fill(int64_t n_atoms, int64_t n_edges, const int64_t* edge_index, void* scratch, int64_t n_triplets,
                        int64_t* triplet_edge_index /* [2,T] */, int64_t* num_triplet_i /* [N] or NULL */,
                        int32_t* num_triplet_ij /* [E] or NULL */, void* stream);
+/* m3g_threebody_count + m3g_threebody_fill in one call when n_triplets is known already (m3g_neighbor_count_triplets): no wait
+ * for the device; scratch from m3g_threebody_scratch_bytes. */
+int m3g_threebody_build(int64_t n_atoms, int64_t n_edges, const int64_t* edge_index, const float* distances, float threebody_cutoff,
+                        void* scratch, size_t scratch_bytes, int64_t n_triplets, int64_t* triplet_edge_index /* [2,T] */,
+                        int64_t* num_triplet_i /* [N] */, int32_t* num_triplet_ij /* [E] */, void* stream);
 
 /* ---- measurement: per-stage device time from HIP events recorded on the call's own stream ---------
  * m3g_profile_enable(plan, 1) makes every following m3g_energy_forces record an event pair around each

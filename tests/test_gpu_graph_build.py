@@ -28,6 +28,11 @@ def _gpu(lats, poss, cutoff, tb):
     batch = torch.tensor(np.repeat(np.arange(len(poss)), [len(p) for p in poss]), device="cuda")
     ei, sh, d = neighbor_list_gpu(lat, pos, batch, cutoff)
     tei, nti, ntij = threebody_index_gpu(pos.size(0), ei, d, tb)
+    # the one-wait path (counts edges AND triplets in the neighbour count pass) must produce the very same tensors
+    from torch_m3gnet.data.graph_gpu import graph_indices_gpu
+
+    for a, b in zip(graph_indices_gpu(lat, pos, batch, cutoff, tb), (ei, sh, d, tei, nti, ntij)):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
     return [t.cpu().numpy() for t in (ei, sh, d, tei, nti, ntij)]
 
 

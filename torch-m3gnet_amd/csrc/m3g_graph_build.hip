@@ -41,6 +41,7 @@ struct NbScratch {
   int32_t* bin_start;     // [Bmax+1] first slot of each bin in perm
   double* pos_s;          // [N,3] wrapped positions in bin order
   int64_t* counts;        // [N*M + 1] matches per (atom, image), then exclusive offsets
+  int64_t* tri;           // [N + 1] triplets per centre d (d - 1) (m3g_neighbor_count_triplets), [N] = their sum
   void* tmp;              // scan / sort temporary
   size_t tmp_bytes;
   int64_t max_bins;
@@ -65,12 +66,15 @@ static NbScratch nb_carve(int64_t N, int64_t S, int64_t M, void* base) {
   w.bin_start = (int32_t*)take(sizeof(int32_t) * (size_t)(w.max_bins + 2));
   w.pos_s = (double*)take(sizeof(double) * 3 * (size_t)(N + 1));
   w.counts = (int64_t*)take(sizeof(int64_t) * (size_t)(N * M + 2));
+  w.tri = (int64_t*)take(sizeof(int64_t) * (size_t)(N + 2));
   size_t t1 = 0, t2 = 0, t3 = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const int64_t*)nullptr, (int64_t*)nullptr, (int)(N * M + 1));
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const int64_t*)nullptr, (int64_t*)nullptr, (int)(S + 1));
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t3, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr,
                                            (int32_t*)nullptr, (int)N);
-  w.tmp_bytes = std::max(t1, std::max(t2, t3));
+  size_t t4 = 0;
+  (void)hipcub::DeviceReduce::Sum(nullptr, t4, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::max<int64_t>(N, 1));
+  w.tmp_bytes = std::max(std::max(t1, t4), std::max(t2, t3));
   w.tmp = take(w.tmp_bytes);
   w.total = off;
   return w;
@@ -203,7 +207,8 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
                                                    const double* __restrict__ pos_s, const double* __restrict__ pos_w,
                                                    const int32_t* __restrict__ binc, const int32_t* __restrict__ wrap, double cutoff,
                                                    int64_t* __restrict__ counts, int64_t E, int64_t* __restrict__ edge_index,
-                                                   int32_t* __restrict__ shift, double* __restrict__ dist) {
+                                                   int32_t* __restrict__ shift, double* __restrict__ dist, float tb_cutoff,
+                                                   int64_t* __restrict__ tri) {
   __shared__ int32_t stage_j[FILL ? 4 * kNbStage : 1];
   __shared__ double stage_d[FILL ? 4 * kNbStage : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -223,6 +228,7 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
   int32_t* sj = stage_j + (FILL ? wave * kNbStage + g * cap : 0);
   double* sd = stage_d + (FILL ? wave * kNbStage + g * cap : 0);
   if (!FILL) for (int64_t img = si.n_img + lane; img < M; img += 64) counts[i * M + img] = 0;   // images this structure does not have
+  int my3 = 0;   // count pass with `tri`: this lane's matches whose fp32 length is within the three-body cutoff
   for (int img0 = 0; img0 < si.n_img; img0 += G) {
     const int img = img0 + g;
     const bool valid = img < si.n_img;
@@ -243,6 +249,7 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
               const double dx = pos_s[(int64_t)k * 3] + im.ox, dy = pos_s[(int64_t)k * 3 + 1] + im.oy, dz = pos_s[(int64_t)k * 3 + 2] + im.oz;
               d2 = dx * dx + dy * dy + dz * dz;
               hit = d2 <= c2 && d2 > 1e-16;
+              if (!FILL && tri && hit && (float)sqrt(d2) <= tb_cutoff) ++my3;   // as the reference thresholds the narrowed lengths
             }
             const unsigned long long m = (__ballot(hit) >> (g * W)) & group_bits;   // this group's lanes (all in this iteration together)
             if (FILL && hit) {
@@ -298,6 +305,10 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // before the next image overwrites the stage
+  }
+  if (!FILL && tri) {
+    const int64_t d = __reduce_add_sync(~0ull, my3);
+    if (lane == 0) tri[i] = d * (d - 1);
   }
 }
 
@@ -425,10 +436,13 @@ extern "C" int m3g_neighbor_scratch_bytes(int64_t N, int64_t S, int64_t max_imag
 
 // Phase 1: counts.  host_n_edges receives E after an internal stream synchronisation (graph construction is not a
 // hot call).  max_images = upper bound of (2rx+1)(2ry+1)(2rz+1) over the structures (the Python host computes it).
-extern "C" int m3g_neighbor_count(int64_t N, int64_t S, int64_t max_images, const double* pos, const double* lattice,
-                                  const int64_t* batch, double cutoff, void* scratch, size_t scratch_bytes,
-                                  int64_t* host_n_edges, void* stream_) {
+// host_n_triplets != nullptr: also the number of triplets the list has under `threebody_cutoff`, from the same pass and the same
+// wait -- a caller that builds both lists can then size every tensor at once (m3g_threebody_build needs no wait of its own).
+extern "C" int m3g_neighbor_count_triplets(int64_t N, int64_t S, int64_t max_images, const double* pos, const double* lattice,
+                                           const int64_t* batch, double cutoff, float threebody_cutoff, void* scratch, size_t scratch_bytes,
+                                           int64_t* host_n_edges, int64_t* host_n_triplets, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
+  if (host_n_triplets) *host_n_triplets = 0;
   size_t need = 0;
   int rc = m3g_neighbor_scratch_bytes(N, S, max_images, &need);
   if (rc) return rc;
@@ -448,16 +462,26 @@ extern "C" int m3g_neighbor_count(int64_t N, int64_t S, int64_t max_images, cons
   hipLaunchKernelGGL(k_bin_ranges, g_for(w.max_bins + 1), dim3(256), 0, s, N, S, w.bin_off, w.bin_key_s, w.perm, w.pos_w, w.bin_start, w.pos_s);
   const int64_t NM = N * max_images;
   hipLaunchKernelGGL((k_neighbors<false>), g_for(N * 64), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm, w.pos_s,
-                     w.pos_w, w.binc, w.wrap, cutoff, w.counts, (int64_t)0, nullptr, nullptr, nullptr);
+                     w.pos_w, w.binc, w.wrap, cutoff, w.counts, (int64_t)0, nullptr, nullptr, nullptr, threebody_cutoff, host_n_triplets ? w.tri : nullptr);
   M3G_HIP_CHECK(hipMemsetAsync(w.counts + NM, 0, sizeof(int64_t), s));
   M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, w.counts, w.counts, (int)(NM + 1), s));
   int h_flags = 0;
+  if (host_n_triplets) {
+    M3G_HIP_CHECK(hipcub::DeviceReduce::Sum(w.tmp, w.tmp_bytes, w.tri, w.tri + N, (int)N, s));
+    M3G_HIP_CHECK(hipMemcpyAsync(host_n_triplets, w.tri + N, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  }
   M3G_HIP_CHECK(hipMemcpyAsync(host_n_edges, w.counts + NM, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipMemcpyAsync(&h_flags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipStreamSynchronize(s));
   if (h_flags & 1) { set_error("singular lattice"); return M3G_ERR_VALUE; }
   if (h_flags & 2) { set_error("batch vector must be sorted, contiguous per structure and within [0, n_structs)"); return M3G_ERR_VALUE; }
   return M3G_OK;
+}
+
+extern "C" int m3g_neighbor_count(int64_t N, int64_t S, int64_t max_images, const double* pos, const double* lattice,
+                                  const int64_t* batch, double cutoff, void* scratch, size_t scratch_bytes,
+                                  int64_t* host_n_edges, void* stream_) {
+  return m3g_neighbor_count_triplets(N, S, max_images, pos, lattice, batch, cutoff, 0.f, scratch, scratch_bytes, host_n_edges, nullptr, stream_);
 }
 
 // Phase 2: fill (same scratch, untouched since the count call).
@@ -468,7 +492,7 @@ extern "C" int m3g_neighbor_fill(int64_t N, int64_t S, int64_t max_images, const
   if (!scratch || !edge_index || !edge_cell_shift || !distances) { set_error("m3g_neighbor_fill: null argument"); return M3G_ERR_VALUE; }
   NbScratch w = nb_carve(N, S, max_images, scratch);
   hipLaunchKernelGGL((k_neighbors<true>), g_for(N * 64), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm,
-                     w.pos_s, w.pos_w, w.binc, w.wrap, cutoff, w.counts, n_edges, edge_index, edge_cell_shift, distances);
+                     w.pos_s, w.pos_w, w.binc, w.wrap, cutoff, w.counts, n_edges, edge_index, edge_cell_shift, distances, 0.f, nullptr);
   M3G_HIP_CHECK(hipGetLastError());
   return M3G_OK;
 }
@@ -501,6 +525,30 @@ extern "C" int m3g_threebody_count(int64_t N, int64_t E, const int64_t* edge_ind
   M3G_HIP_CHECK(hipMemcpyAsync(&h_flags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipStreamSynchronize(s));
   if (h_flags & 1) { set_error("edge_index must be sorted by centre atom (row 0)"); return M3G_ERR_VALUE; }
+  return M3G_OK;
+}
+
+// count + fill in one call for a caller that already knows n_triplets (m3g_neighbor_count_triplets): nothing waits for the
+// device here; a row-0 ordering violation is left to m3g_topology_build, which checks the same property.
+extern "C" int m3g_threebody_build(int64_t N, int64_t E, const int64_t* edge_index, const float* distances, float threebody_cutoff,
+                                   void* scratch, size_t scratch_bytes, int64_t n_triplets, int64_t* triplet_edge_index,
+                                   int64_t* num_triplet_i, int32_t* num_triplet_ij, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  size_t need = 0;
+  int rc = m3g_threebody_scratch_bytes(N, E, &need);
+  if (rc) return rc;
+  if (!scratch || scratch_bytes < need || (n_triplets > 0 && !triplet_edge_index)) { set_error("m3g_threebody_build: scratch too small or null argument"); return M3G_ERR_SIZE; }
+  if (N == 0) return M3G_OK;
+  TbScratch w = tb_carve(N, E, scratch);
+  int* flags = (int*)((char*)scratch + w.total);
+  M3G_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_rows_from_sorted, g_for(N + 1), dim3(256), 0, s, N, E, edge_index, w.row_ptr, flags);
+  hipLaunchKernelGGL(k_rank_valid, g_for(N * 64), dim3(256), 0, s, N, w.row_ptr, distances, threebody_cutoff, w.rank, w.deg, w.counts);
+  M3G_HIP_CHECK(hipMemsetAsync(w.counts + E, 0, sizeof(int64_t), s));
+  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, w.scan_tmp_bytes, w.counts, w.counts, (int)(E + 1), s));
+  hipLaunchKernelGGL(k_fill_triplets, g_for(N * 64), dim3(256), 0, s, N, E, n_triplets, w.row_ptr, w.rank, w.deg, w.counts, triplet_edge_index,
+                     num_triplet_i, num_triplet_ij);
+  M3G_HIP_CHECK(hipGetLastError());
   return M3G_OK;
 }
 

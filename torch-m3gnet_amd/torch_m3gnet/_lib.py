@@ -73,6 +73,10 @@ SYMBOLS = {
     "m3g_neighbor_scratch_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_neighbor_count": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                      C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
+    "m3g_neighbor_count_triplets": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_float,
+                                              C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    "m3g_threebody_build": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "m3g_neighbor_fill": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "m3g_threebody_scratch_bytes": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),

@@ -84,6 +84,42 @@ def threebody_index_gpu(num_nodes: int, edge_index: torch.Tensor, distances: tor
     return tei, nti, ntij   # (no wait: see neighbor_list_gpu)
 
 
+def graph_indices_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Tensor, cutoff: float, threebody_cutoff: float,
+                      host_lattice=None):
+    """neighbor_list_gpu + threebody_index_gpu with ONE wait for the device: the neighbour count pass also counts the triplets
+    (m3g_neighbor_count_triplets), so every tensor is sized at once and the fills are queued back to back.
+    Returns (edge_index, edge_cell_shift, distances f64, triplet_edge_index, num_triplet_i, num_triplet_ij)."""
+    lib = _lib.load_library()
+    dev = pos.device
+    lattice = lattice.to(torch.float64).contiguous()
+    pos = pos.to(torch.float64).contiguous()
+    batch = batch.to(torch.int64).contiguous()
+    N, S = int(pos.size(0)), int(lattice.size(0))
+    M = max_images(lattice.cpu().numpy() if host_lattice is None else np.asarray(host_lattice, dtype=np.float64).reshape(-1, 3, 3), cutoff)
+    nb_bytes = C.c_size_t()
+    _lib.check(lib.m3g_neighbor_scratch_bytes(N, S, M, C.byref(nb_bytes)))
+    scratch = torch.empty(nb_bytes.value, dtype=torch.uint8, device=dev)
+    n_edges, n_trip = C.c_int64(), C.c_int64()
+    with torch.cuda.device(dev):
+        _lib.check(lib.m3g_neighbor_count_triplets(N, S, M, _ptr(pos), _ptr(lattice), _ptr(batch), float(cutoff), float(threebody_cutoff),
+                                                   _ptr(scratch), nb_bytes.value, C.byref(n_edges), C.byref(n_trip), _stream()))
+        E, T = int(n_edges.value), int(n_trip.value)
+        ei = torch.empty(2, E, dtype=torch.int64, device=dev)
+        shift = torch.empty(E, 3, dtype=torch.int32, device=dev)
+        dist = torch.empty(E, dtype=torch.float64, device=dev)
+        tei = torch.empty(2, T, dtype=torch.int64, device=dev)
+        nti = torch.empty(N, dtype=torch.int64, device=dev)
+        ntij = torch.empty(E, dtype=torch.int32, device=dev)
+        _lib.check(lib.m3g_neighbor_fill(N, S, M, _ptr(batch), float(cutoff), _ptr(scratch), E, _ptr(ei), _ptr(shift), _ptr(dist), _stream()))
+        d32 = dist.to(torch.float32)
+        tb_bytes = C.c_size_t()
+        _lib.check(lib.m3g_threebody_scratch_bytes(N, E, C.byref(tb_bytes)))
+        tb_scratch = torch.empty(tb_bytes.value, dtype=torch.uint8, device=dev)
+        _lib.check(lib.m3g_threebody_build(N, E, _ptr(ei), _ptr(d32), float(threebody_cutoff), _ptr(tb_scratch), tb_bytes.value, T,
+                                           _ptr(tei), _ptr(nti), _ptr(ntij), _stream()))
+    return ei, shift, dist, tei, nti, ntij
+
+
 def batch_from_arrays(lattices: Sequence, cart_coords: Sequence, atomic_numbers: Sequence, cutoff: float, threebody_cutoff: float,
                       device="cuda") -> Batch:
     """Build a whole batch of periodic structures on the GPU (lists of [3,3], [n_s,3], [n_s] arrays).
@@ -99,8 +135,7 @@ def batch_from_arrays(lattices: Sequence, cart_coords: Sequence, atomic_numbers:
     lat_d = torch.tensor(lat, device=dev)
     pos_d = torch.tensor(pos, device=dev)
     batch_d = torch.tensor(batch, dtype=torch.int64, device=dev)
-    ei, shift, dist = neighbor_list_gpu(lat_d, pos_d, batch_d, cutoff, host_lattice=lat)
-    tei, nti, ntij = threebody_index_gpu(len(pos), ei, dist, threebody_cutoff)
+    ei, shift, dist, tei, nti, ntij = graph_indices_gpu(lat_d, pos_d, batch_d, cutoff, threebody_cutoff, host_lattice=lat)
     g = Batch.__new__(Batch)
     dict.__init__(g)
     g[K.POS] = pos_d.to(torch.float)
