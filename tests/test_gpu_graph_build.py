@@ -198,3 +198,30 @@ def test_random_cells_match_host_builder():
         mod.main()
     finally:
         sys.argv = argv
+
+
+def test_graphs_without_edges_or_triplets_run_end_to_end():
+    """Isolated atoms (no edge at all), a dimer (edges, no triplet) and a batch mixing an isolated atom with a dense cell, built on
+    the GPU and evaluated: finite energies, zero force on isolated atoms, Newton's third law on the dimer, triplet counts."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.model.build import build_model
+
+    torch.manual_seed(0)
+    model = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
+    big = np.eye(3) * 30.0
+    g = batch_from_arrays([big], [np.array([[1.0, 1.0, 1.0], [15.0, 15.0, 15.0]])], [np.array([29, 8])], 5.0, 4.0)
+    assert g[K.NUM_EDGES] == 0 and g[K.NUM_TRIPLETS] == 0 and tuple(g[K.TRIPLET_EDGE_INDEX].shape) == (2, 0)
+    out = model(g)
+    assert torch.isfinite(out[K.TOTAL_ENERGY]).all() and float(out[K.FORCES].abs().max()) == 0.0
+    g = batch_from_arrays([big], [np.array([[1.0, 1.0, 1.0], [3.0, 1.0, 1.0]])], [np.array([29, 29])], 5.0, 4.0)
+    assert g[K.NUM_EDGES] == 2 and g[K.NUM_TRIPLETS] == 0
+    out = model(g)
+    f = out[K.FORCES]
+    assert torch.isfinite(out[K.TOTAL_ENERGY]).all() and float(f.abs().max()) > 0 and float(f.sum(0).abs().max()) < 1e-6 * float(f.abs().max())
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]]) * a
+    g = batch_from_arrays([big, np.eye(3) * a], [np.array([[1.0, 1.0, 1.0]]), base], [np.array([3]), np.full(4, 29)], 5.0, 4.0)
+    assert g[K.NUM_EDGES] == 4 * 42 and g[K.NUM_TRIPLET_I].tolist() == [0] + [18 * 17] * 4
+    out = model(g)
+    assert torch.isfinite(out[K.TOTAL_ENERGY]).all() and float(out[K.FORCES][0].abs().max()) == 0.0
