@@ -24,7 +24,7 @@ import torch
 from .m3gnet_oracle import OracleConfig, OracleConstants, cutoff_function, radial_basis
 
 
-# Matrix-product hook for the edge-block products (the ones the MFMA kernels execute); tools/split_precision_study.py
+# Matrix-product hook for the edge-block products (the ones the MFMA kernels execute); tests/checkers/split_precision_study.py
 # swaps it for an emulation of split-precision MFMA arithmetic.  Default: plain matmul.
 def MM(a, b):
     return a @ b

@@ -6,7 +6,7 @@ from pathlib import Path
 
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
 from helpers import CASES, build_engine_model, engine_graph, fcc_cu_graph, load_oracle_case  # noqa: E402

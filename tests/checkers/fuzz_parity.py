@@ -7,7 +7,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
 from helpers import random_cell_graph, rel_err  # noqa: E402

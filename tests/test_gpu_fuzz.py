@@ -1,5 +1,5 @@
 """GPU: randomised parity -- random model shapes (l_max, n_max, blocks, cutoffs, scales) x random small batches against
-the CPU oracle, same tolerances as the fixed cases (tools/fuzz_parity.py is the longer version of this sweep)."""
+the CPU oracle, same tolerances as the fixed cases (tests/checkers/fuzz_parity.py is the longer version of this sweep)."""
 import numpy as np
 import pytest
 import torch

@@ -44,7 +44,7 @@ __device__ __forceinline__ float fdsilu(float p) {
 // ---- the dense chains run on v_mfma_f32_16x16x32_bf16 with split operands ("bf16x3") ----------------------------
 // a = a_hi + a_lo (both bf16; the residual a - a_hi is formed exactly in fp32), a.b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi,
 // accumulated in fp32: 3 MFMAs at 16x the fp32-MFMA rate.  bf16 keeps the fp32 exponent range, which the tiny gradient
-// operands of the reverse pass need (f16 would flush them).  Parity effect (tools/split_precision_study.py, same
+// operands of the reverse pass need (f16 would flush them).  Parity effect (tests/checkers/split_precision_study.py, same
 // arithmetic emulated in the oracle): force error 1.1e-5 of max|F| vs 7e-6 for plain fp32 -- budget 1e-4.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
