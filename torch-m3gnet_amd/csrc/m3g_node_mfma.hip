@@ -10,7 +10,9 @@ namespace m3g {
 // re-read 128 KB of weights from L2 for every 16 atoms.  x^b = x^(b-1) + the per-centre message sums of block b-1 is
 // formed while the tile is loaded (x_prev != nullptr) and written back for the later stages.
 constexpr int kNodeXPitch = 68;   // floats per staged x row: 64 + 4 keeps 16-byte alignment and spreads the 16 rows over the banks
-template <int PREC>
+// SPLIT (small systems, whose step is the serial latency of its kernels): a wave takes ONE of the three 11-row-block passes of a
+// tile instead of all three, so a 2-tile system runs 6 waves for a third of the time each.
+template <int PREC, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
                                                        const float* __restrict__ seg_head, const float* __restrict__ seg_first,
                                                        const int32_t* __restrict__ row_ptr, float* __restrict__ x,
@@ -37,7 +39,10 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
   float* xs = lds + kNodeImgFloats + wave * 16 * kNodeXPitch;
   const int64_t tiles = (N + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+  const int64_t items = SPLIT ? tiles * 3 : tiles;
+  for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < items; item += (int64_t)gridDim.x * 4) {
+    const int64_t tile = SPLIT ? item / 3 : item;
+    const int only = SPLIT ? (int)(item - tile * 3) : -1;   // the pass this wave computes (all three when not split)
     // stage the tile's x rows: lane (m, q) brings features 16q .. 16q+15 of atom m
     const int64_t atom = tile * 16 + m;
     const bool live = atom < N;
@@ -51,7 +56,7 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
         src = emb + ty * kDP + 16 * q;
       }
       static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
-      if (types) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+      if (types && only <= 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
       if (x_prev) {
         const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
         if (r1 > r0) {
@@ -59,7 +64,7 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
           for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
             static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
         }
-        static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+        if (only <= 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
       }
     }
     static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
@@ -70,6 +75,7 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
     int lv = lane;
     asm volatile("" : "+v"(lv));   // keep the image reads inside the tile loop
     static_for<3>([&]<int g>() {   // 11 row blocks per pass: bf16x3 chains like the edge kernels' (fp32 accumulate)
+      if (SPLIT && only != g) return;
       f32x4 acc[11];
       static_for<11>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (11 * g + j) * 16 + 4 * q); });
       chain_p<PREC, 11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv);
@@ -218,11 +224,15 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
                           float* v, float* TA, float* TB, const int64_t* types, const float* emb, hipStream_t s) {
   if (t.N == 0) return;
   const int64_t tiles = (t.N + 15) / 16;
-  int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
-  M3G_PREC_SWITCH(plan->precision,
-                  hipLaunchKernelGGL(k_node_pre_mfma<PREC>, dim3(wgs), dim3(256), 0, s, c.C, t.N,
-                                     plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first,
-                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types));
+  const bool split = tiles * 3 <= 256 * 4;   // fewer work items than wave slots on the chip: split the passes over waves
+  const int wgs = (int)std::min<int64_t>(((split ? tiles * 3 : tiles) + 3) / 4, 256);
+#define M3G_NODE_PRE_LAUNCH(SPLIT_)                                                                                            \
+  M3G_PREC_SWITCH(plan->precision,                                                                                             \
+                  hipLaunchKernelGGL((k_node_pre_mfma<PREC, SPLIT_>), dim3(wgs), dim3(256), 0, s, c.C, t.N,                      \
+                                     plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first, \
+                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types))
+  if (split) { M3G_NODE_PRE_LAUNCH(true); } else { M3G_NODE_PRE_LAUNCH(false); }
+#undef M3G_NODE_PRE_LAUNCH
 }
 
 }  // namespace m3g
