@@ -622,7 +622,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     }
     { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }
     if (mfma) {
-      { M3G_STAGE(ST_EDGE_FWD); launch_edge_block_mfma(plan, c, t, w, b, s); }
+      { M3G_STAGE(ST_EDGE_FWD); launch_edge_block_mfma(plan, c, t, w, b, /*for_reverse=*/io->forces != nullptr, s); }
       (void)ST_NODE_SUM;   // the per-centre sums are consumed by the next node_pre / the readout
     } else {
       M3G_STAGE(ST_EDGE_FWD);

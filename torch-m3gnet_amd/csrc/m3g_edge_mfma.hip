@@ -709,7 +709,8 @@ void launch_embed_edges_reverse_soa(const float* adj, const float* h, const floa
     hipLaunchKernelGGL(k_embed_edges_reverse_soa, dim3((unsigned)((tiles * 64 + 255) / 256)), dim3(256), 0, s, E, tiles, adj, h, de_soa, dh);
 }
 
-void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s) {
+// for_reverse = false (energy-only call): nothing is saved for a reverse pass that will not run (2 KB per edge and block of stores)
+void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, bool for_reverse, hipStream_t s) {
   const int64_t tiles = tiles_for(t.E);
   const MfmaFwdLayout L = mfma_fwd_layout();
   if (tiles > 0) {
@@ -718,7 +719,7 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
               saves_p2(plan) ? w.p2_blk[b] : nullptr};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
     const bool first = b == 0 && fused_reverse(plan);   // the fused reverse kernel recomputes e0 as well: no embedded-edge image at all
-    const int save = saved_activations(plan);   // fp32 mode only (saves_p1 / saves_p2)
+    const int save = for_reverse ? saved_activations(plan) : 0;   // fp32 mode only (saves_p1 / saves_p2)
 #define M3G_FWD_LAUNCH(ST_, FIRST_, PREC_, SAVE_) hipLaunchKernelGGL((k_edge_block_mfma<TBS, ST_, FIRST_, PREC_, SAVE_>), grid, block, 0, s, a, L)
 #define M3G_FWD_BY_MODE(ST_, FIRST_)                                                               \
   if (plan->precision == kPrecBf16x3) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecBf16x3, 0); }             \

@@ -419,7 +419,7 @@ inline int saved_activations(const m3g_plan* plan) { return saves_p2(plan) ? 2 :
 inline bool fused_reverse(const m3g_plan* plan) {
   return plan->edge_kernel == 1 && plan->rev_kernel == 1 && (plan->precision == kPrecBf16x3 || saves_p1(plan));
 }
-void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, hipStream_t s);
+void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, bool for_reverse, hipStream_t s);
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
                               hipStream_t s);
 void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
