@@ -95,8 +95,8 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *                   l_max or n_max > 4, more than 8 blocks -- up to the reference's own limits l_max <= 9, n_max <= 10);
  *   "save_p1" / "save_p2" (fp32 mode, default 1): the forward kernel saves SiLU'(p1) / the layer-2 pre-activations of both conv
  *                   MLPs for the reverse kernel (no recompute MFMAs) -- 0 for A/B measurements;
- *   "rev_kernel"  = 1 one fused reverse kernel per block (default; bf16x3 mode only -- the fp32 mode always runs the
- *                   kernel pair), 0 = node-MLP + edge-MLP kernel pair;
+ *   "rev_kernel"  = 1 one fused reverse kernel per block (default; fp32 mode: k_edge_rev_f32 on the saved activations, bf16x3
+ *                   mode: k_edge_rev_fused recomputing them), 0 = node-MLP + edge-MLP kernel pair (both modes, A/B tests);
  *   "stress_mode" = 0 the reference's sum pos (x) F / V (nn/gradient.py:39-62, default), 1 = pair virial
  *                   -(1/V) sum_e r_e (x) dE/dr_e (docs/gradient.md:47-84), invariant under lattice translations;
  *   "overlap"     = 1 the three-body reverse of a block runs on an internal side stream beside the node reverse's gather
@@ -105,7 +105,8 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *   "graph_replay" = 1 m3g_energy_forces captures its launch sequence into a hipGraph the first time it sees a given
  *                   (m3g_io contents, workspace, stream, options) and replays it on later identical calls (launch-bound
  *                   small systems); every buffer of the call must stay alive at the same address.  Default 0;
- *   "stamps"      diagnostic builds with in-kernel cycle stamps (m3g_debug_read_stamps). */
+ *   "stamps"      diagnostic builds with in-kernel cycle stamps (m3g_debug_read_stamps);
+ *   "debug_force_move" = 1 (tests) the next m3g_plan_commit takes the device-move path although the device is unchanged. */
 int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value);
 
 /* Pack and upload everything set so far (synchronous; drains the device first).  Must be called before any compute
@@ -253,6 +254,9 @@ int m3g_profile_read(m3g_plan* plan, int32_t* n_stages, const char** names /* [M
 /* Diagnostic only: with option "stamps" = 1 the forward edge kernel runs a stamped variant (s_memtime per
  * phase); this copies the per-wave phase cycle sums [256][16][12] of the LAST launch to the host. */
 int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
+/* Diagnostic only: number of HIP streams / events the plan currently owns (internal side stream, fork / join events, profiler
+ * event pool).  They are bound to the plan's device: a commit that moves the plan to another device releases all of them. */
+int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out);
 
 #define M3G_ABI_VERSION 1
 

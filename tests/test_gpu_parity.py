@@ -90,23 +90,105 @@ def test_both_edge_kernels_against_oracle(case, mode, edge_kernel):
     assert rel_err(g[K.NODE_FEATURES], o["x"]) < 1e-5
 
 
-def test_fused_and_split_reverse_kernels_agree():
-    """rev_kernel = 1 (one fused reverse kernel per block on dual-use LDS weight images, per-centre sums in the kernel,
-    edge embedding folded into block 0) against rev_kernel = 0 (node-MLP + edge-MLP kernel pair, separate embedding
-    kernels): same math, different summation order -> forces agree to 2e-6 of max|F|, energies to 1e-6."""
+# (rev_kernel, save_p1, save_p2): every reverse-kernel instantiation the public options select.  fp32 mode:
+#   (1,1,1) k_edge_rev_f32<SAVED_P2=true>  on SiLU'(p1) + p2 saved by the forward kernel (SAVE = 2)      -- the default
+#   (1,1,0) k_edge_rev_f32<SAVED_P2=false> on raw p1 (SAVE = 1), layer 2 recomputed
+#   (0,1,0) k_edge_rev_node_mlp / k_edge_rev_edge_mlp<fp32, SAVED=true> on raw p1 (SAVE = 1)
+#   (1,0,0), (0,0,0) the same pair recomputing both layers (SAVE = 0)
+# bf16x3 mode (nothing is ever saved): (1,*,*) k_edge_rev_fused, (0,*,*) the kernel pair.
+_REV_VARIANTS = {"fp32": [(1, 1, 1), (1, 1, 0), (1, 0, 0), (0, 1, 0), (0, 0, 0)], "bf16x3": [(1, 1, 1), (0, 1, 1)]}
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fused_and_split_reverse_kernels_agree(precision):
+    """The forward kernel's SAVE mode and the reverse kernel that consumes it are chosen from the same three options; a
+    mismatch (raw p1 read as SiLU'(p1), a workspace carved for another mode) would give silently wrong forces.  Every
+    combination must give the same energies (1e-6) and forces (2e-6 of max|F|: same math, different summation order),
+    and the workspace the engine allocates for a mode must be the size m3g_workspace_bytes reports for it."""
+    import ctypes as C
+
+    from torch_m3gnet import _lib
+    from torch_m3gnet.nn.modules import _Topology
+
     case, mode = "tio", "doc"
     params, cfg, consts, graph, expect = load_oracle_case(case, mode)
     model, _ = build_engine_model(case, mode)
     model = model.cuda()
-    model.engine.set_precision("bf16x3")   # the fused reverse kernel exists in this mode only
-    outs = []
-    for rk in (1, 0):
-        model.engine.set_option("rev_kernel", rk)
-        o = model(engine_graph(graph))
-        outs.append((o["total_energy"].clone(), o["forces"].clone()))
-    model.engine.set_option("rev_kernel", 1)
-    assert rel_err(outs[0][0], outs[1][0]) < 1e-6
-    assert rel_err(outs[0][1], outs[1][1]) < 2e-6
+    eng = model.engine
+    eng.set_precision(precision)
+    outs, sizes = [], []
+    try:
+        for rk, s1, s2 in _REV_VARIANTS[precision]:
+            eng.set_option("rev_kernel", rk)
+            eng.set_option("save_p1", s1)
+            eng.set_option("save_p2", s2)
+            eng._workspace = None          # a fresh carve per mode: the engine must size it itself
+            g = engine_graph(graph)
+            o = model(g)
+            torch.cuda.synchronize()
+            topo = _Topology.of(g)
+            nbytes = C.c_size_t()
+            _lib.check(eng.lib.m3g_workspace_bytes(eng.plan, topo.N, topo.E, topo.T, topo.S, C.byref(nbytes)))
+            assert eng._workspace.numel() == nbytes.value
+            sizes.append(nbytes.value)
+            outs.append((o["total_energy"].clone(), o["forces"].clone(), o["stresses"].clone()))
+    finally:
+        eng.set_option("rev_kernel", 1)
+        eng.set_option("save_p1", 1)
+        eng.set_option("save_p2", 1)
+    for (e, f, sg), variant in zip(outs[1:], _REV_VARIANTS[precision][1:]):
+        assert rel_err(e, outs[0][0]) < 1e-6, variant
+        assert rel_err(f, outs[0][1]) < 2e-6, variant
+        assert rel_err(sg, outs[0][2]) < 5e-6, variant
+    if precision == "fp32":   # saved activations cost workspace: 2 arrays > 1 array > none
+        assert sizes[0] > sizes[1] > sizes[2] and sizes[1] == sizes[3] and sizes[2] == sizes[4]
+    # and the default of this mode still meets the north_star gates against the reference's numbers
+    assert rel_err(outs[0][0], expect["out_total_energy"]) < E_TOL
+    assert rel_err(outs[0][1], expect["out_forces"]) < 5e-4
+
+
+def test_commit_under_another_device_releases_stream_and_events():
+    """m3g_plan_commit moves a plan to the device that is current (model.to('cuda:1') after a call on cuda:0).  Streams and
+    events are bound to the device they were created under, so the move must release the internal side stream, its fork /
+    join events and the profiler's event pool, not only the weight buffers.  Driven on one GPU through the test hook
+    `debug_force_move` (the commit takes the move path although the device is unchanged); afterwards every handle is gone
+    and the next calls recreate them and return bit-identical results."""
+    import ctypes as C
+
+    from torch_m3gnet import _lib
+
+    case, mode = "cu32", "ref"
+    _, _, _, graph, _ = load_oracle_case(case, mode)
+    model, _ = build_engine_model(case, mode)
+    model = model.cuda()
+    eng = model.engine
+    g = engine_graph(graph)
+
+    def handles():
+        n = C.c_int32()
+        _lib.check(eng.lib.m3g_debug_live_handles(eng.plan, C.byref(n)))
+        return n.value
+
+    eng.set_option("overlap", 1)      # side stream + fork / join events (not used while the profiler is on)
+    ref = model(g)
+    e0, f0 = ref["total_energy"].clone(), ref["forces"].clone()
+    assert handles() == 3
+    eng.profile(True)                 # event pool
+    model(g)
+    eng.profile_read()
+    assert handles() > 3
+    eng.set_option("debug_force_move", 1)
+    eng._sig = None                   # forces Engine.run to commit again
+    out = model(g)                    # commit (move path) + call: handles were released, then recreated lazily
+    assert torch.equal(out["total_energy"], e0) and torch.equal(out["forces"], f0)
+    eng.profile(False)
+    eng.set_option("overlap", 0)
+    eng.set_option("debug_force_move", 1)
+    eng.commit()
+    assert handles() == 0             # nothing survives a move; nothing is recreated until it is needed
+    eng._sig = None
+    out = model(g)
+    assert torch.equal(out["total_energy"], e0)
 
 
 def test_side_stream_overlap_option_gives_identical_results():

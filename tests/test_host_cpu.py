@@ -254,3 +254,103 @@ def test_torch_free_c_abi_host_is_built_and_links():
     assert binary.exists(), "run `make -C torch-m3gnet_amd` (or __graft_entry__.build())"
     proc = subprocess.run([str(binary)], capture_output=True, text=True, timeout=60)
     assert proc.returncode == 1 and "usage:" in proc.stderr
+
+
+class _Lattice:
+    def __init__(self, m):
+        self.matrix = np.asarray(m, dtype=float)
+
+
+class _Specie:
+    def __init__(self, z):
+        self.Z = int(z)
+
+
+class _Site:
+    def __init__(self, z):
+        self.specie = _Specie(z)
+
+
+class _Structure:
+    """Duck-typed stand-in for pymatgen's Structure: the three attributes the reference reads (data/material_graph.py:139-147)."""
+
+    def __init__(self, lattice, cart_coords, zs, with_numbers=True):
+        self.lattice = _Lattice(lattice)
+        self.cart_coords = np.asarray(cart_coords, dtype=float)
+        self._sites = [_Site(z) for z in zs]
+        if with_numbers:
+            self.atomic_numbers = tuple(int(z) for z in zs)
+
+    def __iter__(self):
+        return iter(self._sites)
+
+    def __len__(self):
+        return len(self._sites)
+
+
+def test_reference_data_layer_names_and_tuple_shapes():
+    """Drop-in names of the reference's data layer (data/material_graph.py:132-254): `MaterialGraph.from_structure`,
+    module-level `get_all_neighbors_with_cell_shifts` and `compute_threebody`, with the reference's tuple shapes and dtypes,
+    on a duck-typed structure (no pymatgen in the image)."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.material_graph import MaterialGraph, compute_threebody, get_all_neighbors_with_cell_shifts
+
+    rng = np.random.default_rng(11)
+    lat = np.eye(3) * 6.2 + 0.3 * rng.uniform(-1, 1, (3, 3))
+    pos = rng.uniform(0, 6, (10, 3))
+    zs = rng.integers(1, 90, 10)
+    for with_numbers in (True, False):   # Structure.atomic_numbers, or site.specie.Z as the reference iterates
+        st = _Structure(lat, pos, zs, with_numbers=with_numbers)
+        g = MaterialGraph.from_structure(st, 4.5, 3.5)
+        ref = MaterialGraph.from_arrays(lat, pos, zs, 4.5, 3.5)
+        for key in (K.POS, K.ATOM_TYPES, K.EDGE_INDEX, K.EDGE_CELL_SHIFT, K.TRIPLET_EDGE_INDEX, K.NUM_TRIPLET_I, K.NUM_TRIPLET_IJ, K.LATTICE):
+            assert torch.equal(g[key], ref[key]), key
+        assert g[K.ATOM_TYPES].dtype == torch.long and torch.equal(g[K.ATOM_TYPES], torch.tensor(zs - 1))
+    ei, shift, dist = get_all_neighbors_with_cell_shifts(st, 4.5)
+    assert ei.dtype == torch.long and ei.shape[0] == 2 and shift.dtype == torch.int and shift.shape == (ei.shape[1], 3)
+    assert dist.dtype == torch.float and dist.shape == (ei.shape[1],)
+    assert torch.equal(ei, g[K.EDGE_INDEX]) and torch.equal(shift, g[K.EDGE_CELL_SHIFT])
+    tei, nti, ntij = compute_threebody(len(st), ei, dist, 3.5)
+    assert tei.dtype == torch.long and ntij.dtype == torch.int
+    assert torch.equal(tei, g[K.TRIPLET_EDGE_INDEX]) and torch.equal(nti, g[K.NUM_TRIPLET_I]) and torch.equal(ntij, g[K.NUM_TRIPLET_IJ])
+    with pytest.raises(ValueError, match="Three body cutoff"):
+        MaterialGraph.from_structure(st, 3.0, 3.5)
+
+
+def test_model_config_builds_the_default_model():
+    """`torch_m3gnet.config.ModelConfig`: the model half of the reference's RunConfig (config.py:10-17), used by bench.py."""
+    from torch_m3gnet.config import ModelConfig
+    from torch_m3gnet.model.build import build_model
+
+    cfg = ModelConfig()
+    assert (cfg.cutoff, cfg.threebody_cutoff, cfg.l_max, cfg.n_max, cfg.num_types, cfg.embedding_dim, cfg.num_blocks) == (5.0, 4.0, 3, 3, 95, 64, 3)
+    torch.manual_seed(0)
+    a = cfg.build()
+    torch.manual_seed(0)
+    b = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+
+
+def test_readout_depth_other_than_three_is_refused_loudly():
+    """The reference's AtomWiseReadout takes any num_layers (nn/readout.py:31-37); build_model only ever passes 3
+    (model/build.py:72) and that is what m3g_readout / the engine implement -- anything else must raise, not index the
+    wrong tensors."""
+    from torch_m3gnet.nn import modules as nn
+
+    ro = nn.AtomWiseReadout(8, 2, 1.0)
+    assert [k for k in ro.state_dict()] == ["gated.dense.0.weight", "gated.dense.0.bias", "gated.dense.2.weight", "gated.dense.2.bias",
+                                            "gated.gate.0.weight", "gated.gate.0.bias", "gated.gate.2.weight", "gated.gate.2.bias"]
+
+    class _OnGpu(torch.Tensor):   # the depth check comes right after the device check: a tensor that claims to live on the GPU
+        @property
+        def is_cuda(self):
+            return True
+
+    g = {"x": torch.zeros(2, 8).as_subclass(_OnGpu)}
+    with pytest.raises(ValueError, match="num_layers = 3"):
+        ro(g)
+    head = [nn.ScaleLength(1.0), nn.AtomRef(torch.zeros(5)), nn.DistanceAndAngle(), nn.AtomFeaturizer(5, 8), nn.EdgeFeaturizer(3, 5.0),
+            nn.EdgeAdjustor(3, 8)]
+    with pytest.raises(ValueError, match="num_layers = 3"):
+        nn.Gradient(torch.nn.Sequential(*head, nn.AtomWiseReadout(8, 4, 1.0))).engine

@@ -283,6 +283,25 @@ extern "C" int m3g_plan_create(const m3g_config* cfg, m3g_plan** out) {
   return M3G_OK;
 }
 
+// Streams and events are bound to the device they were created under: the internal side stream (options graph_replay / overlap),
+// its fork / join events and the stage profiler's event pool.  Called with that device current; everything is recreated lazily
+// (ensure_side_stream, StageTimer) under whatever device the plan lives on next.
+static void release_device_handles(m3g_plan* plan) {
+  for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
+  plan->ev_pool.clear();
+  plan->ev_stage.clear();
+  plan->ev_used = 0;
+  if (plan->ev_fork) { (void)hipEventDestroy(plan->ev_fork); plan->ev_fork = nullptr; }
+  if (plan->ev_join) { (void)hipEventDestroy(plan->ev_join); plan->ev_join = nullptr; }
+  if (plan->side_stream) { (void)hipStreamDestroy(plan->side_stream); plan->side_stream = nullptr; }
+}
+
+extern "C" int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out) {
+  if (!plan || !out) { set_error("m3g_debug_live_handles: null argument"); return M3G_ERR_VALUE; }
+  *out = (int32_t)plan->ev_pool.size() + (plan->ev_fork ? 1 : 0) + (plan->ev_join ? 1 : 0) + (plan->side_stream ? 1 : 0);
+  return M3G_OK;
+}
+
 extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   if (!plan) return;
   if (plan->d_weights) (void)hipFree(plan->d_weights);
@@ -290,10 +309,7 @@ extern "C" void m3g_plan_destroy(m3g_plan* plan) {
   generic_free(plan);
   if (plan->d_stamps) (void)hipFree(plan->d_stamps);
   drop_graphs(plan);
-  for (hipEvent_t ev : plan->ev_pool) (void)hipEventDestroy(ev);
-  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
-  if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
-  if (plan->side_stream) (void)hipStreamDestroy(plan->side_stream);
+  release_device_handles(plan);
   delete plan;
 }
 
@@ -359,6 +375,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->stress_mode = value;
     return M3G_OK;
   }
+  if (strcmp(name, "debug_force_move") == 0) {   // test hook: the next commit takes the device-move path although the device is the same
+    plan->debug_force_move = value != 0;
+    plan->committed = false;
+    return M3G_OK;
+  }
   if (strcmp(name, "stamps") == 0) {  // diagnostic: forward edge kernel with s_memtime phase stamps
     plan->stamp_target = value == 2 ? 1 : 0;   // 1: forward edge kernel, 2: reverse edge-MLP kernel
     if (value && !plan->d_stamps) {
@@ -392,14 +413,16 @@ extern "C" int m3g_plan_commit(m3g_plan* plan) {
   {
     int dev = 0;
     M3G_HIP_CHECK(hipGetDevice(&dev));
-    if (plan->device >= 0 && plan->device != dev) {   // the plan moves to the current device
+    if (plan->device >= 0 && (plan->device != dev || plan->debug_force_move)) {   // the plan moves to the current device
       M3G_HIP_CHECK(hipSetDevice(plan->device));
       M3G_HIP_CHECK(hipDeviceSynchronize());
       if (plan->d_weights) { (void)hipFree(plan->d_weights); plan->d_weights = nullptr; }
       free_mfma_images(plan);
       generic_free(plan);
       if (plan->d_stamps) { (void)hipFree(plan->d_stamps); plan->d_stamps = nullptr; }
+      release_device_handles(plan);   // the side stream, its events and the profiler's events belong to the old device too
       M3G_HIP_CHECK(hipSetDevice(dev));
+      plan->debug_force_move = false;
     }
     M3G_HIP_CHECK(hipDeviceSynchronize());   // kernels of earlier calls may still read the buffers this call overwrites
     plan->device = dev;

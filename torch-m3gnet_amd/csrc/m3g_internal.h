@@ -217,6 +217,7 @@ struct m3g_plan {
   // opt-in stage profiler (m3g_profile_*): event pairs recorded around stage launches
   // side stream: the three-body reverse of a block (short, latency-bound, does not fill the chip) runs beside the node
   // reverse's dp1 gather (HBM-bound); fork/join with events, created on first use
+  bool debug_force_move = false;        // option debug_force_move (tests): the next commit runs the device-move path
   mutable hipStream_t side_stream = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int overlap = 0;               // option "overlap": 1 = use the side stream (measured 2 % SLOWER on the 10k-atom step: two fork/join

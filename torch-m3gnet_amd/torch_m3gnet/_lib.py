@@ -85,6 +85,7 @@ SYMBOLS = {
     "m3g_threebody_fill": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "m3g_debug_read_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "m3g_debug_live_handles": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "m3g_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "m3g_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                    C.POINTER(C.c_int32)]),

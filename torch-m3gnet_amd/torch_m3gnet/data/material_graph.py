@@ -5,7 +5,9 @@ mapping from `MaterialGraphKey` names to tensors; batching concatenates node/edg
 offsets `edge_index` by the running atom count and `triplet_edge_index` by the running edge count
 (`__inc__`, :122-130), stacks `lattice` along a new leading dimension (`__cat_dim__` None, :109-120)
 and adds a `batch` vector.  Graph construction uses this package's own periodic neighbour list
-(`neighbors.py`) instead of pymatgen.
+(`neighbors.py`) instead of pymatgen; the reference's entry points keep their names and signatures:
+`MaterialGraph.from_structure` (:132-166, any object with pymatgen's `lattice.matrix`, `cart_coords` and
+`atomic_numbers` / per-site `specie.Z`), `get_all_neighbors_with_cell_shifts` (:168-193), `compute_threebody` (:196-254).
 """
 from __future__ import annotations
 
@@ -66,6 +68,14 @@ class MaterialGraph(dict):
         return self.to("cpu")
 
     @classmethod
+    def from_structure(cls, structure, cutoff: float, threebody_cutoff: float) -> "MaterialGraph":
+        """The reference's constructor (data/material_graph.py:132-166) for any structure-like object: pymatgen's
+        `Structure`, or anything exposing `lattice.matrix` [3,3], `cart_coords` [n,3] and the atomic numbers (see
+        `_atomic_numbers`).  No pymatgen import: the neighbour search is this package's own."""
+        lattice, pos, z = _structure_arrays(structure)
+        return cls.from_arrays(lattice, pos, z, cutoff, threebody_cutoff)
+
+    @classmethod
     def from_arrays(cls, lattice, cart_coords, atomic_numbers, cutoff: float, threebody_cutoff: float) -> "MaterialGraph":
         """Build a graph from a periodic cell (replaces `from_structure`, material_graph.py:132-166).
         `atomic_numbers` are Z (1-based); `atom_types` = Z - 1 as in the reference (:147)."""
@@ -83,6 +93,40 @@ class MaterialGraph(dict):
             edge_cell_shift=torch.tensor(shift, dtype=torch.int), num_triplet_ij=torch.tensor(ntij),
             triplet_edge_index=torch.tensor(tei, dtype=torch.long), lattice=torch.tensor(lattice, dtype=torch.float),
         )
+
+
+def _atomic_numbers(structure) -> np.ndarray:
+    """Z of every site: `structure.atomic_numbers` (pymatgen Structure / IStructure), else `site.specie.Z` per site as the
+    reference reads them (data/material_graph.py:147)."""
+    z = getattr(structure, "atomic_numbers", None)
+    if z is None:
+        z = [site.specie.Z for site in structure]
+    return np.asarray(z, dtype=np.int64).reshape(-1)
+
+
+def _structure_arrays(structure):
+    lattice = np.array(structure.lattice.matrix, dtype=np.float64).reshape(3, 3)
+    pos = np.asarray(structure.cart_coords, dtype=np.float64).reshape(-1, 3)
+    return lattice, pos, _atomic_numbers(structure)
+
+
+def get_all_neighbors_with_cell_shifts(structure, cutoff: float):
+    """Full periodic neighbour list of a structure-like object: (edge_index [2,E] long, edge_cell_shift [E,3] int,
+    distances [E] float) -- the reference's tuple (data/material_graph.py:168-193), in the canonical order of
+    `neighbors.neighbor_list` (sorted by centre; pymatgen leaves the order inside a centre unspecified)."""
+    lattice, pos, _ = _structure_arrays(structure)
+    ei, shift, dist = neighbor_list(lattice, pos, cutoff)
+    return torch.tensor(ei, dtype=torch.long), torch.tensor(shift, dtype=torch.int), torch.tensor(dist, dtype=torch.float)
+
+
+def compute_threebody(num_nodes: int, edge_index: torch.Tensor, distances: torch.Tensor, threebody_cutoff: float):
+    """(triplet_edge_index [2,T] long, num_triplet_i [N] long, num_triplet_ij [E] int) for a centre-sorted edge list: every
+    ordered pair of distinct edges within `threebody_cutoff` that share a centre, in the reference's loop order
+    (data/material_graph.py:196-254), without its O(T) Python loop."""
+    ei = edge_index.detach().cpu().numpy()
+    d = distances.detach().cpu().numpy()
+    tei, nti, ntij = threebody_index(int(num_nodes), ei, d, threebody_cutoff)
+    return torch.tensor(tei, dtype=torch.long), torch.tensor(nti), torch.tensor(ntij, dtype=torch.int)
 
 
 class Batch(MaterialGraph):

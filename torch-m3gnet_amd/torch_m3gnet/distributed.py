@@ -60,6 +60,12 @@ def _world(group):
     return 1, 0
 
 
+def _has_group(group) -> bool:
+    """A process group exists (possibly of one rank): the collectives run through it, so a one-rank RCCL group exercises
+    exactly the calls an eight-rank job makes."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def _comm_device(device: torch.device, group) -> torch.device:
     """RCCL ("nccl") moves device buffers; the gloo rehearsal backend moves host buffers."""
     if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
@@ -134,7 +140,7 @@ class ShardedBatch:
                 priced = _build_batch([structure_fn(i) for i in slice_idx], cutoff, threebody_cutoff, device)
                 mine_cost[: len(slice_idx)] = batch_structure_costs(priced).to(comm)
                 mine_cost[per: per + len(slice_idx)] = torch.bincount(priced[K.BATCH], minlength=len(slice_idx)).to(comm, torch.float64)
-            if world > 1:
+            if _has_group(group):
                 allc = torch.empty(world * 2 * per, dtype=torch.float64, device=comm)
                 dist.all_gather_into_tensor(allc, mine_cost, group=group)
             else:
@@ -156,7 +162,7 @@ class ShardedBatch:
             loc = torch.zeros(n_max, dtype=torch.int64, device=comm)
             if mine:
                 loc[: len(mine)] = torch.bincount(batch[K.BATCH], minlength=len(mine)).to(comm)
-            if world > 1:
+            if _has_group(group):
                 alls = torch.empty(world * n_max, dtype=torch.int64, device=comm)
                 dist.all_gather_into_tensor(alls, loc, group=group)
             else:
@@ -190,7 +196,7 @@ class ShardedBatch:
         if self.batch is not None:
             out = evaluate(self.batch)
             self._local_e[: len(self.mine)] = out[K.TOTAL_ENERGY].to(self._comm, torch.float)
-        if self.world > 1:
+        if _has_group(self.group):
             dist.all_gather_into_tensor(self._gathered, self._local_e, group=self.group)
             energies = self._gathered[self._perm]
         else:
@@ -214,7 +220,7 @@ class ShardedBatch:
             self._fall = torch.empty(self.world * self._f_max, 3, dtype=torch.float, device=self._comm)
         if local_f is not None:
             self._fbuf[: self.n_local_atoms] = local_f.to(self._comm, torch.float)
-        if self.world > 1:
+        if _has_group(self.group):
             dist.all_gather_into_tensor(self._fall, self._fbuf, group=self.group)
             return self._fall[self._fperm]
         return self._fbuf[self._fperm]

@@ -32,6 +32,9 @@ class Engine:
                 "Gradient(model): the fused MI355X path needs the module order of build_model "
                 f"({' -> '.join(head)} -> [ThreeBodyInteration -> M3GNetConv]* -> AtomWiseReadout); got {kinds}"
             )
+        if int(mods[-1].num_layers) != 3:
+            raise ValueError("AtomWiseReadout: the MI355X engine implements the readout of build_model (num_layers = 3, "
+                             f"model/build.py:69-76); got num_layers = {mods[-1].num_layers}")
         self.seq = seq
         self.mods = mods
         self.num_blocks = n_blocks
@@ -150,8 +153,9 @@ class Engine:
                 self.commit()
             self._sig = sig
         with torch.cuda.device(dev):
-            types = graph[K.ATOM_TYPES].contiguous().long()
-            probe = self._species_probe(graph, types)   # queued before the topology build, read after it (no extra wait)
+            types_in = graph[K.ATOM_TYPES]
+            types = types_in.contiguous().long()
+            probe = self._species_probe(graph, types_in, types)   # queued before the topology build, read after it (no extra wait)
             topo = M._Topology.of(graph)
             N, E, T, S = topo.N, topo.E, topo.T, topo.S
             D, R, Cc, B = self.cfg.embedding_dim, self.cfg.n_max, self.cfg.l_max * self.cfg.n_max, self.num_blocks
@@ -202,12 +206,15 @@ class Engine:
             self.atom_ref(graph)
         return graph
 
-    def _species_probe(self, graph, types: torch.Tensor):
+    def _species_probe(self, graph, types_in: torch.Tensor, types: torch.Tensor):
         """The reference fails on a species index outside the model's table (`elemental_energies[atom_types]`,
         nn/atom_ref.py:27, raises IndexError; one_hot raises after it).  Checked once per atom_types tensor and cached on the
         graph like the topology.  The min/max reduction and its copy to pinned host memory are queued here; `_check_species`
-        reads them after the topology build, whose own wait for the stream (new graph) has then already covered them."""
-        sig = (types.data_ptr(), types._version, int(types.numel()), int(self.cfg.num_types))
+        reads them after the topology build, whose own wait for the stream (new graph) has then already covered them.
+        The cache key is taken from the tensor the GRAPH holds (kept alive by it, version-counted), never from the int64 /
+        contiguous temporary made of it: a temporary's address is recycled and its version is always 0."""
+        sig = (types_in.data_ptr(), types_in._version, tuple(types_in.shape), str(types_in.dtype), tuple(types_in.stride()),
+               int(self.cfg.num_types))
         if isinstance(graph, dict) and graph.get("_m3g_species_ok") == sig:
             return None
         if not types.numel():

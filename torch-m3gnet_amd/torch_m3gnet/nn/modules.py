@@ -460,6 +460,9 @@ class AtomWiseReadout(torch.nn.Module):
         """Per-atom gated MLP, elemental reference added, per-structure sums (m3g_readout)."""
         x = graph[K.NODE_FEATURES]
         _require_cuda(x, K.NODE_FEATURES)
+        if self.num_layers != 3:
+            raise ValueError("AtomWiseReadout.forward: m3g_readout implements the readout of build_model (num_layers = 3, "
+                             f"reference model/build.py:69-76); got num_layers = {self.num_layers}")
         dev = x.device
         x = _f32(x)
         N, D = x.shape
