@@ -26,17 +26,25 @@ products, fp32 accumulate -- the reference's arithmetic); the `bf16x3` mode (3 b
 ~2^-16 relative product error) is timed beside it and reported in `bf16x3`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline      the dominant kernel against the roofline that bounds it (fp32 mode: the fp32 matrix peak; bf16x3: HBM,
-                algorithmic bytes), its duration measured live with HIP events in the library
-  roofline_other_kernels   every other kernel of the step with its bound, algorithmic bytes and achieved rate
+  roofline      the dominant kernel against the roofline that bounds it (fp32 mode: the fp32 matrix peak, `frac` on the USEFUL
+                FLOPs of the factorised formulation with the executed-MFMA figure beside it; bf16x3: HBM), its duration measured
+                live with HIP events in the library.  Bytes on three bases, never mixed: `algorithmic_bytes_8d` (SURVEY.md 8(d):
+                the 256-byte edge-feature rows only), `design_bytes` (what the data layout of DESIGN.md section 3 moves) and
+                `traffic` (PMC, from the profile set named in `traffic_source` -- null when that set was collected on other
+                kernel sources than the ones being timed)
+  roofline_other_kernels   every other kernel of the step with its bound, bytes and achieved rate
+  step_traffic_bytes       PMC traffic of one whole step against SURVEY.md 8(d)'s ideal-fusion bytes
   beside        (n_gpus = 1, default run) step latency of the 32-atom Cu cell of BASELINE configs[0] and one MD-style iteration on
                 the headline cell: GPU neighbour list + triplets + topology + step from fresh positions
-  cpu_baseline  the CPU oracle (oracle/m3gnet_oracle.py, a plain-torch port of the reference) timed on the
-                host cores on a bounded sample (2,048-atom Cu supercell), rank 0, N = 1 only: all cores and 1 thread
+  cpu_baseline  the CPU oracle (oracle/m3gnet_oracle.py, a plain-torch port of the reference) timed on the host cores ON THE
+                HEADLINE CONFIGURATION ITSELF (the 10,000-atom cell; 1 warm-up + 3 steps at all cores, 1 step at 1 thread,
+                ~25 s), rank 0, N = 1 only.  `vs_cpu_baseline` = value / cpu_baseline.value (`vs_baseline` stays null:
+                BASELINE.md holds no published number for this metric)
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -46,7 +54,7 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
-for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
+for p in (ROOT, ROOT / "torch-m3gnet_amd"):   # (tests/ is NOT on the path: the bench does not import test modules)
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
 
@@ -58,27 +66,40 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (about 6.3 TB/s achievable)
 F32_MFMA_FLOP = 2048                # v_mfma_f32_16x16x4_f32
 BF16_MFMA_FLOP = 16384              # v_mfma_f32_16x16x32_bf16
-# Per-kernel algorithmic work, per precision mode.  bytes = what the kernel must move per edge and launch:
-# the 256-byte edge-feature rows under ideal fusion and, in the fp32 mode, the activations it saves for /
-# reads back in the reverse pass (SiLU'(p1) and p2 of both MLPs, 1 KB each) and the fp32 dL/dp1 rows (1 KB; blocks > 0 only:
-# averaged over the 3 launches of a step).  FLOPs = SURVEY.md 8(d)'s 134,144 per edge and block forward, the same again for
-# the input-gradient reverse.  MFMA counts per 16-edge tile: (f32 16x16x4, bf16 16x16x32).
+# Per-kernel work of the two fused edge kernels, per edge and launch:
+#   bytes_8d       SURVEY.md 8(d), ideal fusion: forward reads + writes the 256-byte edge-feature row (512), reverse reads the saved
+#                  row and reads + writes its gradient (768) -- the figure `traffic_over_algorithmic` is priced against;
+#   design_bytes   what the data layout moves: + the activations the fp32 mode saves / reads back (SiLU'(p1) and p2 of both MLPs,
+#                  1 KB each) and its fp32 dL/dp1 rows (1 KB, blocks > 0 only: averaged over the 3 launches of a step);
+#   flops_8d       SURVEY.md 8(d): 134,144 per edge and block forward (a14 65,920 + a15 65,920 + a8 MLP 2,304), the same again for
+#                  the input-gradient reverse -- the UNFACTORISED formulation W1 [x_i | x_j | e];
+#   flops_useful   what the kernels really have to do after the exact factorisation W1 [x_i | x_j | e] = TA[i] + TB[j] + W1c e
+#                  (DESIGN.md section 2): the x_i / x_j thirds of layer 1 (2 x 32,768 FLOP per edge and MLP) become per-NODE
+#                  tables built once per block by k_node_pre_mfma (65,536 FLOP per ATOM, counted there), so per edge
+#                  2 MLPs x (16,384 layer 1 + 16,384 layer 2 + 384 W_l h) + 2,304 three-body MLP = 68,608: half of flops_8d;
+#   mfma           MFMAs issued per 16-edge tile (f32 16x16x4, bf16 16x16x32): executed FLOPs incl. zero padding.
 EDGE_KERNELS = {
-    "edge_block_fwd": dict(kernel="k_edge_block_mfma", alg_flops_per_edge=134_144,
-                           alg_bytes_per_edge={"bf16x3": 2 * 256, "fp32": 2 * 256 + 2048},
+    "edge_block_fwd": dict(kernel="k_edge_block_mfma", flops_8d=134_144, flops_useful=68_608, bytes_8d=2 * 256,
+                           design_bytes={"bf16x3": 2 * 256, "fp32": 2 * 256 + 2048},
                            mfma={"bf16x3": (48, 192), "fp32": (545, 0)}),
-    "edge_rev_fused": dict(kernel={"bf16x3": "k_edge_rev_fused", "fp32": "k_edge_rev_f32"}, alg_flops_per_edge=134_144,
-                           alg_bytes_per_edge={"bf16x3": 3 * 256, "fp32": 2048 + (2 * (512 + 1024) + 256) / 3},
+    "edge_rev_fused": dict(kernel={"bf16x3": "k_edge_rev_fused", "fp32": "k_edge_rev_f32"}, flops_8d=134_144, flops_useful=68_608,
+                           bytes_8d=3 * 256,
+                           design_bytes={"bf16x3": 3 * 256 + 256 + (2 * 768) / 3, "fp32": 2048 + (2 * (512 + 1024) + 256) / 3},
                            mfma={"bf16x3": (48, 396), "fp32": (577, 0)}),
     # split reverse kernels (option rev_kernel = 0; fp32: layer 1 saved, layer 2 recomputed)
-    "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", alg_flops_per_edge=65_920,
-                              alg_bytes_per_edge={"bf16x3": 2 * 256, "fp32": 512 + 256 + 512},
+    "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", flops_8d=65_920, flops_useful=33_152, bytes_8d=2 * 256,
+                              design_bytes={"bf16x3": 2 * 256, "fp32": 512 + 256 + 512},
                               mfma={"bf16x3": (8, 192), "fp32": (388, 0)}),
-    "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", alg_flops_per_edge=68_224,
-                              alg_bytes_per_edge={"bf16x3": 4 * 256, "fp32": 512 + 3 * 256 + 512},
+    "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", flops_8d=68_224, flops_useful=35_456, bytes_8d=3 * 256,
+                              design_bytes={"bf16x3": 4 * 256, "fp32": 512 + 3 * 256 + 512},
                               mfma={"bf16x3": (56, 204), "fp32": (444, 0)}),
 }
-PMC_TRAFFIC_FILE = "r02_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE of this build (tools/pmc_traffic.py)
+FLOPS_RATIO_NOTE = ("flops_8d / flops_useful = 2: SURVEY.md 8(d) counts W1 [x_i | x_j | e] per edge; the kernels use the exact "
+                    "factorisation TA[i] + TB[j] + W1c e, whose x_i / x_j parts are per-node tables (k_node_pre_mfma, 65,536 FLOP "
+                    "per atom and block, 42 x fewer rows than edges)")
+BYTES_8D_PER_STEP = lambda E, T, N: 4008 * E + 48 * T + 3504 * N   # noqa: E731  SURVEY.md 8(d), D = 64, B = 3
+PMC_TRAFFIC_FILE = "r03_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py), stamped with
+                                                # the digest of the kernel sources it was collected on
 METRIC = "atom-steps/sec (energy+forces) on 10k-atom PBC batch, 1/2/4/8 MI355X"
 
 
@@ -120,68 +141,122 @@ def cpu_model():
 
 
 def default_model(device):
-    from torch_m3gnet.model.build import build_model
+    from torch_m3gnet.config import ModelConfig   # the reference's defaults (config.py:10-17)
 
     torch.manual_seed(0)
-    model = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
-    return model.to(device)
+    return ModelConfig().build().to(device)
 
 
-def cpu_baseline(sample_cells=(8, 8, 8), steps=3):
-    """Oracle (port of the reference's CPU path) on a bounded sample of the same workload: all cores, then 1 thread."""
-    from helpers import fcc_cu_graph
-    from oracle import m3gnet_oracle as orc
-    from torch_m3gnet.model.build import build_model
+def csrc_digest():
+    """sha256 over the kernel sources of this tree (csrc/*.hip, csrc/*.h, include/*.h): ties a PMC profile set to the build it
+    was collected on (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    files = sorted((ROOT / "torch-m3gnet_amd" / "csrc").glob("*.h*")) + sorted((ROOT / "include").glob("*.h"))
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(cells=(10, 10, 25), steps=3):
+    """Oracle (port of the reference's CPU path) on the headline configuration itself: 1 warm-up + `steps` steps at all cores,
+    then 1 step at 1 thread (BASELINE.md "CPU-baseline plan")."""
+    from oracle import m3gnet_oracle as orc   # the checker, used here only as the thing timed (allowed: cpu_baseline leg)
+    from torch_m3gnet.config import ModelConfig
+    from torch_m3gnet.data.synthetic import fcc_cu_graph
 
     cores = min(host_cores(), 16)  # the GPU box gives 16 cores per GPU
     torch.manual_seed(0)
-    model = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
+    model = ModelConfig().build()
     params = {f"model.{k}": v.detach().clone() for k, v in model.model.state_dict().items()}
     cfg = orc.OracleConfig()
     consts = orc.make_constants(cfg)
-    g = fcc_cu_graph(*sample_cells, seed=0)
+    g = fcc_cu_graph(*cells, seed=0)
     graph = {k: g[k] for k in ("pos", "atom_types", "edge_index", "edge_cell_shift", "triplet_edge_index", "lattice", "batch")}
     n = int(g["pos"].size(0))
 
-    def run(threads, n_steps):
+    def run(threads, n_steps, warm):
         torch.set_num_threads(threads)
-        orc.energy_forces(params, cfg, consts, graph)  # warm-up
+        for _ in range(warm):
+            orc.energy_forces(params, cfg, consts, graph)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             orc.energy_forces(params, cfg, consts, graph)
         return (time.perf_counter() - t0) / n_steps
 
-    log(f"cpu_baseline: {cores} threads")
-    dt = run(cores, steps)
+    log(f"cpu_baseline: {n} atoms, {cores} threads")
+    dt = run(cores, steps, 1)
     log(f"cpu_baseline: {dt * 1e3:.0f} ms/step; 1 thread")
-    dt1 = run(1, 1)
+    dt1 = run(1, 1, 0)   # (code and allocator are warm from the runs above)
     torch.set_num_threads(cores)
     return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "ms_per_step": dt * 1e3,
             "threads_1": {"value": n / dt1, "unit": "atom-steps/s", "cores": 1, "ms_per_step": dt1 * 1e3},
-            "sample": f"{n}-atom fcc Cu supercell ({'x'.join(map(str, sample_cells))} cells), fp32, {steps} timed steps "
-                      f"after 1 warm-up at {cores} threads ({dt * 1e3:.0f} ms/step), 1 timed step after 1 warm-up at 1 thread "
+            "sample": f"the headline workload itself: {n}-atom fcc Cu supercell ({'x'.join(map(str, cells))} cells), fp32, {steps} timed "
+                      f"steps after 1 warm-up at {cores} threads ({dt * 1e3:.0f} ms/step), then 1 timed step at 1 thread "
                       f"({dt1 * 1e3:.0f} ms/step), torch {torch.__version__} CPU"}
 
 
 # ---------------------------------------------------------------------------------------------- self launch
+def supervise(procs, poll_s=0.2, grace_s=5.0):
+    """Wait for all children; as soon as ANY exits non-zero, terminate the others and return (its code, its rank).  A rank that
+    dies before or inside the rendezvous / a collective would otherwise leave its peers waiting until a store or RCCL time-out
+    of tens of minutes.  Returns (0, None) when every child exited cleanly."""
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            return 0, None
+        time.sleep(poll_s)
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    deadline = time.time() + grace_s
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    rank, code = failed
+    return (abs(code) if code else 1), rank
+
+
 def self_launch(args) -> int:
-    """Start one child per rank (before any GPU call in this process) and relay rank 0's output."""
+    """Start one FRESH child per rank (before any GPU call in this process -- a GPU-initialised process is never re-exec'ed),
+    supervise them, relay rank 0's JSON line; any rank failing ends the job with its exit code and the tail of its stderr."""
+    import tempfile
+
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, outs, errs = [], [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out:
-        sys.stdout.write(out)
-        sys.stdout.flush()
-    return max(abs(c) for c in codes)
+        out = tempfile.TemporaryFile(mode="w+") if r == 0 else subprocess.DEVNULL
+        err = tempfile.TemporaryFile(mode="w+")
+        outs.append(out)
+        errs.append(err)
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env, stdout=out, stderr=err, text=True))
+    code, rank = supervise(procs)
+    for r, err in enumerate(errs):   # relay the children's logs: rank 0 in full, the tails of the others
+        err.seek(0)
+        lines = err.read().splitlines()
+        for line in (lines if r == 0 else lines[-15:]):
+            sys.stderr.write(f"[rank {r}] {line}\n")
+    if code:
+        log(f"rank {rank} exited with code {code}: the other ranks were terminated")
+        return code
+    outs[0].seek(0)
+    sys.stdout.write(outs[0].read())
+    sys.stdout.flush()
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------- measurement
@@ -202,14 +277,22 @@ class Job:
         torch.cuda.set_device(dev_index)
         self.device = torch.device("cuda", dev_index)
         self.dist = None
-        if self.world > 1:
+        # M3G_BENCH_FORCE_DIST=1: a ONE-rank process group, so that the RCCL code of the N > 1 path (init with device_id,
+        # device-buffer all-gather, all-reduce, barrier) executes on a one-GPU box (tests/test_gpu_sharded.py)
+        if self.world > 1 or os.environ.get("M3G_BENCH_FORCE_DIST") == "1":
+            import datetime
+
             import torch.distributed as dist
 
+            if os.environ.get("M3G_BENCH_TEST_DIE_RANK") == str(self.rank):   # test hook: this rank dies before the rendezvous
+                os._exit(7)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            timeout = datetime.timedelta(seconds=float(os.environ.get("M3G_BENCH_INIT_TIMEOUT_S", "180")))
             if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.device)
+                dist.init_process_group("nccl", device_id=self.device, timeout=timeout, rank=self.rank, world_size=self.world)
             else:
-                dist.init_process_group(self.backend)
+                dist.init_process_group(self.backend, timeout=timeout, rank=self.rank, world_size=self.world)
             self.dist = dist
         self.comm_device = self.device if self.backend == "nccl" else torch.device("cpu")
 
@@ -254,67 +337,81 @@ def stage_times(model, call, steps):
 
 
 def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc):
-    """Per-kernel roofline records (DESIGN.md section 4 states every byte / FLOP figure used here)."""
+    """Per-kernel roofline records (DESIGN.md section 4 states every byte / FLOP figure used here).  `pmc` = {kernel: {fetch_kb,
+    write_kb}} of the profile set that matches this build, or {} (then every `traffic` is null)."""
     tiles = (n_edges + 15) // 16
     views = {}
+
+    def pmc_bytes(kernel):
+        rec = pmc.get(kernel)
+        return (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 if rec else None   # gfx950: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM)
+
     for stage, spec in EDGE_KERNELS.items():
         if stage not in per_launch:
             continue
         ms = per_launch[stage][0]
+        sec = ms * 1e-3
         n_f32, n_bf16 = spec["mfma"][precision]
         kname = spec["kernel"][precision] if isinstance(spec["kernel"], dict) else spec["kernel"]
-        alg_bytes = n_edges * spec["alg_bytes_per_edge"][precision]
-        alg_flops = n_edges * spec["alg_flops_per_edge"]
+        bytes_8d = n_edges * spec["bytes_8d"]
+        design = n_edges * spec["design_bytes"][precision]
+        useful = n_edges * spec["flops_useful"]
         exe_flops = tiles * (n_f32 * F32_MFMA_FLOP + n_bf16 * BF16_MFMA_FLOP)
-        rec = pmc.get(kname)
-        traffic = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 if rec else None  # gfx950: FETCH_SIZE x 2
-        hbm_rate = alg_bytes / (ms * 1e-3) / 1e9
-        t_exe = exe_flops / (ms * 1e-3) / 1e12
-        common = {"kernel": f"{kname} (stage {stage})", "avg_launch_ms": ms, "launches_per_step": per_launch[stage][1], "traffic": traffic,
-                  "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": alg_flops,
-                  "executed_mfma_flops_per_launch": exe_flops,
-                  "measured_traffic_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None}
+        traffic = pmc_bytes(kname)
+        common = {"kernel": f"{kname} (stage {stage})", "avg_launch_ms": ms, "launches_per_step": per_launch[stage][1],
+                  "algorithmic_bytes_8d": bytes_8d, "design_bytes": design, "traffic": traffic,
+                  "traffic_over_algorithmic": (traffic / bytes_8d) if traffic else None,
+                  "traffic_over_design": (traffic / design) if traffic else None,
+                  "measured_traffic_GBs": (traffic / sec / 1e9) if traffic else None,
+                  "algorithmic_flops": useful, "algorithmic_flops_8d_unfactorised": n_edges * spec["flops_8d"],
+                  "executed_mfma_flops": exe_flops}
+        hbm_rate = bytes_8d / sec / 1e9
         hbm_view = {"bound": "hbm", "achieved": hbm_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_rate / PEAK_HBM_GBS}
         if precision == "fp32":
-            # exact-fp32 MFMA chains: every MFMA the kernel issues is algorithmic work (nothing is recomputed in this mode), so
-            # the matrix view prices executed fp32 MFMA FLOPs against the fp32 matrix peak; the byte view prices the rows
-            # above against HBM.  The kernel's bound is the view with the larger fraction.
-            mfma_view = {"bound": "mfma", "achieved": t_exe, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": t_exe / PEAK_F32_MFMA_TFLOPS,
-                         "algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12}
-            first, second = (mfma_view, hbm_view) if mfma_view["frac"] >= hbm_view["frac"] else (hbm_view, mfma_view)
-            views[stage] = dict(common, **first, other_view=second)
+            # exact-fp32 MFMA chains: priced on the USEFUL FLOPs of the factorised formulation against the fp32 matrix peak, the
+            # executed-MFMA rate (zero padding of the K = 9 / 3 products included) beside it.  fp32 MFMAs and vector instructions
+            # share the SIMD's fp32 datapath on gfx950 (profiles/r03_mfma_filler_probe.txt): the kernel's own floor is
+            # 32 cycles x MFMAs + its vector instructions, not the MFMAs alone.
+            t_useful, t_exe = useful / sec / 1e12, exe_flops / sec / 1e12
+            mfma_view = {"bound": "mfma", "achieved": t_useful, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": t_useful / PEAK_F32_MFMA_TFLOPS, "executed_mfma_tflops": t_exe,
+                         "executed_mfma_frac": t_exe / PEAK_F32_MFMA_TFLOPS, "flops_note": FLOPS_RATIO_NOTE}
+            views[stage] = dict(common, **mfma_view, other_view=hbm_view)
         else:
             views[stage] = dict(common, **hbm_view,
-                                mfma_view={"algorithmic_tflops": alg_flops / (ms * 1e-3) / 1e12, "executed_tflops": t_exe,
-                                           "executed_frac_of_bf16_peak": t_exe / PEAK_BF16_MFMA_TFLOPS})
-    # HBM-bound kernels: bytes the data layout of DESIGN.md section 3 makes each launch move (algorithmic = every array the
-    # kernel must read or write once; gathers from L2/MALL-resident node tables not counted)
+                                mfma_view={"useful_tflops": useful / sec / 1e12, "executed_tflops": exe_flops / sec / 1e12,
+                                           "executed_frac_of_bf16_peak": exe_flops / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS})
+    # HBM-bound kernels: bytes the data layout of DESIGN.md section 3 makes each launch move (every array the kernel must read or
+    # write once; gathers from L2/MALL-resident node tables not counted)
     E, T, N, A = n_edges, n_trip, n_atoms, n_active
+    dp1_row = 1024 if precision == "fp32" else 768
     hbm_kernels = {
-        "geometry_basis": ("k_geometry", E * (8 + 12 + 12 + 4 + 16 + 16) + A * (64 + 64 + 8)),
-        "threebody_fwd": ("k_threebody_fwd", A * (64 + 12 + 4 + 4 + 64) + T * 1),
-        "threebody_rev": ("k_threebody_rev", A * (64 + 64 + 12 + 4 + 4 + 64 + 64 + 16) + 2 * T * 1),
-        "node_rev": ("k_node_reverse", E * (768 + 8) + N * (64 + 256 + 256) * 4),
-        "node_pre": ("k_node_pre_mfma", N * (256 + 2 * 1024 + 64 + 256) + 135 * 1024 * 256),
-        "geometry_rev_forces": ("k_geometry_reverse+k_force_gather+k_stress", E * (16 * 3 + 12 + 4 + 12 + 12 * 2 + 8) + N * 12),
+        "geometry_basis": ("k_geometry", E * (8 + 12 + 12 + 4 + 16 + 16) + A * (64 + 64 + 8), 0),
+        "threebody_fwd": ("k_threebody_fwd", A * (64 + 12 + 4 + 4 + 64) + T * 1, 0),
+        "threebody_rev": ("k_threebody_rev", A * (64 + 64 + 12 + 4 + 4 + 64 + 64 + 16) + 2 * T * 1, 0),
+        "node_rev": ("k_node_reverse", E * (dp1_row + 8) + N * (64 + 256 + 256) * 4, N * 2 * 256 * 64 * 2),
+        "node_pre": ("k_node_pre_mfma", N * (256 + 2 * 1024 + 64 + 256) + 135 * 1024 * 256, N * 2 * 528 * 64),
+        "geometry_rev_forces": ("k_geometry_reverse+k_force_gather+k_struct_stress", E * (16 * 3 + 12 + 4 + 12 + 12 * 2 + 8) + N * 12, 0),
     }
-    for stage, (kernel, nbytes) in hbm_kernels.items():
+    for stage, (kernel, nbytes, flops) in hbm_kernels.items():
         if stage not in per_launch:
             continue
         ms = per_launch[stage][0]
-        rec = pmc.get(kernel)
-        traffic = (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 if rec else None
+        parts = [pmc_bytes(k) for k in kernel.split("+")]
+        traffic = sum(parts) if all(x is not None for x in parts) else None
         rate = nbytes / (ms * 1e-3) / 1e9
         views[stage] = {"bound": "hbm", "kernel": f"{kernel} (stage {stage})", "achieved": rate, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": rate / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_ms": ms, "launches_per_step": per_launch[stage][1],
-                        "algorithmic_bytes_per_launch": nbytes}
+                        "design_bytes": nbytes, "measured_traffic_GBs": (traffic / (ms * 1e-3) / 1e9) if traffic else None}
+        if flops:
+            views[stage]["table_flops_per_launch"] = flops   # the per-node share of the factorised layer 1 (see FLOPS_RATIO_NOTE)
     return views
 
 
 def measure_config4(job, model, steps, warmup):
     """BASELINE config 4: 512 x world independent 64-atom cells sharded by ShardedBatch; returns the record."""
-    from helpers import random_cell_arrays
     from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.synthetic import random_cell_arrays
     from torch_m3gnet.distributed import ShardedBatch
 
     n_structs = 512 * job.world
@@ -348,8 +445,8 @@ def measure_beside(model, device):
     one MD-style iteration on the headline cell -- fresh positions -> GPU neighbour list + triplets -> topology -> energies and
     forces (tools/time_small_systems.py, tools/profile_graph_build.py)."""
     import numpy as np
-    from helpers import fcc_cu_graph
     from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.synthetic import fcc_cu_graph
 
     def per_call(fn, reps, warm=3):
         for _ in range(warm):
@@ -430,18 +527,18 @@ def main():
         job.close()
         return
 
-    from helpers import fcc_cu_graph
+    from torch_m3gnet.data.synthetic import fcc_cu_graph
 
     log("building workload graph on the host")
     graph = fcc_cu_graph(*args.cells, seed=rank).to(device)
     n_atoms = int(graph[K.POS].size(0))
     n_edges = int(graph[K.EDGE_INDEX].size(1))
     n_trip = int(graph[K.TRIPLET_EDGE_INDEX].size(1))
-    energies_all = torch.empty(world, 1, device=job.comm_device) if world > 1 else None
+    energies_all = torch.empty(world, 1, device=job.comm_device) if job.dist is not None else None
 
     def step():
         model(graph, forces=True, extras=False)
-        if world > 1:
+        if job.dist is not None:
             job.dist.all_gather_into_tensor(energies_all, graph[K.TOTAL_ENERGY].view(1, 1).to(job.comm_device))
 
     t_first = time.perf_counter()
@@ -464,8 +561,22 @@ def main():
     topo_ms = (time.perf_counter() - t1) * 1e3
     n_active = topo.n_active()
 
+    # PMC traffic is a property of a build: the profile set carries the digest of the kernel sources it was collected on
+    # (tools/pmc_traffic.py); a set from other sources than the ones being timed yields `traffic: null`
     pmc_path = ROOT / "profiles" / PMC_TRAFFIC_FILE
-    pmc_all = json.loads(pmc_path.read_text()) if (pmc_path.exists() and tuple(args.cells) == (10, 10, 25)) else {}
+    pmc_all, digest = {}, csrc_digest()
+    traffic_source = {"file": f"profiles/{PMC_TRAFFIC_FILE}", "csrc_sha256_of_this_build": digest, "valid": False}
+    if pmc_path.exists() and tuple(args.cells) == (10, 10, 25):
+        loaded = json.loads(pmc_path.read_text())
+        src = loaded.get("_source", {})
+        traffic_source.update({k: src.get(k) for k in ("csrc_sha256", "git_commit", "command")})
+        if src.get("csrc_sha256") == digest:
+            pmc_all = loaded
+            traffic_source["valid"] = True
+        else:
+            traffic_source["note"] = "profile set collected on other kernel sources than this build: traffic fields are null"
+    else:
+        traffic_source["note"] = "no profile set for this workload"
 
     def record(precision, ms_step):
         """Roofline objects of one precision mode from live stage timers (the mode must be the engine's current one)."""
@@ -474,10 +585,16 @@ def main():
         edge = {k: v for k, v in views.items() if k in EDGE_KERNELS}
         dom = max(edge, key=lambda k: edge[k]["avg_launch_ms"] * per_launch[k][1])   # dominant kernel = largest share of the step
         stage_ms = {k: round(ms * cnt, 4) for k, (ms, cnt) in per_launch.items()}
-        return views[dom], [v for k, v in views.items() if k != dom], stage_ms
+        views[dom]["traffic_source"] = traffic_source
+        pm = pmc_all.get(precision, {})
+        total = sum(r["launches_per_step"] * (2.0 * r["fetch_kb"] + r["write_kb"]) * 1024.0 for r in pm.values()) if pm else None
+        ideal = BYTES_8D_PER_STEP(n_edges, n_trip, n_atoms)
+        step_bytes = {"traffic": total, "algorithmic_bytes_8d": ideal, "traffic_over_algorithmic": (total / ideal) if total else None,
+                      "source": traffic_source["file"] if total else None}
+        return views[dom], [v for k, v in views.items() if k != dom], stage_ms, step_bytes
 
-    roofline, others, stage_ms = record(args.precision, ms_per_step)
-    out.update(value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_other_kernels=others,
+    roofline, others, stage_ms, step_bytes = record(args.precision, ms_per_step)
+    out.update(value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_other_kernels=others, step_traffic_bytes=step_bytes,
                config={"workload": f"single {n_atoms}-atom fcc Cu PBC supercell per GPU ({'x'.join(map(str, args.cells))} cells, "
                                    "a=3.61 A, jitter 0.025 A), r_cut 5 A / 3-body 4 A, default M3GNet (l_max=n_max=3, D=64, "
                                    "3 blocks), energy+forces+stress",
@@ -489,10 +606,10 @@ def main():
         model.engine.set_precision(other)
         step()
         el2 = job.timed(step, args.steps, args.warmup)
-        r2, o2, st2 = record(other, el2 / args.steps * 1e3)
+        r2, o2, st2, sb2 = record(other, el2 / args.steps * 1e3)
         out[other] = {"value": world * n_atoms * args.steps / el2, "unit": "atom-steps/s", "ms_per_step": el2 / args.steps * 1e3,
                       "dtype": "f32" if other == "fp32" else "f32 operands split into 2 bf16 parts, 3 bf16 MFMA products per fp32 product, fp32 accumulate",
-                      "roofline": r2, "stage_ms_per_step": st2}
+                      "roofline": r2, "stage_ms_per_step": st2, "step_traffic_bytes": sb2}
         model.engine.set_precision(args.precision)
         log(f"{other}: {el2 / args.steps * 1e3:.3f} ms/step")
         out["config4_sharded"] = measure_config4(job, model, max(5, args.steps // 2), 2)
@@ -502,7 +619,8 @@ def main():
             log(f"beside: {out['beside']}")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(tuple(args.cells))
+            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]   # (vs_baseline stays null: nothing published)
         print(json.dumps(out), flush=True)
     job.close()
 

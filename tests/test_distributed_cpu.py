@@ -141,3 +141,46 @@ def test_sharded_batch_single_process_matches_plain_batch():
     e, f = sb.evaluate(_stub_evaluate, gather_forces=True)
     np.testing.assert_allclose(e.numpy(), ref[K.TOTAL_ENERGY].numpy(), rtol=1e-6)
     np.testing.assert_allclose(f.numpy(), ref[K.FORCES].numpy(), rtol=1e-6)
+
+
+def test_launcher_supervision_terminates_peers_of_a_failed_rank():
+    """bench.py's `supervise`: a child that exits non-zero ends the job at once -- the survivors are terminated and the
+    failing rank's code is returned (a rank dying in RCCL init would otherwise leave rank 0 waiting in the rendezvous)."""
+    import importlib.util
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("m3g_bench", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sleeper = [sys.executable, "-c", "import time; time.sleep(120)"]
+    t0 = time.time()
+    procs = [subprocess.Popen(sleeper), subprocess.Popen([sys.executable, "-c", "import time, sys; time.sleep(0.5); sys.exit(3)"]),
+             subprocess.Popen(sleeper)]
+    code, rank = bench.supervise(procs)
+    assert (code, rank) == (3, 1) and time.time() - t0 < 30
+    assert all(p.poll() is not None for p in procs)           # nobody left behind
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
+    assert bench.supervise(ok) == (0, None)
+    killed = [subprocess.Popen(sleeper), subprocess.Popen([sys.executable, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGKILL)"])]
+    code, rank = bench.supervise(killed)
+    assert rank == 1 and code == 9 and killed[0].poll() is not None
+
+
+def test_assemble_matches_the_collective_layout():
+    """`ShardedBatch.assemble` (one-process rehearsal of an N-rank job) reproduces what the all-gathers deliver."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+    from torch_m3gnet.distributed import ShardedBatch, partition_structures, structure_cost
+
+    graphs = [MaterialGraph.from_arrays(*_structure(i), 3.5, 3.0) for i in range(7)]
+    ref = _stub_evaluate(Batch.from_data_list(graphs))
+    costs = [structure_cost(g) for g in graphs]
+    shards = partition_structures(costs, 3)
+    sb = ShardedBatch(shards, [int(g[K.NUM_NODES]) for g in graphs], costs, None, "cpu", None)
+    outs = [_stub_evaluate(Batch.from_data_list([graphs[i] for i in s])) for s in shards]
+    e, f = sb.assemble([o[K.TOTAL_ENERGY] for o in outs], [o[K.FORCES] for o in outs])
+    np.testing.assert_allclose(e.numpy(), ref[K.TOTAL_ENERGY].numpy(), rtol=1e-6)
+    np.testing.assert_allclose(f.numpy(), ref[K.FORCES].numpy(), rtol=1e-6)

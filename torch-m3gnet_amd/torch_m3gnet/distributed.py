@@ -96,7 +96,7 @@ class ShardedBatch:
         self.device = torch.device(device)
         self.group = group
         self.world, self.rank = _world(group)
-        self.mine = shards[self.rank]
+        self.mine = shards[self.rank] if self.rank < len(shards) else []
         self.n_total = len(self.sizes)
         self._comm = _comm_device(self.device, group)
         self._n_max = max(1, max(len(s) for s in shards))
@@ -206,7 +206,26 @@ class ShardedBatch:
             forces = self._gather_forces(forces)
         return energies, forces
 
-    def _gather_forces(self, local_f):
+    # ------------------------------------------------------------------ one-process rehearsal of an N-rank job
+    def assemble(self, per_rank_energies, per_rank_forces=None):
+        """What the all-gathers of `evaluate` deliver, put together on ONE process: `per_rank_energies[r]` / `per_rank_forces[r]`
+        are the local results of shard r (its structures in ascending order).  Uses the same padded layout and the same
+        permutation tensors as the collective path, so an 8-way partition can be checked end to end on one GPU
+        (tests/test_gpu_sharded.py::test_config4_full_partition_on_one_gpu).  Returns (energies, forces) in input order."""
+        gathered = torch.zeros(len(self.shards) * self._n_max, dtype=torch.float, device=self._comm)
+        for r, e in enumerate(per_rank_energies):
+            gathered[r * self._n_max: r * self._n_max + len(self.shards[r])] = e.to(self._comm, torch.float)
+        energies = gathered[self._perm]
+        forces = None
+        if per_rank_forces is not None:
+            self._force_layout()
+            fall = torch.zeros(len(self.shards) * self._f_max, 3, dtype=torch.float, device=self._comm)
+            for r, f in enumerate(per_rank_forces):
+                fall[r * self._f_max: r * self._f_max + f.size(0)] = f.to(self._comm, torch.float)
+            forces = fall[self._fperm]
+        return energies, forces
+
+    def _force_layout(self):
         if self._fperm is None:
             starts = np.concatenate([[0], np.cumsum(self.sizes)])
             perm = torch.empty(int(starts[-1]), dtype=torch.long)
@@ -218,6 +237,9 @@ class ShardedBatch:
             self._fperm = perm.to(self._comm)
             self._fbuf = torch.zeros(self._f_max, 3, dtype=torch.float, device=self._comm)
             self._fall = torch.empty(self.world * self._f_max, 3, dtype=torch.float, device=self._comm)
+
+    def _gather_forces(self, local_f):
+        self._force_layout()
         if local_f is not None:
             self._fbuf[: self.n_local_atoms] = local_f.to(self._comm, torch.float)
         if _has_group(self.group):
