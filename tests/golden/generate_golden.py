@@ -16,6 +16,17 @@ Cases:
   alna   Al-fcc(4)+Na-bcc(2) batch of tests/conftest.py:89-115, perturbed as tests/test_model.py:90-95,
          small test model (l_max=2, n_max=3, 93 types, dim 17, 2 blocks)
   mix    two random-species cells batched, non-unit length/energy scales and elemental energies
+  cu32fit, mixfit   the cu32 cell and the mix batch on `model_fitted_lj`: the default model FITTED, with the reference's own nn code
+         (Gradient with create_graph=True, nn/gradient.py:30-34; Adam), to Lennard-Jones energies and forces of strongly jittered
+         Cu cells -- weights whose forces are O(0.1-1 eV/A) for physical reasons and whose activations are no longer near-linear
+  tri    the Ti8O24 cell sheared (strain_cell of the reference's utils.py:19-28, as tests/test_invariance.py:41-47), rotated
+         (rotate_cell without its re-wrapping), made left-handed (two lattice vectors swapped) and with a third of the atoms
+         moved OUT of the home cell by lattice vectors; default model; stresses included
+  cu32pair   the cu32 cell with a triplet list of ONE pair (nothing to average over: the single fp32 Bessel x Legendre x envelope
+         product of the reference, entry by entry)
+  nsb_small_r.npz   NormalizedSphericalBessel.forward of the reference in fp32 on r in [0, 0.6] A (cutoff 4.2, l_max 4, n_max 5,
+         documented factors): its upward recurrence (nn/interaction.py:293-318) is ill-conditioned there, and the stand-alone
+         kernel is compared with THESE numbers, not with an argument about them
 Each case is stored in two `factors` modes:
   ref    NormalizedSphericalBessel.factors exactly as the reference constructs them
   doc    factors overwritten by the documented normalisation 1/(sqrt(2/rc^3)/|j_{l+1}(z_ln)|)
@@ -106,6 +117,62 @@ def random_cell(n_atoms, box, seed, zmax=94, dmin=1.6):
         if ok:
             pos.append(p)
     return lat, np.array(pos), rng.integers(1, zmax + 1, n_atoms)
+
+
+def lennard_jones(lat, pos, cutoff=5.0, eps=0.167, sigma=2.3):
+    """Truncated 12-6 potential on the periodic neighbour list (fp64): (energy, forces [n,3]).  eps / sigma put the minimum at
+    2^(1/6) sigma = 2.58 A, the nearest-neighbour distance of fcc Cu at a = 3.61 A."""
+    ei, shift, dist = nb.neighbor_list(lat, pos, cutoff)
+    r = pos[ei[1]] + shift @ lat - pos[ei[0]]
+    sr6 = (sigma / dist) ** 6
+    energy = 0.5 * np.sum(4 * eps * (sr6 * sr6 - sr6))
+    dedr = 4 * eps * (-12 * sr6 * sr6 + 6 * sr6) / dist          # dE_pair/dr
+    f = np.zeros_like(pos)
+    np.add.at(f, ei[0], (dedr / dist)[:, None] * r)              # the half factor and the two ends of each pair cancel
+    return energy, f
+
+
+def triclinic_ti8o24():
+    """Sheared + rotated + left-handed cell with atoms outside the home cell (tests/test_invariance.py:41-50,
+    utils.py:8-28): everything the cubic fixtures never exercise in the geometry and virial code."""
+    lat, pos, z = ti8o24()
+    frac = pos @ np.linalg.inv(lat)
+    lat = lat @ (np.eye(3) + 0.1 * np.array([[0, 1, 0], [1, 0, 0], [0, 0, 1.0]]))     # strain_cell(..., delta=0.1)
+    rot = np.dot(np.array([[0.5, np.sqrt(3) / 2, 0], [-np.sqrt(3) / 2, 0.5, 0], [0, 0, 1]]),
+                 np.array([[0, 0, 1], [1 / np.sqrt(2), -1 / np.sqrt(2), 0], [1 / np.sqrt(2), 1 / np.sqrt(2), 0]]))  # tests/conftest.py:23-43
+    lat = lat @ rot.T
+    lat = lat[[1, 0, 2]]                                                                 # left-handed: det < 0
+    frac = frac[:, [1, 0, 2]]
+    rng = np.random.default_rng(7)
+    hop = rng.integers(-2, 3, frac.shape)
+    hop[rng.random(len(frac)) > 0.35] = 0                                                # about a third of the atoms leave the home cell
+    assert np.linalg.det(lat) < 0 and np.abs(hop).sum() > 0
+    return lat, (frac + hop) @ lat, z
+
+
+def fit_lennard_jones(model, steps=240, lr=2e-3, jitter=0.15):
+    """A few hundred Adam steps of the REFERENCE's own modules (Gradient with create_graph=True) on LJ energies and forces of
+    strongly jittered 32-atom Cu cells.  Deterministic: one thread, fixed seeds, fixed order."""
+    data = []
+    for seed in (11, 12, 13, 14):
+        lat, pos, z = fcc_cu(2, 2, 2, jitter=jitter, seed=seed)
+        e, f = lennard_jones(lat, pos)
+        gr = single_graph(lat, pos, z, 5.0, 4.0, use_reference_threebody=False)
+        data.append((gr, torch.tensor(e / len(pos), dtype=torch.float), torch.tensor(f, dtype=torch.float)))
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    for step in range(steps):
+        gr, e_ref, f_ref = data[step % len(data)]
+        g = collate([gr])
+        opt.zero_grad()
+        out = model(g)
+        loss = (out[K.TOTAL_ENERGY][0] / len(f_ref) - e_ref) ** 2 + ((out[K.FORCES] - f_ref) ** 2).mean()
+        loss.backward()
+        opt.step()
+        if step % 40 == 0 or step == steps - 1:
+            print(f"  fit step {step:4d}: loss {float(loss):.4e}  max|F_model| {float(out[K.FORCES].abs().max()):.3f}  max|F_LJ| {float(f_ref.abs().max()):.3f}")
+    for p in model.parameters():
+        p.requires_grad_(True)
+    return model
 
 
 # ------------------------------------------------------------------ graph assembly
@@ -214,7 +281,7 @@ def save_model(path, model, cfg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", type=Path, default=HERE, help="directory the .npz files are written to")
-    ap.add_argument("--cases", nargs="*", default=["cu32", "tio", "alna", "mix"], help="cases to (re)generate")
+    ap.add_argument("--cases", nargs="*", default=["cu32", "tio", "alna", "mix", "fit", "tri", "cu32pair", "nsb"], help="cases to (re)generate")
     args = ap.parse_args()
     out_dir, cases = args.out, set(args.cases)
     out_dir.mkdir(parents=True, exist_ok=True)
@@ -276,6 +343,51 @@ def main():
         if mode == "ref":
             save_model(out_dir / "model_mix_seed3.npz", m, cfg_mix)
         run_case("mix", m, graphs, mode, out)
+
+    # ---- round 3: fitted weights, triclinic cell, single-pair triplet list, small-argument Bessel basis
+    if "tri" in cases:
+        lat, pos, z = triclinic_ti8o24()
+        for mode in ("ref", "doc"):
+            run_case("tri", make(cfg_default, 0), [single_graph(lat, pos, z, 5.0, 4.0)], mode, out)
+    if "cu32pair" in cases:
+        lat, pos, z = fcc_cu(2, 2, 2)
+        gr = single_graph(lat, pos, z, 5.0, 4.0)
+        gr["tei"] = gr["tei"][:, :1].copy()
+        run_case("cu32pair", make(cfg_default, 0), [gr], "doc", out)
+    if "fit" in cases:
+        cfg_fit = dict(cfg_default)
+        elemental_fit = torch.zeros(95)
+        elemental_fit[28] = -1.2          # Cu: most of the LJ cohesive energy sits in the reference energy, the network fits the rest
+        m = make(cfg_fit, 0, elemental_fit)
+        for tbm in (mm for mm in m.model if type(mm).__name__ == "ThreeBodyInteration"):   # fitted with the three-body path visible
+            tbm.nsb.factors = documented_factors(tbm.nsb.cutoff, tbm.nsb.l_max, tbm.nsb.n_max)
+        fit_lennard_jones(m)
+        save_model(out_dir / "model_fitted_lj.npz", m, cfg_fit)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        mix_graphs = []
+        for seed, n_at in ((0, 24), (1, 17)):
+            lat, pos, z = random_cell(n_at, 7.3 if seed == 0 else 6.1, seed)
+            mix_graphs.append(single_graph(lat, pos, z, 5.0, 4.0))
+        lat, pos, z = fcc_cu(2, 2, 2, jitter=0.12, seed=21)
+        for mode in ("ref", "doc"):
+            for name, graphs_ in (("cu32fit", [single_graph(lat, pos, z, 5.0, 4.0)]), ("mixfit", mix_graphs)):
+                mm = make(cfg_fit, 0, elemental_fit)
+                mm.load_state_dict(sd)
+                run_case(name, mm, graphs_, mode, out)
+    if "nsb" in cases:
+        from torch_m3gnet.nn.interaction import NormalizedSphericalBessel   # REFERENCE module
+
+        nsb = NormalizedSphericalBessel(cutoff=4.2, l_max=4, n_max=5)
+        nsb.factors = documented_factors(4.2, 4, 5)
+        rs = torch.cat([torch.linspace(0.0, 0.6, 49), torch.linspace(0.0, 4.2, 57)])
+        chi = nsb(rs)                                                       # [4, 5, len(rs)] fp32, the reference's arithmetic
+        z = torch.tensor(SPHERICAL_BESSEL_ZEROS, dtype=torch.float64)[:4, :5]
+        chi64 = torch.stack([spherical_bessel(z[l][:, None] * rs.double()[None, :] / 4.2, l) / nsb.factors[l].double()[:, None] for l in range(4)])
+        np.savez_compressed(out_dir / "nsb_small_r.npz", rs=rs.numpy(), chi_fp32=chi.detach().numpy(), chi_fp64=chi64.numpy(),
+                            factors=nsb.factors.numpy(), cutoff=np.asarray(4.2), l_max=np.asarray(4), n_max=np.asarray(5))
+        err = (chi.double() - chi64).abs()
+        print(f"nsb_small_r: reference fp32 vs fp64, r < 0.6: max abs err per l = {[float(err[l][:, :49].max()) for l in range(4)]}, "
+              f"scale per l = {[float(chi64[l].abs().max()) for l in range(4)]}")
 
     for name, d in out.items():
         np.savez_compressed(out_dir / f"case_{name}.npz", **d)

@@ -388,6 +388,17 @@ def test_config3_10k_atom_cu_supercell_vs_oracle():
     out2 = model(shifted)
     assert rel_err(out2[K.TOTAL_ENERGY], out[K.TOTAL_ENERGY]) < 1e-5
     assert rel_err(out2[K.FORCES], out[K.FORCES]) < 1e-3
+    # the opt-in bf16x3 mode at full size, against the same oracle run (its own gates: random-init weights keep every MLP
+    # near-linear, where the mode meets north_star's tolerances -- tests/test_gpu_parity.py has the saturated case)
+    model.engine.set_precision("bf16x3")
+    try:
+        out3 = model(g)
+        assert rel_err(out3[K.SCALED_ATOMIC_ENERGIES], o["scaled_atomic_energies"]) < 1e-5
+        assert abs(float(out3[K.TOTAL_ENERGY][0]) - e_exact) < 1e-5 * abs(e_exact)
+        assert rel_err(out3[K.FORCES], o["forces"]) < 1e-4
+        assert rel_err(out3[K.MID_EDGE_FEATURES][0], o["mid_edge_features_0"]) < 1e-4
+    finally:
+        model.engine.set_precision("fp32")
 
 
 def test_config2_batched_random_species_cells():

@@ -106,3 +106,32 @@ def test_normalized_spherical_bessel_forward():
         err = (out[l].double() - ref).abs()
         assert float(err[:, well].max()) < 3e-6 * float(ref.abs().max())
         assert float(err.max()) < 1e-3 * float(ref.abs().max())
+
+
+def test_normalized_spherical_bessel_small_arguments_against_the_reference():
+    """r in [0, 0.6] A, where the reference's fp32 upward recurrence (nn/interaction.py:293-318) is ill-conditioned: the
+    stand-alone kernel against the reference's OWN fp32 output (fixture nsb_small_r.npz, generated by its forward code) and both
+    against fp64.  The kernel must be at least as close to the exact value as the reference is (per l, with 3e-6 of the basis
+    scale of slack), and where the reference is accurate (l <= 1: 3e-6) it must agree with the reference itself."""
+    import numpy as np
+    from helpers import GOLDEN
+    from torch_m3gnet.nn.interaction import NormalizedSphericalBessel
+
+    z = np.load(GOLDEN / "nsb_small_r.npz")
+    nsb = NormalizedSphericalBessel(cutoff=float(z["cutoff"]), l_max=int(z["l_max"]), n_max=int(z["n_max"]))
+    nsb.factors = torch.tensor(z["factors"])
+    rs = torch.tensor(z["rs"])
+    out = nsb(rs.to(DEV)).cpu().double()
+    ref32, ref64 = torch.tensor(z["chi_fp32"]).double(), torch.tensor(z["chi_fp64"])
+    small = rs <= 0.6
+    for l in range(int(z["l_max"])):
+        scale = float(ref64[l].abs().max())
+        mine = float((out[l] - ref64[l]).abs()[:, small].max())
+        theirs = float((ref32[l] - ref64[l]).abs()[:, small].max())
+        print(f"l = {l}: kernel vs fp64 {mine / scale:.2e}, reference fp32 vs fp64 {theirs / scale:.2e}, kernel vs reference fp32 "
+              f"{float((out[l] - ref32[l]).abs()[:, small].max()) / scale:.2e}  (of the basis scale {scale:.3f})")
+        assert mine <= theirs + 3e-6 * scale, (l, mine, theirs)
+        if theirs < 3e-6 * scale:
+            assert float((out[l] - ref32[l]).abs()[:, small].max()) < 6e-6 * scale
+        # beyond the ill-conditioned region the kernel agrees with the reference's fp32 numbers to 3e-6
+        assert float((out[l] - ref32[l]).abs()[:, rs >= 0.6].max()) < 3e-6 * scale
