@@ -53,6 +53,28 @@ def engine_graph(graph: dict, device="cuda"):
     return g
 
 
+def preactivation_stats(params, cfg, consts, graph):
+    """Pre-activation statistics of every 64-wide Linear of the gated MLPs, in call order, from one oracle evaluation (checker):
+    per layer (in_features, mean |p|, share of |p| > 2, share of |p| > 4, max |p|).  Per conv block the order is edge MLP
+    {dense.0, gate.0, dense.2, gate.2}, node MLP likewise; the readout's layers come last."""
+    stats = []
+    orig = torch.nn.functional.linear
+
+    def spy(x, w, b=None):
+        y = orig(x, w, b)
+        if w.shape[0] == cfg.embedding_dim and w.shape[1] in (cfg.embedding_dim, 3 * cfg.embedding_dim):
+            a = y.detach().abs().double()
+            stats.append((int(w.shape[1]), float(a.mean()), float((a > 2).double().mean()), float((a > 4).double().mean()), float(a.max())))
+        return y
+
+    torch.nn.functional.linear = spy
+    try:
+        orc.energy_forces(params, cfg, consts, graph, want_forces=False)
+    finally:
+        torch.nn.functional.linear = orig
+    return stats
+
+
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max|a-b| / max|b| (the metric SURVEY.md §8(d) prescribes for forces)."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()

@@ -64,19 +64,32 @@ def test_engine_vs_golden_and_oracle(case, mode, precision):
             key = f"mid_mid_edge_features_{b}"
             if key in expect:
                 assert rel_err(g[K.MID_EDGE_FEATURES][b], expect[key]) < M_TOL, (b, "mid_edge_features")
-    f_tol_golden = F_TOL if mode == "ref" else 5e-4
-    assert rel_err(g[K.FORCES], expect["out_forces"]) < f_tol_golden
-    assert rel_err(g[K.STRESSES], expect["out_stresses"]) < 5e-4
-
-    # ---- against the oracle's exact derivative (fp64 restatement of the same math)
+    # ---- the oracle's exact derivative (fp64 restatement of the same math)
     p64, cfg64, c64, graph64, _ = load_oracle_case(case, mode, dtype=torch.float64)
     o = orc.energy_forces(p64, cfg64, c64, graph64, legendre_backward="exact")
+    # forces / stresses against the reference's numbers.  `ref` mode: directly, at north_star's tolerance.  `doc` mode (three-body
+    # path visible): the reference's own autograd forces are OFF the true gradient by its Legendre-backward defect (SURVEY
+    # finding 2; 1.1e-4 on mix_doc, 1.9e-3 on mixfit_doc whose fitted weights give the three-body path real weight) -- the engine
+    # computes the exact derivative, so the gate is that measured defect plus the tolerance (and never more than 5e-3)
+    defect_f = rel_err(expect["out_forces"], o["forces"]) if mode == "doc" else 0.0
+    defect_s = rel_err(expect["out_stresses"], o["stresses"]) if mode == "doc" else 0.0
+    assert defect_f < 5e-3 and defect_s < 5e-3
+    assert rel_err(g[K.FORCES], expect["out_forces"]) < F_TOL + defect_f
+    assert rel_err(g[K.STRESSES], expect["out_stresses"]) < 5e-4 + defect_s
+
+    # ---- against the oracle's exact derivative
     assert rel_err(g[K.FORCES], o["forces"]) < F_TOL
     assert float(((g[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < E_TOL
     assert rel_err(g[K.STRESSES], o["stresses"]) < F_TOL
     if case != "alna":
         for b in range(cfg.num_blocks):
             assert rel_err(g[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) < M_TOL
+    import os
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/parity_margins.txt", "a") as fh:
+            fh.write(f"    vs fp64 oracle (exact derivative): F {rel_err(g[K.FORCES], o['forces']):.2e}  stress {rel_err(g[K.STRESSES], o['stresses']):.2e}  "
+                     f"E {float(((g[K.TOTAL_ENERGY].cpu().double() - o['total_energy']).abs() / o['total_energy'].abs()).max()):.2e}"
+                     f"   [reference's own forces vs the exact derivative: {defect_f:.2e}]\n")
 
 
 def test_energy_only_call_matches():
@@ -284,20 +297,21 @@ def test_saturated_activations_stress_case(case, precision):
     cfg.energy_scale = 10.0
     p64 = {f"model.{k}": v.detach().cpu().double() for k, v in model.model.state_dict().items()}
     o = orc.energy_forces(p64, cfg, consts, graph, legendre_backward="exact")
-    # saturation really happens: a sizeable share of the hidden pre-activations of the first edge MLP lies beyond |p| > 4
-    # (random-init weights: none do), i.e. SiLU and sigmoid work in their flat parts
-    src, dst = graph["edge_index"]
-    cat = torch.cat([o["x0"][src], o["x0"][dst], o["edge_attr_tb0"]], dim=1)
-    shares = []
-    for branch in ("dense", "gate"):
-        pre = cat @ p64[f"model.7.concat_edge_update.{branch}.0.weight"].T + p64[f"model.7.concat_edge_update.{branch}.0.bias"]
-        shares.append(float((pre.abs() > 4).double().mean()))
-    assert min(shares) > 0.02, shares
+    # what "trained-like" means here, measured and asserted (random-init: every |p| < 0.2): in the LAST block the second-layer
+    # pre-activations have mean |p| ~ 1 or more, more than a tenth of them lie beyond |p| > 2 and the largest beyond 3.5 -- SiLU and
+    # sigmoid work well outside their linear part.  (The LJ-fitted fixture cu32fit goes further for physical reasons: 45 % of
+    # the first edge MLP's layer-2 pre-activations beyond 2, 10 % beyond 4 -- tests/test_oracle_golden.py.)
+    from helpers import preactivation_stats
+
+    stats = preactivation_stats(p64, cfg, consts, graph)
+    last_block_l2 = [st for st in stats if st[0] == cfg.embedding_dim][-8:-4]   # the 4 layer-2 Linears of the last conv block
+    shares = [st[2] for st in last_block_l2]
+    assert min(st[1] for st in last_block_l2) > 0.9 and min(shares) > 0.1 and max(st[4] for st in last_block_l2) > 3.5, last_block_l2
     e_err = float(((g[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max())
     f_err = rel_err(g[K.FORCES], o["forces"])
     s_err = rel_err(g[K.STRESSES], o["stresses"])
     line = (f"stress case {case} {precision}: E rel err {e_err:.2e}, F err {f_err:.2e} of max|F| = {float(o['forces'].abs().max()):.3e}, "
-            f"stress err {s_err:.2e}; share of first-layer pre-activations beyond |p| > 4: dense {shares[0]:.2f}, gate {shares[1]:.2f}")
+            f"stress err {s_err:.2e}; last block, layer-2 pre-activations beyond |p| > 2: {min(shares):.2f}-{max(shares):.2f}")
     print(line)
     import os
     if os.path.isdir("gpurun_out"):
@@ -325,7 +339,9 @@ def test_single_pair_triplet_list_against_the_reference_entry_by_entry():
         mid = g[K.MID_EDGE_FEATURES][0].cpu()
         ref = expect["mid_mid_edge_features_0"]
         e1 = int(graph["triplet_edge_index"][0, 0])
-        assert float(ref[e1].abs().max()) > 0 and float(ref.abs().sum() - ref[e1].abs().sum()) == 0.0   # one live row
+        others = torch.ones(ref.size(0), dtype=torch.bool)
+        others[e1] = False
+        assert float(ref[e1].abs().max()) > 0 and float(ref[others].abs().max()) == 0.0   # one live row
         scale = float(ref.abs().max())
         worst = float((mid - ref).abs().max()) / scale
         p64, cfg64, c64, graph64, _ = load_oracle_case("cu32pair", "doc", dtype=torch.float64)

@@ -111,8 +111,10 @@ def test_normalized_spherical_bessel_forward():
 def test_normalized_spherical_bessel_small_arguments_against_the_reference():
     """r in [0, 0.6] A, where the reference's fp32 upward recurrence (nn/interaction.py:293-318) is ill-conditioned: the
     stand-alone kernel against the reference's OWN fp32 output (fixture nsb_small_r.npz, generated by its forward code) and both
-    against fp64.  The kernel must be at least as close to the exact value as the reference is (per l, with 3e-6 of the basis
-    scale of slack), and where the reference is accurate (l <= 1: 3e-6) it must agree with the reference itself."""
+    against fp64.  The kernel must be as close to the exact value as the reference is (per l: the reference's own error + 1 % of
+    it + 3e-6 of the basis scale -- for l = 3 both are 12 % of the scale away from fp64 and 0.8 % from each other: the recurrence
+    amplifies the rounding of sin / cos at x ~ 0.1, whichever libm evaluates them), and where the reference is accurate
+    (l <= 1: 3e-6) it must agree with the reference itself."""
     import numpy as np
     from helpers import GOLDEN
     from torch_m3gnet.nn.interaction import NormalizedSphericalBessel
@@ -130,7 +132,7 @@ def test_normalized_spherical_bessel_small_arguments_against_the_reference():
         theirs = float((ref32[l] - ref64[l]).abs()[:, small].max())
         print(f"l = {l}: kernel vs fp64 {mine / scale:.2e}, reference fp32 vs fp64 {theirs / scale:.2e}, kernel vs reference fp32 "
               f"{float((out[l] - ref32[l]).abs()[:, small].max()) / scale:.2e}  (of the basis scale {scale:.3f})")
-        assert mine <= theirs + 3e-6 * scale, (l, mine, theirs)
+        assert mine <= 1.01 * theirs + 3e-6 * scale, (l, mine, theirs)
         if theirs < 3e-6 * scale:
             assert float((out[l] - ref32[l]).abs()[:, small].max()) < 6e-6 * scale
         # beyond the ill-conditioned region the kernel agrees with the reference's fp32 numbers to 3e-6

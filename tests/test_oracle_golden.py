@@ -4,7 +4,7 @@ restatement (oracle/staged.py, the kernels' blueprint) is pinned against the ora
 import pytest
 import torch
 
-from helpers import CASES, GOLDEN, load_oracle_case, rel_err
+from helpers import CASES, GOLDEN, load_oracle_case, preactivation_stats, rel_err
 from oracle import m3gnet_oracle as orc, staged
 
 STAGE_KEYS = [
@@ -97,3 +97,17 @@ def test_forces_match_finite_differences_fp64():
             e.append(orc.energy_forces(params, cfg, consts, g2, want_forces=False)["total_energy"].sum())
         fd = -(e[0] - e[1]) / (2 * delta)
         assert abs(float(fd - o["forces"][atom, axis])) < 1e-7 * max(1.0, float(o["forces"].abs().max()))
+
+
+def test_fitted_weights_work_outside_the_linear_part_of_their_activations():
+    """Why the LJ-fitted fixture matters for parity: random-init weights keep every pre-activation below 0.2 (every MLP is
+    near-linear, product errors average away); the fitted weights put 40 % of the first edge MLP's layer-2 pre-activations
+    beyond |p| > 2 and 8 % beyond 4, with forces of ~2 eV/A."""
+    params, cfg, consts, graph, expect = load_oracle_case("cu32fit", "doc")
+    stats = preactivation_stats(params, cfg, consts, graph)
+    d2, g2 = stats[2], stats[3]          # block 0, edge MLP, layer 2 (dense, gate)
+    assert d2[0] == g2[0] == cfg.embedding_dim
+    assert min(d2[2], g2[2]) > 0.35 and min(d2[3], g2[3]) > 0.05 and min(d2[1], g2[1]) > 1.5, (d2, g2)
+    assert 1.0 < float(expect["out_forces"].abs().max()) < 5.0
+    params, cfg, consts, graph, _ = load_oracle_case("cu32", "doc")
+    assert max(st[4] for st in preactivation_stats(params, cfg, consts, graph)) < 0.3
