@@ -31,23 +31,72 @@ inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
   const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; \
   if (gid >= (n_total)) return;
 
-// ---- small dense products -------------------------------------------------------------------------------------------
-// C[n, j] = (beta ? C[n, j] : 0) + (bias ? bias[j] : 0) + sum_k A[n*lda + k] * B[k*sbk + j*sbj]
+// ---- dense products ---------------------------------------------------------------------------------------------------
+// C[n, j] = (beta ? C[n, j] : 0) + (bias ? bias[j] : 0) + sum_k A[n*lda + k] * B[k*sbk + j*sbj]     (any strides of B: W or W^T)
+// 64 x 64 output tile per workgroup, K walked in slabs of 16 staged in LDS, 4 x 4 outputs per thread.  Every output is still
+// the k-ordered fp32 sum bias + a_0 b_0 + a_1 b_1 + ... of round 2's one-thread-per-output kernel (bit-identical results), but
+// an A row is read once per 64 columns instead of once per column and B is read coalesced whichever way it is strided:
+// 183 -> see DESIGN.md section 4c ms/step for the default model at the 10k-atom cell.
+constexpr int kGemmTile = 64, kGemmK = 16;
 __global__ void __launch_bounds__(256) g_gemm(int64_t n, int cols, int K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                               int sbk, int sbj, const float* __restrict__ bias, float* __restrict__ Cm, int64_t ldc, int beta) {
-  GEN_IDX(n * cols);
-  const int64_t r = gid / cols;
-  const int j = (int)(gid % cols);
-  const float* a = A + r * lda;
-  const float* b = B + (int64_t)j * sbj;
-  float acc = bias ? bias[j] : 0.f;
-  for (int k = 0; k < K; ++k) acc += a[k] * b[(int64_t)k * sbk];
-  float* c = Cm + r * ldc + j;
-  *c = beta ? *c + acc : acc;
+  __shared__ float sa[kGemmK][kGemmTile + 1], sb[kGemmK][kGemmTile + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kGemmTile;
+  const int col0 = blockIdx.y * kGemmTile;
+  float acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = col0 + tx * 4 + j;
+    const float b0 = (bias && c < cols) ? bias[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][j] = b0;
+  }
+  for (int k0 = 0; k0 < K; k0 += kGemmK) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {   // A slab: 64 rows x 16 k, k fastest (rows of A are contiguous in k)
+      const int idx = tid + it * 256, r = idx >> 4, kk = idx & 15;
+      const int64_t row = row0 + r;
+      sa[kk][r] = (row < n && k0 + kk < K) ? A[row * lda + k0 + kk] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {   // B slab: 16 k x 64 columns, the contiguous index fastest
+      const int idx = tid + it * 256;
+      const int kk = sbj == 1 ? idx >> 6 : idx & 15, cc = sbj == 1 ? idx & 63 : idx >> 4;
+      const int c = col0 + cc;
+      sb[kk][cc] = (c < cols && k0 + kk < K) ? B[(int64_t)(k0 + kk) * sbk + (int64_t)c * sbj] : 0.f;
+    }
+    __syncthreads();
+    const int kn = K - k0 < kGemmK ? K - k0 : kGemmK;
+    for (int kk = 0; kk < kn; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = sa[kk][ty * 4 + i]; b[i] = sb[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = row0 + ty * 4 + i;
+    if (row >= n) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = col0 + tx * 4 + j;
+      if (c >= cols) continue;
+      float* out = Cm + row * ldc + c;
+      *out = beta ? *out + acc[i][j] : acc[i][j];
+    }
+  }
 }
 static void gemm(hipStream_t s, int64_t n, int cols, int K, const float* A, int64_t lda, const float* B, int sbk, int sbj, const float* bias,
                  float* C, int64_t ldc, bool beta = false) {
-  if (n > 0 && cols > 0) hipLaunchKernelGGL(g_gemm, grid1(n * cols), dim3(256), 0, s, n, cols, K, A, lda, B, sbk, sbj, bias, C, ldc, beta ? 1 : 0);
+  if (n > 0 && cols > 0)
+    hipLaunchKernelGGL(g_gemm, dim3((unsigned)((n + kGemmTile - 1) / kGemmTile), (unsigned)((cols + kGemmTile - 1) / kGemmTile)), dim3(256), 0, s, n,
+                       cols, K, A, lda, B, sbk, sbj, bias, C, ldc, beta ? 1 : 0);
 }
 // y[n, j] = x[idx[n], j]  (row gather), optionally y += ...
 __global__ void __launch_bounds__(256) g_gather(int64_t n, int w, const int32_t* __restrict__ idx, const float* __restrict__ X, int64_t ldx,

@@ -196,61 +196,25 @@ __global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_
   }
 }
 
-// Adds one 6-vector per atom into stresses[structure]: summed inside the wave, then across the workgroup's four waves in LDS,
-// so a workgroup whose atoms share one structure issues 6 float atomics instead of 24 (10k atoms of one structure: every
-// atomic of the launch hits the same cache line and they serialise -- 14 us with one set per wave).  Waves or workgroups
-// spanning several structures fall back to finer-grained atomics.  Must be reached by all 256 threads.
-__device__ __forceinline__ void stress_accumulate(const float (&val)[6], int s, bool live, float* __restrict__ stresses) {
-  __shared__ float part[4][6];
-  __shared__ int part_s[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s0 = __shfl(s, 0);
-  const bool uniform = __all(s == s0 || !live) && s0 >= 0;
-  float red[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    float v = val[k];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    red[k] = v;
-  }
-  if (lane == 0) {
-    part_s[wave] = uniform ? s0 : -2;   // -2: this wave handles its own atomics
-#pragma unroll
-    for (int k = 0; k < 6; ++k) part[wave][k] = red[k];
-  }
-  __syncthreads();
-  // wave w joins the group led by wave 0 when both are uniform in the same structure; others add on their own
-  const int lead = part_s[0];
-  const bool joined = uniform && lead == s0;
-  if (wave == 0 && uniform) {
-    if (lane < 6) {
-      float v = part[0][lane];
-      for (int w = 1; w < 4; ++w) v += part_s[w] == lead ? part[w][lane] : 0.f;
-      atomicAdd(&stresses[(int64_t)s0 * 6 + lane], v);
-    }
-  } else if (uniform && !joined) {
-    if (lane < 6) atomicAdd(&stresses[(int64_t)s0 * 6 + lane], part[wave][lane]);
-  } else if (!uniform && live) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) atomicAdd(&stresses[(int64_t)s * 6 + k], val[k]);
-  }
-}
-
 // Per-structure sums without atomics: the atoms of a structure are contiguous when `batch` is sorted (as the reference's
 // batching produces it), so one workgroup per structure adds its atoms in a fixed order -- strided private sums, then a
-// fixed LDS tree: energies and stresses are then bit-reproducible like the forces.  An unsorted `batch` (flags[3] != 0)
-// takes the float-atomic kernels instead; both kinds are launched and the wrong one returns at once.
+// fixed LDS tree: energies and stresses are then bit-reproducible like the forces.  An unsorted `batch` (flags[3] != 0, which
+// the reference's scatter_sum accepts) has no contiguous range: the structure's workgroup then walks ALL atoms and keeps its
+// own -- O(N S) index tests on a path nobody benchmarks, in exchange for the same fixed order, no float atomics anywhere and
+// no second set of kernels that is launched only to return (round 2 launched both kinds every step).
 constexpr int kStructThreads = 1024;   // one large cell is ONE workgroup: 1,024 threads keep its strided loop at ~10 trips for 10k atoms
 template <int W, class F>
-__device__ __forceinline__ void struct_reduce(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags, float* __restrict__ out,
-                                              F per_atom) {
+__device__ __forceinline__ void struct_reduce(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags, int64_t n_atoms,
+                                              const int32_t* __restrict__ batch, float (&total)[W], F per_atom) {
   __shared__ float part[kStructThreads][W];
-  if (flags[3] != 0) return;
   const int s = blockIdx.x;
   float acc[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) acc[k] = 0.f;
-  for (int a = struct_ptr[s] + (int)threadIdx.x; a < struct_ptr[s + 1]; a += kStructThreads) {
+  const bool sorted = flags[3] == 0;   // uniform
+  const int a0 = sorted ? struct_ptr[s] : 0, a1 = sorted ? struct_ptr[s + 1] : (int)n_atoms;
+  for (int a = a0 + (int)threadIdx.x; a < a1; a += kStructThreads) {
+    if (!sorted && batch[a] != s) continue;
     float v[W];
     per_atom(a, s, v);
 #pragma unroll
@@ -265,28 +229,34 @@ __device__ __forceinline__ void struct_reduce(const int32_t* __restrict__ struct
       for (int k = 0; k < W; ++k) part[threadIdx.x][k] += part[threadIdx.x + off][k];
     __syncthreads();
   }
-  if (threadIdx.x < W) out[(int64_t)s * W + threadIdx.x] = part[0][threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < W; ++k) total[k] = part[0][k];   // every thread holds the sums
 }
 __device__ __forceinline__ float inv_volume(const float* __restrict__ L) {
   const float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
   return 1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
 }
 __global__ void __launch_bounds__(kStructThreads) k_struct_stress(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
+                                                       int64_t n_atoms, const int32_t* __restrict__ batch,
                                                        const float* __restrict__ pos, const float* __restrict__ lattice,
                                                        const float* __restrict__ forces, float* __restrict__ stresses) {
-  struct_reduce<6>(struct_ptr, flags, stresses, [&](int a, int s, float* v) {
+  float tot[6];
+  struct_reduce<6>(struct_ptr, flags, n_atoms, batch, tot, [&](int a, int s, float* v) {
     const float inv = inv_volume(lattice + (int64_t)s * 9);
     const float px = pos[a * 3], py = pos[a * 3 + 1], pz = pos[a * 3 + 2];
     const float fx = forces[a * 3], fy = forces[a * 3 + 1], fz = forces[a * 3 + 2];
     v[0] = px * fx * inv; v[1] = py * fy * inv; v[2] = pz * fz * inv;
     v[3] = py * fz * inv; v[4] = pz * fx * inv; v[5] = px * fy * inv;
   });
+  if (threadIdx.x < 6) stresses[(int64_t)blockIdx.x * 6 + threadIdx.x] = tot[threadIdx.x];
 }
 __global__ void __launch_bounds__(kStructThreads) k_struct_stress_pair(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
+                                                            int64_t n_atoms, const int32_t* __restrict__ batch,
                                                             const int32_t* __restrict__ row_ptr, const float* __restrict__ lattice,
                                                             const float* __restrict__ u, const float* __restrict__ dist,
                                                             const float* __restrict__ dr, float* __restrict__ stresses) {
-  struct_reduce<6>(struct_ptr, flags, stresses, [&](int a, int s, float* v) {
+  float tot[6];
+  struct_reduce<6>(struct_ptr, flags, n_atoms, batch, tot, [&](int a, int s, float* v) {
     const float inv = -inv_volume(lattice + (int64_t)s * 9);
 #pragma unroll
     for (int k = 0; k < 6; ++k) v[k] = 0.f;
@@ -300,67 +270,31 @@ __global__ void __launch_bounds__(kStructThreads) k_struct_stress_pair(const int
 #pragma unroll
     for (int k = 0; k < 6; ++k) v[k] *= inv;
   });
+  if (threadIdx.x < 6) stresses[(int64_t)blockIdx.x * 6 + threadIdx.x] = tot[threadIdx.x];
 }
-// scaled_total[s] = sum of the structure's scaled atomic energies (nn/readout.py:49-53), total = energy_scale * that
+// scaled_total[s] = sum of the structure's scaled atomic energies (nn/readout.py:49-53), total[s] = energy_scale * that (:55-57)
 __global__ void __launch_bounds__(kStructThreads) k_struct_energy(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
-                                                       const float* __restrict__ ea, float* __restrict__ scaled_total) {
-  struct_reduce<1>(struct_ptr, flags, scaled_total, [&](int a, int, float* v) { v[0] = ea[a]; });
-}
-void launch_struct_energy(const Topo& t, const float* ea, float* scaled_total, hipStream_t s) {
-  if (t.S > 0) hipLaunchKernelGGL(k_struct_energy, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, ea, scaled_total);
-}
-
-// virial: sum_a pos_a (x) F_a / V in Voigt order xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62)  [float-atomic fallback: unsorted batch]
-__global__ void __launch_bounds__(256) k_stress(int64_t N, const int32_t* __restrict__ batch, const float* __restrict__ pos,
-                                                const float* __restrict__ lattice, const float* __restrict__ forces,
-                                                float* __restrict__ stresses, const int32_t* __restrict__ flags) {
-  if (flags[3] == 0) return;   // sorted batch: k_struct_stress does the sums
-  int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  bool live = a < N;
-  int s = live ? batch[a] : -1;
-  float val[6] = {0, 0, 0, 0, 0, 0};
-  if (live) {
-    const float* L = lattice + (int64_t)s * 9;
-    float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
-    float inv = 1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
-    float px = pos[a * 3], py = pos[a * 3 + 1], pz = pos[a * 3 + 2];
-    float fx = forces[a * 3], fy = forces[a * 3 + 1], fz = forces[a * 3 + 2];
-    val[0] = px * fx * inv; val[1] = py * fy * inv; val[2] = pz * fz * inv;
-    val[3] = py * fz * inv; val[4] = pz * fx * inv; val[5] = px * fy * inv;
+                                                       int64_t n_atoms, const int32_t* __restrict__ batch, const float* __restrict__ ea,
+                                                       float energy_scale, float* __restrict__ scaled_total, float* __restrict__ total) {
+  float tot[1];
+  struct_reduce<1>(struct_ptr, flags, n_atoms, batch, tot, [&](int a, int, float* v) { v[0] = ea[a]; });
+  if (threadIdx.x == 0) {
+    scaled_total[blockIdx.x] = tot[0];
+    total[blockIdx.x] = energy_scale * tot[0];
   }
-  stress_accumulate(val, s, live, stresses);
+}
+void launch_struct_energy(const Consts& c, const Topo& t, const float* ea, float* scaled_total, float* total, hipStream_t s) {
+  if (t.S > 0)
+    hipLaunchKernelGGL(k_struct_energy, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, t.N, t.batch, ea, c.energy_scale,
+                       scaled_total, total);
 }
 
+// virial: sum_a pos_a (x) F_a / V in Voigt order xx,yy,zz,yz,zx,xy (nn/gradient.py:39-62): k_struct_stress above.
 // PBC-consistent virial (docs/gradient.md:47-84): with every pair vector r_e = d_e u_e
 // straining as r -> (1 + eps) r, dE/d eps = sum_e r_e (x) dE/dr_e over the directed edges, so
 //   sigma = -(1/V) sum_e r_e (x) dE/dr_e      (same sign convention as the reference's sum_a pos_a (x) F_a / V, to
-// which it reduces when no edge crosses a cell boundary).  One thread per atom sums its own CSR row; the tensor is
-// symmetric up to rounding and stored symmetrised.  d and dr are both in scaled length, so the scale cancels.
-__global__ void __launch_bounds__(256) k_stress_pair(int64_t N, const int32_t* __restrict__ batch, const int32_t* __restrict__ row_ptr,
-                                                     const float* __restrict__ lattice, const float* __restrict__ u,
-                                                     const float* __restrict__ dist, const float* __restrict__ dr,
-                                                     float* __restrict__ stresses, const int32_t* __restrict__ flags) {
-  if (flags[3] == 0) return;   // sorted batch: k_struct_stress_pair does the sums
-  int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  bool live = a < N;
-  int s = live ? batch[a] : -1;
-  float val[6] = {0, 0, 0, 0, 0, 0};
-  if (live) {
-    const float* L = lattice + (int64_t)s * 9;
-    float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
-    float inv = -1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
-    for (int e = row_ptr[a]; e < row_ptr[a + 1]; ++e) {
-      const float d = dist[e];
-      const float rx = d * u[e * 3], ry = d * u[e * 3 + 1], rz = d * u[e * 3 + 2];
-      const float gx = dr[e * 3], gy = dr[e * 3 + 1], gz = dr[e * 3 + 2];
-      val[0] += rx * gx; val[1] += ry * gy; val[2] += rz * gz;
-      val[3] += 0.5f * (ry * gz + rz * gy); val[4] += 0.5f * (rz * gx + rx * gz); val[5] += 0.5f * (rx * gy + ry * gx);
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) val[k] *= inv;
-  }
-  stress_accumulate(val, s, live, stresses);
-}
+// which it reduces when no edge crosses a cell boundary): k_struct_stress_pair above, each atom summing its own CSR row; the
+// tensor is symmetric up to rounding and stored symmetrised.  d and dr are both in scaled length, so the scale cancels.
 
 __global__ void __launch_bounds__(256) k_triplet_angles(int64_t T, const int64_t* __restrict__ tei, const float* __restrict__ u,
                                                         float* __restrict__ out) {
@@ -429,16 +363,16 @@ void launch_force_gather(float length_scale, const Topo& t, const float* dr, flo
 
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s) {
-  (void)c;   // stresses were cleared by launch_geometry_reverse
-  if (t.N > 0) hipLaunchKernelGGL(k_stress, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, pos, lattice, forces, stresses, t.flags);
-  if (t.S > 0) hipLaunchKernelGGL(k_struct_stress, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, pos, lattice, forces, stresses);
+  (void)c;
+  if (t.S > 0)
+    hipLaunchKernelGGL(k_struct_stress, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, t.N, t.batch, pos, lattice, forces,
+                       stresses);
 }
 
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s) {
-  if (t.N > 0)   // stresses were cleared by launch_geometry_reverse
-    hipLaunchKernelGGL(k_stress_pair, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, t.row_ptr, lattice, w.u, w.d, w.dr, stresses, t.flags);
   if (t.S > 0)
-    hipLaunchKernelGGL(k_struct_stress_pair, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, t.row_ptr, lattice, w.u, w.d, w.dr, stresses);
+    hipLaunchKernelGGL(k_struct_stress_pair, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, t.N, t.batch, t.row_ptr, lattice,
+                       w.u, w.d, w.dr, stresses);
 }
 
 void launch_triplet_angles(const Topo& t, const int64_t* tei, const float* u, float* out, hipStream_t s) {

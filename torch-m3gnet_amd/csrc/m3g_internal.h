@@ -364,7 +364,7 @@ void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, cons
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s);
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s);
-void launch_struct_energy(const Topo& t, const float* ea, float* scaled_total, hipStream_t s);
+void launch_struct_energy(const Consts& c, const Topo& t, const float* ea, float* scaled_total, float* total, hipStream_t s);
 void launch_force_gather(float length_scale, const Topo& t, const float* dr, float* forces, float* stresses, hipStream_t s);
 // generic.hip: any-size path (embedding_dim, l_max, n_max beyond the MFMA kernels' tiles)
 size_t generic_workspace_bytes(const m3g_plan* plan, int64_t N, int64_t E, int64_t T, int64_t S);

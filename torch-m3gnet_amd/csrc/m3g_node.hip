@@ -419,27 +419,6 @@ __global__ void __launch_bounds__(256) k_readout(Consts c, int64_t N, const floa
 }
 
 // per-structure energy sum: wave-level pre-reduction when the wave's atoms share a structure
-__global__ void __launch_bounds__(256) k_energy_sum(int64_t N, const int32_t* __restrict__ batch, const float* __restrict__ ea,
-                                                    float* __restrict__ scaled_total, const int32_t* __restrict__ flags) {
-  if (flags[3] == 0) return;   // sorted batch: k_struct_energy (m3g_geometry.hip) sums without atomics
-  int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  bool live = a < N;
-  int s = live ? batch[a] : -1;
-  float val = live ? ea[a] : 0.f;
-  int s0 = __shfl(s, 0);
-  bool uniform = __all(s == s0 || !live);
-  if (uniform && s0 >= 0) {
-    for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&scaled_total[s0], val);
-  } else if (live) {
-    atomicAdd(&scaled_total[s], val);
-  }
-}
-__global__ void k_scale(int64_t S, float scale, const float* __restrict__ in, float* __restrict__ out) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < S) out[i] = scale * in[i];
-}
-
 __global__ void __launch_bounds__(256) k_gather_rows(int64_t n, int width, int table_stride, int table_rows,
                                                      const float* __restrict__ table, const int64_t* __restrict__ idx,
                                                      float* __restrict__ out, int transposed) {
@@ -516,11 +495,9 @@ void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& b
                        dx_out, reinterpret_cast<const int2*>(t.in_pair));
 }
 
-// per-structure sums of the scaled atomic energies (atomics into the cleared scaled_total) and total = energy_scale * sum
+// per-structure sums of the scaled atomic energies and total = energy_scale * sum: one launch (k_struct_energy, fixed order)
 void launch_energy_sums(const Consts& c, const Topo& t, const float* scaled_atomic, float* scaled_total, float* total, hipStream_t s) {
-  if (t.N > 0) hipLaunchKernelGGL(k_energy_sum, grid_for(t.N), dim3(256), 0, s, t.N, t.batch, scaled_atomic, scaled_total, t.flags);
-  launch_struct_energy(t, scaled_atomic, scaled_total, s);
-  if (t.S > 0) hipLaunchKernelGGL(k_scale, grid_for(t.S), dim3(256), 0, s, t.S, c.energy_scale, scaled_total, total);
+  launch_struct_energy(c, t, scaled_atomic, scaled_total, total, s);
 }
 
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,

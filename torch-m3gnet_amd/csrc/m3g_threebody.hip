@@ -79,12 +79,14 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_fwd(Consts c, TbArg
   __shared__ float su[CAP * 3];
   __shared__ float sp[CAP * C];
   __shared__ unsigned char s_other[kTbListCap];
-  // independent first-level loads: A, this workgroup's window, this thread's row
+  // The number of active rows A lives on the device: the grid is a fixed number of workgroups (at most what the chip holds at
+  // once) that walk the row blocks, instead of one workgroup per block of the worst case A = E of which, on the benchmark cell,
+  // 57 % were dispatched only to read A and leave.
   const int A = *a.n_act;
-  const int rb = blockIdx.x * kTbRows;
-  if (rb >= A) return;                       // the grid is sized for the worst case A = E
-  const int lo = a.tb_win[6 * blockIdx.x], hi_full = a.tb_win[6 * blockIdx.x + 1];
-  const int t_lo = a.tb_win[6 * blockIdx.x + 2], t_hi = a.tb_win[6 * blockIdx.x + 3];
+  for (int blk = blockIdx.x; blk * kTbRows < A; blk += gridDim.x) {
+  const int rb = blk * kTbRows;
+  const int lo = a.tb_win[6 * blk], hi_full = a.tb_win[6 * blk + 1];
+  const int t_lo = a.tb_win[6 * blk + 2], t_hi = a.tb_win[6 * blk + 3];
   // the rows' partner lists are one contiguous range: staged once, coalesced, as window-relative byte ids (precomputed
   // in the topology) -- a global load per triplet inside the loop serialises ~17 L2 round trips per thread
   const int n_list = (t_hi - t_lo) < kTbListCap ? (t_hi - t_lo) : kTbListCap;
@@ -110,11 +112,10 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_fwd(Consts c, TbArg
   const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
   const float fc = a.fc3[e];
   __syncthreads();
-  if (!live) return;
   float acc[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) acc[k] = 0.f;
-  for (int t = t0 + sub; t < t1; t += LPR) {
+  for (int t = live ? t0 + sub : t1; t < t1; t += LPR) {
     const int kk = t - t_lo;
     const int bid = kk < kTbListCap ? s_other[kk] : 255;
     const int idx = bid < CAP ? bid : a.t_other[t] - lo;
@@ -141,15 +142,18 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_fwd(Consts c, TbArg
   }
 #pragma unroll
   for (int k = 0; k < C; ++k) acc[k] = group_sum<LPR>(acc[k]);
-  if (sub != 0) return;
+  if (live && sub == 0) {
 #pragma unroll
-  for (int k = 0; k < kCP; k += 4) {
-    float4 o;
-    o.x = k + 0 < C ? fc * acc[k + 0 < C ? k + 0 : 0] : 0.f;
-    o.y = k + 1 < C ? fc * acc[k + 1 < C ? k + 1 : 0] : 0.f;
-    o.z = k + 2 < C ? fc * acc[k + 2 < C ? k + 2 : 0] : 0.f;
-    o.w = k + 3 < C ? fc * acc[k + 3 < C ? k + 3 : 0] : 0.f;
-    *(float4*)(a.m + (int64_t)r * kCP + k) = o;
+    for (int k = 0; k < kCP; k += 4) {
+      float4 o;
+      o.x = k + 0 < C ? fc * acc[k + 0 < C ? k + 0 : 0] : 0.f;
+      o.y = k + 1 < C ? fc * acc[k + 1 < C ? k + 1 : 0] : 0.f;
+      o.z = k + 2 < C ? fc * acc[k + 2 < C ? k + 2 : 0] : 0.f;
+      o.w = k + 3 < C ? fc * acc[k + 3 < C ? k + 3 : 0] : 0.f;
+      *(float4*)(a.m + (int64_t)r * kCP + k) = o;
+    }
+  }
+  __syncthreads();   // the staged window is rewritten by the next row block
   }
 }
 
@@ -177,11 +181,11 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRev
   __shared__ float ss[CAP * C];
   __shared__ unsigned char s1[kTbRevList], s2[kTbRevList];
   const int A = *a.n_act;
-  const int rb = blockIdx.x * kTbRows;
-  if (rb >= A) return;
-  const int lo = a.tb_win[6 * blockIdx.x], hi_full = a.tb_win[6 * blockIdx.x + 1];
-  const int t1_lo = a.tb_win[6 * blockIdx.x + 2], t1_hi = a.tb_win[6 * blockIdx.x + 3];
-  const int t2_lo = a.tb_win[6 * blockIdx.x + 4], t2_hi = a.tb_win[6 * blockIdx.x + 5];
+  for (int blk = blockIdx.x; blk * kTbRows < A; blk += gridDim.x) {   // fixed grid walking the row blocks (see k_threebody_fwd)
+  const int rb = blk * kTbRows;
+  const int lo = a.tb_win[6 * blk], hi_full = a.tb_win[6 * blk + 1];
+  const int t1_lo = a.tb_win[6 * blk + 2], t1_hi = a.tb_win[6 * blk + 3];
+  const int t2_lo = a.tb_win[6 * blk + 4], t2_hi = a.tb_win[6 * blk + 5];
   const int sub = threadIdx.x % LPR;
   const int r = rb + (int)threadIdx.x / LPR;
   const bool live = r < A;
@@ -223,7 +227,6 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRev
 #pragma unroll
   for (int k = 0; k < C; ++k) gv[k] = qv[k] * vv[k];
   __syncthreads();
-  if (!live) return;
   // partner (window-relative id, or the global fallback) -> unit vector and payload row
   auto fetch = [&](int id, const int32_t* list, int t, const float* sp, bool want_s, float& vx, float& vy, float& vz, float* pr) {
     if (id < CAP) {
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRev
 #pragma unroll
   for (int k = 0; k < C; ++k) { S[k] = 0.f; dg[k] = 0.f; }
   float a1x = 0.f, a1y = 0.f, a1z = 0.f, a2x = 0.f, a2y = 0.f, a2z = 0.f;
-  for (int t = t10 + sub; t < t11; t += LPR) {      // this edge as e1: S += Y g[e2], d cos += dm1 dY g[e2]
+  for (int t = live ? t10 + sub : t11; t < t11; t += LPR) {      // this edge as e1: S += Y g[e2], d cos += dm1 dY g[e2]
     const int kk = t - t1_lo;
     float vx, vy, vz, pr[C];
     fetch(kk < kTbRevList ? s1[kk] : 255, a.t1_other, t, sg, false, vx, vy, vz, pr);
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRev
     dcos = (raw >= -1.f && raw <= 1.f) ? dcos : 0.f;   // torch.clamp passes the gradient only inside [-1, 1]
     a1x += dcos * vx; a1y += dcos * vy; a1z += dcos * vz;
   }
-  for (int t = t20 + sub; t < t21; t += LPR) {      // this edge as e2: dg += dS[e1] Y, d cos += dS[e1] dY g_own
+  for (int t = live ? t20 + sub : t21; t < t21; t += LPR) {      // this edge as e2: dg += dS[e1] Y, d cos += dS[e1] dY g_own
     const int kk = t - t2_lo;
     float vx, vy, vz, pr[C];
     fetch(kk < kTbRevList ? s2[kk] : 255, a.t2_other, t, ss, true, vx, vy, vz, pr);
@@ -294,26 +297,36 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRev
   dfc = group_sum<LPR>(dfc);
   a1x = group_sum<LPR>(a1x); a1y = group_sum<LPR>(a1y); a1z = group_sum<LPR>(a1z);
   a2x = group_sum<LPR>(a2x); a2y = group_sum<LPR>(a2y); a2z = group_sum<LPR>(a2z);
-  if (sub != 0) return;
-  float ddv = 0.f, val[kCP];
+  if (live && sub == 0) {
+    float ddv = 0.f, val[kCP];
 #pragma unroll
-  for (int k = 0; k < kCP; ++k) {
-    val[k] = 0.f;
-    if (k < C) {
-      const int kc = k < C ? k : 0;
-      ddv += dg[kc] * vv[kc] * qpv[kc];
-      val[k] = dg[kc] * qv[kc];
+    for (int k = 0; k < kCP; ++k) {
+      val[k] = 0.f;
+      if (k < C) {
+        const int kc = k < C ? k : 0;
+        ddv += dg[kc] * vv[kc] * qpv[kc];
+        val[k] = dg[kc] * qv[kc];
+      }
     }
-  }
 #pragma unroll
-  for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + (int64_t)r * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
-  a.dd[r] = (dd0 + fcp * dfc) + ddv;
-  a.du[(int64_t)r * 3] = (du0 + fc * a1x) + a2x;
-  a.du[(int64_t)r * 3 + 1] = (du1 + fc * a1y) + a2y;
-  a.du[(int64_t)r * 3 + 2] = (du2 + fc * a1z) + a2z;
+    for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + (int64_t)r * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
+    a.dd[r] = (dd0 + fcp * dfc) + ddv;
+    a.du[(int64_t)r * 3] = (du0 + fc * a1x) + a2x;
+    a.du[(int64_t)r * 3 + 1] = (du1 + fc * a1y) + a2y;
+    a.du[(int64_t)r * 3 + 2] = (du2 + fc * a1z) + a2z;
+  }
+  __syncthreads();   // the staged window is rewritten by the next row block
+  }
 }
 
-static inline dim3 grid_rows(int64_t n) { return dim3((unsigned)((n + kTbRows - 1) / kTbRows)); }
+// at most kTbGridCap workgroups (what 256 CUs hold at once at this LDS footprint and then some): they walk the row blocks
+#ifndef M3G_TB_GRID_CAP
+#define M3G_TB_GRID_CAP 2048
+#endif
+static inline dim3 grid_rows(int64_t n) {
+  const int64_t blocks = (n + kTbRows - 1) / kTbRows;
+  return dim3((unsigned)(blocks < M3G_TB_GRID_CAP ? blocks : M3G_TB_GRID_CAP));
+}
 // Long partner lists?  Triplets per edge is a host-side lower bound of triplets per ACTIVE edge (the number of active edges
 // lives on the device); either choice is correct, the wrong one only costs time (global-memory fallback or LDS footprint).
 static inline bool long_lists(const Topo& t) { return t.T > 24 * t.E; }
