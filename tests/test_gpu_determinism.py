@@ -17,7 +17,7 @@ def _K():
     return K
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("case,mode", CASES)
 def test_forces_bitwise_reproducible_on_golden_cases(case, mode, precision):
     K = _K()
@@ -34,7 +34,7 @@ def test_forces_bitwise_reproducible_on_golden_cases(case, mode, precision):
         assert torch.equal(out[K.TOTAL_ENERGY], ref_e) and torch.equal(out[K.STRESSES], ref_s)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x3"])
 def test_forces_bitwise_reproducible_on_a_1500_atom_cell(precision):
     """Enough tiles that every workgroup of the persistent kernels is busy and waves overlap in every phase."""
     from torch_m3gnet.model.build import build_model

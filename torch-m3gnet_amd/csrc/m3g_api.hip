@@ -344,7 +344,10 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     return M3G_OK;
   }
   if (strcmp(name, "precision") == 0) {
-    if (value != kPrecF32 && value != kPrecBf16x3) { set_error("precision must be 0 (fp32: exact fp32 MFMA products) or 1 (bf16x3 split products)"); return M3G_ERR_VALUE; }
+    if (value != kPrecF32 && value != kPrecBf16x3 && value != kPrecF16x3) {
+      set_error("precision must be 0 (fp32: exact fp32 MFMA products), 1 (bf16x3 split products) or 2 (f16x3: scaled fp16 split products)");
+      return M3G_ERR_VALUE;
+    }
     plan->precision = value;   // both image sets are resident: no recommit needed
     return M3G_OK;
   }
@@ -706,7 +709,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         M3G_HIP_CHECK(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
         launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, plan->side_stream);
         M3G_HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
-        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*dp1_packed=*/plan->precision == kPrecBf16x3, /*with_v_term=*/false, s);
+        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*dp1_packed=*/plan->precision == kPrecBf16x3, /*with_v_term=*/false, s);   // (f16x3: fp32 rows)
         M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_join, 0));
         launch_node_reverse_v_term(c, W, wl.blk[b], t, w, w.v[b], dx_alt, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;

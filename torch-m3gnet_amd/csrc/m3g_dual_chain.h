@@ -95,7 +95,85 @@ __device__ __forceinline__ void chain_dual_t(const float* img, const f32x4 (&d)[
   M3G_CHAIN_PRIO(0);
 }
 
+// ---- f16x3 mode: the same dual-use image holding fp16 parts of the SCALED weights (m3g_mfma_common.h); acc[AOFF + ob] += (W x)
+// in TRUE units -- the scaled sum of one row block at a time is folded in with one fma per value (x's per-edge scale is taken
+// over the chain's own input blocks) ------------------------------------------------------------------------------------------
+__device__ __forceinline__ f16x8 join_halves_h(s16x4 a, s16x4 b) {
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(f16x8, v);
+}
+template <int OB, int KS, int ROWS, int XOFF = 0, int AOFF = 0, int RB0 = 0, int NX, int NA>
+__device__ __forceinline__ void chain_dual_h(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane, float w_inv) {
+  static_assert(KS == 2, "the image holds 64 input features");
+  static_assert(XOFF + 2 * KS <= NX && AOFF + OB <= NA && (RB0 + OB) * 16 <= ROWS, "chain_dual_h operand out of range");
+  const EdgeScale sc = edge_scale<2 * KS, XOFF>(x);
+  const HalfB<KS> b = split_h<KS, XOFF>(x, sc.s);
+  const float inv = sc.inv * w_inv;
+  const int m = lane & 15, q = lane >> 4, sw = dual_swz(m);
+  const char* base = reinterpret_cast<const char*>(img) + (m >> 3) * 1024 + (m & 7) * 64;
+  constexpr int plane = 512, lo = ROWS * 128;
+  M3G_CHAIN_PRIO(1);
+  static_for<OB>([&]<int ob>() {
+    constexpr int roff = (RB0 + ob) * 2048;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    static_for<KS>([&]<int s>() {
+      const char* u = base + (((s * 4 + q) ^ sw) << 3);
+      const f16x8 ah = join_halves_h(*(const s16x4*)(u + roff), *(const s16x4*)(u + roff + plane));
+      const f16x8 al = join_halves_h(*(const s16x4*)(u + roff + lo), *(const s16x4*)(u + roff + lo + plane));
+      t = mfma_f16(ah, b.hi[s], t);
+      t = mfma_f16(ah, b.lo[s], t);
+      t = mfma_f16(al, b.hi[s], t);
+    });
+    static_for<4>([&]<int r>() { acc[AOFF + ob][r] = __builtin_fmaf(t[r], inv, acc[AOFF + ob][r]); });
+  });
+  M3G_CHAIN_PRIO(0);
+}
+template <int OB, int KS, int ROWS, int DOFF = 0, int AOFF = 0, int KB0 = 0, int ND, int NA>
+__device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d)[ND], f32x4 (&acc)[NA], int lane, float w_inv) {
+  static_assert(OB == 4, "64 input features");
+  static_assert(DOFF + 2 * KS <= ND && AOFF + OB <= NA && (KB0 + 2 * KS) * 16 <= ROWS, "chain_dual_t_h operand out of range");
+  const EdgeScale sc = edge_scale<2 * KS, DOFF>(d);
+  const HalfB<KS> b = split_h<KS, DOFF>(d, sc.s);
+  const float inv = sc.inv * w_inv;
+  const int q = lane >> 4, qp = (lane & 15) >> 2, p = lane & 3;
+  const int row_lo = 4 * q + qp, sw = dual_swz(row_lo);
+  const char* base = reinterpret_cast<const char*>(img) + (row_lo >> 3) * 1024 + (row_lo & 7) * 64;
+  constexpr int plane = 512, lo = ROWS * 128;
+  M3G_CHAIN_PRIO(1);
+  static_for<OB>([&]<int ob>() {
+    const char* u = base + (ob & 1) * plane + ((((ob >> 1) * 4 + p) ^ sw) << 3);
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    static_for<KS>([&]<int s>() {
+      constexpr int r0 = (KB0 + 2 * s) * 2048, r1 = (KB0 + 2 * s + 1) * 2048;
+      const f16x8 ah = join_halves_h(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0)),
+                                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1)));
+      const f16x8 al = join_halves_h(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0 + lo)),
+                                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1 + lo)));
+      t = mfma_f16(ah, b.hi[s], t);
+      t = mfma_f16(ah, b.lo[s], t);
+      t = mfma_f16(al, b.hi[s], t);
+    });
+    static_for<4>([&]<int r>() { acc[AOFF + ob][r] = __builtin_fmaf(t[r], inv, acc[AOFF + ob][r]); });
+  });
+  M3G_CHAIN_PRIO(0);
+}
+
 // host: img receives ROWS*64 floats (hi part, then lo part); get(row, col) with col < 64
+template <class F>
+inline void pack_dual_image_h(float* img, int rows, float scale, F get) {
+  auto to_h = [](float w) { const _Float16 h = (_Float16)w; uint16_t u; memcpy(&u, &h, 2); return u; };
+  auto to_f = [](uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; };
+  uint16_t* hi = reinterpret_cast<uint16_t*>(img);
+  uint16_t* lo = hi + (size_t)rows * 64;
+  for (int row = 0; row < rows; ++row)
+    for (int col = 0; col < 64; ++col) {
+      const float w = get(row, col) * scale;
+      const uint16_t h = to_h(w);
+      const size_t idx = (size_t)(dual_unit_byte(rows, row, col >> 2) >> 1) + (col & 3);
+      hi[idx] = h;
+      lo[idx] = to_h(w - to_f(h));
+    }
+}
 template <class F>
 inline void pack_dual_image(float* img, int rows, F get) {
   auto rne = [](float w) {

@@ -105,8 +105,43 @@ __device__ __forceinline__ void chain_f32(const float* img, const f32x4 (&x)[NX]
 // Both read an image of the same size and offsets (an fp32 image is as large as a bf16 hi + lo pair); KS counts 32-wide
 // k-steps, i.e. 2*KS accumulator blocks of x.
 template <int PREC, int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
-__device__ __forceinline__ void chain_p(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane) {
+__device__ __forceinline__ void chain_p(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane, float w_inv = 1.f);
+
+// ---- f16x3 mode: scaled two-part fp16 operands (edge_scale / split_h: m3g_mfma_common.h) -----------------------------------------
+// out(ob, t): t = Ws(ob-th 16-row block, :) . (s x), Ws = the image's weights (scaled by the model's power of two at pack time);
+// the caller unscales with EdgeScale::inv * w_inv where it consumes t (an fma with the bias / table row it would add anyway).
+// One accumulator at a time: the scaled sums never coexist with the unscaled pre-activations they are folded into.
+template <int OB, int KS, class OUT>
+__device__ __forceinline__ void chain_h(const float* img, const HalfB<KS>& b, int lane, OUT&& out) {
+  const f16x8* hi_img = reinterpret_cast<const f16x8*>(img) + lane;
+  const f16x8* lo_img = hi_img + OB * KS * 64;
+  static_for<OB>([&]<int ob>() {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    static_for<KS>([&]<int s>() {
+      const f16x8 ah = hi_img[(ob * KS + s) * 64], al = lo_img[(ob * KS + s) * 64];
+      t = mfma_f16(ah, b.hi[s], t);
+      t = mfma_f16(ah, b.lo[s], t);
+      t = mfma_f16(al, b.hi[s], t);
+    });
+    out.template operator()<ob>(t);
+  });
+}
+// acc[AOFF + ob] += (W x)[ob-th row block] in true units: the f16x3 counterpart of chain_p (scale of x taken over its 2 KS blocks)
+template <int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
+__device__ __forceinline__ void chain_h_acc(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane, float w_inv) {
+  static_assert(AOFF + OB <= NA, "chain_h_acc operand out of range");
+  const EdgeScale sc = edge_scale<2 * KS, XOFF>(x);
+  const HalfB<KS> b = split_h<KS, XOFF>(x, sc.s);
+  const float inv = sc.inv * w_inv;
+  chain_h<OB, KS>(img, b, lane, [&]<int ob>(const f32x4& t) {
+    static_for<4>([&]<int r>() { acc[AOFF + ob][r] = __builtin_fmaf(t[r], inv, acc[AOFF + ob][r]); });
+  });
+}
+
+template <int PREC, int OB, int KS, int XOFF, int AOFF, int NX, int NA>
+__device__ __forceinline__ void chain_p(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane, float w_inv) {
   if constexpr (PREC == kPrecBf16x3) chain<OB, KS, XOFF, AOFF>(img, x, acc, lane);
+  else if constexpr (PREC == kPrecF16x3) chain_h_acc<OB, KS, XOFF, AOFF>(img, x, acc, lane, w_inv);
   else chain_f32<OB, 2 * KS, XOFF, AOFF>(img, x, acc, lane);
 }
 
@@ -307,6 +342,7 @@ struct FwdArgs {
   unsigned long long* stamps;  // diagnostic build: [gridDim.x][kWaves][12] phase cycle sums
   float* p1_out;               // fp32 mode: saved layer-1 pre-activations [tiles][2 mlp][8 blk][64 lanes][4], else nullptr
   float* p2_out;               // fp32 mode, saves_p2: layer-2 pre-activations, same shape (p1_out then holds SiLU'(p1)), else nullptr
+  float w_inv;                 // f16x3 mode: 1 / the model's weight scale (plan->w_scale_inv), else 1
 };
 
 // three-body MLP pre-activations: p[0..3] dense, p[4..7] gate
@@ -351,6 +387,7 @@ struct RevArgs {
   float *seg_head, *seg_first;   // fused kernel: per-centre sums of the dp1 rows (see seg_scan)
   const float* p1;      // saved layer-1 pre-activations of this block (fp32 mode; SiLU'(p1) when p2 is saved too), else nullptr
   const float* p2;      // saved layer-2 pre-activations (fp32 mode, saves_p2), else nullptr
+  float w_inv;          // f16x3 mode: 1 / the model's weight scale (plan->w_scale_inv), else 1
 };
 
 // x summed over the four lane quarters (lanes l, l^16, l^32, l^48), result in every lane.  v_permlane16/32_swap
@@ -397,8 +434,9 @@ inline int64_t tiles_for(int64_t E) { return (E + kTileEdges - 1) / kTileEdges; 
     default: { constexpr int TBS = 4; CALL; } break; \
   }
 
-#define M3G_PREC_SWITCH(P_, CALL)                                      \
-  if ((P_) == kPrecF32) { constexpr int PREC = kPrecF32; CALL; }       \
+#define M3G_PREC_SWITCH(P_, CALL)                                            \
+  if ((P_) == kPrecF32) { constexpr int PREC = kPrecF32; CALL; }             \
+  else if ((P_) == kPrecF16x3) { constexpr int PREC = kPrecF16x3; CALL; }    \
   else { constexpr int PREC = kPrecBf16x3; CALL; }
 
 }  // namespace m3g

@@ -41,8 +41,8 @@ namespace m3g {
 // p1_out and p2 -> p2_out
 template <bool KEEP_P1, int PREC, int SAVE = 0>
 __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, int w2g, int b2, const f32x4 (&x)[4], f32x4 (&p1)[8],
-                                            f32x4 (&p2)[8], int lane, float* p1_out = nullptr, float* p2_out = nullptr) {
-  chain_p<PREC, 8, 2>(lds + w1c, x, p1, lane);
+                                            f32x4 (&p2)[8], int lane, float* p1_out = nullptr, float* p2_out = nullptr, float w_inv = 1.f) {
+  chain_p<PREC, 8, 2>(lds + w1c, x, p1, lane, w_inv);
   if constexpr (SAVE == 1) static_for<8>([&]<int ob>() { *(f32x4*)(p1_out + ob * 256) = p1[ob]; });
   bias_step<4, 0>(lds + b2, p2, lane);
   bias_step<4, 4>(lds + b2 + 4 * 64, p2, lane);
@@ -58,8 +58,8 @@ __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, 
       });
       M3G_SAVE_STORE(p1_out + ob * 256, ds);
     });
-    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, p1, p2, lane);
-    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, p1, p2, lane);
+    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, p1, p2, lane, w_inv);
+    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, p1, p2, lane, w_inv);
     static_for<8>([&]<int ob>() { M3G_SAVE_STORE(p2_out + ob * 256, p2[ob]); });
     return;
   }
@@ -73,12 +73,12 @@ __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, 
         p1[ob][r] = sg * (1.f + p * (1.f - sg));
       });
     });
-    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, hid, p2, lane);
-    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, hid, p2, lane);
+    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, hid, p2, lane, w_inv);
+    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, hid, p2, lane, w_inv);
   } else {
     static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); }); });
-    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, p1, p2, lane);  // hidden dense = p1[0..3]
-    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, p1, p2, lane);  // hidden gate  = p1[4..7]
+    chain_p<PREC, 4, 2, 0, 0>(lds + w2d, p1, p2, lane, w_inv);  // hidden dense = p1[0..3]
+    chain_p<PREC, 4, 2, 4, 4>(lds + w2g, p1, p2, lane, w_inv);  // hidden gate  = p1[4..7]
   }
 }
 
@@ -90,7 +90,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
   f32x4 p1[8], p2[8];
   gather_tables(a.TA, a.TB, mlp, ci, cj, lane >> 4, p1);
   st.template mark<S0>();      // table gather
-  mlp_preacts<false, PREC, SAVE>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane, p1_out, p2_out);
+  mlp_preacts<false, PREC, SAVE>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, p2, lane, p1_out, p2_out, a.w_inv);
   st.template mark<S0 + 1>();  // both layers
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -220,12 +220,12 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
         p1[ob][r] = sg * (1.f + p * (1.f - sg));
       });
     });
-    chain_p<PREC, 4, 2, 0, 0>(lds + L.w2d, hid, d2, lane);
-    chain_p<PREC, 4, 2, 4, 4>(lds + L.w2g, hid, d2, lane);
+    chain_p<PREC, 4, 2, 0, 0>(lds + L.w2d, hid, d2, lane, a.w_inv);
+    chain_p<PREC, 4, 2, 4, 4>(lds + L.w2g, hid, d2, lane, a.w_inv);
   } else {
     gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
     st.template mark<2>();   // table gather (+ wait for the tile loads)
-    mlp_preacts<true, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, d2, lane);
+    mlp_preacts<true, PREC>(lds, L.w1c, L.w2d, L.w2g, L.b2, x, p1, d2, lane, nullptr, nullptr, a.w_inv);
   }
   st.template mark<3>();   // recompute both layers
   static_for<4>([&]<int ob>() {
@@ -247,8 +247,8 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
   st.template mark<4>();   // gating derivatives (VALU)
   f32x4 dp1[8];
   zero(dp1);
-  chain_p<PREC, 4, 2, 0, 0>(lds + L.w2dT, d2, dp1, lane);  // d hidden dense -> dp1[0..3]
-  chain_p<PREC, 4, 2, 4, 4>(lds + L.w2gT, d2, dp1, lane);  // d hidden gate  -> dp1[4..7]
+  chain_p<PREC, 4, 2, 0, 0>(lds + L.w2dT, d2, dp1, lane, a.w_inv);  // d hidden dense -> dp1[0..3]
+  chain_p<PREC, 4, 2, 4, 4>(lds + L.w2gT, d2, dp1, lane, a.w_inv);  // d hidden gate  -> dp1[4..7]
   static_for<8>([&]<int ob>() { dp1[ob] *= p1[ob]; });   // p1 holds SiLU'(p1) here (mlp_preacts<true>)
   st.template mark<5>();   // layer-2 transposed chains + SiLU'
   if (edge < a.E) {
@@ -256,7 +256,7 @@ __device__ __forceinline__ void mlp_reverse_mfma(const float* lds, const MfmaMlp
     static_for<8>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
   }
   zero(contrib);
-  chain_p<PREC, 4, 4>(lds + L.w1cT, dp1, contrib, lane);
+  chain_p<PREC, 4, 4>(lds + L.w1cT, dp1, contrib, lane, a.w_inv);
   st.template mark<6>();   // dp1 stores + layer-1 transposed chain
 }
 
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(64 * kWavesRev) k_edge_rev_edge_mlp(RevArgs a,
     });
     f32x4 dmv[1];
     zero(dmv);
-    chain_p<PREC, 1, 4>(lds + L.tbT, d8, dmv, lv);
+    chain_p<PREC, 1, 4>(lds + L.tbT, d8, dmv, lv, a.w_inv);
     store_dh(a.dh, edge, a.E, dhv, qd);
     if (edge < a.E && arow >= 0) *(f32x4*)(a.dm + (int64_t)arow * kCP + 4 * qd) = dmv[0];  // rows c = 4*qd + reg
     st.template mark<7>();   // de store + three-body reverse + dm/dh stores
@@ -398,6 +398,19 @@ __global__ void __launch_bounds__(64 * kWavesRev) k_edge_rev_edge_mlp(RevArgs a,
 // kernels this drops the node->edge hand-over buffer (256 B written + read per edge), the second read of the edge
 // features, the second table gather, and one dh slice; block 0 also skips the dp1 rows nobody reads.
 constexpr int kRevFusedFloats = 8 * kTbSteps * 64 + 8 * 4 * 64 + 2 * (128 * 64 + 2 * 64 * 64 + 2 * 4 * 64 + 64 * 4 + 4 * 64) + 4 * 64 + 64 * 4;
+
+// dual-image chains in the precision mode of the fused reverse kernel (bf16x3: m3g_dual_chain.h chain_dual / chain_dual_t;
+// f16x3: chain_dual_h / chain_dual_t_h on fp16 images of the scaled weights, per-edge input scales, results in true units)
+template <int PREC, int OB, int KS, int ROWS, int XOFF = 0, int AOFF = 0, int RB0 = 0, int NX, int NA>
+__device__ __forceinline__ void cdual(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane, float w_inv) {
+  if constexpr (PREC == kPrecF16x3) chain_dual_h<OB, KS, ROWS, XOFF, AOFF, RB0>(img, x, acc, lane, w_inv);
+  else chain_dual<OB, KS, ROWS, XOFF, AOFF, RB0>(img, x, acc, lane);
+}
+template <int PREC, int OB, int KS, int ROWS, int DOFF = 0, int AOFF = 0, int KB0 = 0, int ND, int NA>
+__device__ __forceinline__ void cdual_t(const float* img, const f32x4 (&d)[ND], f32x4 (&acc)[NA], int lane, float w_inv) {
+  if constexpr (PREC == kPrecF16x3) chain_dual_t_h<OB, KS, ROWS, DOFF, AOFF, KB0>(img, d, acc, lane, w_inv);
+  else chain_dual_t<OB, KS, ROWS, DOFF, AOFF, KB0>(img, d, acc, lane);
+}
 
 template <bool KEEP_P1>
 __device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlpFused& L, const f32x4 (&x)[4], f32x4 (&p1)[8],
@@ -436,7 +449,7 @@ __device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlp
 // The dense and the gate branch are independent between layer 1 and the final product, so each is carried through
 // layer 2, and later through the transposed layers, on its own: 16 instead of 32 registers for the hidden values and
 // for dL/dp1, which is what lets the kernel approach three waves per SIMD.
-template <bool NEED_DP1, int MLP>
+template <bool NEED_DP1, int MLP, int PREC>
 __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlpFused& L, const RevArgs& a, int64_t edge, int64_t tile,
                                                  int64_t ci, int64_t cj, const SegMasks& sk, const f32x4& hv, const f32x4 (&x)[4],
                                                  const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane) {
@@ -444,7 +457,7 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
   const int qd = lane >> 4;
   f32x4 p1[8], d2[8];
   gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
-  chain_dual<8, 2, 128>(lds + L.w1c, x, p1, lane);
+  cdual<PREC, 8, 2, 128>(lds + L.w1c, x, p1, lane, a.w_inv);
   M3G_SCHED_FENCE();
   bias_step<4, 0>(lds + L.b2, d2, lane);
   bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
@@ -457,7 +470,7 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
         p1[4 * half + ob][r] = sg * (1.f + p * (1.f - sg));   // p1 is only needed again as SiLU'(p1)
       });
     });
-    chain_dual<4, 2, 64, 0, 4 * half>(lds + (half == 0 ? L.w2d : L.w2g), hid, d2, lane);
+    cdual<PREC, 4, 2, 64, 0, 4 * half>(lds + (half == 0 ? L.w2d : L.w2g), hid, d2, lane, a.w_inv);
     M3G_SCHED_FENCE();
   });
   // W_l h on the matrix pipe (4 small MFMAs, as the forward kernel) instead of a 4-term dot per element on the vector ALU
@@ -483,19 +496,19 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
   static_for<2>([&]<int half>() {
     f32x4 dp1[4];
     zero(dp1);
-    chain_dual_t<4, 2, 64, 4 * half, 0>(lds + (half == 0 ? L.w2d : L.w2g), d2, dp1, lane);
+    cdual_t<PREC, 4, 2, 64, 4 * half, 0>(lds + (half == 0 ? L.w2d : L.w2g), d2, dp1, lane, a.w_inv);
     static_for<4>([&]<int ob>() { dp1[ob] *= p1[4 * half + ob]; });
     if (NEED_DP1 && edge < a.E) {
-#ifndef M3G_DP1_F32
-      // 24-bit rows (pack24): group index = column / 4 = mlp*32 + half*16 + ob*4 + qd
-      unsigned* row = reinterpret_cast<unsigned*>(a.dp1) + edge * kDp1PackedDwords + 3 * (mlp * 32 + half * 16 + qd);
-      static_for<4>([&]<int ob>() { *(u32x3_a4*)(row + 12 * ob) = pack24(dp1[ob]); });
-#else
-      float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + half * kDP + 4 * qd;
-      static_for<4>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
-#endif
+      if constexpr (PREC == kPrecBf16x3) {
+        // 24-bit rows (pack24): group index = column / 4 = mlp*32 + half*16 + ob*4 + qd
+        unsigned* row = reinterpret_cast<unsigned*>(a.dp1) + edge * kDp1PackedDwords + 3 * (mlp * 32 + half * 16 + qd);
+        static_for<4>([&]<int ob>() { *(u32x3_a4*)(row + 12 * ob) = pack24(dp1[ob]); });
+      } else {   // f16x3 mode: every hand-over stays fp32 (a 24-bit row would be its largest error by two orders of magnitude)
+        float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + half * kDP + 4 * qd;
+        static_for<4>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
+      }
     }
-    chain_dual_t<4, 2, 128, 0, 0, 4 * half>(lds + L.w1c, dp1, contrib, lane);   // rows half*64 .. +63 of W1c
+    cdual_t<PREC, 4, 2, 128, 0, 0, 4 * half>(lds + L.w1c, dp1, contrib, lane, a.w_inv);   // rows half*64 .. +63 of W1c
     if (NEED_DP1) {
       // sum of the dp1 rows per centre (the x_i half of the node reverse): scanned here, so the node kernel reads a few
       // partial rows per atom instead of every row of the centre.  The rows themselves are still stored above for the
@@ -508,7 +521,7 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
   });
 }
 
-template <int TBS, bool NEED_DP1, int WAVES>
+template <int TBS, bool NEED_DP1, int WAVES, int PREC = kPrecBf16x3>
 __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRevFusedLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kRevFusedFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevFusedFloats);
@@ -554,7 +567,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       f32x4 dmsg[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
       static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
-      mlp_reverse_dual<NEED_DP1, 1>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv);
+      mlp_reverse_dual<NEED_DP1, 1, PREC>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv);
     }
     // dL/d e2 = what flows in from later blocks + the node MLP's contribution
     if (a.de_is_zero) {
@@ -579,7 +592,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       tb_preact<TBS>(lds + L.tb, mb, p, lv);
       static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
     }
-    mlp_reverse_dual<NEED_DP1, 0>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv);
+    mlp_reverse_dual<NEED_DP1, 0, PREC>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
       if (!FIRST) *(f32x4*)(de_tile + blk * 256) = de[blk];
@@ -609,7 +622,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     });
     f32x4 dmv[1];
     zero(dmv);
-    chain<1, 4>(lds + L.tbT, d8, dmv, lv);
+    chain_p<PREC, 1, 4>(lds + L.tbT, d8, dmv, lv, a.w_inv);
     store_dh(a.dh, edge, a.E, dhv, qd);
     if (edge < a.E && arow >= 0) *(f32x4*)(a.dm + (int64_t)arow * kCP + 4 * qd) = dmv[0];
     if (!has_next) break;
@@ -716,13 +729,14 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
   if (tiles > 0) {
     FwdArgs a{t.E, tiles, plan->d_mfma_fwd[plan->precision] + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], t.act_id,
               w.e_blk[b], w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps, saves_p1(plan) ? w.p1_blk[b] : nullptr,
-              saves_p2(plan) ? w.p2_blk[b] : nullptr};
+              saves_p2(plan) ? w.p2_blk[b] : nullptr, plan->precision == kPrecF16x3 ? plan->w_scale_inv : 1.f};
     dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
     const bool first = b == 0 && fused_reverse(plan);   // the fused reverse kernel recomputes e0 as well: no embedded-edge image at all
     const int save = for_reverse ? saved_activations(plan) : 0;   // fp32 mode only (saves_p1 / saves_p2)
 #define M3G_FWD_LAUNCH(ST_, FIRST_, PREC_, SAVE_) hipLaunchKernelGGL((k_edge_block_mfma<TBS, ST_, FIRST_, PREC_, SAVE_>), grid, block, 0, s, a, L)
 #define M3G_FWD_BY_MODE(ST_, FIRST_)                                                               \
   if (plan->precision == kPrecBf16x3) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecBf16x3, 0); }             \
+  else if (plan->precision == kPrecF16x3) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecF16x3, 0); }          \
   else if (save == 2) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecF32, 2); }                                \
   else if (save == 1) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecF32, 1); }                                \
   else { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecF32, 0); }
@@ -749,7 +763,8 @@ void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const float* img_n = plan->d_mfma_rev[plan->precision] + (size_t)b * L.per_block + L.total_e;
   const bool saved = saves_p1(plan);
   RevArgs an{t.E, tiles, img_n, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b + 1], nullptr, w.de_soa, w.dcn, 0, w.dm,
-             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr, saved ? w.p1_blk[b] : nullptr, nullptr};
+             w.dh_parts + (size_t)(2 * b + 1) * t.E * kRP, w.dp1, nullptr, nullptr, nullptr, saved ? w.p1_blk[b] : nullptr, nullptr,
+             plan->precision == kPrecF16x3 ? plan->w_scale_inv : 1.f};
   if (saved) { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_rev_node_mlp<PREC, true>), dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L)); }
   else { M3G_PREC_SWITCH(plan->precision, hipLaunchKernelGGL((k_edge_rev_node_mlp<PREC, false>), dim3(grid_for_tiles(tiles)), dim3(64 * kWavesRev), 0, s, an, L)); }
 }
@@ -762,7 +777,7 @@ void launch_edge_rev_edge_mlp(const m3g_plan* plan, const Consts& c, const Topo&
   const float* img_e = plan->d_mfma_rev[plan->precision] + (size_t)b * L.per_block;
   RevArgs ae{t.E, tiles, img_e, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], nullptr, w.de_soa, w.dcn,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)(2 * b) * t.E * kRP, w.dp1, plan->d_stamps, nullptr, nullptr,
-             saves_p1(plan) ? w.p1_blk[b] : nullptr, nullptr};
+             saves_p1(plan) ? w.p1_blk[b] : nullptr, nullptr, plan->precision == kPrecF16x3 ? plan->w_scale_inv : 1.f};
   dim3 grid(grid_for_tiles(tiles)), block(64 * kWavesRev);
   if (plan->d_stamps && plan->stamp_target == 1 && tb_steps_for(c.C) == 3 && plan->precision == kPrecBf16x3) {  // diagnostic build
     hipLaunchKernelGGL((k_edge_rev_edge_mlp<3, true>), grid, block, 0, s, ae, L);
@@ -777,16 +792,19 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
   const int64_t tiles = tiles_for(t.E);
   if (tiles == 0) return;
   const MfmaRevFusedLayout L = mfma_rev_fused_layout();
-  const float* img = plan->d_mfma_revf + (size_t)b * L.total;
+  const bool f16 = plan->precision == kPrecF16x3;
+  const float* img = (f16 ? plan->d_mfma_revf_h : plan->d_mfma_revf) + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, nullptr, nullptr};
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, nullptr, nullptr,
+             f16 ? plan->w_scale_inv : 1.f};
   constexpr int WV = kWavesRevFused;
   dim3 grid(grid_for_tiles(tiles)), block(64 * WV);
-  if (b > 0) {
-    M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_fused<TBS, true, WV>), grid, block, 0, s, ar, L));
-  } else {   // x^0 has no position dependence: nobody reads block 0's dp1 rows
-    M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_fused<TBS, false, WV>), grid, block, 0, s, ar, L));
-  }
+#define M3G_REVF_LAUNCH(NEED_) \
+  if (f16) { M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_fused<TBS, NEED_, WV, kPrecF16x3>), grid, block, 0, s, ar, L)); } \
+  else { M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_fused<TBS, NEED_, WV, kPrecBf16x3>), grid, block, 0, s, ar, L)); }
+  if (b > 0) { M3G_REVF_LAUNCH(true); }
+  else { M3G_REVF_LAUNCH(false); }   // x^0 has no position dependence: nobody reads block 0's dp1 rows
+#undef M3G_REVF_LAUNCH
 }
 
 }  // namespace m3g

@@ -233,7 +233,7 @@ void launch_edge_rev_f32(const m3g_plan* plan, const Consts& c, const Topo& t, c
   const float* img = plan->d_mfma_revf32 + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, nullptr, nullptr, nullptr, nullptr, w.de_soa, nullptr,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, w.p1_blk[b],
-             saves_p2(plan) ? w.p2_blk[b] : nullptr};
+             saves_p2(plan) ? w.p2_blk[b] : nullptr, 1.f};
   constexpr int WV = kWavesRevF32;
   dim3 grid(grid_for_tiles(tiles, WV)), block(64 * WV);
   const bool p2 = saves_p2(plan);

@@ -21,7 +21,9 @@ constexpr int kMaxBlocks = 8;
 // arithmetic of the dense chains (plan option "precision"; m3g_edge_mfma.hip: chain_p)
 constexpr int kPrecF32 = 0;      // v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate -- the reference's arithmetic (default)
 constexpr int kPrecBf16x3 = 1;   // 3 v_mfma_f32_16x16x32_bf16 products of 2-way bf16 splits per fp32 product, fp32 accumulate
-constexpr int kNumPrec = 2;
+constexpr int kPrecF16x3 = 2;    // 3 v_mfma_f32_16x16x32_f16 products of 2-way fp16 splits of power-of-two SCALED operands: both parts of
+                                 // an operand together carry 22-24 significant bits (an fp32 value to within its own rounding), fp32 accumulate
+constexpr int kNumPrec = 3;
 
 void set_error(const char* fmt, ...);
 #define M3G_HIP_CHECK(expr)                                                               \
@@ -194,12 +196,14 @@ struct m3g_plan {
   std::map<std::string, std::vector<float>> cvals;   // raw constants (host)
   float* d_weights = nullptr;
   // MFMA weight images, one set per precision mode (same layouts and sizes: an fp32 image is as large as a bf16 hi + lo pair)
-  float* d_mfma_fwd[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][MfmaFwdLayout.total]
-  float* d_mfma_rev[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][MfmaRevLayout.total]
+  float* d_mfma_fwd[m3g::kNumPrec] = {nullptr, nullptr, nullptr};   // [num_blocks][MfmaFwdLayout.total]
+  float* d_mfma_rev[m3g::kNumPrec] = {nullptr, nullptr, nullptr};   // [num_blocks][MfmaRevLayout.total]
   float* d_mfma_revf = nullptr;  // [num_blocks][MfmaRevFusedLayout.total] (bf16x3 dual-use images)
+  float* d_mfma_revf_h = nullptr;  // the same layout holding fp16 parts of the scaled weights (f16x3 mode)
   float* d_mfma_revf32 = nullptr;  // [num_blocks][MfmaRevF32Layout.total] (fused fp32 reverse kernel)
-  float* d_node_img[m3g::kNumPrec] = {nullptr, nullptr};   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
+  float* d_node_img[m3g::kNumPrec] = {nullptr, nullptr, nullptr};   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
   int precision = m3g::kPrecF32; // option "precision"
+  float w_scale_inv = 1.f;       // f16x3 mode: 1 / (the power of two all chain-image weights were multiplied by), set by pack_mfma_images
   int save_p1 = 1;               // option "save_p1" (fp32 mode only): 0 = recompute layer 1 in the reverse kernels (A/B tests)
   int save_p2 = 1;               // option "save_p2" (fp32 mode, fused reverse): 0 = recompute layer 2 in the reverse kernel
   int device = -1;               // HIP device the plan's buffers live on (set by m3g_plan_commit)
@@ -418,7 +422,7 @@ inline bool saves_p1(const m3g_plan* plan) { return plan->edge_kernel == 1 && pl
 inline bool saves_p2(const m3g_plan* plan) { return saves_p1(plan) && plan->rev_kernel == 1 && plan->save_p2 != 0; }
 inline int saved_activations(const m3g_plan* plan) { return saves_p2(plan) ? 2 : saves_p1(plan) ? 1 : 0; }
 inline bool fused_reverse(const m3g_plan* plan) {
-  return plan->edge_kernel == 1 && plan->rev_kernel == 1 && (plan->precision == kPrecBf16x3 || saves_p1(plan));
+  return plan->edge_kernel == 1 && plan->rev_kernel == 1 && (plan->precision != kPrecF32 || saves_p1(plan));
 }
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, bool for_reverse, hipStream_t s);
 void launch_edge_rev_node_mlp(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,

@@ -64,6 +64,73 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
   });
 }
 
+// ---- f16x3 mode: the dense chains on v_mfma_f32_16x16x32_f16 with operands SCALED by powers of two and split in two fp16 parts --
+// x s = h + l, h = fp16(x s) (round to nearest), l = fp16(x s - h): h carries 11 significant bits, l the next 11-12, so h + l is
+// x s to within 2^-23 relative -- an fp32 value to about its own rounding -- PROVIDED both parts are normal fp16 numbers.  That
+// is what the scales are for: every B operand (a tile's activations or gradients) is multiplied per EDGE by the power of two that
+// puts the largest of the edge's K inputs into [2^12, 2^13) (edge_scale: gradients of 1e-9 and saturated activations of 30 alike),
+// every weight matrix by one power of two for the whole model (plan->w_scale_inv).  Entries within 2^-14 of their column's
+// largest keep the full 22-23 bits; smaller ones carry an absolute error below 2^-37 of the largest, irrelevant in a dot product.
+// Products of parts are exact in fp32 (11 x 11 bits); a b ~ h_a h_b + h_a l_b + l_a h_b drops l_a l_b <= 2^-22 a b, accumulated in
+// fp32: measured (tests/checkers/split_precision_study.py) rms error 1.8 x that of an fp32 fmaf chain, 17 x below bf16x3's.
+// Powers of two commute with fp32 rounding, so results do not depend on the scales as long as nothing leaves the fp16 range.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// scaled split of one value pair: hi = fp16(s x) (v_fma_mixlo/cvt_pk, RNE), lo = fp16(s x - hi) (v_fma_mix + v_cvt_pkrtz: the
+// residual has at most 12 significant bits, truncation loses at most one)
+__device__ __forceinline__ void split_pair_h(float a, float b, float s, f16x2& hi, f16x2& lo) {
+  const float as = a * s, bs = b * s;
+  hi = f16x2{(_Float16)as, (_Float16)bs};
+  const float ra = __builtin_fmaf((float)hi[0], -1.0f, as), rb = __builtin_fmaf((float)hi[1], -1.0f, bs);
+  lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+// B operand of one k-step (accumulator blocks a, b scaled by s): element j < 4 from a, j >= 4 from b (as split8)
+__device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, float s, f16x8& hi, f16x8& lo) {
+  f16x2 h[4], l[4];
+  split_pair_h(a[0], a[1], s, h[0], l[0]);
+  split_pair_h(a[2], a[3], s, h[1], l[1]);
+  split_pair_h(b[0], b[1], s, h[2], l[2]);
+  split_pair_h(b[2], b[3], s, h[3], l[3]);
+  hi = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+  lo = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+}
+
+// max over the four lane quarters (lanes l, l^16, l^32, l^48), result in every lane (v_permlane16/32_swap are VALU moves on gfx950)
+__device__ __forceinline__ float max_lane_quarters(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float y = fmaxf(__builtin_bit_cast(float, (unsigned)r16[0]), __builtin_bit_cast(float, (unsigned)r16[1]));
+  const unsigned v = __builtin_bit_cast(unsigned, y);
+  auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)r32[0]), __builtin_bit_cast(float, (unsigned)r32[1]));
+}
+// power of two that puts the largest |x| of this lane's EDGE (over blocks XOFF .. XOFF + NB, all four lane quarters) into
+// [2^12, 2^13), and its inverse.  An all-zero column gets 2^13 (0 stays 0); exponents below -100 are treated as -100.
+struct EdgeScale { float s, inv; };
+template <int NB, int XOFF = 0, int NX>
+__device__ __forceinline__ EdgeScale edge_scale(const f32x4 (&x)[NX]) {
+  static_assert(XOFF + NB <= NX, "edge_scale operand out of range");
+  float m = 0.f;
+  static_for<NB>([&]<int b>() { static_for<4>([&]<int r>() { m = fmaxf(m, fabsf(x[XOFF + b][r])); }); });
+  m = max_lane_quarters(m);
+  int e = __builtin_amdgcn_frexp_expf(m);   // m in [2^(e-1), 2^e)
+  e = e < -100 ? -100 : e;
+  return EdgeScale{__builtin_ldexpf(1.f, 13 - e), __builtin_ldexpf(1.f, e - 13)};
+}
+// the scaled, split B operands of a whole chain (KS 32-wide k-steps = blocks XOFF .. XOFF + 2 KS of x)
+template <int KS>
+struct HalfB { f16x8 hi[KS], lo[KS]; };
+template <int KS, int XOFF = 0, int NX>
+__device__ __forceinline__ HalfB<KS> split_h(const f32x4 (&x)[NX], float s) {
+  static_assert(XOFF + 2 * KS <= NX, "split_h operand out of range");
+  HalfB<KS> b;
+  static_for<KS>([&]<int k>() { split8h(x[XOFF + 2 * k], x[XOFF + 2 * k + 1], s, b.hi[k], b.lo[k]); });
+  return b;
+}
+
 // ---- 24-bit rows for the dp1 hand-over (fused reverse -> node reverse) -------------------------------------------
 // The x_j half of the node reverse gathers one dp1 row per incoming edge, the largest stream of the reverse pass.  The
 // rows are stored with 16 significand bits (sign, exponent and the top 15 mantissa bits, rounded: relative error

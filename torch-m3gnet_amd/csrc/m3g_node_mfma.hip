@@ -17,7 +17,8 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
                                                        const float* __restrict__ seg_head, const float* __restrict__ seg_first,
                                                        const int32_t* __restrict__ row_ptr, float* __restrict__ x,
                                                        float* __restrict__ v, float* __restrict__ TA, float* __restrict__ TB,
-                                                       const int64_t* __restrict__ types, const float* __restrict__ emb, int num_types) {
+                                                       const int64_t* __restrict__ types, const float* __restrict__ emb, int num_types,
+                                                       float w_inv) {
   __shared__ __attribute__((aligned(16))) float lds[kNodeImgFloats + 4 * 16 * kNodeXPitch];
   {  // image -> LDS, 16 independent 16-byte loads in flight per thread (a load-store-load chain would pay one L2 round trip
      // per 4 KB of the 137 KB image)
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
       if (SPLIT && only != g) return;
       f32x4 acc[11];
       static_for<11>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (11 * g + j) * 16 + 4 * q); });
-      chain_p<PREC, 11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv);
+      chain_p<PREC, 11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv, w_inv);
       if (live) {
         static_for<11>([&]<int j>() {
           constexpr int ob = 11 * g + j;
@@ -230,7 +231,8 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
   M3G_PREC_SWITCH(plan->precision,                                                                                             \
                   hipLaunchKernelGGL((k_node_pre_mfma<PREC, SPLIT_>), dim3(wgs), dim3(256), 0, s, c.C, t.N,                      \
                                      plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first, \
-                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types))
+                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types,                                              \
+                                     plan->precision == kPrecF16x3 ? plan->w_scale_inv : 1.f))
   if (split) { M3G_NODE_PRE_LAUNCH(true); } else { M3G_NODE_PRE_LAUNCH(false); }
 #undef M3G_NODE_PRE_LAUNCH
 }

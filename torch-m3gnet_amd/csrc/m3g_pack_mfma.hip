@@ -1,6 +1,7 @@
 // Host-side packing of the per-block weight images the MFMA edge kernels copy into LDS.
 // Layout rules: m3g_internal.h (MfmaFwdLayout / MfmaRevLayout).  Source tensors: the reference's state_dict
 // entries of ThreeBodyInteration.gated_mlp (nn/interaction.py:180-185) and of M3GNetConv (nn/conv.py:39-61).
+#include <cmath>
 #include <cstring>
 
 #include "m3g_dual_chain.h"
@@ -102,6 +103,35 @@ static void chain_image(float* img, int OB, int KS, F get) {
           lo[idx] = bf16_rne(w - bf16_to_float(h));
         }
 }
+// fp16 helpers for the f16x3 mode (round to nearest even; inputs are finite and, after scaling, inside the fp16 range)
+static inline uint16_t f16_rne(float w) {
+  const _Float16 h = (_Float16)w;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+static inline float f16_to_float(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
+// the same image for v_mfma_f32_16x16x32_f16: W * scale = W_hi + W_lo, both fp16 (m3g_mfma_common.h, f16x3 mode)
+template <class F>
+static void chain_image_h(float* img, int OB, int KS, float scale, F get) {
+  uint16_t* hi = reinterpret_cast<uint16_t*>(img);
+  uint16_t* lo = hi + (size_t)OB * KS * 512;
+  for (int ob = 0; ob < OB; ++ob)
+    for (int s = 0; s < KS; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int feat = (2 * s + (j >> 2)) * 16 + 4 * (lane >> 4) + (j & 3);
+          const float w = get(ob * 16 + (lane & 15), feat) * scale;
+          const uint16_t h = f16_rne(w);
+          const size_t idx = (((size_t)ob * KS + s) * 64 + lane) * 8 + j;
+          hi[idx] = h;
+          lo[idx] = f16_rne(w - f16_to_float(h));
+        }
+}
 // direct image: img[(ob*S + s)*64 + lane] = get(row = ob*16 + (lane&15), k = 4*s + (lane>>4))
 template <class F>
 static void direct_image(float* img, int OB, int S, F get) {
@@ -122,9 +152,11 @@ static void f32_chain_image(float* img, int OB, int S, F get) {
 }
 
 // chain image of a layer in the given precision mode: bf16x3 hi/lo pair or exact fp32 (KS 32-wide k-steps = 8*KS fp32 k-steps)
+static float g_f16_weight_scale = 1.f;   // set by pack_mfma_images for the plan being packed (host side, one commit at a time)
 template <class F>
 static void chain_image_p(int prec, float* img, int OB, int KS, F get) {
   if (prec == kPrecBf16x3) chain_image(img, OB, KS, get);
+  else if (prec == kPrecF16x3) chain_image_h(img, OB, KS, g_f16_weight_scale, get);
   else f32_chain_image(img, OB, 8 * KS, get);
 }
 
@@ -132,6 +164,7 @@ void free_mfma_images(m3g_plan* plan) {
   auto drop = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   for (int prec = 0; prec < kNumPrec; ++prec) { drop(plan->d_mfma_fwd[prec]); drop(plan->d_mfma_rev[prec]); drop(plan->d_node_img[prec]); }
   drop(plan->d_mfma_revf);
+  drop(plan->d_mfma_revf_h);
   drop(plan->d_mfma_revf32);
   drop(plan->d_readout_img);
 }
@@ -151,6 +184,22 @@ int pack_mfma_images(m3g_plan* plan) {
   const MfmaRevFusedLayout Rf = mfma_rev_fused_layout();
   const MfmaRevF32Layout R32 = mfma_rev_f32_layout();
   std::vector<float> revf((size_t)std::max(B, 1) * Rf.total, 0.f), revf32((size_t)std::max(B, 1) * R32.total, 0.f);
+  std::vector<float> revfh((size_t)std::max(B, 1) * Rf.total, 0.f);   // fused reverse kernel, f16x3 mode
+  {  // f16x3 mode: ONE power of two for every weight that enters a chain image, putting the largest of them into [2^12, 2^13)
+     // (entries down to 2^-14 of it keep both fp16 parts normal; m3g_mfma_common.h)
+    float wmax = 0.f;
+    for (const auto& kv : plan->params) {
+      const std::string& k = kv.first;
+      const bool chain_weight = k.find(".concat_") != std::string::npos || k.find(".gated_mlp.") != std::string::npos ||
+                                k.find(".linear_sigmoid1.weight") != std::string::npos;
+      if (!chain_weight || k.find(".bias") != std::string::npos) continue;
+      for (float v : kv.second) wmax = std::max(wmax, std::fabs(v));
+    }
+    int e = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) (void)std::frexp(wmax, &e);   // wmax in [2^(e-1), 2^e)
+    g_f16_weight_scale = std::ldexp(1.f, 13 - e);
+    plan->w_scale_inv = std::ldexp(1.f, e - 13);
+  }
   for (int prec = 0; prec < kNumPrec; ++prec) {
   std::vector<float> node((size_t)std::max(B, 1) * kNodeImgFloats, 0.f);
   std::vector<float> fwd((size_t)std::max(B, 1) * F.total, 0.f), rev((size_t)std::max(B, 1) * Rv.per_block, 0.f);
@@ -169,7 +218,9 @@ int pack_mfma_images(m3g_plan* plan) {
     direct_image(f + F.tb, 8, kTbSteps, tbw);
     direct_image(r + Rv.tb, 8, kTbSteps, tbw);
     float* rf = revf.data() + (size_t)b * Rf.total;
+    float* rfh = revfh.data() + (size_t)b * Rf.total;
     direct_image(rf + Rf.tb, 8, kTbSteps, tbw);
+    direct_image(rfh + Rf.tb, 8, kTbSteps, tbw);
     // reverse three-body: rows = c (16), k = 0..127 over (dense f | gate f)
     auto tbT = [&](int row, int k) -> float {
       const float* w = k < 64 ? wd : wg;
@@ -178,6 +229,7 @@ int pack_mfma_images(m3g_plan* plan) {
     };
     chain_image_p(prec, r + Rv.tbT, 1, 4, tbT);
     chain_image(rf + Rf.tbT, 1, 4, tbT);
+    chain_image_h(rfh + Rf.tbT, 1, 4, g_f16_weight_scale, tbT);
     float* r32 = revf32.data() + (size_t)b * R32.total;   // fused fp32 reverse kernel
     direct_image(r32 + R32.tb, 8, kTbSteps, tbw);
     f32_chain_image(r32 + R32.tbT, 1, 32, tbT);
@@ -186,9 +238,10 @@ int pack_mfma_images(m3g_plan* plan) {
       auto adj = [&](int row, int k) -> float { return (row < D && k < R) ? wadj[(size_t)row * R + k] : 0.f; };
       direct_image(f + F.adj, 4, 1, adj);
       direct_image(rf + Rf.adj, 4, 1, adj);
+      direct_image(rfh + Rf.adj, 4, 1, adj);
       direct_image(r32 + R32.adj, 4, 1, adj);
       for (int o = 0; o < 64; ++o)
-        for (int rr = 0; rr < 4; ++rr) rf[Rf.adjp + o * 4 + rr] = r32[R32.adjp + o * 4 + rr] = adj(o, rr);
+        for (int rr = 0; rr < 4; ++rr) rf[Rf.adjp + o * 4 + rr] = rfh[Rf.adjp + o * 4 + rr] = r32[R32.adjp + o * 4 + rr] = adj(o, rr);
     }
     {  // node tables on the matrix pipe (k_node_pre_mfma): rows = table columns, k = node feature
       float* ni = node.data() + (size_t)b * kNodeImgFloats;
@@ -273,6 +326,12 @@ int pack_mfma_images(m3g_plan* plan) {
       bias_image(rf + Rf.mlp[m].b2);
       memcpy(rf + Rf.mlp[m].wl, rm + Rv.mlp.wl, sizeof(float) * 64 * 4);
       direct_image(rf + Rf.mlp[m].wld, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
+      pack_dual_image_h(rfh + Rf.mlp[m].w1c, 128, g_f16_weight_scale, w1c);
+      pack_dual_image_h(rfh + Rf.mlp[m].w2d, 64, g_f16_weight_scale, sq(w2d));
+      pack_dual_image_h(rfh + Rf.mlp[m].w2g, 64, g_f16_weight_scale, sq(w2g));
+      bias_image(rfh + Rf.mlp[m].b2);
+      memcpy(rfh + Rf.mlp[m].wl, rm + Rv.mlp.wl, sizeof(float) * 64 * 4);
+      memcpy(rfh + Rf.mlp[m].wld, rf + Rf.mlp[m].wld, sizeof(float) * 4 * 64);
       // fused fp32 reverse kernel: W2 as dual-use fp32 images, W1c transposed only
       pack_dual32_image(r32 + R32.mlp[m].w2d, 64, sq(w2d));
       pack_dual32_image(r32 + R32.mlp[m].w2g, 64, sq(w2g));
@@ -319,6 +378,7 @@ int pack_mfma_images(m3g_plan* plan) {
     { int rc = upload(plan->d_readout_img, img); if (rc) return rc; }
   }
   { int rc = upload(plan->d_mfma_revf, revf); if (rc) return rc; }
+  { int rc = upload(plan->d_mfma_revf_h, revfh); if (rc) return rc; }
   { int rc = upload(plan->d_mfma_revf32, revf32); if (rc) return rc; }
   return M3G_OK;
 }

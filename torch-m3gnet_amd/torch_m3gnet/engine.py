@@ -108,7 +108,7 @@ class Engine:
             _lib.check(lib.m3g_plan_set_const(plan, name.encode(), arr.ctypes.data, arr.size))
         _lib.check(lib.m3g_plan_commit(plan))
 
-    PRECISIONS = {"fp32": 0, "bf16x3": 1}
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "f16x3": 2}
 
     def set_precision(self, name: str) -> None:
         """Arithmetic of the dense gated-MLP products: "fp32" (default: exact fp32 MFMA products, the reference's arithmetic)
