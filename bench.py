@@ -80,19 +80,20 @@ BF16_MFMA_FLOP = 16384              # v_mfma_f32_16x16x32_bf16
 #   mfma           MFMAs issued per 16-edge tile (f32 16x16x4, bf16 16x16x32): executed FLOPs incl. zero padding.
 EDGE_KERNELS = {
     "edge_block_fwd": dict(kernel="k_edge_block_mfma", flops_8d=134_144, flops_useful=68_608, bytes_8d=2 * 256,
-                           design_bytes={"bf16x3": 2 * 256, "fp32": 2 * 256 + 2048},
-                           mfma={"bf16x3": (48, 192), "fp32": (545, 0)}),
-    "edge_rev_fused": dict(kernel={"bf16x3": "k_edge_rev_fused", "fp32": "k_edge_rev_f32"}, flops_8d=134_144, flops_useful=68_608,
-                           bytes_8d=3 * 256,
-                           design_bytes={"bf16x3": 3 * 256 + 256 + (2 * 768) / 3, "fp32": 2048 + (2 * (512 + 1024) + 256) / 3},
-                           mfma={"bf16x3": (48, 396), "fp32": (577, 0)}),
+                           design_bytes={"bf16x3": 2 * 256, "f16x3": 2 * 256, "fp32": 2 * 256 + 2048},
+                           mfma={"bf16x3": (48, 192), "f16x3": (48, 192), "fp32": (545, 0)}),
+    "edge_rev_fused": dict(kernel={"bf16x3": "k_edge_rev_fused", "f16x3": "k_edge_rev_fused", "fp32": "k_edge_rev_f32"}, flops_8d=134_144,
+                           flops_useful=68_608, bytes_8d=3 * 256,
+                           design_bytes={"bf16x3": 3 * 256 + 256 + (2 * 768) / 3, "f16x3": 3 * 256 + 256 + (2 * 1024) / 3,
+                                         "fp32": 2048 + (2 * (512 + 1024) + 256) / 3},
+                           mfma={"bf16x3": (48, 396), "f16x3": (48, 396), "fp32": (577, 0)}),
     # split reverse kernels (option rev_kernel = 0; fp32: layer 1 saved, layer 2 recomputed)
     "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", flops_8d=65_920, flops_useful=33_152, bytes_8d=2 * 256,
-                              design_bytes={"bf16x3": 2 * 256, "fp32": 512 + 256 + 512},
-                              mfma={"bf16x3": (8, 192), "fp32": (388, 0)}),
+                              design_bytes={"bf16x3": 2 * 256, "f16x3": 2 * 256, "fp32": 512 + 256 + 512},
+                              mfma={"bf16x3": (8, 192), "f16x3": (8, 192), "fp32": (388, 0)}),
     "edge_rev_edge_mlp": dict(kernel="k_edge_rev_edge_mlp", flops_8d=68_224, flops_useful=35_456, bytes_8d=3 * 256,
-                              design_bytes={"bf16x3": 4 * 256, "fp32": 512 + 3 * 256 + 512},
-                              mfma={"bf16x3": (56, 204), "fp32": (444, 0)}),
+                              design_bytes={"bf16x3": 4 * 256, "f16x3": 4 * 256, "fp32": 512 + 3 * 256 + 512},
+                              mfma={"bf16x3": (56, 204), "f16x3": (56, 204), "fp32": (444, 0)}),
 }
 FLOPS_RATIO_NOTE = ("flops_8d / flops_useful = 2: SURVEY.md 8(d) counts W1 [x_i | x_j | e] per edge; the kernels use the exact "
                     "factorisation TA[i] + TB[j] + W1c e, whose x_i / x_j parts are per-node tables (k_node_pre_mfma, 65,536 FLOP "
@@ -100,6 +101,10 @@ FLOPS_RATIO_NOTE = ("flops_8d / flops_useful = 2: SURVEY.md 8(d) counts W1 [x_i 
 BYTES_8D_PER_STEP = lambda E, T, N: 4008 * E + 48 * T + 3504 * N   # noqa: E731  SURVEY.md 8(d), D = 64, B = 3
 PMC_TRAFFIC_FILE = "r03_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py), stamped with
                                                 # the digest of the kernel sources it was collected on
+DEFAULT_PRECISION = "f16x3"
+DTYPE = {"fp32": "f32",
+         "f16x3": "f32 (every operand as two power-of-two-scaled f16 parts = 22-24 significant bits, 3 f16 MFMA products, f32 accumulate)",
+         "bf16x3": "f32 (operands as two bf16 parts = 16 significant bits, 3 bf16 MFMA products, f32 accumulate)"}
 METRIC = "atom-steps/sec (energy+forces) on 10k-atom PBC batch, 1/2/4/8 MI355X"
 
 
@@ -377,6 +382,17 @@ def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc):
                          "frac": t_useful / PEAK_F32_MFMA_TFLOPS, "executed_mfma_tflops": t_exe,
                          "executed_mfma_frac": t_exe / PEAK_F32_MFMA_TFLOPS, "flops_note": FLOPS_RATIO_NOTE}
             views[stage] = dict(common, **mfma_view, other_view=hbm_view)
+        elif precision == "f16x3":
+            # fp32-grade results from two-part f16 operands: priced like the fp32 mode -- USEFUL fp32 FLOPs against the fp32 matrix peak,
+            # the rate a native fp32 MFMA kernel could at best reach -- with the f16 pipe's own view beside it: the three products per
+            # fp32 product execute on the f16 matrix pipe, which (unlike the fp32 MFMA) co-executes with the vector instructions; the
+            # kernel is bound by its vector instruction issue (operand scaling / splitting, activations), not by either pipe.
+            t_useful, t_exe = useful / sec / 1e12, exe_flops / sec / 1e12
+            mfma_view = {"bound": "mfma", "achieved": t_useful, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": t_useful / PEAK_F32_MFMA_TFLOPS, "peak_is": "fp32 matrix peak (the arithmetic this mode reproduces)",
+                         "f16_pipe_view": {"executed_tflops": t_exe, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": t_exe / PEAK_BF16_MFMA_TFLOPS},
+                         "flops_note": FLOPS_RATIO_NOTE}
+            views[stage] = dict(common, **mfma_view, other_view=hbm_view)
         else:
             views[stage] = dict(common, **hbm_view,
                                 mfma_view={"useful_tflops": useful / sec / 1e12, "executed_tflops": exe_flops / sec / 1e12,
@@ -384,7 +400,7 @@ def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc):
     # HBM-bound kernels: bytes the data layout of DESIGN.md section 3 makes each launch move (every array the kernel must read or
     # write once; gathers from L2/MALL-resident node tables not counted)
     E, T, N, A = n_edges, n_trip, n_atoms, n_active
-    dp1_row = 1024 if precision == "fp32" else 768
+    dp1_row = 768 if precision == "bf16x3" else 1024
     hbm_kernels = {
         "geometry_basis": ("k_geometry", E * (8 + 12 + 12 + 4 + 16 + 16) + A * (64 + 64 + 8), 0),
         "threebody_fwd": ("k_threebody_fwd", A * (64 + 12 + 4 + 4 + 64) + T * 1, 0),
@@ -498,7 +514,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=("config3", "config4"), default="config3")
-    ap.add_argument("--precision", choices=("fp32", "bf16x3"), default="fp32", help="arithmetic of the headline figure")
+    ap.add_argument("--precision", choices=("f16x3", "fp32", "bf16x3"), default=DEFAULT_PRECISION, help="arithmetic of the headline figure")
     ap.add_argument("--cells", type=int, nargs=3, default=[10, 10, 25], help="config3: fcc cells per axis (4 atoms each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other-precision and config4 secondary figures")
@@ -513,10 +529,9 @@ def main():
     torch.set_num_threads(min(host_cores(), 16))
     model = default_model(device)
     model.engine.set_precision(args.precision)
-    other = "bf16x3" if args.precision == "fp32" else "fp32"
+    other_modes = [m for m in ("fp32", "f16x3", "bf16x3") if m != args.precision]
     out = {"metric": METRIC, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-           "dtype": "f32" if args.precision == "fp32" else "f32 (dense chains: 3x bf16 split MFMA, fp32 accumulate)"}
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic", "dtype": DTYPE[args.precision]}
 
     if args.workload == "config4":
         rec = measure_config4(job, model, args.steps, args.warmup)
@@ -603,15 +618,15 @@ def main():
                        "topology_build_ms": topo_ms, "stage_ms_per_step": stage_ms,
                        "multi_gpu": "replicas (a single cell does not shard); config4_sharded below runs the sharded path"})
     if not args.no_secondary:
-        model.engine.set_precision(other)
-        step()
-        el2 = job.timed(step, args.steps, args.warmup)
-        r2, o2, st2, sb2 = record(other, el2 / args.steps * 1e3)
-        out[other] = {"value": world * n_atoms * args.steps / el2, "unit": "atom-steps/s", "ms_per_step": el2 / args.steps * 1e3,
-                      "dtype": "f32" if other == "fp32" else "f32 operands split into 2 bf16 parts, 3 bf16 MFMA products per fp32 product, fp32 accumulate",
-                      "roofline": r2, "stage_ms_per_step": st2, "step_traffic_bytes": sb2}
+        for other in other_modes:   # the other arithmetic modes of the same engine, same workload, same timed-region rules
+            model.engine.set_precision(other)
+            step()
+            el2 = job.timed(step, args.steps, args.warmup)
+            r2, o2, st2, sb2 = record(other, el2 / args.steps * 1e3)
+            out[other] = {"value": world * n_atoms * args.steps / el2, "unit": "atom-steps/s", "ms_per_step": el2 / args.steps * 1e3,
+                          "dtype": DTYPE[other], "roofline": r2, "stage_ms_per_step": st2, "step_traffic_bytes": sb2}
+            log(f"{other}: {el2 / args.steps * 1e3:.3f} ms/step")
         model.engine.set_precision(args.precision)
-        log(f"{other}: {el2 / args.steps * 1e3:.3f} ms/step")
         out["config4_sharded"] = measure_config4(job, model, max(5, args.steps // 2), 2)
         log(f"config4_sharded: {out['config4_sharded']['ms_per_step']:.3f} ms/step")
         if world == 1 and tuple(args.cells) == (10, 10, 25):

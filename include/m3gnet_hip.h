@@ -85,11 +85,15 @@ int m3g_plan_set_param(m3g_plan* plan, const char* key, const float* host_data, 
 int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data, int64_t numel);
 
 /* Engine options (not part of the reference):
- *   "precision"   = 0 (default) every dense product of the gated MLPs on v_mfma_f32_16x16x4_f32: exact fp32 products, fp32
- *                   accumulate -- the reference's arithmetic (nn/core.py:61-62, fp32 Linear layers);
- *                   1 = "bf16x3": each fp32 operand split into two bf16 parts, three v_mfma_f32_16x16x32_bf16 products per fp32
- *                   product, fp32 accumulate (relative product error ~2^-16; faster, parity within north_star's tolerances);
- *                   both weight image sets are resident after a commit, switching costs nothing;
+ *   "precision"   arithmetic of the dense products of the gated MLPs (nn/core.py:61-62: fp32 Linear layers), fp32 accumulate in all modes:
+ *                   2 (default) "f16x3": every operand scaled by a power of two (weights: one for the model; activations and gradients:
+ *                   one per edge and chain, chosen from the data) and split in two fp16 parts that together carry 22-24 significant
+ *                   bits, three v_mfma_f32_16x16x32_f16 products per fp32 product -- errors ~1.8 x those of an fp32 fmaf chain,
+ *                   parity inside north_star's tolerances with the margins of the exact mode on every case;
+ *                   0 "fp32": every product on v_mfma_f32_16x16x4_f32, exact fp32 products (the reference's arithmetic);
+ *                   1 "bf16x3": two bf16 parts (16 significant bits), three v_mfma_f32_16x16x32_bf16 products (relative product
+ *                   error ~2^-16; the fastest mode, parity within north_star's tolerances on near-linear weights only);
+ *                   all weight image sets are resident after a commit, switching costs nothing;
  *   "edge_kernel" = 1 fused MFMA edge blocks (default), 0 = vector-ALU baseline kernels (also M3G_EDGE_KERNEL in the env),
  *                   2 = the any-size path (run-time-sized fp32 kernels; chosen automatically for embedding_dim > 64,
  *                   l_max or n_max > 4, more than 8 blocks -- up to the reference's own limits l_max <= 9, n_max <= 10);

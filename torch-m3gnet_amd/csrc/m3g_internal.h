@@ -202,7 +202,7 @@ struct m3g_plan {
   float* d_mfma_revf_h = nullptr;  // the same layout holding fp16 parts of the scaled weights (f16x3 mode)
   float* d_mfma_revf32 = nullptr;  // [num_blocks][MfmaRevF32Layout.total] (fused fp32 reverse kernel)
   float* d_node_img[m3g::kNumPrec] = {nullptr, nullptr, nullptr};   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
-  int precision = m3g::kPrecF32; // option "precision"
+  int precision = m3g::kPrecF16x3; // option "precision" (default: fp32-grade results from scaled two-part fp16 operands; 0 = exact fp32 MFMA products)
   float w_scale_inv = 1.f;       // f16x3 mode: 1 / (the power of two all chain-image weights were multiplied by), set by pack_mfma_images
   int save_p1 = 1;               // option "save_p1" (fp32 mode only): 0 = recompute layer 1 in the reverse kernels (A/B tests)
   int save_p2 = 1;               // option "save_p2" (fp32 mode, fused reverse): 0 = recompute layer 2 in the reverse kernel

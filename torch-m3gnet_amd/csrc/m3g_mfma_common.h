@@ -79,14 +79,35 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// scaled split of one value pair: hi = fp16(s x) (v_fma_mixlo/cvt_pk, RNE), lo = fp16(s x - hi) (v_fma_mix + v_cvt_pkrtz: the
-// residual has at most 12 significant bits, truncation loses at most one)
+// scaled split of one value pair: hi = fp16(s x) (round to nearest), lo = fp16(s x - hi) (the residual has at most 12
+// significant bits: truncation loses at most one).  Five vector instructions per PAIR, the scaling included: v_fma_mixlo_f16 /
+// v_fma_mixhi_f16 form fp16(s a) and fp16(s b) in the two halves of one register straight from the fp32 inputs, v_fma_mix_f32
+// forms s a - hi with the fp16 half as its addend (op_sel picks the half), v_cvt_pkrtz_f16_f32 packs the residuals.  The compiler
+// finds the mix forms too but builds the packed hi with two extra multiplies and a v_cvt_pk on top (8 per pair).
+// Hazards inside the block (the recogniser does not look into inline assembly): a half-register write (v_fma_mixlo/hi) needs one
+// wait state before a vector instruction reads that register (dst_sel / op_sel forwarding, gfx940+): the reader of the low half
+// comes two instructions after its writer, the reader of the high half two after its.
+#ifndef M3G_SPLIT_H_PLAIN
+__device__ __forceinline__ void split_pair_h(float a, float b, float s, f16x2& hi, f16x2& lo) {
+  unsigned h;
+  float ra, rb;
+  asm("v_fma_mixlo_f16 %0, %3, %4, 0\n\t"
+      "v_fma_mixhi_f16 %0, %3, %5, 0\n\t"
+      "v_fma_mix_f32 %1, %3, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %2, %3, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(h), "=&v"(ra), "=v"(rb)
+      : "v"(s), "v"(a), "v"(b));
+  hi = __builtin_bit_cast(f16x2, h);
+  lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+#else
 __device__ __forceinline__ void split_pair_h(float a, float b, float s, f16x2& hi, f16x2& lo) {
   const float as = a * s, bs = b * s;
   hi = f16x2{(_Float16)as, (_Float16)bs};
   const float ra = __builtin_fmaf((float)hi[0], -1.0f, as), rb = __builtin_fmaf((float)hi[1], -1.0f, bs);
   lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
+#endif
 // B operand of one k-step (accumulator blocks a, b scaled by s): element j < 4 from a, j >= 4 from b (as split8)
 __device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, float s, f16x8& hi, f16x8& lo) {
   f16x2 h[4], l[4];
