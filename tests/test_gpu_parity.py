@@ -353,3 +353,48 @@ def test_single_pair_triplet_list_against_the_reference_entry_by_entry():
         assert mine_vs_64 < 1e-5
         assert rel_err(g[K.FORCES], expect["out_forces"]) < F_TOL
         assert rel_err(g[K.TOTAL_ENERGY], expect["out_total_energy"]) < E_TOL
+
+
+@pytest.mark.parametrize("energy_scale,w_scale,outlier", [(1e-6, 1.0, 0.0), (1e6, 1.0, 0.0), (1.0, 4.0, 0.0), (1.0, 1.0, 60.0), (3e-4, 4.0, 25.0)])
+def test_f16x3_range_handling_tracks_the_exact_mode(energy_scale, w_scale, outlier):
+    """The f16x3 mode represents every operand as two fp16 parts of a power-of-two-scaled value; fp16 has 5 exponent bits.  What
+    keeps that safe is the per-edge scale taken from the data and the per-model weight scale -- exercised here where a fixed
+    scale would overflow or flush: gradients of 1e-9 and of 1e+6 (energy_scale 1e-6 / 1e6 multiplies the whole reverse pass),
+    saturated activations (weights x4; at x5.5 this random model is chaotic -- max|F| = 3e4 eV/A, node features of the two modes
+    7e-6 apart -- and at x8 its forces underflow to exactly zero in the exact mode as well), and single weights 25-60 x larger than the rest of their
+    matrix (the model's weight scale is set by the largest, the others must keep their precision).  The exact-fp32 mode of the
+    same engine is the witness: energies to 1e-5, forces to 5e-5 of max|F|, stresses to 1e-4 (measured: 2e-7 .. 2e-6 on the well-conditioned
+    cases); a range failure would show as inf / NaN or errors of order one."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.model.build import build_model
+
+    params, cfg, consts, graph, expect = load_oracle_case("mix", "doc")
+    torch.manual_seed(11)
+    model = build_model(cfg.cutoff, cfg.threebody_cutoff, cfg.l_max, cfg.n_max, cfg.num_types, cfg.embedding_dim, cfg.num_blocks,
+                        elemental_energies=consts.elemental_energies.float(), energy_scale=energy_scale, length_scale=cfg.length_scale)
+    with torch.no_grad():
+        for name, p in model.model.named_parameters():
+            if not name.endswith("bias"):
+                p.mul_(w_scale)
+        if outlier:
+            for name, p in model.model.named_parameters():
+                if name.endswith("dense.2.weight") or name.endswith("gate.0.weight"):
+                    p.view(-1)[7] = outlier * float(p.abs().mean())
+                    p.view(-1)[-3] = -outlier * float(p.abs().mean())
+    for m in model.model:
+        if type(m).__name__ == "ThreeBodyInteration":
+            m.nsb.factors = expect["const_factors"].clone()
+    outs = {}
+    for precision in ("fp32", "f16x3"):
+        model.engine.set_precision(precision)
+        g = model(engine_graph(graph))
+        outs[precision] = {k: g[k].clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES, K.NODE_FEATURES, K.EDGE_ATTR)}
+    a, b = outs["fp32"], outs["f16x3"]
+    assert torch.isfinite(b[K.FORCES]).all() and torch.isfinite(b[K.TOTAL_ENERGY]).all()
+    assert float(a[K.FORCES].abs().max()) > 0
+    e_err = float(((a[K.TOTAL_ENERGY] - b[K.TOTAL_ENERGY]).abs() / a[K.TOTAL_ENERGY].abs()).max())
+    f_err, s_err = rel_err(b[K.FORCES], a[K.FORCES]), rel_err(b[K.STRESSES], a[K.STRESSES])
+    print(f"f16x3 vs fp32 mode (energy_scale {energy_scale:g}, weights x{w_scale:g}, outlier {outlier:g}): E {e_err:.1e} F {f_err:.1e} of max|F| = "
+          f"{float(a[K.FORCES].abs().max()):.2e}, stress {s_err:.1e}, x {rel_err(b[K.NODE_FEATURES], a[K.NODE_FEATURES]):.1e}")
+    assert e_err < 1e-5 and f_err < 5e-5 and s_err < 1e-4
+    assert rel_err(b[K.NODE_FEATURES], a[K.NODE_FEATURES]) < 1e-5 and rel_err(b[K.EDGE_ATTR], a[K.EDGE_ATTR]) < 1e-5

@@ -124,7 +124,7 @@ __device__ __forceinline__ void chain_dual_h(const float* img, const f32x4 (&x)[
       t = mfma_f16(ah, b.lo[s], t);
       t = mfma_f16(al, b.hi[s], t);
     });
-    static_for<4>([&]<int r>() { acc[AOFF + ob][r] = __builtin_fmaf(t[r], inv, acc[AOFF + ob][r]); });
+    acc[AOFF + ob] = t * inv + acc[AOFF + ob];   // (vector form: the compiler emits two v_pk_fma_f32)
   });
   M3G_CHAIN_PRIO(0);
 }
@@ -153,7 +153,7 @@ __device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d
       t = mfma_f16(ah, b.lo[s], t);
       t = mfma_f16(al, b.hi[s], t);
     });
-    static_for<4>([&]<int r>() { acc[AOFF + ob][r] = __builtin_fmaf(t[r], inv, acc[AOFF + ob][r]); });
+    acc[AOFF + ob] = t * inv + acc[AOFF + ob];   // (vector form: the compiler emits two v_pk_fma_f32)
   });
   M3G_CHAIN_PRIO(0);
 }

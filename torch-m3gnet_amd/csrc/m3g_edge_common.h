@@ -134,7 +134,7 @@ __device__ __forceinline__ void chain_h_acc(const float* img, const f32x4 (&x)[N
   const HalfB<KS> b = split_h<KS, XOFF>(x, sc.s);
   const float inv = sc.inv * w_inv;
   chain_h<OB, KS>(img, b, lane, [&]<int ob>(const f32x4& t) {
-    static_for<4>([&]<int r>() { acc[AOFF + ob][r] = __builtin_fmaf(t[r], inv, acc[AOFF + ob][r]); });
+    acc[AOFF + ob] = t * inv + acc[AOFF + ob];   // (vector form: the compiler emits two v_pk_fma_f32)
   });
 }
 
