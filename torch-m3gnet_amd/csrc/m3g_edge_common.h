@@ -355,6 +355,56 @@ __device__ __forceinline__ void tb_preact(const float* tbimg, const float (&mb)[
   });
 }
 
+// The three-body MLP input of one tile in the form its precision mode consumes.  fp32 / bf16x3: TBS k-step values per lane for
+// exact fp32 MFMAs (24 per tile -- which occupy the SIMD's fp32 datapath for 32 cycles each, section 4a of DESIGN.md).  f16x3:
+// the aggregate row as ONE K = 32 f16 k-step -- lane (edge, q) carries columns 8q .. 8q+7 (q < 2; l_max n_max <= 16), scaled per edge
+// and split once, used by both evaluations of the reverse kernel -- so the 128 pre-activations cost 24 f16 MFMAs on the matrix
+// pipe, which runs beside the vector work, plus ~60 vector instructions (scale, split, unscale).
+template <int PREC, int TBS>
+struct TbIn { float mb[TBS]; };
+template <int TBS>
+struct TbIn<kPrecF16x3, TBS> { f16x8 hi, lo; float inv; };
+
+template <int PREC, int TBS>
+__device__ __forceinline__ TbIn<PREC, TBS> tb_load(const float* __restrict__ m, int arow, int q, float w_inv) {
+  TbIn<PREC, TBS> r;
+  if constexpr (PREC == kPrecF16x3) {
+    f32x4 v[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (arow >= 0 && q < 2) {   // (< 0: the edge takes part in no triplet, its aggregate is zero)
+      const float* row = m + (int64_t)arow * kCP + 8 * q;
+      v[0] = *(const f32x4*)row;
+      v[1] = *(const f32x4*)(row + 4);
+    }
+    const EdgeScale sc = edge_scale<2>(v);
+    split8h(v[0], v[1], sc.s, r.hi, r.lo);
+    r.inv = sc.inv * w_inv;
+  } else {
+    static_for<TBS>([&]<int s>() { r.mb[s] = arow >= 0 ? m[(int64_t)arow * kCP + 4 * s + q] : 0.f; });
+  }
+  return r;
+}
+// p[0..3] dense, p[4..7] gate pre-activations of the three-body MLP.  f16x3 image (tb_image_h, m3g_pack_mfma.hip): [hi | lo]
+// [8 row blocks][32 lanes (q < 2)][8 halves]: lanes of quarters 2, 3 supply zeros (their k range is beyond l_max n_max)
+template <int PREC, int TBS>
+__device__ __forceinline__ void tb_preact_p(const float* tbimg, const TbIn<PREC, TBS>& in, f32x4 (&p)[8], int lane) {
+  if constexpr (PREC == kPrecF16x3) {
+    const int q = lane >> 4;
+    const f16x8* hi = reinterpret_cast<const f16x8*>(tbimg) + (lane & 31);
+    const f16x8* lo = hi + 8 * 32;
+    static_for<8>([&]<int ob>() {
+      f16x8 ah = {0, 0, 0, 0, 0, 0, 0, 0}, al = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < 2) { ah = hi[ob * 32]; al = lo[ob * 32]; }
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      t = mfma_f16(ah, in.hi, t);
+      t = mfma_f16(ah, in.lo, t);
+      t = mfma_f16(al, in.hi, t);
+      p[ob] = t * in.inv;
+    });
+  } else {
+    tb_preact<TBS>(tbimg, in.mb, p, lane);
+  }
+}
+
 // layer-1 accumulators start from the gathered per-node tables TA[i] + TB[j] (x_i / x_j parts, bias folded)
 __device__ __forceinline__ void gather_tables(const float* __restrict__ TA, const float* __restrict__ TB, int mlp, int64_t ci,
                                               int64_t cj, int qd, f32x4 (&p1)[8]) {

@@ -142,13 +142,8 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
     float* e_otile = a.e_out + tile * kTileFloats + tl_out * 4;
     f32x4 x[4];
     if (!FIRST) static_for<4>([&]<int blk>() { x[blk] = load_tile4(e_tile + blk * 256); });
-    float mb[TBS];
     const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
-    static_for<TBS>([&]<int s>() { mb[s] = 0.f; });
-    if (arow >= 0) {                 // one masked region: the TBS loads issue back to back
-      const float* mrow = a.m + (int64_t)arow * kCP + qv;
-      static_for<TBS>([&]<int s>() { mb[s] = mrow[4 * s]; });
-    }
+    const TbIn<PREC, TBS> tbin = tb_load<PREC, TBS>(a.m, arow, qv, a.w_inv);
     const float hb = a.h[ec * kRP + qv];
     if (FIRST) {
       static_for<4>([&]<int blk>() {
@@ -159,7 +154,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
     st.template mark<0>();  // tile loads issued
     {  // three-body gated update (nn/interaction.py:220-221)
       f32x4 p[8];
-      tb_preact<TBS>(lds + L.tb, mb, p, lv);
+      tb_preact_p<PREC, TBS>(lds + L.tb, tbin, p, lv);
       static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
     }
     st.template mark<1>();  // three-body MLP
@@ -551,9 +546,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     const float* e_tile = a.e_tile + tile * kTileFloats + lane * 4;
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
-    float mb[TBS];
     const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
-    static_for<TBS>([&]<int s>() { mb[s] = arow >= 0 ? a.m[(int64_t)arow * kCP + 4 * s + qd] : 0.f; });
+    const TbIn<PREC, TBS> tbin = tb_load<PREC, TBS>(a.m, arow, qd, a.w_inv);
     f32x4 x[4], de[4], contrib[4];
     constexpr bool FIRST = !NEED_DP1;   // block 0: its input is the edge embedding e0 = SiLU(W_adj h), formed here
     {
@@ -589,7 +583,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     }
     {  // e1 = e_in + three-body gated update (the edge MLP's input)
       f32x4 p[8];
-      tb_preact<TBS>(lds + L.tb, mb, p, lv);
+      tb_preact_p<PREC, TBS>(lds + L.tb, tbin, p, lv);
       static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
     }
     mlp_reverse_dual<NEED_DP1, 0, PREC>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv);
@@ -612,7 +606,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     }
     // three-body gated update, reverse
     f32x4 d8[8];
-    tb_preact<TBS>(lds + L.tb, mb, d8, lv);
+    tb_preact_p<PREC, TBS>(lds + L.tb, tbin, d8, lv);
     static_for<4>([&]<int blk>() {
       static_for<4>([&]<int r>() {
         const float p = d8[blk][r], sgd = fsigmoid(p), sg = fsigmoid(d8[4 + blk][r]);

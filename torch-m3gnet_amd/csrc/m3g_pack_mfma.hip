@@ -132,6 +132,22 @@ static void chain_image_h(float* img, int OB, int KS, float scale, F get) {
           lo[idx] = f16_rne(w - f16_to_float(h));
         }
 }
+// three-body MLP image of the f16x3 mode (tb_preact_p, m3g_edge_common.h): one K = 32 k-step whose columns beyond 16 are zero,
+// so only lane quarters 0 and 1 are stored: [hi | lo][8 row blocks][32 lanes][8 halves] = 8 KB, the size of the fp32 direct image
+template <class F>
+static void tb_image_h(float* img, float scale, F get) {
+  uint16_t* hi = reinterpret_cast<uint16_t*>(img);
+  uint16_t* lo = hi + 8 * 32 * 8;
+  for (int ob = 0; ob < 8; ++ob)
+    for (int lane = 0; lane < 32; ++lane)
+      for (int j = 0; j < 8; ++j) {
+        const float w = get(ob * 16 + (lane & 15), 8 * (lane >> 4) + j) * scale;
+        const uint16_t h = f16_rne(w);
+        const size_t idx = ((size_t)ob * 32 + lane) * 8 + j;
+        hi[idx] = h;
+        lo[idx] = f16_rne(w - f16_to_float(h));
+      }
+}
 // direct image: img[(ob*S + s)*64 + lane] = get(row = ob*16 + (lane&15), k = 4*s + (lane>>4))
 template <class F>
 static void direct_image(float* img, int OB, int S, F get) {
@@ -152,11 +168,11 @@ static void f32_chain_image(float* img, int OB, int S, F get) {
 }
 
 // chain image of a layer in the given precision mode: bf16x3 hi/lo pair or exact fp32 (KS 32-wide k-steps = 8*KS fp32 k-steps)
-static float g_f16_weight_scale = 1.f;   // set by pack_mfma_images for the plan being packed (host side, one commit at a time)
+// (`wscale`: the f16x3 mode's power of two for the weights of this plan; unused in the other modes)
 template <class F>
-static void chain_image_p(int prec, float* img, int OB, int KS, F get) {
+static void chain_image_p(int prec, float wscale, float* img, int OB, int KS, F get) {
   if (prec == kPrecBf16x3) chain_image(img, OB, KS, get);
-  else if (prec == kPrecF16x3) chain_image_h(img, OB, KS, g_f16_weight_scale, get);
+  else if (prec == kPrecF16x3) chain_image_h(img, OB, KS, wscale, get);
   else f32_chain_image(img, OB, 8 * KS, get);
 }
 
@@ -185,6 +201,7 @@ int pack_mfma_images(m3g_plan* plan) {
   const MfmaRevF32Layout R32 = mfma_rev_f32_layout();
   std::vector<float> revf((size_t)std::max(B, 1) * Rf.total, 0.f), revf32((size_t)std::max(B, 1) * R32.total, 0.f);
   std::vector<float> revfh((size_t)std::max(B, 1) * Rf.total, 0.f);   // fused reverse kernel, f16x3 mode
+  float wscale = 1.f;
   {  // f16x3 mode: ONE power of two for every weight that enters a chain image, putting the largest of them into [2^12, 2^13)
      // (entries down to 2^-14 of it keep both fp16 parts normal; m3g_mfma_common.h)
     float wmax = 0.f;
@@ -197,7 +214,7 @@ int pack_mfma_images(m3g_plan* plan) {
     }
     int e = 0;
     if (wmax > 0.f && std::isfinite(wmax)) (void)std::frexp(wmax, &e);   // wmax in [2^(e-1), 2^e)
-    g_f16_weight_scale = std::ldexp(1.f, 13 - e);
+    wscale = std::ldexp(1.f, 13 - e);
     plan->w_scale_inv = std::ldexp(1.f, e - 13);
   }
   for (int prec = 0; prec < kNumPrec; ++prec) {
@@ -215,21 +232,22 @@ int pack_mfma_images(m3g_plan* plan) {
       int o = row & 63;
       return (o < D && k < C) ? w[(size_t)o * C + k] : 0.f;
     };
-    direct_image(f + F.tb, 8, kTbSteps, tbw);
-    direct_image(r + Rv.tb, 8, kTbSteps, tbw);
+    if (prec == kPrecF16x3) tb_image_h(f + F.tb, wscale, tbw);
+    else direct_image(f + F.tb, 8, kTbSteps, tbw);
+    direct_image(r + Rv.tb, 8, kTbSteps, tbw);   // (the split reverse kernels keep the exact fp32 three-body products in every mode)
     float* rf = revf.data() + (size_t)b * Rf.total;
     float* rfh = revfh.data() + (size_t)b * Rf.total;
     direct_image(rf + Rf.tb, 8, kTbSteps, tbw);
-    direct_image(rfh + Rf.tb, 8, kTbSteps, tbw);
+    tb_image_h(rfh + Rf.tb, wscale, tbw);
     // reverse three-body: rows = c (16), k = 0..127 over (dense f | gate f)
     auto tbT = [&](int row, int k) -> float {
       const float* w = k < 64 ? wd : wg;
       int o = k & 63;
       return (row < C && o < D) ? w[(size_t)o * C + row] : 0.f;
     };
-    chain_image_p(prec, r + Rv.tbT, 1, 4, tbT);
+    chain_image_p(prec, wscale, r + Rv.tbT, 1, 4, tbT);
     chain_image(rf + Rf.tbT, 1, 4, tbT);
-    chain_image_h(rfh + Rf.tbT, 1, 4, g_f16_weight_scale, tbT);
+    chain_image_h(rfh + Rf.tbT, 1, 4, wscale, tbT);
     float* r32 = revf32.data() + (size_t)b * R32.total;   // fused fp32 reverse kernel
     direct_image(r32 + R32.tb, 8, kTbSteps, tbw);
     f32_chain_image(r32 + R32.tbT, 1, 32, tbT);
@@ -267,7 +285,7 @@ int pack_mfma_images(m3g_plan* plan) {
       };
       // three bf16x3 chain images of 11 row blocks each (the kernel keeps 11 accumulator blocks per pass)
       for (int g = 0; g < 3; ++g)
-        chain_image_p(prec, ni + (size_t)g * 11 * 2 * 512, 11, 2, [&](int row, int k) -> float { return row_w(g * 176 + row, k); });
+        chain_image_p(prec, wscale, ni + (size_t)g * 11 * 2 * 512, 11, 2, [&](int row, int k) -> float { return row_w(g * 176 + row, k); });
       float* bias = ni + kNodeRowBlocks * 16 * 64;
       for (int row = 0; row < kNodeRowBlocks * 16; ++row) {
         float v = 0.f;
@@ -303,20 +321,20 @@ int pack_mfma_images(m3g_plan* plan) {
               img[(g * 4 + ob) * 64 + lane] = (lane < 16 && o < D) ? (g == 0 ? b2d[o] : b2g[o]) : 0.f;
             }
       };
-      chain_image_p(prec, f + F.mlp[m].w1c, 8, 2, w1c);
-      chain_image_p(prec, f + F.mlp[m].w2d, 4, 2, sq(w2d));
-      chain_image_p(prec, f + F.mlp[m].w2g, 4, 2, sq(w2g));
+      chain_image_p(prec, wscale, f + F.mlp[m].w1c, 8, 2, w1c);
+      chain_image_p(prec, wscale, f + F.mlp[m].w2d, 4, 2, sq(w2d));
+      chain_image_p(prec, wscale, f + F.mlp[m].w2g, 4, 2, sq(w2g));
       bias_image(f + F.mlp[m].b2);
       direct_image(f + F.mlp[m].wl, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
       // reverse images: m == 0 (edge MLP) at offset 0, m == 1 (node MLP) after the edge image
       float* rm = r + (m == 0 ? 0 : Rv.total_e);
-      chain_image_p(prec, rm + Rv.mlp.w1c, 8, 2, w1c);
-      chain_image_p(prec, rm + Rv.mlp.w2d, 4, 2, sq(w2d));
-      chain_image_p(prec, rm + Rv.mlp.w2g, 4, 2, sq(w2g));
+      chain_image_p(prec, wscale, rm + Rv.mlp.w1c, 8, 2, w1c);
+      chain_image_p(prec, wscale, rm + Rv.mlp.w2d, 4, 2, sq(w2d));
+      chain_image_p(prec, wscale, rm + Rv.mlp.w2g, 4, 2, sq(w2g));
       bias_image(rm + Rv.mlp.b2);
-      chain_image_p(prec, rm + Rv.mlp.w2dT, 4, 2, sqT(w2d));
-      chain_image_p(prec, rm + Rv.mlp.w2gT, 4, 2, sqT(w2g));
-      chain_image_p(prec, rm + Rv.mlp.w1cT, 4, 4, [&](int row, int k) -> float { return w1c(k, row); });
+      chain_image_p(prec, wscale, rm + Rv.mlp.w2dT, 4, 2, sqT(w2d));
+      chain_image_p(prec, wscale, rm + Rv.mlp.w2gT, 4, 2, sqT(w2g));
+      chain_image_p(prec, wscale, rm + Rv.mlp.w1cT, 4, 4, [&](int row, int k) -> float { return w1c(k, row); });
       for (int o = 0; o < 64; ++o)
         for (int rr = 0; rr < 4; ++rr) rm[Rv.mlp.wl + o * 4 + rr] = (o < D && rr < R) ? wl[(size_t)o * R + rr] : 0.f;
       // fused reverse kernel: one dual-use image per matrix
@@ -326,9 +344,9 @@ int pack_mfma_images(m3g_plan* plan) {
       bias_image(rf + Rf.mlp[m].b2);
       memcpy(rf + Rf.mlp[m].wl, rm + Rv.mlp.wl, sizeof(float) * 64 * 4);
       direct_image(rf + Rf.mlp[m].wld, 4, 1, [&](int row, int k) -> float { return (row < D && k < R) ? wl[(size_t)row * R + k] : 0.f; });
-      pack_dual_image_h(rfh + Rf.mlp[m].w1c, 128, g_f16_weight_scale, w1c);
-      pack_dual_image_h(rfh + Rf.mlp[m].w2d, 64, g_f16_weight_scale, sq(w2d));
-      pack_dual_image_h(rfh + Rf.mlp[m].w2g, 64, g_f16_weight_scale, sq(w2g));
+      pack_dual_image_h(rfh + Rf.mlp[m].w1c, 128, wscale, w1c);
+      pack_dual_image_h(rfh + Rf.mlp[m].w2d, 64, wscale, sq(w2d));
+      pack_dual_image_h(rfh + Rf.mlp[m].w2g, 64, wscale, sq(w2g));
       bias_image(rfh + Rf.mlp[m].b2);
       memcpy(rfh + Rf.mlp[m].wl, rm + Rv.mlp.wl, sizeof(float) * 64 * 4);
       memcpy(rfh + Rf.mlp[m].wld, rf + Rf.mlp[m].wld, sizeof(float) * 4 * 64);
