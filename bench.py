@@ -602,7 +602,9 @@ def main():
         stage_ms = {k: round(ms * cnt, 4) for k, (ms, cnt) in per_launch.items()}
         views[dom]["traffic_source"] = traffic_source
         pm = pmc_all.get(precision, {})
-        total = sum(r["launches_per_step"] * (2.0 * r["fetch_kb"] + r["write_kb"]) * 1024.0 for r in pm.values()) if pm else None
+        # (kernels that run less than once per step belong to the topology build of the first call, not to the step)
+        total = sum(r["launches_per_step"] * (2.0 * r["fetch_kb"] + r["write_kb"]) * 1024.0 for r in pm.values()
+                    if r["launches_per_step"] >= 0.99) if pm else None
         ideal = BYTES_8D_PER_STEP(n_edges, n_trip, n_atoms)
         step_bytes = {"traffic": total, "algorithmic_bytes_8d": ideal, "traffic_over_algorithmic": (total / ideal) if total else None,
                       "source": traffic_source["file"] if total else None}

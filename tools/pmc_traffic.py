@@ -59,7 +59,7 @@ else:
 total = 0.0
 for k, v in sorted(kernels.items(), key=lambda kv: -(2 * kv[1]["fetch_kb"] + kv[1]["write_kb"]) * kv[1]["launches_per_step"]):
     b = (2 * v["fetch_kb"] + v["write_kb"]) * 1024.0
-    total += b * v["launches_per_step"]
+    total += b * v["launches_per_step"] if v["launches_per_step"] >= 0.99 else 0.0   # (< 1: topology build of the first call)
     print(f"{k:32s} fetch {v['fetch_kb'] / 1024:9.1f} MiB (x2 corrected {2 * v['fetch_kb'] / 1024:9.1f})  write {v['write_kb'] / 1024:9.1f} MiB"
           f"   x {v['launches_per_step']:.2f} per step = {b * v['launches_per_step'] / 1e6:9.1f} MB")
 print(f"{'whole step':32s} {total / 1e9:.3f} GB")
