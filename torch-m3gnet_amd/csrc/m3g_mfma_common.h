@@ -79,8 +79,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// scaled split of one value pair: hi = fp16(s x) (round to nearest), lo = fp16(s x - hi) (the residual has at most 12
-// significant bits: truncation loses at most one).  Five vector instructions per PAIR, the scaling included: v_fma_mixlo_f16 /
+// scaled split of one value pair: hi = fp16(s x), lo = fp16(s x - hi), both rounded to nearest (the residual has at most 12
+// significant bits, so hi + lo is s x to within 2^-24 relative: half an fp32 ulp).  Five vector instructions per PAIR, the scaling included: v_fma_mixlo_f16 /
 // v_fma_mixhi_f16 form fp16(s a) and fp16(s b) in the two halves of one register straight from the fp32 inputs, v_fma_mix_f32
 // forms s a - hi with the fp16 half as its addend (op_sel picks the half), v_cvt_pkrtz_f16_f32 packs the residuals.  The compiler
 // finds the mix forms too but builds the packed hi with two extra multiplies and a v_cvt_pk on top (8 per pair).
@@ -98,14 +98,14 @@ __device__ __forceinline__ void split_pair_h(float a, float b, float s, f16x2& h
       : "=&v"(h), "=&v"(ra), "=v"(rb)
       : "v"(s), "v"(a), "v"(b));
   hi = __builtin_bit_cast(f16x2, h);
-  lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+  lo = f16x2{(_Float16)ra, (_Float16)rb};   // v_cvt_pk_f16_f32: round to nearest, like the high part
 }
 #else
 __device__ __forceinline__ void split_pair_h(float a, float b, float s, f16x2& hi, f16x2& lo) {
   const float as = a * s, bs = b * s;
   hi = f16x2{(_Float16)as, (_Float16)bs};
   const float ra = __builtin_fmaf((float)hi[0], -1.0f, as), rb = __builtin_fmaf((float)hi[1], -1.0f, bs);
-  lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+  lo = f16x2{(_Float16)ra, (_Float16)rb};
 }
 #endif
 // B operand of one k-step (accumulator blocks a, b scaled by s): element j < 4 from a, j >= 4 from b (as split8)
