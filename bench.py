@@ -516,6 +516,8 @@ def main():
     ap.add_argument("--workload", choices=("config3", "config4"), default="config3")
     ap.add_argument("--precision", choices=("f16x3", "fp32", "bf16x3"), default=DEFAULT_PRECISION, help="arithmetic of the headline figure")
     ap.add_argument("--cells", type=int, nargs=3, default=[10, 10, 25], help="config3: fcc cells per axis (4 atoms each)")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=INT",
+                    help="engine option for A/B timing (m3g_plan_set_option), e.g. threebody_moments=0; recorded in config.engine_options")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other-precision and config4 secondary figures")
     args = ap.parse_args()
@@ -529,6 +531,9 @@ def main():
     torch.set_num_threads(min(host_cores(), 16))
     model = default_model(device)
     model.engine.set_precision(args.precision)
+    for opt in args.engine_option:
+        name, _, val = opt.partition("=")
+        model.engine.set_option(name, int(val))
     other_modes = [m for m in ("fp32", "f16x3", "bf16x3") if m != args.precision]
     out = {"metric": METRIC, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic", "dtype": DTYPE[args.precision]}
@@ -615,7 +620,8 @@ def main():
                config={"workload": f"single {n_atoms}-atom fcc Cu PBC supercell per GPU ({'x'.join(map(str, args.cells))} cells, "
                                    "a=3.61 A, jitter 0.025 A), r_cut 5 A / 3-body 4 A, default M3GNet (l_max=n_max=3, D=64, "
                                    "3 blocks), energy+forces+stress",
-                       "precision": args.precision, "atoms_per_gpu": n_atoms, "edges_per_gpu": n_edges, "triplets_per_gpu": n_trip,
+                       "precision": args.precision, **({"engine_options": args.engine_option} if args.engine_option else {}),
+                       "atoms_per_gpu": n_atoms, "edges_per_gpu": n_edges, "triplets_per_gpu": n_trip,
                        "active_edges_per_gpu": n_active, "first_call_s_incl_topology_build": first_call_s,
                        "topology_build_ms": topo_ms, "stage_ms_per_step": stage_ms,
                        "multi_gpu": "replicas (a single cell does not shard); config4_sharded below runs the sharded path"})

@@ -130,6 +130,15 @@ int m3g_topology_build(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int
                        const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
                        void* topo, size_t topo_bytes, int32_t* host_flags, void* stream);
 
+/* What the build found out about the graph that lets m3g_energy_forces pick cheaper kernels: an opaque word for m3g_io.topo_hints
+ * (0 is always valid).  Today: M3G_TOPO_TB_COMPLETE -- every centre atom's triplet list holds each ordered pair of its active
+ * edges exactly once (what compute_threebody emits, data/material_graph.py:196-254), so the three-body sums may run over per-atom
+ * moments instead of the lists -- plus the largest window sizes the kernels then need.  Synchronises the stream; call once per
+ * topology and keep the word with the buffer. */
+#define M3G_TOPO_TB_COMPLETE 1
+int m3g_topology_hints(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
+                       int32_t* host_hints, void* stream);
+
 /* Number of ACTIVE edges of a built topology: edges that appear in either column of triplet_edge_index (the three-body
  * arrays of the workspace hold one row per active edge).  Synchronises the stream. */
 int m3g_topology_active_edges(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
@@ -162,6 +171,8 @@ typedef struct {
   float* edge_weights;           /* [E,n_max] */
   float* triplet_angles;         /* [T] cos(theta_jik), original triplet order */
   float* mid_edge_features;      /* [num_blocks,E,l_max*n_max] three-body aggregate of every block */
+  /* optional input */
+  int32_t topo_hints;            /* from m3g_topology_hints for `topo` (0: none -- always valid, the general kernels) */
 } m3g_io;
 
 int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes, void* stream);
@@ -262,7 +273,7 @@ int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
  * event pool).  They are bound to the plan's device: a commit that moves the plan to another device releases all of them. */
 int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out);
 
-#define M3G_ABI_VERSION 1
+#define M3G_ABI_VERSION 2   /* 2: m3g_io.topo_hints, m3g_topology_hints */
 
 #ifdef __cplusplus
 }

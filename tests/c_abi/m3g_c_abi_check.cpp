@@ -116,6 +116,7 @@ int main(int argc, char** argv) {
   io.n_atoms = N; io.n_edges = E; io.n_triplets = T; io.n_structs = S;
   io.pos = d_pos; io.atom_types = d_types; io.edge_cell_shift = d_shift; io.lattice = d_lat; io.topo = topo;
   io.triplet_edge_index = d_tei;
+  CK(m3g_topology_hints(N, E, T, S, topo, &io.topo_hints, stream));   // complete partner lists -> the three-body moment kernels
   io.total_energy = d_e; io.forces = d_f; io.stresses = d_s;
   CK(m3g_energy_forces(plan, &io, work, work_bytes, stream));
   HK(hipStreamSynchronize(stream));

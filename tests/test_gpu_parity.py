@@ -121,6 +121,39 @@ def test_both_edge_kernels_against_oracle(case, mode, edge_kernel):
     assert rel_err(g[K.NODE_FEATURES], o["x"]) < 1e-5
 
 
+@pytest.mark.parametrize("case,mode", [("cu32", "doc"), ("mix", "doc"), ("tri", "doc"), ("mixfit", "doc"), ("cu32fit", "ref")])
+def test_threebody_moment_and_list_paths_agree(case, mode):
+    """Option "threebody_moments" (default 1): where a centre's partner lists are complete -- every fixture the reference's
+    compute_threebody produced is -- the three-body sums run over per-atom moments instead of walking the lists
+    (csrc/m3g_threebody.hip).  Both paths against the fp64 oracle at north_star's tolerances, and against each other far below
+    them; the two sum in different orders, so bit-identical aggregates would mean the moment path never ran."""
+    from oracle import m3gnet_oracle as orc
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    _, cfg, _, graph, _ = load_oracle_case(case, mode)
+    p64, cfg64, c64, graph64, _ = load_oracle_case(case, mode, dtype=torch.float64)
+    o = orc.energy_forces(p64, cfg64, c64, graph64, legendre_backward="exact")
+    model, _ = build_engine_model(case, mode)
+    model.engine.set_precision("fp32")
+    out = {}
+    for moments in (1, 0):
+        model.engine.set_option("threebody_moments", moments)
+        g = model(engine_graph(graph))
+        torch.cuda.synchronize()
+        out[moments] = {k: g[k].detach().clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES, K.MID_EDGE_FEATURES)}
+        assert float(((g[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < E_TOL
+        assert rel_err(g[K.FORCES], o["forces"]) < F_TOL
+        assert rel_err(g[K.STRESSES], o["stresses"]) < F_TOL
+        for b in range(cfg.num_blocks):
+            assert rel_err(g[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) < M_TOL
+    a, b = out[1], out[0]
+    assert not torch.equal(a[K.MID_EDGE_FEATURES], b[K.MID_EDGE_FEATURES]), "the moment path did not run"
+    assert rel_err(a[K.MID_EDGE_FEATURES], b[K.MID_EDGE_FEATURES]) < 5e-6
+    assert rel_err(a[K.FORCES], b[K.FORCES]) < 1e-5
+    assert rel_err(a[K.STRESSES], b[K.STRESSES]) < 1e-5
+    assert float(((a[K.TOTAL_ENERGY] - b[K.TOTAL_ENERGY]).abs() / b[K.TOTAL_ENERGY].abs()).max()) < 2e-6
+
+
 # (rev_kernel, save_p1, save_p2): every reverse-kernel instantiation the public options select.  fp32 mode:
 #   (1,1,1) k_edge_rev_f32<SAVED_P2=true>  on SiLU'(p1) + p2 saved by the forward kernel (SAVE = 2)      -- the default
 #   (1,1,0) k_edge_rev_f32<SAVED_P2=false> on raw p1 (SAVE = 1), layer 2 recomputed

@@ -25,6 +25,9 @@ for tb in (4.0, 6.0):
     torch.manual_seed(0)
     model = build_model(6.0, tb, 3, 3, 95, 64, 3).cuda()
     g = batch_from_arrays([lat], [pos], [z], 6.0, tb)
+    import os
+    for opt in filter(None, os.environ.get("M3G_ENGINE_OPTIONS", "").split(",")):   # e.g. threebody_moments=0
+        model.engine.set_option(opt.split("=")[0], int(opt.split("=")[1]))
     for _ in range(3):
         model(g, forces=True, extras=False)
     torch.cuda.synchronize()

@@ -373,6 +373,10 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->overlap = value != 0;
     return M3G_OK;
   }
+  if (strcmp(name, "threebody_moments") == 0) {
+    plan->tb_moments = value != 0;
+    return M3G_OK;
+  }
   if (strcmp(name, "stress_mode") == 0) {
     if (value != 0 && value != 1) { set_error("stress_mode must be 0 (reference: sum pos (x) F / V) or 1 (pair virial)"); return M3G_ERR_VALUE; }
     plan->stress_mode = value;
@@ -617,6 +621,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   const WeightLayout& wl = plan->wl;
   const float* W = plan->d_weights;
   Topo t = topo_carve(N, E, T, S, const_cast<void*>(io->topo));
+  const int tb_hints = plan->tb_moments ? io->topo_hints : 0;   // (0: the list kernels, always valid)
   const bool mfma = plan->edge_kernel == 1;
   const bool fused_rev = fused_reverse(plan);
   Work w = work_carve(c, mfma, saved_activations(plan), N, E, T, S, nullptr);
@@ -646,7 +651,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
                                      b == 0 ? io->atom_types : nullptr, W + wl.emb, s);
       else launch_node_pre(c, W, wl.blk[b], t, w, nullptr, w.x[b], w.v[b], w.TA, w.TB, s);
     }
-    { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s); }
+    { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s, tb_hints); }
     if (mfma) {
       { M3G_STAGE(ST_EDGE_FWD); launch_edge_block_mfma(plan, c, t, w, b, /*for_reverse=*/io->forces != nullptr, s); }
       (void)ST_NODE_SUM;   // the per-centre sums are consumed by the next node_pre / the readout
@@ -707,14 +712,14 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         // side stream beside it, then add the v-gradient share (which needs its dL/dg) once both are done
         M3G_HIP_CHECK(hipEventRecord(plan->ev_fork, s));
         M3G_HIP_CHECK(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
-        launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, plan->side_stream);
+        launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, plan->side_stream, tb_hints);
         M3G_HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
         launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*dp1_packed=*/plan->precision == kPrecBf16x3, /*with_v_term=*/false, s);   // (f16x3: fp32 rows)
         M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_join, 0));
         launch_node_reverse_v_term(c, W, wl.blk[b], t, w, w.v[b], dx_alt, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
       } else {
-        { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s); }
+        { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s, tb_hints); }
         if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
           M3G_STAGE(ST_NODE_REV);
           launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*dp1_packed=*/fused_rev && plan->precision == kPrecBf16x3,

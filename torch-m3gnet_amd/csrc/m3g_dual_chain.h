@@ -120,9 +120,18 @@ __device__ __forceinline__ void chain_dual_h(const float* img, const f32x4 (&x)[
       const char* u = base + (((s * 4 + q) ^ sw) << 3);
       const f16x8 ah = join_halves_h(*(const s16x4*)(u + roff), *(const s16x4*)(u + roff + plane));
       const f16x8 al = join_halves_h(*(const s16x4*)(u + roff + lo), *(const s16x4*)(u + roff + lo + plane));
+#ifdef M3G_DIAG_NO_AL   // timing diagnostic only (wrong results): no LDS reads of the low-part image
+      const f16x8& al_ = ah;
+#else
+      const f16x8& al_ = al;
+#endif
       t = mfma_f16(ah, b.hi[s], t);
+#ifndef M3G_DIAG_H1
       t = mfma_f16(ah, b.lo[s], t);
-      t = mfma_f16(al, b.hi[s], t);
+      t = mfma_f16(al_, b.hi[s], t);
+#elif defined(M3G_DIAG_H1_KEEP)   // ... with the low-part reads and splits kept alive: the MFMAs alone
+      asm volatile("" ::"v"(al_), "v"(b.lo[s]));
+#endif
     });
     acc[AOFF + ob] = t * inv + acc[AOFF + ob];   // (vector form: the compiler emits two v_pk_fma_f32)
   });
@@ -149,9 +158,18 @@ __device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d
                                      __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1)));
       const f16x8 al = join_halves_h(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0 + lo)),
                                      __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1 + lo)));
+#ifdef M3G_DIAG_NO_AL   // timing diagnostic only (wrong results): no LDS reads of the low-part image
+      const f16x8& al_ = ah;
+#else
+      const f16x8& al_ = al;
+#endif
       t = mfma_f16(ah, b.hi[s], t);
+#ifndef M3G_DIAG_H1
       t = mfma_f16(ah, b.lo[s], t);
-      t = mfma_f16(al, b.hi[s], t);
+      t = mfma_f16(al_, b.hi[s], t);
+#elif defined(M3G_DIAG_H1_KEEP)   // ... with the low-part reads and splits kept alive: the MFMAs alone
+      asm volatile("" ::"v"(al_), "v"(b.lo[s]));
+#endif
     });
     acc[AOFF + ob] = t * inv + acc[AOFF + ob];   // (vector form: the compiler emits two v_pk_fma_f32)
   });

@@ -119,9 +119,18 @@ __device__ __forceinline__ void chain_h(const float* img, const HalfB<KS>& b, in
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
     static_for<KS>([&]<int s>() {
       const f16x8 ah = hi_img[(ob * KS + s) * 64], al = lo_img[(ob * KS + s) * 64];
+#ifdef M3G_DIAG_NO_AL   // timing diagnostic only (wrong results): no LDS reads of the low-part image
+      const f16x8& al_ = ah;
+#else
+      const f16x8& al_ = al;
+#endif
       t = mfma_f16(ah, b.hi[s], t);
+#ifndef M3G_DIAG_H1   // timing diagnostic only (wrong results): one product per k-step instead of three
       t = mfma_f16(ah, b.lo[s], t);
-      t = mfma_f16(al, b.hi[s], t);
+      t = mfma_f16(al_, b.hi[s], t);
+#elif defined(M3G_DIAG_H1_KEEP)   // ... with the low-part reads and splits kept alive: the MFMAs alone
+      asm volatile("" ::"v"(al_), "v"(b.lo[s]));
+#endif
     });
     out.template operator()<ob>(t);
   });
@@ -384,16 +393,16 @@ __device__ __forceinline__ TbIn<PREC, TBS> tb_load(const float* __restrict__ m, 
   return r;
 }
 // p[0..3] dense, p[4..7] gate pre-activations of the three-body MLP.  f16x3 image (tb_image_h, m3g_pack_mfma.hip): [hi | lo]
-// [8 row blocks][32 lanes (q < 2)][8 halves]: lanes of quarters 2, 3 supply zeros (their k range is beyond l_max n_max)
+// [8 row blocks][32 lanes (q < 2)][8 halves]: the k range of quarters 2, 3 is beyond l_max n_max -- tb_load gives those lanes
+// zero activations, so whatever finite weights they multiply do not matter and they read the rows of lanes 0..31 again (a
+// conditional read costs a branch and eight register clears per row block)
 template <int PREC, int TBS>
 __device__ __forceinline__ void tb_preact_p(const float* tbimg, const TbIn<PREC, TBS>& in, f32x4 (&p)[8], int lane) {
   if constexpr (PREC == kPrecF16x3) {
-    const int q = lane >> 4;
     const f16x8* hi = reinterpret_cast<const f16x8*>(tbimg) + (lane & 31);
     const f16x8* lo = hi + 8 * 32;
     static_for<8>([&]<int ob>() {
-      f16x8 ah = {0, 0, 0, 0, 0, 0, 0, 0}, al = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (q < 2) { ah = hi[ob * 32]; al = lo[ob * 32]; }
+      const f16x8 ah = hi[ob * 32], al = lo[ob * 32];   // quarters 2, 3 re-read rows 0..31: their activation parts are zero
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
       t = mfma_f16(ah, in.hi, t);
       t = mfma_f16(ah, in.lo, t);

@@ -213,6 +213,7 @@ struct m3g_plan {
   std::map<std::string, size_t> generic_off;
   float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as bf16x3 chain images (k_readout_mfma)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
+  bool tb_moments = true;   // option "threebody_moments": per-atom moment sums where the partner lists are complete (m3g_threebody.hip)
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
   int stamp_target = 0;          // which kernel runs its stamped variant: 0 forward edge block, 1 reverse edge-MLP kernel
@@ -279,6 +280,7 @@ constexpr int kTbCap = M3G_TB_CAP;   // staged three-body window: the rows of th
 // ids per row takes the dense case from 61 to 24 us (forward) and 137 to 86 us (reverse) per launch, but costs the 10k-atom
 // Cu cell 25 % of its three-body reverse (LDS footprint -> fewer resident workgroups), hence the choice per launch.
 constexpr int kTbListShort = 32, kTbListLong = 96;
+constexpr int kTbFastAtoms = 64;   // most centre atoms per workgroup window the moment path keeps sums for (more: the list path)
 constexpr int kTbCapShort = kTbRows + 64 < kTbCap ? kTbRows + 64 : kTbCap;   // window rows the short-list instantiation stages
    // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
 struct Topo {
@@ -308,10 +310,16 @@ struct Topo {
   int32_t* act_dst;    // [A] neighbour atom of each active edge (saves a dependent load when staging)
   int32_t* tb_win;     // [6 * blocks] per three-body workgroup: compacted-row window [lo, hi) staged in LDS, then the
                        // ranges [t_lo, t_hi) of its rows' partner lists in t1_e2c and in t2_e1c
+  int32_t* tb_fast;    // [2 * blocks] per three-body workgroup: {number of centre atoms spanned by its window, first of them} when every
+                       // one of those atoms has COMPLETE partner lists (each active edge paired with every other active edge of its
+                       // centre exactly once, in both roles) and there are at most kTbFastAtoms of them -- the workgroup may then use
+                       // per-atom moment sums instead of walking the lists (m3g_threebody.hip); {0, x} otherwise
   int32_t* n_act;      // device scalar A (= flags + 2)
   int32_t* batch;    // [N]
   int32_t* struct_ptr;  // [S+1] atoms of structure s: struct_ptr[s] .. struct_ptr[s+1] (valid when `batch` is non-decreasing, flags[3] == 0)
-  int32_t* flags;    // [4] [0] malformed-graph bits; [2] = A; [3] != 0: `batch` is not sorted (per-structure sums then use atomics)
+  int32_t* flags;    // [8] [0] malformed-graph bits; [2] = A; [3] != 0: `batch` is not sorted (per-structure sums then use atomics);
+                     // [4] three-body workgroups that may NOT use the moment path, [5] largest window (rows), [6] most atoms per window
+                     // (m3g_topology_hints packs 4..6 for the caller)
   void* sort_tmp;    // scratch for the radix sorts
   size_t sort_tmp_bytes;
   size_t total_bytes;
@@ -407,8 +415,8 @@ void launch_copy_expand_rows(const int32_t* row_id, const float* in, int in_stri
 void launch_copy_strided(const float* in, int in_stride, float* out, int out_stride, int width, int64_t rows,
                          hipStream_t s);
 // threebody.hip
-void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s);
-void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s);
+void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s, int topo_hints = 0);
+void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints = 0);
 // pack_mfma.hip / edge_mfma.hip
 int pack_mfma_images(m3g_plan* plan);
 void free_mfma_images(m3g_plan* plan);

@@ -80,14 +80,34 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // scaled split of one value pair: hi = fp16(s x), lo = fp16(s x - hi), both rounded to nearest (the residual has at most 12
-// significant bits, so hi + lo is s x to within 2^-24 relative: half an fp32 ulp).  Five vector instructions per PAIR, the scaling included: v_fma_mixlo_f16 /
-// v_fma_mixhi_f16 form fp16(s a) and fp16(s b) in the two halves of one register straight from the fp32 inputs, v_fma_mix_f32
-// forms s a - hi with the fp16 half as its addend (op_sel picks the half), v_cvt_pkrtz_f16_f32 packs the residuals.  The compiler
-// finds the mix forms too but builds the packed hi with two extra multiplies and a v_cvt_pk on top (8 per pair).
+// significant bits, so hi + lo is s x to within 2^-24 relative: half an fp32 ulp).  Five vector instructions per PAIR, the scaling
+// included: v_fma_mixlo_f16 / v_fma_mixhi_f16 form fp16(s a) and fp16(s b) in the two halves of one register straight from the
+// fp32 inputs, v_fma_mix_f32 forms s a - hi with the fp16 half as its addend (op_sel picks the half), v_cvt_pk_f16_f32 packs the
+// residuals.  The compiler finds the mix forms too but builds the packed hi with two extra multiplies and a v_cvt_pk on top (8
+// per pair).  Measured issue costs (tools/valu_issue_probe.hip, profiles/r03_valu_issue_probe.txt): the half-register writers
+// v_fma_mixlo/hi_f16 cost 1.67 plain instructions each (like v_exp_f32), so forming the low parts with two more of them (4
+// instructions per pair, one rounding) is SLOWER than this form (24.7 against 22.0 cycles per pair) -- tried and reverted.
 // Hazards inside the block (the recogniser does not look into inline assembly): a half-register write (v_fma_mixlo/hi) needs one
 // wait state before a vector instruction reads that register (dst_sel / op_sel forwarding, gfx940+): the reader of the low half
 // comes two instructions after its writer, the reader of the high half two after its.
-#ifndef M3G_SPLIT_H_PLAIN
+#if !defined(M3G_SPLIT_H_MIX) && !defined(M3G_SPLIT_H_PLAIN)
+// default form: the scaling as one packed multiply, the high parts by v_cvt_pk_f16_f32 -- no half-register writers at all, five
+// plain-rate instructions per pair, bit-identical parts (the power-of-two product is exact); same-box A/B against the mix form
+// below: forward 0.452 -> 0.447, fused reverse 0.955 -> 0.943 ms per step
+typedef float f32x2_split __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_h(float a, float b, float s, f16x2& hi, f16x2& lo) {
+  f32x2_split t = f32x2_split{a, b} * s;
+  unsigned h, l;
+  asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "s_nop 0\n\t"
+      "v_fma_mix_f32 %2, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %3, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_cvt_pk_f16_f32 %1, %2, %3"
+      : "=&v"(h), "=&v"(l), "+v"(t[0]), "+v"(t[1]));
+  hi = __builtin_bit_cast(f16x2, h);
+  lo = __builtin_bit_cast(f16x2, l);
+}
+#elif defined(M3G_SPLIT_H_MIX)
 __device__ __forceinline__ void split_pair_h(float a, float b, float s, f16x2& hi, f16x2& lo) {
   unsigned h;
   float ra, rb;
@@ -134,6 +154,9 @@ struct EdgeScale { float s, inv; };
 template <int NB, int XOFF = 0, int NX>
 __device__ __forceinline__ EdgeScale edge_scale(const f32x4 (&x)[NX]) {
   static_assert(XOFF + NB <= NX, "edge_scale operand out of range");
+#ifdef M3G_DIAG_NO_SCALE   // timing diagnostic only (wrong results): what finding the per-edge scales costs
+  return EdgeScale{1024.f, 1.f / 1024.f};
+#endif
   float m = 0.f;
   static_for<NB>([&]<int b>() { static_for<4>([&]<int r>() { m = fmaxf(m, fabsf(x[XOFF + b][r])); }); });
   m = max_lane_quarters(m);

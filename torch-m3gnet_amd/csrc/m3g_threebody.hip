@@ -319,6 +319,211 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRev
   }
 }
 
+// ---- moment path -------------------------------------------------------------------------------------------------------------
+// When the partner lists of a centre atom are COMPLETE (every ordered pair of its active edges, which is what the graph builders
+// emit: data/material_graph.py:196-254) the sums over partners separate: P_l(u1.u2) is a polynomial in the components of u2, so
+//   sum_{e2 != e1} P_l(u1.u2) g[e2,(l,n)] = contraction of u1 with the per-atom MOMENTS  G0[n] = sum g[.,(0,n)],
+//   G1[n] = sum u g[.,(1,n)],  G2[n] = sum u u^T g[.,(2,n)],  G2s[n] = sum g[.,(2,n)]          -- minus the row's own term.
+// 11 sums per radial index n and atom replace ~17 (58 in dense cells) Legendre evaluations per edge: the kernels become O(edges)
+// instead of O(triplets), and what is left is the latency of their three dependent loads.  The reverse pass needs the same
+// moments of the incoming gradient rows dS = fc dm.  Exactness: the polynomial is evaluated on the raw dot product instead of the
+// clamped one (nn/invariant.py:40 clamps the rounding overshoot |u1.u2| - 1 <= ~1e-7 of collinear partners; the clamp's zero
+// gradient there only removes a component parallel to u1, which the projection onto the displacement removes anyway); l_max <= 3
+// only (higher l needs rank-3 moments: those models take the list path).  Whether a graph qualifies is decided in the topology
+// build (Topo::tb_fast, m3g_topology_hints): every window complete -> these kernels, anything else (filtered, one-sided,
+// permuted-with-duplicates lists) -> the list kernels above.  One thread per row, 128 rows per workgroup, the window of the
+// workgroup's centre atoms staged in LDS as in the list kernels.
+// moment j of one (atom, n): weight W[ia] W[ib] with W = (1, ux, uy, uz), payload channel l:  j = 0: G0 | 1-3: G1 | 4-9: G2 xx yy zz
+// xy xz yz | 10: G2s
+__device__ __forceinline__ int mom_ia(int j) { return (int)((0x02113210000ull >> (4 * j)) & 15); }
+__device__ __forceinline__ int mom_ib(int j) { return (int)((0x03323213210ull >> (4 * j)) & 15); }
+__device__ __forceinline__ int mom_l(int j) { return (int)((0x22222221110ull >> (4 * j)) & 15); }
+template <int L>
+constexpr int mom_count() { return L == 1 ? 1 : L == 2 ? 4 : 11; }
+// moments of the staged payload rows `pay` ([rows][C]) for the atoms of the window (row ranges s_arow[at] .. s_arow[at + 1]); fixed
+// summation order -> reproducible
+template <int L, int R, int THREADS>
+__device__ __forceinline__ void window_moments(int na, const int* s_arow, const float* su4, const float* pay, float* mom) {
+  constexpr int C = L * R, NM = mom_count<L>();
+  for (int p = threadIdx.x; p < na * R * NM; p += THREADS) {
+    const int at = p / (R * NM), rem = p % (R * NM), nn = rem / NM, j = rem % NM;
+    const int ia = mom_ia(j), ib = mom_ib(j), ch = mom_l(j) * R + nn;
+    // four rows in flight (the loop is a chain of LDS round trips otherwise); the sum keeps its row order
+    const int i1 = s_arow[at + 1];
+    float acc = 0.f;
+    int i = s_arow[at];
+    for (; i + 4 <= i1; i += 4) {
+      float w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = su4[(i + k) * 4 + ia] * su4[(i + k) * 4 + ib] * pay[(i + k) * C + ch];
+      acc = (((acc + w[0]) + w[1]) + w[2]) + w[3];
+    }
+    for (; i < i1; ++i) acc += su4[i * 4 + ia] * su4[i * 4 + ib] * pay[i * C + ch];
+    mom[p] = acc;
+  }
+}
+// contraction of the moments M (one n) with the row's own direction, own term subtracted: S_l = sum over the OTHER rows of
+// P_l(u.u') pay';  for l >= 1 also the vector  V_l = sum over the other rows of P_l'(u.u') u' pay'  (gradient with respect to u)
+struct MomEval { float S0, S1, S2; float V1x, V1y, V1z, V2x, V2y, V2z; };
+template <int L>
+__device__ __forceinline__ MomEval mom_eval(const float* M, float ux, float uy, float uz, float s, float p0, float p1, float p2) {
+  MomEval r{};
+  r.S0 = M[0] - p0;
+  if constexpr (L >= 2) {
+    r.S1 = (ux * M[1] + uy * M[2] + uz * M[3]) - s * p1;
+    r.V1x = M[1] - ux * p1; r.V1y = M[2] - uy * p1; r.V1z = M[3] - uz * p1;
+  }
+  if constexpr (L >= 3) {
+    const float gx = M[4] * ux + M[7] * uy + M[8] * uz, gy = M[7] * ux + M[5] * uy + M[9] * uz, gz = M[8] * ux + M[9] * uy + M[6] * uz;
+    const float quad = ux * gx + uy * gy + uz * gz;
+    r.S2 = 1.5f * (quad - s * s * p2) - 0.5f * (M[10] - p2);
+    const float sp = s * p2;
+    r.V2x = 3.f * (gx - sp * ux); r.V2y = 3.f * (gy - sp * uy); r.V2z = 3.f * (gz - sp * uz);
+  }
+  return r;
+}
+
+struct TbMomArgs {
+  int blocks;   // E / kTbRows + 1: block indices with a window record
+  const int32_t *src, *arow_ptr, *tb_fast, *act_list, *act_dst, *tb_win, *n_act;
+  const float *u, *fc3, *fc3p, *q, *qp, *v, *dm;   // reverse only: fc3p, qp, dm
+  float* m;                                        // forward out
+  float *dd, *du, *dgq;                            // reverse out
+  int first;
+};
+
+// LDS of one workgroup for windows of at most `rows` rows over at most `atoms` centre atoms (both from the topology hints)
+template <int L, int R, bool REV>
+constexpr size_t mom_lds_bytes(int rows, int atoms) {
+  return sizeof(float) * ((size_t)rows * 4 + (size_t)rows * L * R * (REV ? 2 : 1) + (size_t)(REV ? 2 : 1) * atoms * R * mom_count<L>()) + sizeof(int) * (atoms + 1);
+}
+template <int L, int R, bool REV>
+__global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomArgs a, int cap_rows, int cap_atoms) {
+  constexpr int C = L * R, NM = mom_count<L>(), kThreads = kTbRows;
+  extern __shared__ __attribute__((aligned(16))) float lds_mom[];
+  float* su = lds_mom;                                        // (1, ux, uy, uz) per window row
+  float* sg = su + cap_rows * 4;                              // g = q v[dst]
+  float* ss = sg + cap_rows * C;                              // dS = fc dm (reverse)
+  float* s_mom = ss + (REV ? cap_rows * C : 0);               // moments of g, then (reverse) of dS
+  int* s_arow = reinterpret_cast<int*>(s_mom + (REV ? 2 : 1) * cap_atoms * R * NM);
+  // (the row count A lives on the device; a workgroup beyond it finds an empty window -- k_tb_windows writes one for every block
+  // index the grid can reach -- so nothing here waits for A: one dependent load less in a kernel that is a chain of them)
+  for (int blk = blockIdx.x; blk < a.blocks; blk += gridDim.x) {
+    const int rb = blk * kTbRows;
+    const int lo = a.tb_win[6 * blk], n = a.tb_win[6 * blk + 1] - lo;
+    if (n <= 0) break;   // windows are in row order: the first empty one ends the list
+    const int A = lo + n;   // rows of this block are < lo + n (the window covers them), rows >= A of the last block are not
+    const int na = a.tb_fast[2 * blk], a0 = a.tb_fast[2 * blk + 1];   // (0 < na <= cap_atoms, n <= cap_rows: the launch is only made
+                                                                     // for graphs whose every window qualifies, with the sizes from the hints)
+    const int r = rb + (int)threadIdx.x;
+    const bool live = r < A;
+    const int rr = live ? r : A - 1;
+    const int64_t e = a.act_list[rr];
+    const int64_t kd = a.act_dst[rr];
+    for (int idx = threadIdx.x; idx < n; idx += kThreads) {
+      const int64_t es = a.act_list[lo + idx], ks = a.act_dst[lo + idx];
+      su[idx * 4 + 0] = 1.f;
+      su[idx * 4 + 1] = a.u[es * 3];
+      su[idx * 4 + 2] = a.u[es * 3 + 1];
+      su[idx * 4 + 3] = a.u[es * 3 + 2];
+      float qr[C], vr[C];
+      load_row<C>(a.q + (int64_t)(lo + idx) * kCP, qr);
+      load_row<C>(a.v + ks * kCP, vr);
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) sg[idx * C + cc] = qr[cc] * vr[cc];
+      if constexpr (REV) {
+        const float f = a.fc3[es];
+        float dr[C];
+        load_row<C>(a.dm + (int64_t)(lo + idx) * kCP, dr);
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) ss[idx * C + cc] = f * dr[cc];
+      }
+    }
+    if ((int)threadIdx.x <= na) s_arow[threadIdx.x] = a.arow_ptr[a0 + threadIdx.x] - lo;
+    // this row's own data, requested before the barrier
+    const int at = a.src[e] - a0;
+    const float fc = a.fc3[e];
+    float fcp = 0.f, dd0 = 0.f, du0 = 0.f, du1 = 0.f, du2 = 0.f;
+    float dmv[C], qv[C], qpv[C], vv[C];
+    if constexpr (REV) {
+      fcp = a.fc3p[e];
+      if (!a.first) { dd0 = a.dd[rr]; du0 = a.du[(int64_t)rr * 3]; du1 = a.du[(int64_t)rr * 3 + 1]; du2 = a.du[(int64_t)rr * 3 + 2]; }
+      load_row<C>(a.dm + (int64_t)rr * kCP, dmv);
+      load_row<C>(a.q + (int64_t)rr * kCP, qv);
+      load_row<C>(a.qp + (int64_t)rr * kCP, qpv);
+      load_row<C>(a.v + kd * kCP, vv);
+    }
+    __syncthreads();
+    window_moments<L, R, kThreads>(na, s_arow, su, sg, s_mom);
+    if constexpr (REV) window_moments<L, R, kThreads>(na, s_arow, su, ss, s_mom + cap_atoms * R * NM);
+    __syncthreads();
+    if (live) {
+      const int own = r - lo;
+      const float ux = su[own * 4 + 1], uy = su[own * 4 + 2], uz = su[own * 4 + 3], s2 = ux * ux + uy * uy + uz * uz;
+      const float* g = sg + own * C;
+      if constexpr (!REV) {
+        float acc[kCP];
+#pragma unroll
+        for (int k = 0; k < kCP; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int nn = 0; nn < R; ++nn) {
+          const MomEval ev = mom_eval<L>(s_mom + (at * R + nn) * NM, ux, uy, uz, s2, g[nn], L >= 2 ? g[R + nn] : 0.f, L >= 3 ? g[2 * R + nn] : 0.f);
+          acc[nn] = fc * c.ynorm[0] * ev.S0;
+          if constexpr (L >= 2) acc[R + nn] = fc * c.ynorm[1] * ev.S1;
+          if constexpr (L >= 3) acc[2 * R + nn] = fc * c.ynorm[2] * ev.S2;
+        }
+#pragma unroll
+        for (int k = 0; k < kCP; k += 4) *(float4*)(a.m + (int64_t)r * kCP + k) = float4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+      } else {
+        const float* ds = ss + own * C;   // fc dm of this row
+        float dg[kCP], dfc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+        for (int k = 0; k < kCP; ++k) dg[k] = 0.f;
+#pragma unroll
+        for (int nn = 0; nn < R; ++nn) {
+          const float g0 = g[nn], g1 = L >= 2 ? g[R + nn] : 0.f, g2 = L >= 3 ? g[2 * R + nn] : 0.f;
+          const float d0 = ds[nn], d1 = L >= 2 ? ds[R + nn] : 0.f, d2 = L >= 3 ? ds[2 * R + nn] : 0.f;
+          const MomEval eg = mom_eval<L>(s_mom + (at * R + nn) * NM, ux, uy, uz, s2, g0, g1, g2);
+          const MomEval eh = mom_eval<L>(s_mom + ((cap_atoms + at) * R + nn) * NM, ux, uy, uz, s2, d0, d1, d2);
+          dfc += dmv[nn] * (c.ynorm[0] * eg.S0);
+          dg[nn] = c.ynorm[0] * eh.S0;
+          if constexpr (L >= 2) {
+            dfc += dmv[R + nn] * (c.ynorm[1] * eg.S1);
+            dg[R + nn] = c.ynorm[1] * eh.S1;
+            ax += c.ynorm[1] * (d1 * eg.V1x + g1 * eh.V1x);
+            ay += c.ynorm[1] * (d1 * eg.V1y + g1 * eh.V1y);
+            az += c.ynorm[1] * (d1 * eg.V1z + g1 * eh.V1z);
+          }
+          if constexpr (L >= 3) {
+            dfc += dmv[2 * R + nn] * (c.ynorm[2] * eg.S2);
+            dg[2 * R + nn] = c.ynorm[2] * eh.S2;
+            ax += c.ynorm[2] * (d2 * eg.V2x + g2 * eh.V2x);
+            ay += c.ynorm[2] * (d2 * eg.V2y + g2 * eh.V2y);
+            az += c.ynorm[2] * (d2 * eg.V2z + g2 * eh.V2z);
+          }
+        }
+        float ddv = 0.f, val[kCP];
+#pragma unroll
+        for (int k = 0; k < kCP; ++k) {
+          val[k] = 0.f;
+          if (k < C) {
+            const int kc = k < C ? k : 0;
+            ddv += dg[kc] * vv[kc] * qpv[kc];
+            val[k] = dg[kc] * qv[kc];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kCP; k += 4) *(float4*)(a.dgq + (int64_t)r * kCP + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
+        a.dd[r] = (dd0 + fcp * dfc) + ddv;
+        a.du[(int64_t)r * 3] = du0 + ax;
+        a.du[(int64_t)r * 3 + 1] = du1 + ay;
+        a.du[(int64_t)r * 3 + 2] = du2 + az;
+      }
+    }
+    __syncthreads();   // the staged window is rewritten by the next row block
+  }
+}
+
 // at most kTbGridCap workgroups (what 256 CUs hold at once at this LDS footprint and then some): they walk the row blocks
 #ifndef M3G_TB_GRID_CAP
 #define M3G_TB_GRID_CAP 2048
@@ -331,17 +536,51 @@ static inline dim3 grid_rows(int64_t n) {
 // lives on the device); either choice is correct, the wrong one only costs time (global-memory fallback or LDS footprint).
 static inline bool long_lists(const Topo& t) { return t.T > 24 * t.E; }
 
-void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s) {
+// the moment kernels apply when the topology build found every window complete (hint bit, read back by the caller once per
+// topology: m3g_topology_hints) and l_max <= 3
+static inline bool use_moments(const Consts& c, int topo_hints) {
+  return (topo_hints & M3G_TOPO_TB_COMPLETE) && c.L <= 3 && ((topo_hints >> 8) & 0xff) > 0 && ((topo_hints >> 16) & 0xff) > 0;
+}
+#define M3G_DISPATCH_LR3(Lv, Rv, BODY)                          \
+  switch ((Lv) * 8 + (Rv)) {                                    \
+    case 1 * 8 + 1: { constexpr int L = 1, R = 1; BODY; } break; \
+    case 1 * 8 + 2: { constexpr int L = 1, R = 2; BODY; } break; \
+    case 1 * 8 + 3: { constexpr int L = 1, R = 3; BODY; } break; \
+    case 1 * 8 + 4: { constexpr int L = 1, R = 4; BODY; } break; \
+    case 2 * 8 + 1: { constexpr int L = 2, R = 1; BODY; } break; \
+    case 2 * 8 + 2: { constexpr int L = 2, R = 2; BODY; } break; \
+    case 2 * 8 + 3: { constexpr int L = 2, R = 3; BODY; } break; \
+    case 2 * 8 + 4: { constexpr int L = 2, R = 4; BODY; } break; \
+    case 3 * 8 + 1: { constexpr int L = 3, R = 1; BODY; } break; \
+    case 3 * 8 + 2: { constexpr int L = 3, R = 2; BODY; } break; \
+    case 3 * 8 + 3: { constexpr int L = 3, R = 3; BODY; } break; \
+    case 3 * 8 + 4: { constexpr int L = 3, R = 4; BODY; } break; \
+    default: break;                                             \
+  }
+
+void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s, int topo_hints) {
   if (t.E == 0) return;
   if (t.T == 0) return;   // no active edge: every consumer reads zeros through act_id < 0
+  if (use_moments(c, topo_hints)) {
+    TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, w.u, w.fc3, nullptr, w.q, nullptr, v, nullptr, m, nullptr, nullptr, nullptr, 0};
+    const int rows = (topo_hints >> 8) & 0xff, atoms = (topo_hints >> 16) & 0xff;
+    M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments<L, R, false>), grid_rows(t.E), dim3(kTbRows), (mom_lds_bytes<L, R, false>(rows, atoms)), s, c, a, rows, atoms));
+    return;
+  }
   TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t1_b, w.u, w.fc3, w.q, v, m};
   if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListLong, kTbCap, kTbLprLong>), grid_rows(t.E), dim3(kTbRows * kTbLprLong), 0, s, c, a)); }
   else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListShort, kTbCapShort, kTbLprShort>), grid_rows(t.E), dim3(kTbRows * kTbLprShort), 0, s, c, a)); }
 }
 
-void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s) {
+void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints) {
   if (t.E == 0) return;
   if (t.T == 0) return;
+  if (use_moments(c, topo_hints)) {
+    TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd, w.du, w.dg, first ? 1 : 0};
+    const int rows = (topo_hints >> 8) & 0xff, atoms = (topo_hints >> 16) & 0xff;
+    M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments<L, R, true>), grid_rows(t.E), dim3(kTbRows), (mom_lds_bytes<L, R, true>(rows, atoms)), s, c, a, rows, atoms));
+    return;
+  }
   TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, t.t1_b, t.t2_b, w.u, w.fc3, w.fc3p, w.q,
               w.qp, v,
               w.dm, w.dd, w.du, w.dg, first ? 1 : 0};

@@ -49,13 +49,14 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   t.arow_ptr = (int32_t*)take(sizeof(int32_t) * (N + 2));
   t.act_dst = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.tb_win = (int32_t*)take(sizeof(int32_t) * 6 * (E / kTbRows + 2));
+  t.tb_fast = (int32_t*)take(sizeof(int32_t) * 2 * (E / kTbRows + 2));
   t.t1_e2c = (int32_t*)take(sizeof(int32_t) * (T + 1));
   t.t2_e1c = (int32_t*)take(sizeof(int32_t) * (T + 1));
   t.t1_b = (uint8_t*)take((size_t)T + 16);
   t.t2_b = (uint8_t*)take((size_t)T + 16);
   t.batch = (int32_t*)take(sizeof(int32_t) * (N + 1));
   t.struct_ptr = (int32_t*)take(sizeof(int32_t) * (S + 2));
-  t.flags = (int32_t*)take(sizeof(int32_t) * 4);
+  t.flags = (int32_t*)take(sizeof(int32_t) * 8);
   t.n_act = t.flags ? t.flags + 2 : nullptr;
   t.sort_tmp_bytes = topo_sort_tmp_bytes(E, T);
   t.sort_tmp = take(t.sort_tmp_bytes);
@@ -184,6 +185,47 @@ __global__ void k_tb_windows(int64_t blocks, const int32_t* __restrict__ n_act, 
   }
   for (int k = 0; k < 6; ++k) win[6 * b + k] = w[k];
 }
+// Are the partner lists of compacted row r complete -- every other active edge of its centre exactly once, as first AND as
+// second edge?  (Ascending order inside a row is what the sorted lists have; it makes "exactly once" a local test.)
+__global__ void k_tb_row_complete(const int32_t* __restrict__ n_act, const int32_t* __restrict__ act_list, const int32_t* __restrict__ src,
+                                  const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ t1_e2c,
+                                  const int32_t* __restrict__ t2_ptr, const int32_t* __restrict__ t2_e1c, uint8_t* ok) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= *n_act) return;
+  const int e = act_list[r], c = src[e];
+  const int s0 = arow_ptr[c], s1 = arow_ptr[c + 1];
+  auto complete = [&](const int32_t* ptr, const int32_t* other) {
+    const int b = ptr[e], end = ptr[e + 1];
+    if (end - b != s1 - s0 - 1) return false;
+    int prev = -1;
+    for (int t = b; t < end; ++t) {
+      const int o = other[t];
+      if (o <= prev || o < s0 || o >= s1 || o == (int)r) return false;
+      prev = o;
+    }
+    return true;
+  };
+  ok[r] = complete(t1_ptr, t1_e2c) && complete(t2_ptr, t2_e1c) ? 1 : 0;
+}
+// per three-body workgroup: may it use the moment path (Topo::tb_fast)?  stats: [0] workgroups that may not, [1] largest window,
+// [2] most atoms per window (Topo::flags[4..6])
+__global__ void k_tb_fast(int64_t blocks, const int32_t* __restrict__ n_act, const int32_t* __restrict__ act_list, const int32_t* __restrict__ src,
+                          const int32_t* __restrict__ win, const uint8_t* __restrict__ ok, int32_t* fast, int32_t* stats) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= blocks) return;
+  int na = 0, a0 = 0;
+  if (b * kTbRows < *n_act) {
+    const int lo = win[6 * b], hi = win[6 * b + 1];
+    a0 = src[act_list[lo]];
+    na = src[act_list[hi - 1]] - a0 + 1;
+    bool all = na <= kTbFastAtoms && hi - lo <= kTbCap;
+    for (int r = lo; all && r < hi; ++r) all = ok[r] != 0;
+    if (all) { atomicMax(stats + 1, hi - lo); atomicMax(stats + 2, na); }
+    else { na = 0; atomicAdd(stats, 1); }
+  }
+  fast[2 * b] = na;
+  fast[2 * b + 1] = a0;
+}
 __global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ table, int32_t* out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) { out[2 * i] = idx[i]; out[2 * i + 1] = table[idx[i]]; }
@@ -250,7 +292,7 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   Topo t = topo_carve(N, E, T, S, topo_buf);
   const int TPB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TPB - 1) / TPB)); };
-  M3G_HIP_CHECK(hipMemsetAsync(t.flags, 0, 4 * sizeof(int32_t), s));
+  M3G_HIP_CHECK(hipMemsetAsync(t.flags, 0, 8 * sizeof(int32_t), s));
 
   size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
   char* tmp = (char*)t.sort_tmp;
@@ -335,6 +377,15 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
       hipLaunchKernelGGL(k_partner_bytes<false>, grid(T), dim3(TPB), 0, s, E, T, t.t2_ptr, nullptr, t.act_id, t.tb_win, t.t2_e1c, t.t2_b);
     }
   }
+  // which three-body workgroups may use the moment path (complete partner lists): row flags in the sort scratch, free by now
+  M3G_HIP_CHECK(hipMemsetAsync(t.tb_fast, 0, sizeof(int32_t) * 2 * (E / kTbRows + 1), s));
+  if (T == 0 || cub_bytes < (size_t)E + 1) {
+    M3G_HIP_CHECK(hipMemsetAsync(t.flags + 4, 0xff, sizeof(int32_t), s));   // "some workgroup may not": no moment path
+  } else {
+    uint8_t* row_ok = (uint8_t*)cub_tmp;
+    hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok);
+    hipLaunchKernelGGL(k_tb_fast, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
+  }
   M3G_HIP_CHECK(hipGetLastError());
   if (host_flags) {
     if (!flags_read) {   // no triplets: nothing above waited for the device
@@ -343,6 +394,17 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
     }
     host_flags[0] = h[0];
   }
+  return M3G_OK;
+}
+
+extern "C" int m3g_topology_hints(int64_t N, int64_t E, int64_t T, int64_t S, const void* topo_buf, int32_t* host_hints, void* stream_) {
+  if (!topo_buf || !host_hints) { set_error("m3g_topology_hints: null argument"); return M3G_ERR_VALUE; }
+  hipStream_t s = (hipStream_t)stream_;
+  Topo t = topo_carve(N, E, T, S, const_cast<void*>(topo_buf));
+  int32_t h[3] = {0, 0, 0};
+  M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags + 4, sizeof(h), hipMemcpyDeviceToHost, s));
+  M3G_HIP_CHECK(hipStreamSynchronize(s));
+  *host_hints = (T > 0 && h[0] == 0 && h[1] > 0) ? (M3G_TOPO_TB_COMPLETE | ((h[1] & 0xff) << 8) | ((h[2] & 0xff) << 16)) : 0;
   return M3G_OK;
 }
 

@@ -10,7 +10,7 @@ _PKG_ROOT = Path(__file__).resolve().parent.parent  # .../torch-m3gnet_amd
 LIB_PATH = _PKG_ROOT / "lib" / "libm3gnet_hip.so"
 
 M3G_OK, M3G_ERR_VALUE, M3G_ERR_STATE, M3G_ERR_SIZE, M3G_ERR_HIP, M3G_ERR_UNSUPPORTED = range(6)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class M3GConfig(C.Structure):
@@ -34,6 +34,7 @@ class M3GIO(C.Structure):
         ("stresses", C.c_void_p), ("scaled_total_energy", C.c_void_p), ("scaled_atomic_energies", C.c_void_p),
         ("node_features", C.c_void_p), ("edge_attr", C.c_void_p), ("edge_distances", C.c_void_p),
         ("edge_weights", C.c_void_p), ("triplet_angles", C.c_void_p), ("mid_edge_features", C.c_void_p),
+        ("topo_hints", C.c_int32),
     ]
 
 
@@ -50,6 +51,7 @@ SYMBOLS = {
     "m3g_topology_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_topology_build": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]),
+    "m3g_topology_hints": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_active_edges": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "m3g_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_energy_forces": (C.c_int, [C.c_void_p, C.POINTER(M3GIO), C.c_void_p, C.c_size_t, C.c_void_p]),

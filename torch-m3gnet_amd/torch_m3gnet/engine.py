@@ -201,6 +201,7 @@ class Engine:
                 node_features=p(out.get(K.NODE_FEATURES)), edge_attr=p(out.get(K.EDGE_ATTR)),
                 edge_distances=p(out.get(K.EDGE_DISTANCES)), edge_weights=p(out.get(K.EDGE_WEIGHTS)),
                 triplet_angles=p(out.get(K.TRIPLET_ANGLES)), mid_edge_features=p(out.get(K.MID_EDGE_FEATURES)),
+                topo_hints=topo.hints,
             )
             _lib.check(self.lib.m3g_energy_forces(self.plan, C.byref(io), p(self._workspace), self._workspace.numel(), M._stream()))
         for key, val in out.items():

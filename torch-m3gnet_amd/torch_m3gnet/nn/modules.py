@@ -110,6 +110,11 @@ class _Topology:
             raise ValueError("graph index out of range (edge_index / triplet_edge_index / batch)")
         if flags[0] & 4:
             raise ValueError("triplet_edge_index pairs edges that do not share a centre atom")
+        # what the build learned about the lists (complete partner lists -> the three-body moment kernels): one word, read back
+        # once per topology and handed to every m3g_energy_forces call with this buffer
+        hints = C.c_int32(0)
+        _lib.check(lib.m3g_topology_hints(self.N, self.E, self.T, self.S, _ptr(self.buf), C.byref(hints), _stream()))
+        self.hints = int(hints.value)
 
     def n_active(self) -> int:
         """Edges that take part in a triplet (rows of the three-body arrays)."""
