@@ -103,6 +103,8 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *                   mode: k_edge_rev_fused recomputing them), 0 = node-MLP + edge-MLP kernel pair (both modes, A/B tests);
  *   "stress_mode" = 0 the reference's sum pos (x) F / V (nn/gradient.py:39-62, default), 1 = pair virial
  *                   -(1/V) sum_e r_e (x) dE/dr_e (docs/gradient.md:47-84), invariant under lattice translations;
+ *   "threebody_moments" = 1 (default) the three-body sums run over per-atom moments when m3g_io.topo_hints says every centre's
+ *                   triplet list is complete (m3g_topology_hints), 0 = always walk the lists (A/B tests);
  *   "overlap"     = 1 the three-body reverse of a block runs on an internal side stream beside the node reverse's gather
  *                   (fork/join with events on the caller's stream), 0 = everything on the caller's stream (default: the
  *                   cross-stream waits measured slower than the overlap gains on the benchmark workload);
@@ -173,6 +175,7 @@ typedef struct {
   float* mid_edge_features;      /* [num_blocks,E,l_max*n_max] three-body aggregate of every block */
   /* optional input */
   int32_t topo_hints;            /* from m3g_topology_hints for `topo` (0: none -- always valid, the general kernels) */
+  int32_t reserved;              /* 0 */
 } m3g_io;
 
 int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes, void* stream);

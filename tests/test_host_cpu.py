@@ -33,7 +33,7 @@ def test_struct_layouts_match_header_sizes():
     from torch_m3gnet import _lib
 
     assert C.sizeof(_lib.M3GConfig) == 4 * 8 + 6 * 4
-    assert C.sizeof(_lib.M3GIO) == 4 * 8 + 17 * 8 + 8   # + topo_hints (int32, padded to the struct's 8-byte alignment)
+    assert C.sizeof(_lib.M3GIO) == 4 * 8 + 17 * 8 + 8   # + topo_hints, reserved (int32 each)
 
 
 def test_seeded_build_model_reproduces_reference_weights_and_keys():

@@ -572,7 +572,7 @@ static int energy_forces_graph(const m3g_plan* plan, const m3g_io* io, void* wor
   memcpy(k, &workspace, sizeof(void*)); k += sizeof(void*);
   memcpy(k, &s, sizeof(void*)); k += sizeof(void*);
   memcpy(k, &workspace_bytes, sizeof(size_t)); k += sizeof(size_t);
-  const int opts[4] = {plan->edge_kernel, plan->rev_kernel + 2 * plan->precision + 4 * plan->save_p1 + 8 * plan->save_p2, plan->stress_mode, plan->overlap};
+  const int opts[4] = {plan->edge_kernel, plan->rev_kernel + 2 * plan->save_p1 + 4 * plan->save_p2 + 8 * plan->tb_moments + 16 * plan->precision, plan->stress_mode, plan->overlap};
   memcpy(k, opts, sizeof(opts));
   for (auto& g : plan->graphs)
     if (g.key == key) { M3G_HIP_CHECK(hipGraphLaunch(g.exec, s)); return join(); }

@@ -34,7 +34,7 @@ class M3GIO(C.Structure):
         ("stresses", C.c_void_p), ("scaled_total_energy", C.c_void_p), ("scaled_atomic_energies", C.c_void_p),
         ("node_features", C.c_void_p), ("edge_attr", C.c_void_p), ("edge_distances", C.c_void_p),
         ("edge_weights", C.c_void_p), ("triplet_angles", C.c_void_p), ("mid_edge_features", C.c_void_p),
-        ("topo_hints", C.c_int32),
+        ("topo_hints", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
