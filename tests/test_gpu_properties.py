@@ -358,6 +358,39 @@ def test_one_sided_and_filtered_triplet_lists():
             assert rel_err(out[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) < m_tol, (name, b)
 
 
+def test_topology_hints_tell_complete_lists_from_the_rest():
+    """m3g_topology_hints (include/m3gnet_hip.h): bit 0 is set exactly when every centre's triplet list holds each ordered
+    pair of its active edges once -- what compute_threebody emits (data/material_graph.py:196-254) -- and then the word also
+    carries the largest three-body window (rows, atoms) the moment kernels size their LDS by.  Any other list (one-sided,
+    thinned, a duplicated pair, a permuted-but-complete list is still complete) must say 0 or the moment kernels would be
+    wrong for it."""
+    from torch_m3gnet.data.material_graph import Batch
+    from torch_m3gnet.nn.modules import _Topology
+
+    K = _K()
+    base = Batch.from_data_list([random_cell_graph(20, 6.5, s) for s in (7, 8)]).to(DEV)
+    tei = base[K.TRIPLET_EDGE_INDEX]
+
+    def hints_of(sub):
+        g = base.clone()
+        g[K.TRIPLET_EDGE_INDEX] = sub.contiguous()
+        g[K.NUM_TRIPLETS] = int(sub.size(1))
+        return _Topology(g).hints
+
+    h = hints_of(tei)
+    rows, atoms = (h >> 8) & 0xFF, (h >> 16) & 0xFF
+    assert h & 1 and 0 < rows <= 255 and 0 < atoms <= 64
+    perm = torch.randperm(tei.size(1), generator=torch.Generator().manual_seed(1)).to(tei.device)
+    assert hints_of(tei[:, perm]) == h                       # order of the list does not matter
+    assert hints_of(tei[:, tei[0] < tei[1]]) == 0            # one-sided
+    assert hints_of(tei[:, 1:]) == 0                         # one pair missing
+    assert hints_of(torch.cat([tei, tei[:, :1]], dim=1)) == 0   # one pair twice
+    g0 = base.clone()
+    g0[K.TRIPLET_EDGE_INDEX] = tei[:, :0].contiguous()
+    g0[K.NUM_TRIPLETS] = 0
+    assert _Topology(g0).hints == 0                          # no triplets at all
+
+
 # ------------------------------------------------------------------ BASELINE.json configurations
 def test_config3_10k_atom_cu_supercell_vs_oracle():
     """10,000-atom Cu supercell (BASELINE config 3): full-size parity against the fp32 CPU oracle plus
