@@ -341,7 +341,7 @@ def stage_times(model, call, steps):
     return {k: (ms / cnt, cnt / steps) for k, (ms, cnt) in stages.items() if cnt}
 
 
-def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc):
+def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc, moments=True):
     """Per-kernel roofline records (DESIGN.md section 4 states every byte / FLOP figure used here).  `pmc` = {kernel: {fetch_kb,
     write_kb}} of the profile set that matches this build, or {} (then every `traffic` is null)."""
     tiles = (n_edges + 15) // 16
@@ -403,8 +403,12 @@ def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc):
     dp1_row = 768 if precision == "bf16x3" else 1024
     hbm_kernels = {
         "geometry_basis": ("k_geometry", E * (8 + 12 + 12 + 4 + 16 + 16) + A * (64 + 64 + 8), 0),
-        "threebody_fwd": ("k_threebody_fwd", A * (64 + 12 + 4 + 4 + 64) + T * 1, 0),
-        "threebody_rev": ("k_threebody_rev", A * (64 + 64 + 12 + 4 + 4 + 64 + 64 + 16) + 2 * T * 1, 0),
+        # three-body aggregate: the moment kernels (complete partner lists) read no partner ids; the list kernels
+        # one byte per triplet and role.  Which pair ran is read off the profile set (tools/pmc_traffic.py names them apart).
+        **({"threebody_fwd": ("k_threebody_moments_fwd", A * (64 + 12 + 4 + 4 + 64), 0),
+            "threebody_rev": ("k_threebody_moments_rev", A * (64 + 64 + 12 + 4 + 4 + 64 + 64 + 16), 0)} if moments else
+           {"threebody_fwd": ("k_threebody_fwd", A * (64 + 12 + 4 + 4 + 64) + T * 1, 0),
+            "threebody_rev": ("k_threebody_rev", A * (64 + 64 + 12 + 4 + 4 + 64 + 64 + 16) + 2 * T * 1, 0)}),
         "node_rev": ("k_node_reverse", E * (dp1_row + 8) + N * (64 + 256 + 256) * 4, N * 2 * 256 * 64 * 2),
         "node_pre": ("k_node_pre_mfma", N * (256 + 2 * 1024 + 64 + 256) + 135 * 1024 * 256, N * 2 * 528 * 64),
         "geometry_rev_forces": ("k_geometry_reverse+k_force_gather+k_struct_stress", E * (16 * 3 + 12 + 4 + 12 + 12 * 2 + 8) + N * 12, 0),
@@ -580,6 +584,7 @@ def main():
     torch.cuda.synchronize()
     topo_ms = (time.perf_counter() - t1) * 1e3
     n_active = topo.n_active()
+    topo_hints = topo.hints   # bit 0: complete partner lists -> the three-body moment kernels ran (include/m3gnet_hip.h)
 
     # PMC traffic is a property of a build: the profile set carries the digest of the kernel sources it was collected on
     # (tools/pmc_traffic.py); a set from other sources than the ones being timed yields `traffic: null`
@@ -601,7 +606,8 @@ def main():
     def record(precision, ms_step):
         """Roofline objects of one precision mode from live stage timers (the mode must be the engine's current one)."""
         per_launch = stage_times(model, lambda: model(graph, forces=True, extras=False), args.steps)
-        views = rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc_all.get(precision, {}))
+        views = rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc_all.get(precision, {}),
+                          moments=bool(topo_hints & 1) and "threebody_moments=0" not in args.engine_option)
         edge = {k: v for k, v in views.items() if k in EDGE_KERNELS}
         dom = max(edge, key=lambda k: edge[k]["avg_launch_ms"] * per_launch[k][1])   # dominant kernel = largest share of the step
         stage_ms = {k: round(ms * cnt, 4) for k, (ms, cnt) in per_launch.items()}
@@ -622,7 +628,7 @@ def main():
                                    "3 blocks), energy+forces+stress",
                        "precision": args.precision, **({"engine_options": args.engine_option} if args.engine_option else {}),
                        "atoms_per_gpu": n_atoms, "edges_per_gpu": n_edges, "triplets_per_gpu": n_trip,
-                       "active_edges_per_gpu": n_active, "first_call_s_incl_topology_build": first_call_s,
+                       "active_edges_per_gpu": n_active, "topology_hints": topo_hints, "first_call_s_incl_topology_build": first_call_s,
                        "topology_build_ms": topo_ms, "stage_ms_per_step": stage_ms,
                        "multi_gpu": "replicas (a single cell does not shard); config4_sharded below runs the sharded path"})
     if not args.no_secondary:

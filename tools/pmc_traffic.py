@@ -34,7 +34,8 @@ def collect(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = re.sub(r"^void ", "", r["Kernel_Name"].split("(")[0]).replace("m3g::", "")
-        k = re.sub(r"<.*", "", k)
+        rev = re.match(r"k_threebody_moments<.*,\s*(true|false)>", k)   # forward and reverse are one template: keep them apart
+        k = re.sub(r"<.*", "", k) + (("_rev" if rev.group(1) == "true" else "_fwd") if rev else "")
         tot[k] += float(r["Counter_Value"])
         launches[k].add(r["Dispatch_Id"])
     return {k: tot[k] / len(launches[k]) for k in tot}, {k: len(v) for k, v in launches.items()}
