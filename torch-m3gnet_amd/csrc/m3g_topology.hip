@@ -209,22 +209,31 @@ __global__ void k_tb_row_complete(const int32_t* __restrict__ n_act, const int32
 }
 // per three-body workgroup: may it use the moment path (Topo::tb_fast)?  stats: [0] workgroups that may not, [1] largest window,
 // [2] most atoms per window (Topo::flags[4..6])
-__global__ void k_tb_fast(int64_t blocks, const int32_t* __restrict__ n_act, const int32_t* __restrict__ act_list, const int32_t* __restrict__ src,
-                          const int32_t* __restrict__ win, const uint8_t* __restrict__ ok, int32_t* fast, int32_t* stats) {
-  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_tb_fast(int64_t blocks, const int32_t* __restrict__ n_act, const int32_t* __restrict__ act_list,
+                                                 const int32_t* __restrict__ src, const int32_t* __restrict__ win, const uint8_t* __restrict__ ok,
+                                                 int32_t* fast, int32_t* stats) {
+  // one wave per window: its lanes test the rows, a ballot combines them
+  const int64_t b = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (b >= blocks) return;
   int na = 0, a0 = 0;
   if (b * kTbRows < *n_act) {
     const int lo = win[6 * b], hi = win[6 * b + 1];
     a0 = src[act_list[lo]];
     na = src[act_list[hi - 1]] - a0 + 1;
-    bool all = na <= kTbFastAtoms && hi - lo <= kTbCap;
-    for (int r = lo; all && r < hi; ++r) all = ok[r] != 0;
-    if (all) { atomicMax(stats + 1, hi - lo); atomicMax(stats + 2, na); }
-    else { na = 0; atomicAdd(stats, 1); }
+    bool mine = true;
+    for (int r = lo + lane; r < hi; r += 64) mine = mine && ok[r] != 0;
+    const bool all = na <= kTbFastAtoms && hi - lo <= kTbCap && __all(mine);
+    if (lane == 0) {
+      if (all) { atomicMax(stats + 1, hi - lo); atomicMax(stats + 2, na); }
+      else atomicAdd(stats, 1);
+    }
+    if (!all) na = 0;
   }
-  fast[2 * b] = na;
-  fast[2 * b + 1] = a0;
+  if (lane == 0) {
+    fast[2 * b] = na;
+    fast[2 * b + 1] = a0;
+  }
 }
 __global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ table, int32_t* out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -378,13 +387,13 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
     }
   }
   // which three-body workgroups may use the moment path (complete partner lists): row flags in the sort scratch, free by now
-  M3G_HIP_CHECK(hipMemsetAsync(t.tb_fast, 0, sizeof(int32_t) * 2 * (E / kTbRows + 1), s));
-  if (T == 0 || cub_bytes < (size_t)E + 1) {
+  // (no triplets: the three-body kernels never run and m3g_topology_hints answers 0 without looking)
+  if (T > 0 && cub_bytes < (size_t)E + 1) {
     M3G_HIP_CHECK(hipMemsetAsync(t.flags + 4, 0xff, sizeof(int32_t), s));   // "some workgroup may not": no moment path
-  } else {
+  } else if (T > 0) {
     uint8_t* row_ok = (uint8_t*)cub_tmp;
     hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok);
-    hipLaunchKernelGGL(k_tb_fast, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
+    hipLaunchKernelGGL(k_tb_fast, grid((E / kTbRows + 1) * 64), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
   }
   M3G_HIP_CHECK(hipGetLastError());
   if (host_flags) {
