@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: energy + forces of M3GNet (default model) on the HIP engine.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config4] [--precision fp32|bf16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config4] [--precision f16x3|fp32|bf16x3]
 
 `--gpus N` (N > 1) without a torch.distributed launcher in the environment starts the N ranks itself (one child
 process per GPU, before anything touches the GPU in the parent) and relays rank 0's JSON line; under
@@ -11,8 +11,8 @@ Workloads
   config3 (default; BASELINE.json configs[2], the "10k-atom PBC batch" the metric is quoted on): one jittered fcc-Cu
           supercell of 10 x 10 x 25 cells = 10,000 atoms per GPU, cutoff 5 A / three-body cutoff 4 A (E = 420,000
           directed edges, T = 3,060,000 triplets).  A single cell does not shard: with N > 1
-          every rank owns one independent supercell -- replicas, weak scaling, no data-path collective; the
-          per-structure energies are all-gathered over RCCL every step.
+          every rank owns one independent supercell -- replicas, weak scaling, nothing crosses ranks inside a step; after
+          the timed region the replicas' energies are all-gathered over RCCL once and compared.
   config4 (BASELINE.json configs[3]): 512 x N independent 64-atom random-species cells (seeds 0 .. 512 N - 1)
           partitioned over the N ranks by `torch_m3gnet.distributed.ShardedBatch` (greedy by triplet/edge cost, priced
           cooperatively, shard graphs built on the GPU), one RCCL all-gather of the per-structure energies per step.
@@ -21,9 +21,10 @@ Model: default M3GNet (l_max = n_max = 3, D = 64, 3 blocks, 95 species), random-
 A step = one `model(graph)` call = the m3g_energy_forces launch sequence (forward + analytic reverse pass + virial),
 graph tensors resident in HBM.
 
-Precision: the headline runs the engine's `fp32` mode (every dense product on v_mfma_f32_16x16x4_f32: exact fp32
-products, fp32 accumulate -- the reference's arithmetic); the `bf16x3` mode (3 bf16 split products per fp32 product,
-~2^-16 relative product error) is timed beside it and reported in `bf16x3`.
+Precision: the headline runs the engine's default `f16x3` mode (every operand of the dense products as two power-of-two-scaled
+fp16 parts, three f16 MFMA products, fp32 accumulate: 22-24 significant bits, the parity margins of the exact mode); the exact
+`fp32` mode (v_mfma_f32_16x16x4_f32: the reference's arithmetic) and the `bf16x3` mode (~2^-16 relative product error) are timed
+beside it and reported under `fp32` / `bf16x3`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      the dominant kernel against the roofline that bounds it (fp32 mode: the fp32 matrix peak, `frac` on the USEFUL
@@ -558,12 +559,8 @@ def main():
     n_atoms = int(graph[K.POS].size(0))
     n_edges = int(graph[K.EDGE_INDEX].size(1))
     n_trip = int(graph[K.TRIPLET_EDGE_INDEX].size(1))
-    energies_all = torch.empty(world, 1, device=job.comm_device) if job.dist is not None else None
-
-    def step():
+    def step():   # replicas: nothing crosses ranks inside a step (a single cell does not shard)
         model(graph, forces=True, extras=False)
-        if job.dist is not None:
-            job.dist.all_gather_into_tensor(energies_all, graph[K.TOTAL_ENERGY].view(1, 1).to(job.comm_device))
 
     t_first = time.perf_counter()
     step()  # first call: plan commit + topology build (index-only, cached on the graph) + workspace allocation
@@ -574,6 +571,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_atoms * args.steps / elapsed
     log(f"timed region done ({args.precision}): {ms_per_step:.3f} ms/step")
+    replica_spread = None
+    if job.dist is not None:   # after the timed region: the replicas' energies side by side (same cell, same weights: they must agree)
+        energies_all = torch.empty(world, 1, device=job.comm_device)
+        job.dist.all_gather_into_tensor(energies_all, graph[K.TOTAL_ENERGY].view(1, 1).to(job.comm_device))
+        replica_spread = float(((energies_all - energies_all[0]).abs().max() / energies_all[0].abs().clamp_min(1e-30)).item())
 
     # index-only CSR build (m3g_topology_build), timed on its own: reused while the neighbour list is unchanged
     from torch_m3gnet.nn.modules import _Topology
@@ -630,7 +632,8 @@ def main():
                        "atoms_per_gpu": n_atoms, "edges_per_gpu": n_edges, "triplets_per_gpu": n_trip,
                        "active_edges_per_gpu": n_active, "topology_hints": topo_hints, "first_call_s_incl_topology_build": first_call_s,
                        "topology_build_ms": topo_ms, "stage_ms_per_step": stage_ms,
-                       "multi_gpu": "replicas (a single cell does not shard); config4_sharded below runs the sharded path"})
+                       "multi_gpu": "replicas (a single cell does not shard; no collective inside the timed steps); config4_sharded below runs the sharded path",
+                       **({"replica_energy_rel_spread": replica_spread} if replica_spread is not None else {})})
     if not args.no_secondary:
         for other in other_modes:   # the other arithmetic modes of the same engine, same workload, same timed-region rules
             model.engine.set_precision(other)

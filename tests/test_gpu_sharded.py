@@ -108,8 +108,8 @@ def test_one_rank_nccl_group_runs_the_rccl_branch():
 
 
 def test_bench_nccl_branch_with_one_rank():
-    """bench.py's own RCCL code (Job: init with device_id, per-step all-gather of the energies into a device buffer, barrier,
-    all-reduce of the elapsed time) with a forced one-rank group, on a small cell."""
+    """bench.py's own RCCL code (Job: init with device_id, barrier, all-reduce of the elapsed time, the all-gather of the replicas'
+    energies into a device buffer after the timed region) with a forced one-rank group, on a small cell."""
     import json
     from pathlib import Path
 
@@ -120,6 +120,7 @@ def test_bench_nccl_branch_with_one_rank():
     assert proc.returncode == 0, proc.stderr[-3000:]
     rec = json.loads(proc.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["atoms_per_gpu"] == 256
+    assert rec["config"]["replica_energy_rel_spread"] == 0.0
 
 
 def test_self_launched_job_fails_fast_when_a_rank_dies():
