@@ -33,24 +33,30 @@ inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 // ---- dense products ---------------------------------------------------------------------------------------------------
 // C[n, j] = (beta ? C[n, j] : 0) + (bias ? bias[j] : 0) + sum_k A[n*lda + k] * B[k*sbk + j*sbj]     (any strides of B: W or W^T)
-// 64 x 64 output tile per workgroup, K walked in slabs of 16 staged in LDS, 4 x 4 outputs per thread.  Every output is still
-// the k-ordered fp32 sum bias + a_0 b_0 + a_1 b_1 + ... of round 2's one-thread-per-output kernel (bit-identical results), but
-// an A row is read once per 64 columns instead of once per column and B is read coalesced whichever way it is strided:
-// 183 -> see DESIGN.md section 4c ms/step for the default model at the 10k-atom cell.
+// 64 x 64 output tile per workgroup, K walked in slabs of 16 staged in LDS (an A row is read once per 64 columns, B coalesced
+// whichever way it is strided); each of the four waves owns 16 rows of the tile and forms its 16 x 64 outputs with
+// v_mfma_f32_16x16x4_f32 -- exact fp32 products, fp32 accumulation, the arithmetic of the reference's matmul -- four column blocks
+// per 4-deep k-step.  Round 2: one thread per output element (1,064 ms per step at D = 128); round 3: this tiling on the vector
+// ALU (43 ms), then on the matrix pipe.
+typedef float g_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kGemmTile = 64, kGemmK = 16;
+// NCB: 16-column blocks per workgroup.  4 (a 64 x 64 tile) everywhere: tiles of 128 / 256 columns, which read the activation
+// operand once instead of once per 64 columns, measured SLOWER at D = 96 / 128 (30.6 / 40.1 against 28.2 / 37.3 ms per step: fewer
+// workgroups in flight to hide the row-strided A loads)
+template <int NCB>
 __global__ void __launch_bounds__(256) g_gemm(int64_t n, int cols, int K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                               int sbk, int sbj, const float* __restrict__ bias, float* __restrict__ Cm, int64_t ldc, int beta) {
-  __shared__ float sa[kGemmK][kGemmTile + 1], sb[kGemmK][kGemmTile + 1];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  constexpr int TN = 16 * NCB;
+  __shared__ float sa[kGemmK][kGemmTile + 1], sb[kGemmK][TN + 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 15, q = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * kGemmTile;
-  const int col0 = blockIdx.y * kGemmTile;
-  float acc[4][4];
+  const int col0 = blockIdx.y * TN;
+  g_f32x4 acc[NCB];   // column block cb: rows 16 wave + 4 q + r, column 16 cb + m
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = col0 + tx * 4 + j;
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int c = col0 + 16 * cb + m;
     const float b0 = (bias && c < cols) ? bias[c] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i][j] = b0;
+    acc[cb] = g_f32x4{b0, b0, b0, b0};
   }
   for (int k0 = 0; k0 < K; k0 += kGemmK) {
 #pragma unroll
@@ -60,43 +66,42 @@ __global__ void __launch_bounds__(256) g_gemm(int64_t n, int cols, int K, const 
       sa[kk][r] = (row < n && k0 + kk < K) ? A[row * lda + k0 + kk] : 0.f;
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {   // B slab: 16 k x 64 columns, the contiguous index fastest
+    for (int it = 0; it < NCB; ++it) {   // B slab: 16 k x TN columns, the contiguous index fastest
       const int idx = tid + it * 256;
-      const int kk = sbj == 1 ? idx >> 6 : idx & 15, cc = sbj == 1 ? idx & 63 : idx >> 4;
+      const int kk = sbj == 1 ? idx / TN : idx & 15, cc = sbj == 1 ? idx % TN : idx >> 4;
       const int c = col0 + cc;
       sb[kk][cc] = (c < cols && k0 + kk < K) ? B[(int64_t)(k0 + kk) * sbk + (int64_t)c * sbj] : 0.f;
     }
     __syncthreads();
-    const int kn = K - k0 < kGemmK ? K - k0 : kGemmK;
-    for (int kk = 0; kk < kn; ++kk) {
-      float a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = sa[kk][ty * 4 + i]; b[i] = sb[kk][tx * 4 + i]; }
+    for (int ks = 0; ks < kGemmK / 4; ++ks) {   // (rows of the slab beyond K hold zeros)
+      const float a = sa[4 * ks + q][16 * wave + m];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+      for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[4 * ks + q][16 * cb + m], acc[cb], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t row = row0 + ty * 4 + i;
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = row0 + 16 * wave + 4 * q + r;
     if (row >= n) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = col0 + tx * 4 + j;
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int c = col0 + 16 * cb + m;
       if (c >= cols) continue;
       float* out = Cm + row * ldc + c;
-      *out = beta ? *out + acc[i][j] : acc[i][j];
+      *out = beta ? *out + acc[cb][r] : acc[cb][r];
     }
   }
 }
 static void gemm(hipStream_t s, int64_t n, int cols, int K, const float* A, int64_t lda, const float* B, int sbk, int sbj, const float* bias,
                  float* C, int64_t ldc, bool beta = false) {
-  if (n > 0 && cols > 0)
-    hipLaunchKernelGGL(g_gemm, dim3((unsigned)((n + kGemmTile - 1) / kGemmTile), (unsigned)((cols + kGemmTile - 1) / kGemmTile)), dim3(256), 0, s, n,
-                       cols, K, A, lda, B, sbk, sbj, bias, C, ldc, beta ? 1 : 0);
+  if (n <= 0 || cols <= 0) return;
+  const unsigned gx = (unsigned)((n + kGemmTile - 1) / kGemmTile);
+#define M3G_GEMM_LAUNCH(NCB_) \
+  hipLaunchKernelGGL(g_gemm<NCB_>, dim3(gx, (unsigned)((cols + 16 * NCB_ - 1) / (16 * NCB_))), dim3(256), 0, s, n, cols, K, A, lda, B, sbk, sbj, bias, C, ldc, beta ? 1 : 0)
+  M3G_GEMM_LAUNCH(4);
+#undef M3G_GEMM_LAUNCH
 }
 // y[n, j] = x[idx[n], j]  (row gather), optionally y += ...
 __global__ void __launch_bounds__(256) g_gather(int64_t n, int w, const int32_t* __restrict__ idx, const float* __restrict__ X, int64_t ldx,
