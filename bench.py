@@ -586,7 +586,7 @@ def main():
     torch.cuda.synchronize()
     topo_ms = (time.perf_counter() - t1) * 1e3
     n_active = topo.n_active()
-    topo_hints = topo.hints   # bit 0: complete partner lists -> the three-body moment kernels ran (include/m3gnet_hip.h)
+    topo_hints = topo.query_hints()   # bit 0: complete partner lists -> the three-body moment kernels ran (include/m3gnet_hip.h)
 
     # PMC traffic is a property of a build: the profile set carries the digest of the kernel sources it was collected on
     # (tools/pmc_traffic.py); a set from other sources than the ones being timed yields `traffic: null`

@@ -136,9 +136,10 @@ def test_threebody_moment_and_list_paths_agree(case, mode):
     model, _ = build_engine_model(case, mode)
     model.engine.set_precision("fp32")
     out = {}
+    eg = engine_graph(graph)
     for moments in (1, 0):
         model.engine.set_option("threebody_moments", moments)
-        g = model(engine_graph(graph))
+        g = model(eg)
         torch.cuda.synchronize()
         out[moments] = {k: g[k].detach().clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES, K.MID_EDGE_FEATURES)}
         assert float(((g[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < E_TOL

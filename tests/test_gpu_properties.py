@@ -375,7 +375,7 @@ def test_topology_hints_tell_complete_lists_from_the_rest():
         g = base.clone()
         g[K.TRIPLET_EDGE_INDEX] = sub.contiguous()
         g[K.NUM_TRIPLETS] = int(sub.size(1))
-        return _Topology(g).hints
+        return _Topology(g).query_hints()
 
     h = hints_of(tei)
     rows, atoms = (h >> 8) & 0xFF, (h >> 16) & 0xFF
@@ -388,7 +388,7 @@ def test_topology_hints_tell_complete_lists_from_the_rest():
     g0 = base.clone()
     g0[K.TRIPLET_EDGE_INDEX] = tei[:, :0].contiguous()
     g0[K.NUM_TRIPLETS] = 0
-    assert _Topology(g0).hints == 0                          # no triplets at all
+    assert _Topology(g0).query_hints() == 0                  # no triplets at all
 
 
 # ------------------------------------------------------------------ BASELINE.json configurations

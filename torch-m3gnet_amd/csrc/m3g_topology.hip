@@ -189,8 +189,9 @@ __global__ void k_tb_windows(int64_t blocks, const int32_t* __restrict__ n_act, 
 // second edge?  (Ascending order inside a row is what the sorted lists have; it makes "exactly once" a local test.)
 __global__ void k_tb_row_complete(const int32_t* __restrict__ n_act, const int32_t* __restrict__ act_list, const int32_t* __restrict__ src,
                                   const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ t1_e2c,
-                                  const int32_t* __restrict__ t2_ptr, const int32_t* __restrict__ t2_e1c, uint8_t* ok) {
+                                  const int32_t* __restrict__ t2_ptr, const int32_t* __restrict__ t2_e1c, uint8_t* ok, int32_t* stats) {
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r < 3) stats[r] = 0;   // k_tb_fast, the next kernel, accumulates into them
   if (r >= *n_act) return;
   const int e = act_list[r], c = src[e];
   const int s0 = arow_ptr[c], s1 = arow_ptr[c + 1];
@@ -386,15 +387,6 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
       hipLaunchKernelGGL(k_partner_bytes<false>, grid(T), dim3(TPB), 0, s, E, T, t.t2_ptr, nullptr, t.act_id, t.tb_win, t.t2_e1c, t.t2_b);
     }
   }
-  // which three-body workgroups may use the moment path (complete partner lists): row flags in the sort scratch, free by now
-  // (no triplets: the three-body kernels never run and m3g_topology_hints answers 0 without looking)
-  if (T > 0 && cub_bytes < (size_t)E + 1) {
-    M3G_HIP_CHECK(hipMemsetAsync(t.flags + 4, 0xff, sizeof(int32_t), s));   // "some workgroup may not": no moment path
-  } else if (T > 0) {
-    uint8_t* row_ok = (uint8_t*)cub_tmp;
-    hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok);
-    hipLaunchKernelGGL(k_tb_fast, grid((E / kTbRows + 1) * 64), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
-  }
   M3G_HIP_CHECK(hipGetLastError());
   if (host_flags) {
     if (!flags_read) {   // no triplets: nothing above waited for the device
@@ -408,12 +400,26 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
 
 extern "C" int m3g_topology_hints(int64_t N, int64_t E, int64_t T, int64_t S, const void* topo_buf, int32_t* host_hints, void* stream_) {
   if (!topo_buf || !host_hints) { set_error("m3g_topology_hints: null argument"); return M3G_ERR_VALUE; }
+  *host_hints = 0;
+  if (T <= 0 || E <= 0) return M3G_OK;   // no triplets: the three-body kernels never run
   hipStream_t s = (hipStream_t)stream_;
   Topo t = topo_carve(N, E, T, S, const_cast<void*>(topo_buf));
+  // The certificate for the three-body moment kernels, formed on demand (a topology that is used once does not pay for it): per
+  // compacted row, are its partner lists complete; per 128-row window, are all its rows, and how large do the windows get.  Row
+  // flags live in the sort scratch of the buffer, which nothing reads after the build.
+  size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
+  char* tmp = (char*)t.sort_tmp;
+  uint8_t* row_ok = (uint8_t*)(tmp + 2 * align_up(m * sizeof(uint64_t)));
+  if (t.sort_tmp_bytes < 2 * align_up(m * sizeof(uint64_t)) + (size_t)E + 1) return M3G_OK;
+  const int TPB = 256;
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + TPB - 1) / TPB)); };
+  hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok,
+                     t.flags + 4);
+  hipLaunchKernelGGL(k_tb_fast, grid((E / kTbRows + 1) * 64), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
   int32_t h[3] = {0, 0, 0};
   M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags + 4, sizeof(h), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipStreamSynchronize(s));
-  *host_hints = (T > 0 && h[0] == 0 && h[1] > 0) ? (M3G_TOPO_TB_COMPLETE | ((h[1] & 0xff) << 8) | ((h[2] & 0xff) << 16)) : 0;
+  if (h[0] == 0 && h[1] > 0) *host_hints = M3G_TOPO_TB_COMPLETE | ((h[1] & 0xff) << 8) | ((h[2] & 0xff) << 16);
   return M3G_OK;
 }
 

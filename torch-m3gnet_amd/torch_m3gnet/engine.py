@@ -65,6 +65,9 @@ class Engine:
             self.set_precision(env_prec)
         self._workspace = None
         self._graph_replay = False
+        # ask every new topology for its m3g_topology_hints word (complete triplet lists -> three-body moment kernels); False for
+        # loops that rebuild the neighbour list every step on sparse cells, where the certificate costs more than it returns
+        self.topology_hints = True
         self._species_host = None   # pinned [min, max] of the last species check
         self._out_cache = {}
 
@@ -201,7 +204,7 @@ class Engine:
                 node_features=p(out.get(K.NODE_FEATURES)), edge_attr=p(out.get(K.EDGE_ATTR)),
                 edge_distances=p(out.get(K.EDGE_DISTANCES)), edge_weights=p(out.get(K.EDGE_WEIGHTS)),
                 triplet_angles=p(out.get(K.TRIPLET_ANGLES)), mid_edge_features=p(out.get(K.MID_EDGE_FEATURES)),
-                topo_hints=topo.hints,
+                topo_hints=topo.hints_for_call() if self.topology_hints else 0,
             )
             _lib.check(self.lib.m3g_energy_forces(self.plan, C.byref(io), p(self._workspace), self._workspace.numel(), M._stream()))
         for key, val in out.items():

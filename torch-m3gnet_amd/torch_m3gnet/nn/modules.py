@@ -110,11 +110,24 @@ class _Topology:
             raise ValueError("graph index out of range (edge_index / triplet_edge_index / batch)")
         if flags[0] & 4:
             raise ValueError("triplet_edge_index pairs edges that do not share a centre atom")
-        # what the build learned about the lists (complete partner lists -> the three-body moment kernels): one word, read back
-        # once per topology and handed to every m3g_energy_forces call with this buffer
-        hints = C.c_int32(0)
-        _lib.check(lib.m3g_topology_hints(self.N, self.E, self.T, self.S, _ptr(self.buf), C.byref(hints), _stream()))
-        self.hints = int(hints.value)
+        self._hints = None   # m3g_topology_hints, asked for before the first m3g_energy_forces call (`hints_for_call`)
+
+    def query_hints(self) -> int:
+        """The word m3g_topology_hints returns for this topology (certifies complete triplet lists for the three-body moment
+        kernels; a few small kernels and one wait for the stream).  Cached."""
+        if self._hints is None:
+            hints = C.c_int32(0)
+            with torch.cuda.device(self.buf.device):
+                _lib.check(_lib.load_library().m3g_topology_hints(self.N, self.E, self.T, self.S, _ptr(self.buf), C.byref(hints), _stream()))
+            self._hints = int(hints.value)
+        return self._hints
+
+    def hints_for_call(self) -> int:
+        """m3g_io.topo_hints for m3g_energy_forces calls with this topology: asked for before the first call, so that every
+        evaluation of a graph runs the same kernels (bit-identical results from the first call on).  The certificate costs a
+        topology that is used once about 0.08 ms on the 10k-atom cell -- `Engine.topology_hints = False` turns it off for such
+        loops (the list kernels, always valid)."""
+        return self.query_hints()
 
     def n_active(self) -> int:
         """Edges that take part in a triplet (rows of the three-body arrays)."""
