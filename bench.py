@@ -411,7 +411,8 @@ def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc, mo
            {"threebody_fwd": ("k_threebody_fwd", A * (64 + 12 + 4 + 4 + 64) + T * 1, 0),
             "threebody_rev": ("k_threebody_rev", A * (64 + 64 + 12 + 4 + 4 + 64 + 64 + 16) + 2 * T * 1, 0)}),
         "node_rev": ("k_node_reverse", E * (dp1_row + 8) + N * (64 + 256 + 256) * 4, N * 2 * 256 * 64 * 2),
-        "node_pre": ("k_node_pre_mfma", N * (256 + 2 * 1024 + 64 + 256) + 135 * 1024 * 256, N * 2 * 528 * 64),
+        # (x in, TA / TB / v / x out, and a third of the 135-KB weight image per workgroup: 3 x min(ceil(tiles / 4), 256) workgroups)
+        "node_pre": ("k_node_pre_mfma", N * (3 * 256 + 2 * 1024 + 64 + 256) + 47 * 1024 * 3 * min((N + 63) // 64, 256), N * 2 * 528 * 64),
         "geometry_rev_forces": ("k_geometry_reverse+k_force_gather+k_struct_stress", E * (16 * 3 + 12 + 4 + 12 + 12 * 2 + 8) + N * 12, 0),
     }
     for stage, (kernel, nbytes, flops) in hbm_kernels.items():

@@ -10,40 +10,42 @@ namespace m3g {
 // re-read 128 KB of weights from L2 for every 16 atoms.  x^b = x^(b-1) + the per-centre message sums of block b-1 is
 // formed while the tile is loaded (x_prev != nullptr) and written back for the later stages.
 constexpr int kNodeXPitch = 68;   // floats per staged x row: 64 + 4 keeps 16-byte alignment and spreads the 16 rows over the banks
-// SPLIT (small systems, whose step is the serial latency of its kernels): a wave takes ONE of the three 11-row-block passes of a
-// tile instead of all three, so a 2-tile system runs 6 waves for a third of the time each.
-template <int PREC, bool SPLIT = false>
+// One of the three 11-row-block passes per WORKGROUP (blockIdx.x % 3): its third of the weight image (45 KB + the biases) is all
+// the workgroup stages, two to three workgroups share a CU, and a small system's tiles spread over three times as many waves.
+// (Until round 3 every workgroup staged the whole 135-KB image and walked all three passes -- or, for small systems, gave its
+// waves one pass each but still staged everything: 35 MB of image reads per launch on the 10k-atom cell, 15 us per launch.)
+constexpr int kNodePassFloats = 11 * 2 * 512;
+template <int PREC>
 __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
                                                        const float* __restrict__ seg_head, const float* __restrict__ seg_first,
                                                        const int32_t* __restrict__ row_ptr, float* __restrict__ x,
                                                        float* __restrict__ v, float* __restrict__ TA, float* __restrict__ TB,
                                                        const int64_t* __restrict__ types, const float* __restrict__ emb, int num_types,
                                                        float w_inv) {
-  __shared__ __attribute__((aligned(16))) float lds[kNodeImgFloats + 4 * 16 * kNodeXPitch];
-  {  // image -> LDS, 16 independent 16-byte loads in flight per thread (a load-store-load chain would pay one L2 round trip
-     // per 4 KB of the 137 KB image)
-    constexpr int kVec = kNodeImgFloats / 4, kBatch = 16;
-    for (int base = 0; base < kVec; base += 256 * kBatch) {
-      f32x4 t[kBatch];
-      static_for<kBatch>([&]<int j>() {
-        const int i = base + j * 256 + (int)threadIdx.x;
-        t[j] = i < kVec ? *(const f32x4*)(img + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      });
-      static_for<kBatch>([&]<int j>() {
-        const int i = base + j * 256 + (int)threadIdx.x;
-        if (i < kVec) *(f32x4*)(lds + 4 * i) = t[j];
-      });
-    }
+  constexpr int kBiasFloats = kNodeRowBlocks * 16;
+  __shared__ __attribute__((aligned(16))) float lds[kNodePassFloats + kBiasFloats + 4 * 16 * kNodeXPitch];
+  const int g = blockIdx.x % 3;   // this workgroup's pass (uniform)
+  {  // this pass's image chunk and the biases -> LDS, every 16-byte load of a thread in flight at once
+    constexpr int kVec = kNodePassFloats / 4, kPer = (kVec + 255) / 256;
+    const float* src = img + (size_t)g * kNodePassFloats;
+    f32x4 t[kPer];
+    static_for<kPer>([&]<int j>() {
+      const int i = j * 256 + (int)threadIdx.x;
+      t[j] = i < kVec ? *(const f32x4*)(src + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    });
+    const f32x4 tb = (int)threadIdx.x < kBiasFloats / 4 ? *(const f32x4*)(img + kNodeRowBlocks * 16 * 64 + 4 * threadIdx.x) : f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<kPer>([&]<int j>() {
+      const int i = j * 256 + (int)threadIdx.x;
+      if (i < kVec) *(f32x4*)(lds + 4 * i) = t[j];
+    });
+    if ((int)threadIdx.x < kBiasFloats / 4) *(f32x4*)(lds + kNodePassFloats + 4 * threadIdx.x) = tb;
   }
   __syncthreads();
-  const float* bias = lds + kNodeRowBlocks * 16 * 64;
+  const float* bias = lds + kNodePassFloats;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
-  float* xs = lds + kNodeImgFloats + wave * 16 * kNodeXPitch;
+  float* xs = lds + kNodePassFloats + kBiasFloats + wave * 16 * kNodeXPitch;
   const int64_t tiles = (N + 15) / 16;
-  const int64_t items = SPLIT ? tiles * 3 : tiles;
-  for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < items; item += (int64_t)gridDim.x * 4) {
-    const int64_t tile = SPLIT ? item / 3 : item;
-    const int only = SPLIT ? (int)(item - tile * 3) : -1;   // the pass this wave computes (all three when not split)
+  for (int64_t tile = (int64_t)(blockIdx.x / 3) * 4 + wave; tile < tiles; tile += (int64_t)(gridDim.x / 3) * 4) {
     // stage the tile's x rows: lane (m, q) brings features 16q .. 16q+15 of atom m
     const int64_t atom = tile * 16 + m;
     const bool live = atom < N;
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
         src = emb + ty * kDP + 16 * q;
       }
       static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
-      if (types && only <= 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+      if (types && g == 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
       if (x_prev) {
         const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
         if (r1 > r0) {
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
           for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
             static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
         }
-        if (only <= 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+        if (g == 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });   // (the pass-0 workgroup writes x^b back)
       }
     }
     static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
@@ -75,14 +77,14 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
     static_for<4>([&]<int blk>() { xb[blk] = *(const f32x4*)(xs + m * kNodeXPitch + blk * 16 + 4 * q); });
     int lv = lane;
     asm volatile("" : "+v"(lv));   // keep the image reads inside the tile loop
-    static_for<3>([&]<int g>() {   // 11 row blocks per pass: bf16x3 chains like the edge kernels' (fp32 accumulate)
-      if (SPLIT && only != g) return;
+    static_for<3>([&]<int G>() {   // 11 row blocks: split-precision chains like the edge kernels' (fp32 accumulate)
+      if (g != G) return;
       f32x4 acc[11];
-      static_for<11>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (11 * g + j) * 16 + 4 * q); });
-      chain_p<PREC, 11, 2>(lds + g * (11 * 2 * 512), xb, acc, lv, w_inv);
+      static_for<11>([&]<int j>() { acc[j] = *(const f32x4*)(bias + (11 * G + j) * 16 + 4 * q); });
+      chain_p<PREC, 11, 2>(lds, xb, acc, lv, w_inv);
       if (live) {
         static_for<11>([&]<int j>() {
-          constexpr int ob = 11 * g + j;
+          constexpr int ob = 11 * G + j;
           if (ob < 16) *(f32x4*)(TA + atom * (4 * kDP) + ob * 16 + 4 * q) = acc[j];
           else if (ob < 32) *(f32x4*)(TB + atom * (4 * kDP) + (ob - 16) * 16 + 4 * q) = acc[j];
           else {
@@ -225,16 +227,12 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
                           float* v, float* TA, float* TB, const int64_t* types, const float* emb, hipStream_t s) {
   if (t.N == 0) return;
   const int64_t tiles = (t.N + 15) / 16;
-  const bool split = tiles * 3 <= 256 * 4;   // fewer work items than wave slots on the chip: split the passes over waves
-  const int wgs = (int)std::min<int64_t>(((split ? tiles * 3 : tiles) + 3) / 4, 256);
-#define M3G_NODE_PRE_LAUNCH(SPLIT_)                                                                                            \
-  M3G_PREC_SWITCH(plan->precision,                                                                                             \
-                  hipLaunchKernelGGL((k_node_pre_mfma<PREC, SPLIT_>), dim3(wgs), dim3(256), 0, s, c.C, t.N,                      \
-                                     plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first, \
-                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types,                                              \
-                                     plan->precision == kPrecF16x3 ? plan->w_scale_inv : 1.f))
-  if (split) { M3G_NODE_PRE_LAUNCH(true); } else { M3G_NODE_PRE_LAUNCH(false); }
-#undef M3G_NODE_PRE_LAUNCH
+  const int wgs = 3 * (int)std::min<int64_t>((tiles + 3) / 4, 256);   // (pass, group of four tiles); groups beyond 256 loop
+  M3G_PREC_SWITCH(plan->precision,
+                  hipLaunchKernelGGL((k_node_pre_mfma<PREC>), dim3(wgs), dim3(256), 0, s, c.C, t.N,
+                                     plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first,
+                                     t.row_ptr, x, v, TA, TB, types, emb, c.num_types,
+                                     plan->precision == kPrecF16x3 ? plan->w_scale_inv : 1.f));
 }
 
 }  // namespace m3g
