@@ -211,7 +211,9 @@ struct m3g_plan {
   bool generic = false;          // sizes beyond the MFMA kernels' tiles (or option "edge_kernel" = 2)
   float* d_generic = nullptr;
   std::map<std::string, size_t> generic_off;
-  float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as bf16x3 chain images (k_readout_mfma)
+  float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as exact-fp32 chain images (k_readout_mfma; fp32 and bf16x3 modes)
+  float* d_readout_img_h = nullptr; // the same layout as scaled two-part fp16 chain images (f16x3 mode), weights scaled by 1 / ro_w_scale_inv
+  float ro_w_scale_inv = 1.f;
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   bool tb_moments = true;   // option "threebody_moments": per-atom moment sums where the partner lists are complete (m3g_threebody.hip)
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)

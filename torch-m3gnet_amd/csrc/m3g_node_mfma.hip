@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
 // branch as exact-fp32 MFMA chains (this stage seeds the reverse pass), the final 64 -> 1 products as lane-local dots + a lane-quarter sum, then (forces wanted) the
 // transposed chains back to dE/dx.  All seven weight images (130 KB) resident in LDS; x^B = x^(B-1) + per-centre message
 // sums of the last block is formed while the tile is loaded.  Replaces the vector-ALU k_readout on the MFMA path.
-__global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const float* __restrict__ img, const float* __restrict__ elemental,
+template <int PREC>   // kPrecF32: exact fp32 MFMA chains; kPrecF16x3: the same layers on scaled two-part fp16 operands (w_inv = 1 / weight scale)
+__global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const float* __restrict__ img, float w_inv, const float* __restrict__ elemental,
                                                       const int64_t* __restrict__ types, const float* __restrict__ x_prev,
                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
                                                       const int32_t* __restrict__ row_ptr, float* __restrict__ x,
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const
     // layer 1 (dense blocks 0-3, gate 4-7): p1 -> hidden, p1 keeps SiLU'
     f32x4 p1[8], hid[8];
     static_for<8>([&]<int ob>() { p1[ob] = *(const f32x4*)(lds + ReadoutImg::b1 + ob * 16 + 4 * q); });
-    chain_f32<8, 4>(lds + ReadoutImg::w1, xb, p1, lv);
+    chain_p<PREC, 8, 2>(lds + ReadoutImg::w1, xb, p1, lv, w_inv);
     static_for<8>([&]<int ob>() {
       static_for<4>([&]<int r>() {
         const float p = p1[ob][r], sg = fsigmoid(p);
@@ -167,8 +168,8 @@ __global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const
     // layer 2
     f32x4 p2[8];
     static_for<8>([&]<int ob>() { p2[ob] = *(const f32x4*)(lds + ReadoutImg::b2 + ob * 16 + 4 * q); });
-    chain_f32<4, 4, 0, 0>(lds + ReadoutImg::w2d, hid, p2, lv);
-    chain_f32<4, 4, 4, 4>(lds + ReadoutImg::w2g, hid, p2, lv);
+    chain_p<PREC, 4, 2, 0, 0>(lds + ReadoutImg::w2d, hid, p2, lv, w_inv);
+    chain_p<PREC, 4, 2, 4, 4>(lds + ReadoutImg::w2g, hid, p2, lv, w_inv);
     // final 64 -> 1 of both branches: lane-local dots over this lane's 16 features, then across the four lane quarters
     float od = 0.f, og = 0.f;
     f32x4 w3[8];
@@ -199,12 +200,12 @@ __global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const
     });
     f32x4 dp1[8];
     zero(dp1);
-    chain_f32<4, 4, 0, 0>(lds + ReadoutImg::w2dT, d2, dp1, lv);
-    chain_f32<4, 4, 4, 4>(lds + ReadoutImg::w2gT, d2, dp1, lv);
+    chain_p<PREC, 4, 2, 0, 0>(lds + ReadoutImg::w2dT, d2, dp1, lv, w_inv);
+    chain_p<PREC, 4, 2, 4, 4>(lds + ReadoutImg::w2gT, d2, dp1, lv, w_inv);
     static_for<8>([&]<int ob>() { dp1[ob] *= p1[ob]; });
     f32x4 dxb[4];
     zero(dxb);
-    chain_f32<4, 8>(lds + ReadoutImg::w1T, dp1, dxb, lv);
+    chain_p<PREC, 4, 4>(lds + ReadoutImg::w1T, dp1, dxb, lv, w_inv);
     if (live) static_for<4>([&]<int blk>() { *(f32x4*)(dx + atom * kDP + blk * 16 + 4 * q) = dxb[blk]; });
   }
 }
@@ -216,8 +217,14 @@ void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayo
   if (t.N > 0) {
     const int64_t tiles = (t.N + 15) / 16;
     const int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
-    hipLaunchKernelGGL(k_readout_mfma, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img, plan->d_weights + wl.elemental, types,
-                       x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic, want_grad ? w.dx : nullptr, scaled_total, t.S);
+    if (plan->precision == kPrecF16x3)
+      hipLaunchKernelGGL(k_readout_mfma<kPrecF16x3>, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img_h, plan->ro_w_scale_inv,
+                         plan->d_weights + wl.elemental, types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic,
+                         want_grad ? w.dx : nullptr, scaled_total, t.S);
+    else   // fp32 mode, and bf16x3 (whose 2^-16 products here moved the Cu-32 virial from 4.5e-5 to 1.2e-4 of its fp64 value)
+      hipLaunchKernelGGL(k_readout_mfma<kPrecF32>, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img, 1.f,
+                         plan->d_weights + wl.elemental, types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic,
+                         want_grad ? w.dx : nullptr, scaled_total, t.S);
   }
   launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
 }

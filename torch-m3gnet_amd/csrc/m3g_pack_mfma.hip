@@ -183,6 +183,7 @@ void free_mfma_images(m3g_plan* plan) {
   drop(plan->d_mfma_revf_h);
   drop(plan->d_mfma_revf32);
   drop(plan->d_readout_img);
+  drop(plan->d_readout_img_h);
 }
 
 static int upload(float*& dst, const std::vector<float>& host) {
@@ -394,6 +395,23 @@ int pack_mfma_images(m3g_plan* plan) {
       img[ReadoutImg::b3 + g] = plan->params.at(ro + br[g] + ".4.bias")[0];
     }
     { int rc = upload(plan->d_readout_img, img); if (rc) return rc; }
+    // f16x3 mode: the same six matrices as scaled two-part fp16 images (fp32-grade products, a fifth of the matrix time of
+    // the fp32 MFMAs; biases and the final 64 -> 1 weights stay fp32); their own power-of-two scale
+    float wmax = 0.f;
+    for (const float* w : {w1d, w1g, w2d, w2g})
+      for (int i = 0; i < D * D; ++i) wmax = std::max(wmax, std::fabs(w[i]));
+    int e = 0;
+    if (wmax > 0.f) (void)std::frexp(wmax, &e);
+    const float ro_scale = std::ldexp(1.f, 13 - e);
+    plan->ro_w_scale_inv = std::ldexp(1.f, e - 13);
+    std::vector<float> imh(img);
+    chain_image_h(imh.data() + ReadoutImg::w1, 8, 2, ro_scale, w1);
+    chain_image_h(imh.data() + ReadoutImg::w2d, 4, 2, ro_scale, sq(w2d));
+    chain_image_h(imh.data() + ReadoutImg::w2g, 4, 2, ro_scale, sq(w2g));
+    chain_image_h(imh.data() + ReadoutImg::w2dT, 4, 2, ro_scale, sqT(w2d));
+    chain_image_h(imh.data() + ReadoutImg::w2gT, 4, 2, ro_scale, sqT(w2g));
+    chain_image_h(imh.data() + ReadoutImg::w1T, 4, 4, ro_scale, [&](int row, int k) -> float { return w1(k, row); });
+    { int rc = upload(plan->d_readout_img_h, imh); if (rc) return rc; }
   }
   { int rc = upload(plan->d_mfma_revf, revf); if (rc) return rc; }
   { int rc = upload(plan->d_mfma_revf_h, revfh); if (rc) return rc; }
