@@ -215,6 +215,12 @@ __device__ __forceinline__ void load_ends(const int32_t* __restrict__ src, const
   ci = src[ec];
   cj = dst ? dst[ec] : 0;
 }
+// ... and its row in the per-active-edge arrays (< 0: the edge takes part in no triplet): fetched with the end atoms, one tile
+// ahead, so the aggregate row `m[arow]` is one round trip away at the tile start instead of two dependent ones
+__device__ __forceinline__ int load_arow(const int32_t* __restrict__ act_id, int64_t tile, int64_t E, int lane) {
+  const int64_t edge = tile * kTileEdges + (lane & 15);
+  return act_id[edge < E ? edge : E - 1];
+}
 
 // ---- per-centre sums inside a tile -------------------------------------------------------------------------------
 // The 16 edges of a tile sit on the 16 lanes of a DPP row and edges of one centre are consecutive, so the sum over a

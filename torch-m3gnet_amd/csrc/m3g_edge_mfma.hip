@@ -116,14 +116,18 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
   if (ticket >= queue.count) return;
   int ci_i, cj_i;
   load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, ci_i, cj_i);
+  int arow_i = load_arow(a.act_id, queue.base + ticket, a.E, lane);
   for (;;) {
     const int64_t tile = queue.base + ticket;
-    // next tile's ticket and end atoms one tile ahead: the table gathers depend on them, and a dependent round trip
-    // per tile is what these latency-bound kernels cannot afford
+    // next tile's ticket, end atoms and active-row id one tile ahead: the table gathers and the aggregate row depend on them,
+    // and a dependent round trip per tile is what these latency-bound kernels cannot afford
     ticket = queue.fetch(lane);
     const bool has_next = ticket < queue.count;   // wave-uniform
-    int nci = 0, ncj = 0;
-    if (has_next) load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
+    int nci = 0, ncj = 0, narow = -1;
+    if (has_next) {
+      load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
+      narow = load_arow(a.act_id, queue.base + ticket, a.E, lane);
+    }
     // the weight-image reads are loop-invariant: without this the compiler hoists hundreds of LDS loads out of
     // the tile loop and spills them; `lv` is the lane id made opaque once per tile
     int lv = lane;
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
     float* e_otile = a.e_out + tile * kTileFloats + tl_out * 4;
     f32x4 x[4];
     if (!FIRST) static_for<4>([&]<int blk>() { x[blk] = load_tile4(e_tile + blk * 256); });
-    const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
+    const int arow = arow_i;   // < 0: the edge takes part in no triplet, its aggregate is zero
     const TbIn<PREC, TBS> tbin = tb_load<PREC, TBS>(a.m, arow, qv, a.w_inv);
     const float hb = a.h[ec * kRP + qv];
     if (FIRST) {
@@ -179,6 +183,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
     if (!has_next) break;
     ci_i = nci;
     cj_i = ncj;
+    arow_i = narow;
   }
   if (ST && lane == 0) {
     const int wave = threadIdx.x >> 6;
@@ -530,12 +535,16 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
   if (ticket >= queue.count) return;
   int ci_i, cj_i;
   load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, ci_i, cj_i);
+  int arow_i = load_arow(a.act_id, queue.base + ticket, a.E, lane);
   for (;;) {
     const int64_t tile = queue.base + ticket;
-    ticket = queue.fetch(lane);  // next tile's ticket and end atoms one tile ahead (see the forward kernel)
+    ticket = queue.fetch(lane);  // next tile's ticket, end atoms and active-row id one tile ahead (see the forward kernel)
     const bool has_next = ticket < queue.count;
-    int nci = 0, ncj = 0;
-    if (has_next) load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
+    int nci = 0, ncj = 0, narow = -1;
+    if (has_next) {
+      load_ends(a.src, a.dst, queue.base + ticket, a.E, lane, nci, ncj);
+      narow = load_arow(a.act_id, queue.base + ticket, a.E, lane);
+    }
     int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
     asm volatile("" : "+v"(lv));
     const int64_t edge = tile * kTileEdges + (lane & 15);
@@ -546,7 +555,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     const float* e_tile = a.e_tile + tile * kTileFloats + lane * 4;
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
-    const int arow = a.act_id[ec];   // < 0: the edge takes part in no triplet, its aggregate is zero
+    const int arow = arow_i;   // < 0: the edge takes part in no triplet, its aggregate is zero
     const TbIn<PREC, TBS> tbin = tb_load<PREC, TBS>(a.m, arow, qd, a.w_inv);
     f32x4 x[4], de[4], contrib[4];
     constexpr bool FIRST = !NEED_DP1;   // block 0: its input is the edge embedding e0 = SiLU(W_adj h), formed here
@@ -622,6 +631,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     if (!has_next) break;
     ci_i = nci;
     cj_i = ncj;
+    arow_i = narow;
   }
 }
 

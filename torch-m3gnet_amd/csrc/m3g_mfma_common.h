@@ -96,14 +96,19 @@ __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __
 // below: forward 0.452 -> 0.447, fused reverse 0.955 -> 0.943 ms per step
 typedef float f32x2_split __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair_h(float a, float b, float s, f16x2& hi, f16x2& lo) {
-  f32x2_split t = f32x2_split{a, b} * s;
+  const f32x2_split t = f32x2_split{a, b} * s;
   unsigned h, l;
-  asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+  float r;
+  // read-only inputs and separate outputs: with the products as tied in/out operands the register allocator could not place
+  // `h` in its slot of the four-register B operand without copying a product out of the way first (one v_mov_b32 for two of
+  // three pairs in the listings of round 3)
+  asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
       "s_nop 0\n\t"
-      "v_fma_mix_f32 %2, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mix_f32 %3, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-      "v_cvt_pk_f16_f32 %1, %2, %3"
-      : "=&v"(h), "=&v"(l), "+v"(t[0]), "+v"(t[1]));
+      "v_fma_mix_f32 %1, %3, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %2, %4, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_cvt_pk_f16_f32 %1, %1, %2"
+      : "=&v"(h), "=&v"(l), "=&v"(r)
+      : "v"(t[0]), "v"(t[1]));
   hi = __builtin_bit_cast(f16x2, h);
   lo = __builtin_bit_cast(f16x2, l);
 }
@@ -139,17 +144,18 @@ __device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, float s,
   lo = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
 }
 
-// max over the four lane quarters (lanes l, l^16, l^32, l^48), result in every lane (v_permlane16/32_swap are VALU moves on gfx950)
-__device__ __forceinline__ float max_lane_quarters(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
+// max over the four lane quarters (lanes l, l^16, l^32, l^48) of a NON-NEGATIVE float given as its bit pattern, result in every
+// lane (v_permlane16/32_swap are VALU moves on gfx950).  Non-negative floats order like their bit patterns, and an integer
+// maximum needs no operand canonicalisation: the float form compiled to three v_max_f32 per exchange (two of them x = max(x, x)).
+__device__ __forceinline__ unsigned max_lane_quarters_bits(unsigned u) {
   auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const float y = fmaxf(__builtin_bit_cast(float, (unsigned)r16[0]), __builtin_bit_cast(float, (unsigned)r16[1]));
-  const unsigned v = __builtin_bit_cast(unsigned, y);
+  const unsigned v = max((unsigned)r16[0], (unsigned)r16[1]);
   auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  return fmaxf(__builtin_bit_cast(float, (unsigned)r32[0]), __builtin_bit_cast(float, (unsigned)r32[1]));
+  return max((unsigned)r32[0], (unsigned)r32[1]);
 }
 // power of two that puts the largest |x| of this lane's EDGE (over blocks XOFF .. XOFF + NB, all four lane quarters) into
-// [2^12, 2^13), and its inverse.  An all-zero column gets 2^13 (0 stays 0); exponents below -100 are treated as -100.
+// [2^12, 2^13), and its inverse, both formed from the exponent field of that maximum (m in [2^(e-1), 2^e): s = 2^(13-e), inv =
+// 2^(e-13)).  Exponents below -100 are treated as -100 (an all-zero column gets s = 2^113: 0 stays 0, nothing overflows).
 struct EdgeScale { float s, inv; };
 template <int NB, int XOFF = 0, int NX>
 __device__ __forceinline__ EdgeScale edge_scale(const f32x4 (&x)[NX]) {
@@ -159,10 +165,10 @@ __device__ __forceinline__ EdgeScale edge_scale(const f32x4 (&x)[NX]) {
 #endif
   float m = 0.f;
   static_for<NB>([&]<int b>() { static_for<4>([&]<int r>() { m = fmaxf(m, fabsf(x[XOFF + b][r])); }); });
-  m = max_lane_quarters(m);
-  int e = __builtin_amdgcn_frexp_expf(m);   // m in [2^(e-1), 2^e)
-  e = e < -100 ? -100 : e;
-  return EdgeScale{__builtin_ldexpf(1.f, 13 - e), __builtin_ldexpf(1.f, e - 13)};
+  unsigned u = max_lane_quarters_bits(__builtin_bit_cast(unsigned, m));
+  u = max(u, 0x0D000000u) & 0x7F800000u;             // biased exponent field E of max(m, 2^-101); m in [2^(E-127), 2^(E-126))
+  return EdgeScale{__builtin_bit_cast(float, 0x85000000u - u),    // 2^(139 - E) = 2^(13 - e), e = E - 126
+                   __builtin_bit_cast(float, u - 0x06000000u)};   // 2^(E - 139)
 }
 // the scaled, split B operands of a whole chain (KS 32-wide k-steps = blocks XOFF .. XOFF + 2 KS of x)
 template <int KS>
