@@ -102,6 +102,16 @@ __device__ __forceinline__ f16x8 join_halves_h(s16x4 a, s16x4 b) {
   const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(f16x8, v);
 }
+// A operands of one 16-row block (both parts, KS k-steps) -- requested one block AHEAD of the MFMAs that consume them: the LDS
+// round trip (64+ cycles, more with eight waves reading) is longer than the two or three MFMAs the compiler's own schedule puts
+// between a ds_read and its use, and with two waves per SIMD those waits are exposed (M3G_CHAIN_PREFETCH).
+template <int KS>
+struct DualA { f16x8 h[KS], l[KS]; };
+#ifndef M3G_NO_CHAIN_PREFETCH
+#define M3G_CHAIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define M3G_CHAIN_FENCE() ((void)0)
+#endif
 template <int OB, int KS, int ROWS, int XOFF = 0, int AOFF = 0, int RB0 = 0, int NX, int NA>
 __device__ __forceinline__ void chain_dual_h(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane, float w_inv) {
   static_assert(KS == 2, "the image holds 64 input features");
@@ -112,28 +122,39 @@ __device__ __forceinline__ void chain_dual_h(const float* img, const f32x4 (&x)[
   const int m = lane & 15, q = lane >> 4, sw = dual_swz(m);
   const char* base = reinterpret_cast<const char*>(img) + (m >> 3) * 1024 + (m & 7) * 64;
   constexpr int plane = 512, lo = ROWS * 128;
-  M3G_CHAIN_PRIO(1);
-  static_for<OB>([&]<int ob>() {
+  auto fetch = [&]<int ob>() {
     constexpr int roff = (RB0 + ob) * 2048;
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    DualA<KS> a;
     static_for<KS>([&]<int s>() {
       const char* u = base + (((s * 4 + q) ^ sw) << 3);
-      const f16x8 ah = join_halves_h(*(const s16x4*)(u + roff), *(const s16x4*)(u + roff + plane));
-      const f16x8 al = join_halves_h(*(const s16x4*)(u + roff + lo), *(const s16x4*)(u + roff + lo + plane));
+      a.h[s] = join_halves_h(*(const s16x4*)(u + roff), *(const s16x4*)(u + roff + plane));
 #ifdef M3G_DIAG_NO_AL   // timing diagnostic only (wrong results): no LDS reads of the low-part image
-      const f16x8& al_ = ah;
+      a.l[s] = a.h[s];
 #else
-      const f16x8& al_ = al;
+      a.l[s] = join_halves_h(*(const s16x4*)(u + roff + lo), *(const s16x4*)(u + roff + lo + plane));
 #endif
-      t = mfma_f16(ah, b.hi[s], t);
+    });
+    return a;
+  };
+  M3G_CHAIN_PRIO(1);
+  DualA<KS> cur = fetch.template operator()<0>();
+  static_for<OB>([&]<int ob>() {
+    DualA<KS> nxt = cur;
+    if constexpr (ob + 1 < OB) nxt = fetch.template operator()<ob + 1>();
+    M3G_CHAIN_FENCE();
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    static_for<KS>([&]<int s>() {
+      t = mfma_f16(cur.h[s], b.hi[s], t);
 #ifndef M3G_DIAG_H1
-      t = mfma_f16(ah, b.lo[s], t);
-      t = mfma_f16(al_, b.hi[s], t);
+      t = mfma_f16(cur.h[s], b.lo[s], t);
+      t = mfma_f16(cur.l[s], b.hi[s], t);
 #elif defined(M3G_DIAG_H1_KEEP)   // ... with the low-part reads and splits kept alive: the MFMAs alone
-      asm volatile("" ::"v"(al_), "v"(b.lo[s]));
+      asm volatile("" ::"v"(cur.l[s]), "v"(b.lo[s]));
 #endif
     });
     acc[AOFF + ob] = t * inv + acc[AOFF + ob];   // (vector form: the compiler emits two v_pk_fma_f32)
+    M3G_CHAIN_FENCE();
+    cur = nxt;
   });
   M3G_CHAIN_PRIO(0);
 }
@@ -148,30 +169,41 @@ __device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d
   const int row_lo = 4 * q + qp, sw = dual_swz(row_lo);
   const char* base = reinterpret_cast<const char*>(img) + (row_lo >> 3) * 1024 + (row_lo & 7) * 64;
   constexpr int plane = 512, lo = ROWS * 128;
-  M3G_CHAIN_PRIO(1);
-  static_for<OB>([&]<int ob>() {
+  auto fetch = [&]<int ob>() {
     const char* u = base + (ob & 1) * plane + ((((ob >> 1) * 4 + p) ^ sw) << 3);
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    DualA<KS> a;
     static_for<KS>([&]<int s>() {
       constexpr int r0 = (KB0 + 2 * s) * 2048, r1 = (KB0 + 2 * s + 1) * 2048;
-      const f16x8 ah = join_halves_h(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0)),
-                                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1)));
-      const f16x8 al = join_halves_h(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0 + lo)),
-                                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1 + lo)));
+      a.h[s] = join_halves_h(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0)),
+                             __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1)));
 #ifdef M3G_DIAG_NO_AL   // timing diagnostic only (wrong results): no LDS reads of the low-part image
-      const f16x8& al_ = ah;
+      a.l[s] = a.h[s];
 #else
-      const f16x8& al_ = al;
+      a.l[s] = join_halves_h(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r0 + lo)),
+                             __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(u + r1 + lo)));
 #endif
-      t = mfma_f16(ah, b.hi[s], t);
+    });
+    return a;
+  };
+  M3G_CHAIN_PRIO(1);
+  DualA<KS> cur = fetch.template operator()<0>();
+  static_for<OB>([&]<int ob>() {
+    DualA<KS> nxt = cur;
+    if constexpr (ob + 1 < OB) nxt = fetch.template operator()<ob + 1>();
+    M3G_CHAIN_FENCE();
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    static_for<KS>([&]<int s>() {
+      t = mfma_f16(cur.h[s], b.hi[s], t);
 #ifndef M3G_DIAG_H1
-      t = mfma_f16(ah, b.lo[s], t);
-      t = mfma_f16(al_, b.hi[s], t);
+      t = mfma_f16(cur.h[s], b.lo[s], t);
+      t = mfma_f16(cur.l[s], b.hi[s], t);
 #elif defined(M3G_DIAG_H1_KEEP)   // ... with the low-part reads and splits kept alive: the MFMAs alone
-      asm volatile("" ::"v"(al_), "v"(b.lo[s]));
+      asm volatile("" ::"v"(cur.l[s]), "v"(b.lo[s]));
 #endif
     });
     acc[AOFF + ob] = t * inv + acc[AOFF + ob];   // (vector form: the compiler emits two v_pk_fma_f32)
+    M3G_CHAIN_FENCE();
+    cur = nxt;
   });
   M3G_CHAIN_PRIO(0);
 }

@@ -464,11 +464,21 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
   static_for<2>([&]<int half>() {   // 0: dense branch (p1[0..3] -> d2[0..3]), 1: gate branch
     f32x4 hid[4];
     static_for<4>([&]<int ob>() {
+#ifndef M3G_NO_PAIR_ACT
+      static_for<2>([&]<int k>() {
+        f32x4& pv = p1[4 * half + ob];
+        f32x2 act, der;
+        silu_pair(f32x2{pv[2 * k], pv[2 * k + 1]}, act, der);
+        hid[ob][2 * k] = act[0]; hid[ob][2 * k + 1] = act[1];
+        pv[2 * k] = der[0]; pv[2 * k + 1] = der[1];   // p1 is only needed again as SiLU'(p1)
+      });
+#else
       static_for<4>([&]<int r>() {
         const float p = p1[4 * half + ob][r], sg = fsigmoid(p);
         hid[ob][r] = p * sg;
         p1[4 * half + ob][r] = sg * (1.f + p * (1.f - sg));   // p1 is only needed again as SiLU'(p1)
       });
+#endif
     });
     cdual<PREC, 4, 2, 64, 0, 4 * half>(lds + (half == 0 ? L.w2d : L.w2g), hid, d2, lane, a.w_inv);
     M3G_SCHED_FENCE();
@@ -478,6 +488,35 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
   const float hb_sel = qd == 0 ? hv[0] : qd == 1 ? hv[1] : qd == 2 ? hv[2] : hv[3];
   static_for<4>([&]<int ob>() {
     const f32x4 sl = mfma16(lds[L.wld + ob * 64 + lane], hb_sel, f32x4{0.f, 0.f, 0.f, 0.f});
+#ifndef M3G_NO_PAIR_ACT
+    // value pairs on packed fp32 instructions (silu_pair): out = SiLU(p2d) sg(p2g) s_lin
+    static_for<2>([&]<int k>() {
+      const f32x2 p2d = {d2[ob][2 * k], d2[ob][2 * k + 1]}, p2g = {d2[4 + ob][2 * k], d2[4 + ob][2 * k + 1]};
+      const f32x2 du = {d_upd[ob][2 * k], d_upd[ob][2 * k + 1]}, s_lin = {sl[2 * k], sl[2 * k + 1]};
+      f32x2 sd, dsd;
+      silu_pair(p2d, sd, dsd);
+#ifdef M3G_DIAG_CHEAP_ACT
+      const f32x2 sg = p2g * 0.25f + 0.5f;
+#else
+      const f32x2 tg = p2g * -1.4426950408889634f;
+      const f32x2 dg = f32x2{__builtin_amdgcn_exp2f(tg[0]), __builtin_amdgcn_exp2f(tg[1])} + 1.f;
+      const f32x2 sg = {__builtin_amdgcn_rcpf(dg[0]), __builtin_amdgcn_rcpf(dg[1])};
+#endif
+      const f32x2 a_g = du * sg;            // dL/d(out) sg(p2g)
+      const f32x2 d_s = a_g * sd;           // dL/d(s_lin)
+      const f32x2 d_o = a_g * s_lin;
+      const f32x2 dd = d_o * dsd;           // dL/d(p2d)
+      const f32x2 dgt = (d_s * s_lin) * (1.f - sg);   // dL/d(p2g)
+      const f32x4 w0 = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + 2 * k) * 4);
+      const f32x4 w1 = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + 2 * k + 1) * 4);
+      f32x2 h01 = {dhv[0], dhv[1]}, h23 = {dhv[2], dhv[3]};
+      h01 += f32x2{w0[0], w0[1]} * d_s[0]; h23 += f32x2{w0[2], w0[3]} * d_s[0];
+      h01 += f32x2{w1[0], w1[1]} * d_s[1]; h23 += f32x2{w1[2], w1[3]} * d_s[1];
+      dhv[0] = h01[0]; dhv[1] = h01[1]; dhv[2] = h23[0]; dhv[3] = h23[1];
+      d2[ob][2 * k] = dd[0]; d2[ob][2 * k + 1] = dd[1];
+      d2[4 + ob][2 * k] = dgt[0]; d2[4 + ob][2 * k + 1] = dgt[1];
+    });
+#else
     static_for<4>([&]<int r>() {
       const float p2d = d2[ob][r], p2g = d2[4 + ob][r];
       const f32x4 w = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + r) * 4);
@@ -489,6 +528,7 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
       d2[ob][r] = d_out * sg * (sgd * (1.f + p2d * (1.f - sgd)));
       d2[4 + ob][r] = d_out * sd * sg * (1.f - sg);
     });
+#endif
     asm volatile("" : "+v"(dhv[0]), "+v"(dhv[1]), "+v"(dhv[2]), "+v"(dhv[3]));   // see mlp_reverse_mfma
   });
   zero(contrib);

@@ -41,6 +41,23 @@ __device__ __forceinline__ float fdsilu(float p) {
   return s * (1.f + p * (1.f - s));
 }
 
+// SiLU and SiLU' of a value PAIR on packed fp32 instructions (v_pk_mul / v_pk_add / v_pk_fma do two values per issue slot; the
+// compiler packs this chain only in part): act = p sg, der = sg + act (1 - sg) = sg (1 + p (1 - sg)); five packed instructions and
+// four transcendentals per pair instead of nine and four.  1 - sg is formed as 1 + (-sg), not as e^-p sg: the latter is inf * 0
+// for p < -88.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void silu_pair(f32x2 p, f32x2& act, f32x2& der) {
+#ifdef M3G_DIAG_CHEAP_ACT
+  const f32x2 sg = p * 0.25f + 0.5f;
+#else
+  const f32x2 t = p * -1.4426950408889634f;
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.f;
+  const f32x2 sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+#endif
+  act = p * sg;
+  der = act * (1.f - sg) + sg;
+}
+
 // ---- the dense chains run on v_mfma_f32_16x16x32_bf16 with split operands ("bf16x3") ----------------------------
 // a = a_hi + a_lo (both bf16; the residual a - a_hi is formed exactly in fp32), a.b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi,
 // accumulated in fp32: 3 MFMAs at 16x the fp32-MFMA rate.  bf16 keeps the fp32 exponent range, which the tiny gradient
