@@ -116,9 +116,6 @@ template <int OB, int KS, int ROWS, int XOFF = 0, int AOFF = 0, int RB0 = 0, int
 __device__ __forceinline__ void chain_dual_h(const float* img, const f32x4 (&x)[NX], f32x4 (&acc)[NA], int lane, float w_inv) {
   static_assert(KS == 2, "the image holds 64 input features");
   static_assert(XOFF + 2 * KS <= NX && AOFF + OB <= NA && (RB0 + OB) * 16 <= ROWS, "chain_dual_h operand out of range");
-  const EdgeScale sc = edge_scale<2 * KS, XOFF>(x);
-  const HalfB<KS> b = split_h<KS, XOFF>(x, sc.s);
-  const float inv = sc.inv * w_inv;
   const int m = lane & 15, q = lane >> 4, sw = dual_swz(m);
   const char* base = reinterpret_cast<const char*>(img) + (m >> 3) * 1024 + (m & 7) * 64;
   constexpr int plane = 512, lo = ROWS * 128;
@@ -136,8 +133,13 @@ __device__ __forceinline__ void chain_dual_h(const float* img, const f32x4 (&x)[
     });
     return a;
   };
-  M3G_CHAIN_PRIO(1);
+  // the first block's operands travel while the vector ALU finds the scale and splits x
   DualA<KS> cur = fetch.template operator()<0>();
+  M3G_CHAIN_FENCE();
+  const EdgeScale sc = edge_scale<2 * KS, XOFF>(x);
+  const HalfB<KS> b = split_h<KS, XOFF>(x, sc.s);
+  const float inv = sc.inv * w_inv;
+  M3G_CHAIN_PRIO(1);
   static_for<OB>([&]<int ob>() {
     DualA<KS> nxt = cur;
     if constexpr (ob + 1 < OB) nxt = fetch.template operator()<ob + 1>();
@@ -162,9 +164,6 @@ template <int OB, int KS, int ROWS, int DOFF = 0, int AOFF = 0, int KB0 = 0, int
 __device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d)[ND], f32x4 (&acc)[NA], int lane, float w_inv) {
   static_assert(OB == 4, "64 input features");
   static_assert(DOFF + 2 * KS <= ND && AOFF + OB <= NA && (KB0 + 2 * KS) * 16 <= ROWS, "chain_dual_t_h operand out of range");
-  const EdgeScale sc = edge_scale<2 * KS, DOFF>(d);
-  const HalfB<KS> b = split_h<KS, DOFF>(d, sc.s);
-  const float inv = sc.inv * w_inv;
   const int q = lane >> 4, qp = (lane & 15) >> 2, p = lane & 3;
   const int row_lo = 4 * q + qp, sw = dual_swz(row_lo);
   const char* base = reinterpret_cast<const char*>(img) + (row_lo >> 3) * 1024 + (row_lo & 7) * 64;
@@ -185,8 +184,13 @@ __device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d
     });
     return a;
   };
-  M3G_CHAIN_PRIO(1);
+  // the first block's operands travel while the vector ALU finds the scale and splits d
   DualA<KS> cur = fetch.template operator()<0>();
+  M3G_CHAIN_FENCE();
+  const EdgeScale sc = edge_scale<2 * KS, DOFF>(d);
+  const HalfB<KS> b = split_h<KS, DOFF>(d, sc.s);
+  const float inv = sc.inv * w_inv;
+  M3G_CHAIN_PRIO(1);
   static_for<OB>([&]<int ob>() {
     DualA<KS> nxt = cur;
     if constexpr (ob + 1 < OB) nxt = fetch.template operator()<ob + 1>();
