@@ -29,7 +29,7 @@ import os
 W = int(os.environ.get("STAMP_WAVES", "16"))   # waves per workgroup of the build under test (M3G_WAVES_FWD)
 buf = np.zeros(256 * 16 * 12, dtype=np.uint64)
 _lib.check(eng.lib.m3g_debug_read_stamps(eng.plan, buf.ctypes.data))
-s = buf[:256 * W * 12].reshape(256, W, 12).astype(np.float64)
+s = buf.reshape(256, 16, 12)[:, :W].astype(np.float64)   # [workgroup][16 wave slots][12]: the first W slots are written
 names = ["tile loads", "three-body MLP", "e: table gather", "e: both layers", "(unused)", "e: gating",
          "e2 residual+store", "n: table gather", "n: both layers", "(unused)", "n: gating", "message sums"]
 print("precision", prec)

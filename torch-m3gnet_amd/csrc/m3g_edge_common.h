@@ -19,6 +19,12 @@ constexpr int kRevEdgeFloats = kRevMlpFloats + 8 * kTbSteps * 64 + 8 * 4 * 64;  
 #define M3G_WAVES_FWD 16        // forward kernel: 16 waves = 4 per SIMD (<= 128 VGPRs)
 #endif
 constexpr int kWaves = M3G_WAVES_FWD;
+#ifndef M3G_WAVES_FWD_H
+#define M3G_WAVES_FWD_H 12      // f16x3 forward: 3 per SIMD (<= 168 VGPRs), which pays for the A operands requested a row block ahead (chain_h)
+#endif
+// waves per workgroup of the forward kernel by precision mode (kPrecF16x3 = 2, m3g_internal.h)
+template <int PREC>
+constexpr int fwd_waves() { return PREC == kPrecF16x3 ? M3G_WAVES_FWD_H : kWaves; }
 #ifndef M3G_WAVES_REV_FUSED
 #define M3G_WAVES_REV_FUSED 8   // 2 waves per SIMD, 256 VGPRs, no spills (12 waves: 168 VGPRs and ~120 spilled, slower)
 #endif
@@ -115,6 +121,31 @@ template <int OB, int KS, class OUT>
 __device__ __forceinline__ void chain_h(const float* img, const HalfB<KS>& b, int lane, OUT&& out) {
   const f16x8* hi_img = reinterpret_cast<const f16x8*>(img) + lane;
   const f16x8* lo_img = hi_img + OB * KS * 64;
+#ifndef M3G_NO_FWD_CHAIN_PREFETCH
+  // A operands of row block ob + 1 requested before the MFMAs of row block ob (as the dual-image chains, m3g_dual_chain.h:
+  // the compiler's own order leaves two or three MFMAs between a ds_read and its use, a third of the LDS round trip; forward kernel
+  // with 12 waves 0.460 -> 0.427 ms per step -- at 16 waves = 128 VGPRs the extra 16 registers spill and it is slower, 0.480)
+  auto fetch = [&]<int ob>() {
+    DualA<KS> a;
+    static_for<KS>([&]<int s>() { a.h[s] = hi_img[(ob * KS + s) * 64]; a.l[s] = lo_img[(ob * KS + s) * 64]; });
+    return a;
+  };
+  DualA<KS> cur = fetch.template operator()<0>();
+  static_for<OB>([&]<int ob>() {
+    DualA<KS> nxt = cur;
+    if constexpr (ob + 1 < OB) nxt = fetch.template operator()<ob + 1>();
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    static_for<KS>([&]<int s>() {
+      t = mfma_f16(cur.h[s], b.hi[s], t);
+      t = mfma_f16(cur.h[s], b.lo[s], t);
+      t = mfma_f16(cur.l[s], b.hi[s], t);
+    });
+    out.template operator()<ob>(t);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  });
+#else
   static_for<OB>([&]<int ob>() {
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
     static_for<KS>([&]<int s>() {
@@ -134,6 +165,7 @@ __device__ __forceinline__ void chain_h(const float* img, const HalfB<KS>& b, in
     });
     out.template operator()<ob>(t);
   });
+#endif
 }
 // acc[AOFF + ob] += (W x)[ob-th row block] in true units: the f16x3 counterpart of chain_p (scale of x taken over its 2 KS blocks)
 template <int OB, int KS, int XOFF = 0, int AOFF = 0, int NX, int NA>
@@ -407,13 +439,23 @@ __device__ __forceinline__ void tb_preact_p(const float* tbimg, const TbIn<PREC,
   if constexpr (PREC == kPrecF16x3) {
     const f16x8* hi = reinterpret_cast<const f16x8*>(tbimg) + (lane & 31);
     const f16x8* lo = hi + 8 * 32;
+    // (quarters 2, 3 re-read rows 0..31: their activation parts are zero); operands one row block ahead, as chain_h
+    f16x8 ah = hi[0], al = lo[0];
     static_for<8>([&]<int ob>() {
-      const f16x8 ah = hi[ob * 32], al = lo[ob * 32];   // quarters 2, 3 re-read rows 0..31: their activation parts are zero
+      f16x8 nh = ah, nl = al;
+      if constexpr (ob + 1 < 8) { nh = hi[(ob + 1) * 32]; nl = lo[(ob + 1) * 32]; }
+#ifndef M3G_NO_FWD_CHAIN_PREFETCH
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
       t = mfma_f16(ah, in.hi, t);
       t = mfma_f16(ah, in.lo, t);
       t = mfma_f16(al, in.hi, t);
       p[ob] = t * in.inv;
+#ifndef M3G_NO_FWD_CHAIN_PREFETCH
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      ah = nh; al = nl;
     });
   } else {
     tb_preact<TBS>(tbimg, in.mb, p, lane);

@@ -102,7 +102,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
 // FIRST: block 0 forms its input e0 = SiLU(W_adj h) (nn/featurizer.py:128-132) from the radial basis instead of reading
 // an embedded-edge image that a separate kernel would have to write (256 B/edge) first
 template <int TBS, bool ST = false, bool FIRST = false, int PREC = kPrecBf16x3, int SAVE = 0>
-__global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
+__global__ void __launch_bounds__(64 * fwd_waves<PREC>()) k_edge_block_mfma(FwdArgs a, MfmaFwdLayout L) {
   __shared__ __attribute__((aligned(16))) float lds[kFwdLdsFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kFwdLdsFloats);
   load_image(lds, a.img, kFwdLdsFloats, q_head);
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(64 * kWaves) k_edge_block_mfma(FwdArgs a, Mfma
   }
   if (ST && lane == 0) {
     const int wave = threadIdx.x >> 6;
-    unsigned long long* dst = a.stamps + ((size_t)blockIdx.x * kWaves + wave) * 12;
+    unsigned long long* dst = a.stamps + ((size_t)blockIdx.x * 16 + wave) * 12;   // [256 workgroups][16 wave slots][12]
     for (int i = 0; i < 12; ++i) dst[i] = st.sum[i];
   }
 }
@@ -774,10 +774,10 @@ void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t
     FwdArgs a{t.E, tiles, plan->d_mfma_fwd[plan->precision] + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], t.act_id,
               w.e_blk[b], w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps, saves_p1(plan) ? w.p1_blk[b] : nullptr,
               saves_p2(plan) ? w.p2_blk[b] : nullptr, plan->precision == kPrecF16x3 ? plan->w_scale_inv : 1.f};
-    dim3 grid(grid_for_tiles(tiles)), block(64 * kWaves);
+    dim3 grid(grid_for_tiles(tiles));
     const bool first = b == 0 && fused_reverse(plan);   // the fused reverse kernel recomputes e0 as well: no embedded-edge image at all
     const int save = for_reverse ? saved_activations(plan) : 0;   // fp32 mode only (saves_p1 / saves_p2)
-#define M3G_FWD_LAUNCH(ST_, FIRST_, PREC_, SAVE_) hipLaunchKernelGGL((k_edge_block_mfma<TBS, ST_, FIRST_, PREC_, SAVE_>), grid, block, 0, s, a, L)
+#define M3G_FWD_LAUNCH(ST_, FIRST_, PREC_, SAVE_) hipLaunchKernelGGL((k_edge_block_mfma<TBS, ST_, FIRST_, PREC_, SAVE_>), grid, dim3(64 * fwd_waves<PREC_>()), 0, s, a, L)
 #define M3G_FWD_BY_MODE(ST_, FIRST_)                                                               \
   if (plan->precision == kPrecBf16x3) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecBf16x3, 0); }             \
   else if (plan->precision == kPrecF16x3) { M3G_FWD_LAUNCH(ST_, FIRST_, kPrecF16x3, 0); }          \
