@@ -388,7 +388,7 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     return M3G_OK;
   }
   if (strcmp(name, "stamps") == 0) {  // diagnostic: forward edge kernel with s_memtime phase stamps
-    plan->stamp_target = value == 2 ? 1 : 0;   // 1: forward edge kernel, 2: reverse edge-MLP kernel
+    plan->stamp_target = value == 3 ? 2 : value == 2 ? 1 : 0;   // 1: forward edge kernel, 2: reverse edge-MLP kernel, 3: fused reverse kernel (f16x3)
     if (value && !plan->d_stamps) {
       M3G_HIP_CHECK(hipMalloc((void**)&plan->d_stamps, 256 * 16 * 12 * sizeof(unsigned long long)));
       M3G_HIP_CHECK(hipMemset(plan->d_stamps, 0, 256 * 16 * 12 * sizeof(unsigned long long)));

@@ -449,16 +449,17 @@ __device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlp
 // The dense and the gate branch are independent between layer 1 and the final product, so each is carried through
 // layer 2, and later through the transposed layers, on its own: 16 instead of 32 registers for the hidden values and
 // for dL/dp1, which is what lets the kernel approach three waves per SIMD.
-template <bool NEED_DP1, int MLP, int PREC>
+template <bool NEED_DP1, int MLP, int PREC, bool ST = false, int S0 = 0>
 __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlpFused& L, const RevArgs& a, int64_t edge, int64_t tile,
                                                  int64_t ci, int64_t cj, const SegMasks& sk, const f32x4& hv, const f32x4 (&x)[4],
-                                                 const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane) {
+                                                 const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane, Stamps<ST>& st) {
   constexpr int mlp = MLP;
   const int qd = lane >> 4;
   f32x4 p1[8], d2[8];
   gather_tables(a.TA, a.TB, mlp, ci, cj, qd, p1);
   cdual<PREC, 8, 2, 128>(lds + L.w1c, x, p1, lane, a.w_inv);
   M3G_SCHED_FENCE();
+  st.template mark<S0>();       // inputs arrived, table gather, layer 1
   bias_step<4, 0>(lds + L.b2, d2, lane);
   bias_step<4, 4>(lds + L.b2 + 4 * 64, d2, lane);
   static_for<2>([&]<int half>() {   // 0: dense branch (p1[0..3] -> d2[0..3]), 1: gate branch
@@ -483,6 +484,7 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
     cdual<PREC, 4, 2, 64, 0, 4 * half>(lds + (half == 0 ? L.w2d : L.w2g), hid, d2, lane, a.w_inv);
     M3G_SCHED_FENCE();
   });
+  st.template mark<S0 + 1>();   // activations, layer 2
   // W_l h on the matrix pipe (4 small MFMAs, as the forward kernel) instead of a 4-term dot per element on the vector ALU
   // (64 VALU instructions per MLP; fused reverse 0.904 -> 0.889 ms per step)
   const float hb_sel = qd == 0 ? hv[0] : qd == 1 ? hv[1] : qd == 2 ? hv[2] : hv[3];
@@ -533,6 +535,7 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
   });
   zero(contrib);
   M3G_SCHED_FENCE();
+  st.template mark<S0 + 2>();   // gating derivatives
   static_for<2>([&]<int half>() {
     f32x4 dp1[4];
     zero(dp1);
@@ -558,11 +561,13 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
       seg_store<MLP * 8 + 4 * half>(dp1, sk, a.seg_head, a.seg_first, tile, ci, qd);
     }
     M3G_SCHED_FENCE();
+    st.template mark<S0 + 3 + half>();   // transposed chains, dp1 stores, per-centre scan of one half
   });
 }
 
-template <int TBS, bool NEED_DP1, int WAVES, int PREC = kPrecBf16x3>
+template <int TBS, bool NEED_DP1, int WAVES, int PREC = kPrecBf16x3, bool ST = false>
 __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRevFusedLayout L) {
+  Stamps<ST> st;
   __shared__ __attribute__((aligned(16))) float lds[kRevFusedFloats + 4];  // + tile-queue head
   int* q_head = reinterpret_cast<int*>(lds + kRevFusedFloats);
   load_image(lds, a.img, kRevFusedFloats, q_head);
@@ -587,6 +592,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     }
     int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
     asm volatile("" : "+v"(lv));
+    st.start();
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
     const int64_t ci = ci_i, cj = cj_i;
@@ -610,7 +616,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       f32x4 dmsg[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
       static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
-      mlp_reverse_dual<NEED_DP1, 1, PREC>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv);
+      mlp_reverse_dual<NEED_DP1, 1, PREC, ST, 0>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv, st);
     }
     // dL/d e2 = what flows in from later blocks + the node MLP's contribution
     if (a.de_is_zero) {
@@ -635,7 +641,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       tb_preact_p<PREC, TBS>(lds + L.tb, tbin, p, lv);
       static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
     }
-    mlp_reverse_dual<NEED_DP1, 0, PREC>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv);
+    st.template mark<5>();   // dL/de and e images arrived, e1 recomputed (three-body MLP)
+    mlp_reverse_dual<NEED_DP1, 0, PREC, ST, 6>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv, st);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
       if (!FIRST) *(f32x4*)(de_tile + blk * 256) = de[blk];
@@ -668,10 +675,16 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     chain_p<PREC, 1, 4>(lds + L.tbT, d8, dmv, lv, a.w_inv);
     store_dh(a.dh, edge, a.E, dhv, qd);
     if (edge < a.E && arow >= 0) *(f32x4*)(a.dm + (int64_t)arow * kCP + 4 * qd) = dmv[0];
+    st.template mark<11>();  // dL/de store, three-body reverse, dm / dh stores
     if (!has_next) break;
     ci_i = nci;
     cj_i = ncj;
     arow_i = narow;
+  }
+  if (ST && lane == 0) {
+    const int wave = threadIdx.x >> 6;
+    unsigned long long* dst = a.stamps + ((size_t)blockIdx.x * 16 + wave) * 12;
+    for (int i = 0; i < 12; ++i) dst[i] += st.sum[i];   // summed over the launches since the option was set (a slot per wave)
   }
 }
 
@@ -839,10 +852,15 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
   const bool f16 = plan->precision == kPrecF16x3;
   const float* img = (f16 ? plan->d_mfma_revf_h : plan->d_mfma_revf) + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
-             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, nullptr, nullptr,
+             de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, plan->d_stamps, w.seg_head, w.seg_first, nullptr, nullptr,
              f16 ? plan->w_scale_inv : 1.f};
   constexpr int WV = kWavesRevFused;
   dim3 grid(grid_for_tiles(tiles)), block(64 * WV);
+  if (plan->d_stamps && plan->stamp_target == 2 && f16 && tb_steps_for(c.C) == 3) {   // diagnostic build (tools/stamp_report_fused.py)
+    if (b > 0) hipLaunchKernelGGL((k_edge_rev_fused<3, true, WV, kPrecF16x3, true>), grid, block, 0, s, ar, L);
+    else hipLaunchKernelGGL((k_edge_rev_fused<3, false, WV, kPrecF16x3, true>), grid, block, 0, s, ar, L);
+    return;
+  }
 #define M3G_REVF_LAUNCH(NEED_) \
   if (f16) { M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_fused<TBS, NEED_, WV, kPrecF16x3>), grid, block, 0, s, ar, L)); } \
   else { M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_fused<TBS, NEED_, WV, kPrecBf16x3>), grid, block, 0, s, ar, L)); }
