@@ -76,7 +76,16 @@ __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, 
     chain_p<PREC, 4, 2, 0, 0>(lds + w2d, hid, p2, lane, w_inv);
     chain_p<PREC, 4, 2, 4, 4>(lds + w2g, hid, p2, lane, w_inv);
   } else {
-    static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); }); });
+    if constexpr (PREC == kPrecF16x3) {   // value pairs on packed fp32 instructions (the 12-wave f16x3 kernel has the registers)
+      static_for<8>([&]<int ob>() {
+        static_for<2>([&]<int k>() {
+          const f32x2 v = silu_pair(f32x2{p1[ob][2 * k], p1[ob][2 * k + 1]});
+          p1[ob][2 * k] = v[0]; p1[ob][2 * k + 1] = v[1];
+        });
+      });
+    } else {
+      static_for<8>([&]<int ob>() { static_for<4>([&]<int r>() { p1[ob][r] = fsilu(p1[ob][r]); }); });
+    }
     chain_p<PREC, 4, 2, 0, 0>(lds + w2d, p1, p2, lane, w_inv);  // hidden dense = p1[0..3]
     chain_p<PREC, 4, 2, 4, 4>(lds + w2g, p1, p2, lane, w_inv);  // hidden gate  = p1[4..7]
   }
@@ -94,7 +103,15 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
   st.template mark<S0 + 1>();  // both layers
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
-    static_for<4>([&]<int r>() { out[ob][r] = fgated(p2[ob][r], p2[4 + ob][r]) * out[ob][r]; });
+    if constexpr (PREC == kPrecF16x3) {
+      static_for<2>([&]<int k>() {
+        const f32x2 v = gated_pair(f32x2{p2[ob][2 * k], p2[ob][2 * k + 1]}, f32x2{p2[4 + ob][2 * k], p2[4 + ob][2 * k + 1]}) *
+                        f32x2{out[ob][2 * k], out[ob][2 * k + 1]};
+        out[ob][2 * k] = v[0]; out[ob][2 * k + 1] = v[1];
+      });
+    } else {
+      static_for<4>([&]<int r>() { out[ob][r] = fgated(p2[ob][r], p2[4 + ob][r]) * out[ob][r]; });
+    }
   });
   st.template mark<S0 + 3>();  // gating
 }
@@ -159,7 +176,16 @@ __global__ void __launch_bounds__(64 * fwd_waves<PREC>()) k_edge_block_mfma(FwdA
     {  // three-body gated update (nn/interaction.py:220-221)
       f32x4 p[8];
       tb_preact_p<PREC, TBS>(lds + L.tb, tbin, p, lv);
-      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
+      if constexpr (PREC == kPrecF16x3) {
+        static_for<4>([&]<int blk>() {
+          static_for<2>([&]<int k>() {
+            const f32x2 v = gated_pair(f32x2{p[blk][2 * k], p[blk][2 * k + 1]}, f32x2{p[4 + blk][2 * k], p[4 + blk][2 * k + 1]});
+            x[blk][2 * k] += v[0]; x[blk][2 * k + 1] += v[1];
+          });
+        });
+      } else {
+        static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
+      }
     }
     st.template mark<1>();  // three-body MLP
     f32x4 out[4];

@@ -58,6 +58,27 @@ __device__ __forceinline__ void silu_pair(f32x2 p, f32x2& act, f32x2& der) {
   der = act * (1.f - sg) + sg;
 }
 
+// SiLU of a value pair / SiLU(p) * sigmoid(g) of two value pairs, the same way (fsilu, fgated)
+__device__ __forceinline__ f32x2 silu_pair(f32x2 p) {
+#ifdef M3G_DIAG_CHEAP_ACT
+  return p * (p * 0.25f + 0.5f);
+#else
+  const f32x2 t = p * -1.4426950408889634f;
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.f;
+  return p * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+#endif
+}
+__device__ __forceinline__ f32x2 gated_pair(f32x2 p, f32x2 g) {
+#ifdef M3G_DIAG_CHEAP_ACT
+  return p * (g * 0.25f + 0.5f);
+#else
+  const f32x2 tp = p * -1.4426950408889634f, tg = g * -1.4426950408889634f;
+  const f32x2 d = (f32x2{__builtin_amdgcn_exp2f(tp[0]), __builtin_amdgcn_exp2f(tp[1])} + 1.f) *
+                  (f32x2{__builtin_amdgcn_exp2f(tg[0]), __builtin_amdgcn_exp2f(tg[1])} + 1.f);
+  return p * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+#endif
+}
+
 // ---- the dense chains run on v_mfma_f32_16x16x32_bf16 with split operands ("bf16x3") ----------------------------
 // a = a_hi + a_lo (both bf16; the residual a - a_hi is formed exactly in fp32), a.b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi,
 // accumulated in fp32: 3 MFMAs at 16x the fp32-MFMA rate.  bf16 keeps the fp32 exponent range, which the tiny gradient
