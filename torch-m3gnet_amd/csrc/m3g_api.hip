@@ -593,6 +593,13 @@ static int energy_forces_graph(const m3g_plan* plan, const m3g_io* io, void* wor
   return join();
 }
 
+// what the reverse edge kernels of this plan hand to k_node_reverse: the fused kernels write 24-bit rows (floating in the bf16x3 mode,
+// fixed point + scales in the f16x3 mode), everything else fp32 rows
+static int dp1_format(const m3g_plan* plan) {
+  if (!fused_reverse(plan)) return kDp1F32;
+  return plan->precision == kPrecBf16x3 ? kDp1Packed : plan->precision == kPrecF16x3 ? kDp1Fixed : kDp1F32;
+}
+
 extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes,
                                  void* stream_) {
   if (!plan || !io) { set_error("m3g_energy_forces: null argument"); return M3G_ERR_VALUE; }
@@ -714,7 +721,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         M3G_HIP_CHECK(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
         launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, plan->side_stream, tb_hints);
         M3G_HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
-        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*dp1_packed=*/plan->precision == kPrecBf16x3, /*with_v_term=*/false, s);   // (f16x3: fp32 rows)
+        launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*dp1 format=*/dp1_format(plan), /*with_v_term=*/false, s);
         M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_join, 0));
         launch_node_reverse_v_term(c, W, wl.blk[b], t, w, w.v[b], dx_alt, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
@@ -722,8 +729,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s, tb_hints); }
         if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
           M3G_STAGE(ST_NODE_REV);
-          launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*dp1_packed=*/fused_rev && plan->precision == kPrecBf16x3,
-                              /*with_v_term=*/true, s);
+          launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*dp1 format=*/dp1_format(plan), /*with_v_term=*/true, s);
           float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
         }
       }

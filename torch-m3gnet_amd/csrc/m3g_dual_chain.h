@@ -160,8 +160,10 @@ __device__ __forceinline__ void chain_dual_h(const float* img, const f32x4 (&x)[
   });
   M3G_CHAIN_PRIO(0);
 }
+// `used` (optional): receives the per-edge scale the chain found for d, for a caller that stores d on the same scale (pack24_fixed)
 template <int OB, int KS, int ROWS, int DOFF = 0, int AOFF = 0, int KB0 = 0, int ND, int NA>
-__device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d)[ND], f32x4 (&acc)[NA], int lane, float w_inv) {
+__device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d)[ND], f32x4 (&acc)[NA], int lane, float w_inv,
+                                               EdgeScale* used = nullptr) {
   static_assert(OB == 4, "64 input features");
   static_assert(DOFF + 2 * KS <= ND && AOFF + OB <= NA && (KB0 + 2 * KS) * 16 <= ROWS, "chain_dual_t_h operand out of range");
   const int q = lane >> 4, qp = (lane & 15) >> 2, p = lane & 3;
@@ -188,6 +190,7 @@ __device__ __forceinline__ void chain_dual_t_h(const float* img, const f32x4 (&d
   DualA<KS> cur = fetch.template operator()<0>();
   M3G_CHAIN_FENCE();
   const EdgeScale sc = edge_scale<2 * KS, DOFF>(d);
+  if (used) *used = sc;
   const HalfB<KS> b = split_h<KS, DOFF>(d, sc.s);
   const float inv = sc.inv * w_inv;
   M3G_CHAIN_PRIO(1);

@@ -495,6 +495,7 @@ struct RevArgs {
   const float* p1;      // saved layer-1 pre-activations of this block (fp32 mode; SiLU'(p1) when p2 is saved too), else nullptr
   const float* p2;      // saved layer-2 pre-activations (fp32 mode, saves_p2), else nullptr
   float w_inv;          // f16x3 mode: 1 / the model's weight scale (plan->w_scale_inv), else 1
+  float* dp1_scale;     // f16x3 fused kernel: [E][4] inverse scales (x 2^-9) of the 24-bit fixed-point dp1 rows (pack24_fixed)
 };
 
 // x summed over the four lane quarters (lanes l, l^16, l^32, l^48), result in every lane.  v_permlane16/32_swap

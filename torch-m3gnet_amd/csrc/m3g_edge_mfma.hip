@@ -478,7 +478,9 @@ __device__ __forceinline__ void mlp_preacts_dual(const float* lds, const MfmaMlp
 template <bool NEED_DP1, int MLP, int PREC, bool ST = false, int S0 = 0>
 __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlpFused& L, const RevArgs& a, int64_t edge, int64_t tile,
                                                  int64_t ci, int64_t cj, const SegMasks& sk, const f32x4& hv, const f32x4 (&x)[4],
-                                                 const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane, Stamps<ST>& st) {
+                                                 const f32x4 (&d_upd)[4], f32x4 (&contrib)[4], f32x4& dhv, int lane, Stamps<ST>& st,
+                                                 f32x4& dp1_inv) {
+  // dp1_inv (f16x3): receives the inverse scales of this MLP's two row quarters (elements 2 MLP, 2 MLP + 1), stored by the caller
   constexpr int mlp = MLP;
   const int qd = lane >> 4;
   f32x4 p1[8], d2[8];
@@ -572,12 +574,24 @@ __device__ __forceinline__ void mlp_reverse_dual(const float* lds, const MfmaMlp
         // 24-bit rows (pack24): group index = column / 4 = mlp*32 + half*16 + ob*4 + qd
         unsigned* row = reinterpret_cast<unsigned*>(a.dp1) + edge * kDp1PackedDwords + 3 * (mlp * 32 + half * 16 + qd);
         static_for<4>([&]<int ob>() { *(u32x3_a4*)(row + 12 * ob) = pack24(dp1[ob]); });
-      } else {   // f16x3 mode: every hand-over stays fp32 (a 24-bit row would be its largest error by two orders of magnitude)
-        float* row = a.dp1 + edge * (4 * kDP) + mlp * (2 * kDP) + half * kDP + 4 * qd;
-        static_for<4>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
       }
     }
-    cdual_t<PREC, 4, 2, 128, 0, 0, 4 * half>(lds + L.w1c, dp1, contrib, lane, a.w_inv);   // rows half*64 .. +63 of W1c
+    if constexpr (PREC == kPrecF16x3) {
+      // f16x3 mode: 24-bit fixed-point rows on the scale the W1c^T chain uses for this quarter of the row anyway (pack24_fixed: within
+      // 2^-22 of the quarter's largest value; a 24-bit FLOATING row, 2^-17 per value, would be this mode's largest error by two
+      // orders of magnitude), 768 B instead of 1 KB per edge to write here and to gather in the node reverse
+      // (stored after the chain, which finds the scale behind its first operand request; dp1 stays live for the scan below anyway)
+      EdgeScale scd;
+      chain_dual_t_h<4, 2, 128, 0, 0, 4 * half>(lds + L.w1c, dp1, contrib, lane, a.w_inv, &scd);   // rows half*64 .. +63 of W1c
+      if (NEED_DP1 && edge < a.E) {
+        unsigned* row = reinterpret_cast<unsigned*>(a.dp1) + edge * kDp1PackedDwords + 3 * (mlp * 32 + half * 16 + qd);
+        const float s9 = scd.s * 512.f;
+        static_for<4>([&]<int ob>() { *(u32x3_a4*)(row + 12 * ob) = pack24_fixed(dp1[ob], s9); });
+      }
+      dp1_inv[mlp * 2 + half] = scd.inv * (1.f / 512.f);
+    } else {
+      cdual_t<PREC, 4, 2, 128, 0, 0, 4 * half>(lds + L.w1c, dp1, contrib, lane, a.w_inv);   // rows half*64 .. +63 of W1c
+    }
     if (NEED_DP1) {
       // sum of the dp1 rows per centre (the x_i half of the node reverse): scanned here, so the node kernel reads a few
       // partial rows per atom instead of every row of the centre.  The rows themselves are still stored above for the
@@ -626,7 +640,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     float* de_tile = a.de_soa + tile * kTileFloats + lane * 4;
     const float* e_tile = a.e_tile + tile * kTileFloats + lane * 4;
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
-    f32x4 dhv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dhv = {0.f, 0.f, 0.f, 0.f}, dp1_inv = {0.f, 0.f, 0.f, 0.f};
     const int arow = arow_i;   // < 0: the edge takes part in no triplet, its aggregate is zero
     const TbIn<PREC, TBS> tbin = tb_load<PREC, TBS>(a.m, arow, qd, a.w_inv);
     f32x4 x[4], de[4], contrib[4];
@@ -642,7 +656,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       f32x4 dmsg[4];
       const float* xrow = a.dx_new + ci * kDP + 4 * qd;
       static_for<4>([&]<int blk>() { dmsg[blk] = *(const f32x4*)(xrow + blk * 16); });
-      mlp_reverse_dual<NEED_DP1, 1, PREC, ST, 0>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv, st);
+      mlp_reverse_dual<NEED_DP1, 1, PREC, ST, 0>(lds, L.mlp[1], a, edge, tile, ci, cj, sk, hv, x2, dmsg, contrib, dhv, lv, st, dp1_inv);
     }
     // dL/d e2 = what flows in from later blocks + the node MLP's contribution
     if (a.de_is_zero) {
@@ -668,7 +682,9 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
       static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
     }
     st.template mark<5>();   // dL/de and e images arrived, e1 recomputed (three-body MLP)
-    mlp_reverse_dual<NEED_DP1, 0, PREC, ST, 6>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv, st);
+    mlp_reverse_dual<NEED_DP1, 0, PREC, ST, 6>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv, st, dp1_inv);
+    // the row's four inverse scales in one 16-byte store per edge (f16x3 mode; 256 contiguous bytes per tile)
+    if (NEED_DP1 && PREC == kPrecF16x3 && qd == 0 && edge < a.E) *(f32x4*)(a.dp1_scale + edge * 4) = dp1_inv;
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
       if (!FIRST) *(f32x4*)(de_tile + blk * 256) = de[blk];
@@ -879,7 +895,7 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
   const float* img = (f16 ? plan->d_mfma_revf_h : plan->d_mfma_revf) + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, w.TAb[b], w.TBb[b], w.e_blk[b], w.e_blk[b + 1], w.de_soa, nullptr,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, plan->d_stamps, w.seg_head, w.seg_first, nullptr, nullptr,
-             f16 ? plan->w_scale_inv : 1.f};
+             f16 ? plan->w_scale_inv : 1.f, dp1_scale_of(w.dp1, t.E)};
   constexpr int WV = kWavesRevFused;
   dim3 grid(grid_for_tiles(tiles)), block(64 * WV);
   if (plan->d_stamps && plan->stamp_target == 2 && f16 && tb_steps_for(c.C) == 3) {   // diagnostic build (tools/stamp_report_fused.py)

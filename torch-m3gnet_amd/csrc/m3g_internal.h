@@ -330,6 +330,13 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base);
 size_t topo_sort_tmp_bytes(int64_t E, int64_t T);
 
 // ---- workspace view ---------------------------------------------------------------------------------
+// 24-bit dp1 rows (768 B per edge) leave the last quarter of the [E,4*kDP] fp32 buffer free: the f16x3 mode's per-row inverse
+// scales ([E][4] floats) live at its start
+inline float* dp1_scale_of(float* dp1, int64_t E) { return dp1 ? dp1 + (size_t)E * 192 : nullptr; }
+// dp1 hand-over formats of k_node_reverse: fp32 rows, 24-bit floating rows (bf16x3 fused kernel), 24-bit fixed-point rows + scales
+// (f16x3 fused kernel)
+enum { kDp1F32 = 0, kDp1Packed = 1, kDp1Fixed = 2 };
+
 struct Work {
   // per-edge geometry / bases
   float *u, *d, *h, *hp, *q, *qp, *fc3, *fc3p;  // [E,3] [E] [E,kRP] [E,kRP] [E,kCP] [E,kCP] [E] [E]
@@ -348,7 +355,7 @@ struct Work {
   float* dh;                  // [E,kRP]
   float* dd;                  // [E]
   float* du;                  // [E,3]
-  float* dp1;                 // [E,4*kDP]
+  float* dp1;                 // [E,4*kDP]  (packed 24-bit rows use the first 3/4 of it, dp1_scale_of() the start of the rest)
   float* dr;                  // [E,3]
   // MFMA path: tile-SoA images ([tile of 16 edges][4 blk][64 lanes][4]) of the edge features BEFORE each block
   // (e_blk[b]; e_blk[B] = final) and of dL/de, per-block node tables, row-major messages.  No activations saved.
@@ -403,7 +410,7 @@ void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayo
                          const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                          bool want_grad, hipStream_t s);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
-                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool dp1_packed, bool with_v_term,
+                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, int dp1_packed, bool with_v_term,
                          hipStream_t s);
 void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,
                                 float* dx_out, hipStream_t s);

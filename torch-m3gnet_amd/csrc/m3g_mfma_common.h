@@ -242,6 +242,28 @@ __device__ __forceinline__ f32x4 unpack24(const u32x3& w) {
 }
 constexpr int kDp1PackedDwords = 3 * kDp1Groups;   // dwords per packed row
 
+// f16x3 mode: the same 768-byte rows as 24-bit FIXED-POINT values relative to the power-of-two scale the W1c^T chain gives the
+// row's 64-column quarter anyway (edge_scale: the quarter's largest |value| times s lies in [2^12, 2^13)):  k = round(x s 2^9), |k| <
+// 2^22, absolute error 2^-10 in scaled units = at most 2^-22 of the quarter's largest value -- what one split product of this mode
+// carries, and every column of a row meets the same 64 outputs of W1b^T in the node reverse, so an error relative to the largest
+// column is the relevant one.  One fma per value forms k in the mantissa of 1.5 * 2^23 + k (round to nearest even), the low three
+// bytes are the value; the four inverse scales of a row (times 2^-9) go to a separate [E][4] array.
+constexpr float kFix24Magic = 12582912.f;   // 1.5 * 2^23: ulp 1 on [2^23, 2^24)
+__device__ __forceinline__ u32x3 pack24_fixed(const f32x4& v, float s9) {
+  const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+  const unsigned a = __builtin_bit_cast(unsigned, __builtin_fmaf(v0, s9, kFix24Magic)), b = __builtin_bit_cast(unsigned, __builtin_fmaf(v1, s9, kFix24Magic)),
+                 c = __builtin_bit_cast(unsigned, __builtin_fmaf(v2, s9, kFix24Magic)), d = __builtin_bit_cast(unsigned, __builtin_fmaf(v3, s9, kFix24Magic));
+  // bytes (a0 a1 a2 b0) (b1 b2 c0 c1) (c2 d0 d1 d2)
+  return u32x3{__builtin_amdgcn_perm(b, a, 0x04020100u), __builtin_amdgcn_perm(c, b, 0x05040201u), __builtin_amdgcn_perm(d, c, 0x06050402u)};
+}
+__device__ __forceinline__ f32x4 unpack24_fixed(const u32x3& w, float inv9) {
+  const unsigned top = 0x4B4B4B4Bu;   // exponent byte of [2^23, 2^24)
+  const unsigned a = __builtin_amdgcn_perm(top, w[0], 0x04020100u), b = __builtin_amdgcn_perm(w[1], w[0], 0x0c050403u) | 0x4B000000u,
+                 c = __builtin_amdgcn_perm(w[2], w[1], 0x0c040302u) | 0x4B000000u, d = __builtin_amdgcn_perm(top, w[2], 0x04030201u);
+  return f32x4{(__builtin_bit_cast(float, a) - kFix24Magic) * inv9, (__builtin_bit_cast(float, b) - kFix24Magic) * inv9,
+               (__builtin_bit_cast(float, c) - kFix24Magic) * inv9, (__builtin_bit_cast(float, d) - kFix24Magic) * inv9};
+}
+
 template <int N>
 __device__ __forceinline__ void zero(f32x4 (&v)[N]) {
   static_for<N>([&]<int i>() { v[i] = f32x4{0.f, 0.f, 0.f, 0.f}; });

@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
                                                       const float* __restrict__ dgq, const float* __restrict__ v,
                                                       const float* __restrict__ dx_new, float* __restrict__ dx_out,
                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
-                                                      int with_v_term, const int2* __restrict__ in_pair, int dp1_packed) {
+                                                      int with_v_term, const int2* __restrict__ in_pair, int dp1_packed,
+                                                      const float* __restrict__ dp1_scale) {
   __shared__ float4 sA[kNodesRev][64], sB[kNodesRev][64];   // row / in-edge sums of dp1, 256 columns as 64 float4
   __shared__ float tv[kNodesRev][kCP];
   __shared__ float part[4][kNodesRev][kDP];
@@ -210,7 +211,23 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
         for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_pair[k + j] : make_int2(-1, -1);
 #endif
 #ifndef M3G_DP1_F32
-        if (dp1_packed) {   // rows written by the fused bf16x3 reverse kernel: 24-bit values, 12 B per lane (m3g_mfma_common.h: pack24)
+        if (dp1_packed == kDp1Fixed) {   // rows of the fused f16x3 reverse kernel: 24-bit fixed point + a scale per 64 columns (pack24_fixed)
+          u32x3 pk[kNrBatch];
+          float sc[kNrBatch];
+#pragma unroll
+          for (int j = 0; j < kNrBatch; ++j) {
+            pk[j] = f[j].x >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(reinterpret_cast<const unsigned*>(dp1) +
+                                                                   (int64_t)f[j].x * kDp1PackedDwords + 3 * ln))
+                                : u32x3{0u, 0u, 0u};   // (any bytes decode to finite numbers; the zero scale makes them 0)
+            sc[j] = f[j].x >= 0 ? dp1_scale[(int64_t)f[j].x * 4 + (ln >> 4)] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < kNrBatch; ++j) {
+            const f32x4 t = unpack24_fixed(pk[j], sc[j]);
+            u[j] = make_float4(t[0], t[1], t[2], t[3]);
+            g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
+          }
+        } else if (dp1_packed) {   // rows written by the fused bf16x3 reverse kernel: 24-bit values, 12 B per lane (m3g_mfma_common.h: pack24)
           u32x3 pk[kNrBatch];
 #pragma unroll
           for (int j = 0; j < kNrBatch; ++j)
@@ -480,12 +497,12 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
 }
 
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
-                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, bool dp1_packed, bool with_v_term,
+                         const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, int dp1_packed, bool with_v_term,
                          hipStream_t s) {
   if (t.N > 0)
     hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge,
                        w.dp1, w.dg, v, dx_new, dx_out, row_sums_in_seg ? w.seg_head : nullptr, row_sums_in_seg ? w.seg_first : nullptr,
-                       with_v_term ? 1 : 0, reinterpret_cast<const int2*>(t.in_pair), dp1_packed ? 1 : 0);
+                       with_v_term ? 1 : 0, reinterpret_cast<const int2*>(t.in_pair), dp1_packed, dp1_scale_of(w.dp1, t.E));
 }
 
 void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,
