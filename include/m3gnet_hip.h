@@ -111,7 +111,7 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *   "graph_replay" = 1 m3g_energy_forces captures its launch sequence into a hipGraph the first time it sees a given
  *                   (m3g_io contents, workspace, stream, options) and replays it on later identical calls (launch-bound
  *                   small systems); every buffer of the call must stay alive at the same address.  Default 0;
- *   "stamps"      diagnostic builds with in-kernel cycle stamps (m3g_debug_read_stamps);
+ *   "stamps"      = 1 / 2 / 3: diagnostic builds with in-kernel cycle stamps (m3g_debug_read_stamps), 0 off;
  *   "debug_force_move" = 1 (tests) the next m3g_plan_commit takes the device-move path although the device is unchanged. */
 int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t value);
 
@@ -271,7 +271,9 @@ int m3g_profile_read(m3g_plan* plan, int32_t* n_stages, const char** names /* [M
                      float* total_ms /* [M3G_MAX_STAGES] */, int32_t* launches /* [M3G_MAX_STAGES] */);
 
 /* Diagnostic only: with option "stamps" = 1 the forward edge kernel runs a stamped variant (s_memtime per
- * phase); this copies the per-wave phase cycle sums [256][16][12] of the LAST launch to the host. */
+ * phase), = 2 the reverse edge-MLP kernel of the two-kernel reverse, = 3 the fused reverse kernel (f16x3 mode; its waves ADD
+ * their sums over the launches since the option was set); this copies the per-wave phase cycle sums [256 workgroups][16 wave
+ * slots][12 phases] to the host. */
 int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
 /* Diagnostic only: number of HIP streams / events the plan currently owns (internal side stream, fork / join events, profiler
  * event pool).  They are bound to the plan's device: a commit that moves the plan to another device releases all of them. */
