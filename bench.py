@@ -71,7 +71,8 @@ BF16_MFMA_FLOP = 16384              # v_mfma_f32_16x16x32_bf16
 #   bytes_8d       SURVEY.md 8(d), ideal fusion: forward reads + writes the 256-byte edge-feature row (512), reverse reads the saved
 #                  row and reads + writes its gradient (768) -- the figure `traffic_over_algorithmic` is priced against;
 #   design_bytes   what the data layout moves: + the activations the fp32 mode saves / reads back (SiLU'(p1) and p2 of both MLPs,
-#                  1 KB each) and its fp32 dL/dp1 rows (1 KB, blocks > 0 only: averaged over the 3 launches of a step);
+#                  1 KB each) and the dL/dp1 hand-over rows (blocks > 0 only: averaged over the 3 launches of a step; 1 KB fp32 rows
+#                  in the fp32 mode, 768-byte 24-bit rows in the others, + 16 B of scales per row in the f16x3 mode);
 #   flops_8d       SURVEY.md 8(d): 134,144 per edge and block forward (a14 65,920 + a15 65,920 + a8 MLP 2,304), the same again for
 #                  the input-gradient reverse -- the UNFACTORISED formulation W1 [x_i | x_j | e];
 #   flops_useful   what the kernels really have to do after the exact factorisation W1 [x_i | x_j | e] = TA[i] + TB[j] + W1c e
@@ -82,12 +83,12 @@ BF16_MFMA_FLOP = 16384              # v_mfma_f32_16x16x32_bf16
 EDGE_KERNELS = {
     "edge_block_fwd": dict(kernel="k_edge_block_mfma", flops_8d=134_144, flops_useful=68_608, bytes_8d=2 * 256,
                            design_bytes={"bf16x3": 2 * 256, "f16x3": 2 * 256, "fp32": 2 * 256 + 2048},
-                           mfma={"bf16x3": (48, 192), "f16x3": (48, 192), "fp32": (545, 0)}),
+                           mfma={"bf16x3": (48, 192), "f16x3": (8, 216), "fp32": (545, 0)}),   # f16x3: the three-body MLP is on the f16 pipe too
     "edge_rev_fused": dict(kernel={"bf16x3": "k_edge_rev_fused", "f16x3": "k_edge_rev_fused", "fp32": "k_edge_rev_f32"}, flops_8d=134_144,
                            flops_useful=68_608, bytes_8d=3 * 256,
-                           design_bytes={"bf16x3": 3 * 256 + 256 + (2 * 768) / 3, "f16x3": 3 * 256 + 256 + (2 * 1024) / 3,
+                           design_bytes={"bf16x3": 3 * 256 + 256 + (2 * 768) / 3, "f16x3": 3 * 256 + 256 + (2 * (768 + 16)) / 3,
                                          "fp32": 2048 + (2 * (512 + 1024) + 256) / 3},
-                           mfma={"bf16x3": (48, 396), "f16x3": (48, 396), "fp32": (577, 0)}),
+                           mfma={"bf16x3": (48, 396), "f16x3": (8, 444), "fp32": (577, 0)}),
     # split reverse kernels (option rev_kernel = 0; fp32: layer 1 saved, layer 2 recomputed)
     "edge_rev_node_mlp": dict(kernel="k_edge_rev_node_mlp", flops_8d=65_920, flops_useful=33_152, bytes_8d=2 * 256,
                               design_bytes={"bf16x3": 2 * 256, "f16x3": 2 * 256, "fp32": 512 + 256 + 512},
