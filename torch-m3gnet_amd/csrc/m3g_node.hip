@@ -292,10 +292,21 @@ __global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const fl
     for (int nb = 0; nb < kNodesRev; ++nb) acc[nb] = 0.f;
     const float* fa = reinterpret_cast<const float*>(&sA[0][0]) + pq * kDP;
     const float* fb = reinterpret_cast<const float*>(&sB[0][0]) + pq * kDP;
-    for (int o = 0; o < kDP; ++o) {
-      const float a = wa[o * kDP], b = wb[o * kDP];
+#ifdef M3G_DIAG_NR_NO_PHASE2   // timing diagnostic only (wrong results): what re-reading W1a^T / W1b^T per 4-atom group costs
+    for (int o = 0; o < 4; o += 4) {
+#else
+    for (int o = 0; o < kDP; o += 4) {
+#endif
+      // four weight rows per trip: the row sums come from LDS as 16-byte broadcasts (a b32 read per term made this phase
+      // LDS-issue-bound: 512 reads per thread), the eight weight loads of a trip are independent
+      float a[4], b[4];
 #pragma unroll
-      for (int nb = 0; nb < kNodesRev; ++nb) acc[nb] += fa[nb * 256 + o] * a + fb[nb * 256 + o] * b;
+      for (int j = 0; j < 4; ++j) { a[j] = wa[(o + j) * kDP]; b[j] = wb[(o + j) * kDP]; }
+#pragma unroll
+      for (int nb = 0; nb < kNodesRev; ++nb) {
+        const float4 va = *reinterpret_cast<const float4*>(fa + nb * 256 + o), vb = *reinterpret_cast<const float4*>(fb + nb * 256 + o);
+        acc[nb] += (va.x * a[0] + vb.x * b[0]) + (va.y * a[1] + vb.y * b[1]) + (va.z * a[2] + vb.z * b[2]) + (va.w * a[3] + vb.w * b[3]);
+      }
     }
 #pragma unroll
     for (int nb = 0; nb < kNodesRev; ++nb) part[pq][nb][k] = acc[nb];
