@@ -529,8 +529,8 @@ def measure_beside(model, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)   # (the clocks settle over the first dozen steps: 3 -> 30 warm-up steps is 1.5 % of the step)
     ap.add_argument("--workload", choices=("config3", "config4"), default="config3")
     ap.add_argument("--precision", choices=("f16x3", "fp32", "bf16x3"), default=DEFAULT_PRECISION, help="arithmetic of the headline figure")
     ap.add_argument("--cells", type=int, nargs=3, default=[10, 10, 25], help="config3: fcc cells per axis (4 atoms each)")
