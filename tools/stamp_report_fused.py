@@ -38,3 +38,12 @@ tiles_per_wave = 26250 / (256 * W) * 3 * STEPS   # three launches per step
 print(f"{W} waves per workgroup; cycles per tile and wave {tot.mean() / tiles_per_wave:.0f} (s_memtime ticks of 100 MHz x ... as read)")
 for i, n in enumerate(names):
     print(f"{n:34s} {s[..., i].mean() / tiles_per_wave:9.1f} per tile  {100 * s[..., i].sum() / tot.sum():5.1f} %")
+per_launch = tot / (3 * STEPS)
+print("busy cycles per wave and launch: mean %.0f  min %.0f  max %.0f  (max / mean %.3f)" % (per_launch.mean(), per_launch.min(), per_launch.max(), per_launch.max() / per_launch.mean()))
+wg = per_launch.max(1)
+print("slowest wave of a workgroup: mean %.0f  min %.0f  max %.0f" % (wg.mean(), wg.min(), wg.max()))
+for x in range(8):
+    sel = per_launch[x::8]
+    print(f"  XCD label {x}: wave mean {sel.mean():.0f}  min {sel.min():.0f}  max {sel.max():.0f}")
+order = np.argsort(wg)
+print("five fastest workgroups (index, cycles):", [(int(i), int(wg[i])) for i in order[:5]], " five slowest:", [(int(i), int(wg[i])) for i in order[-5:]])

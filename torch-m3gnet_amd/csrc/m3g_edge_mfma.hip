@@ -679,7 +679,12 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     {  // e1 = e_in + three-body gated update (the edge MLP's input)
       f32x4 p[8];
       tb_preact_p<PREC, TBS>(lds + L.tb, tbin, p, lv);
-      static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { x[blk][r] += fgated(p[blk][r], p[4 + blk][r]); }); });
+      static_for<4>([&]<int blk>() {
+        static_for<2>([&]<int k>() {   // value pairs on packed fp32 instructions (gated_pair)
+          const f32x2 v = gated_pair(f32x2{p[blk][2 * k], p[blk][2 * k + 1]}, f32x2{p[4 + blk][2 * k], p[4 + blk][2 * k + 1]});
+          x[blk][2 * k] += v[0]; x[blk][2 * k + 1] += v[1];
+        });
+      });
     }
     st.template mark<5>();   // dL/de and e images arrived, e1 recomputed (three-body MLP)
     mlp_reverse_dual<NEED_DP1, 0, PREC, ST, 6>(lds, L.mlp[0], a, edge, tile, ci, cj, sk, hv, x, de, contrib, dhv, lv, st, dp1_inv);
@@ -706,10 +711,15 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_fused(RevArgs a, MfmaRe
     f32x4 d8[8];
     tb_preact_p<PREC, TBS>(lds + L.tb, tbin, d8, lv);
     static_for<4>([&]<int blk>() {
-      static_for<4>([&]<int r>() {
-        const float p = d8[blk][r], sgd = fsigmoid(p), sg = fsigmoid(d8[4 + blk][r]);
-        d8[blk][r] = de[blk][r] * sg * (sgd * (1.f + p * (1.f - sgd)));
-        d8[4 + blk][r] = de[blk][r] * (p * sgd) * sg * (1.f - sg);
+      static_for<2>([&]<int k>() {   // value pairs on packed fp32 instructions (silu_pair)
+        const f32x2 p = {d8[blk][2 * k], d8[blk][2 * k + 1]}, g = {d8[4 + blk][2 * k], d8[4 + blk][2 * k + 1]};
+        const f32x2 dv = {de[blk][2 * k], de[blk][2 * k + 1]};
+        f32x2 sd, dsd, sg;
+        silu_pair(p, sd, dsd);
+        sg = sigmoid_pair(g);
+        const f32x2 a_g = dv * sg, dd = a_g * dsd, dgt = (a_g * sd) * (1.f - sg);
+        d8[blk][2 * k] = dd[0]; d8[blk][2 * k + 1] = dd[1];
+        d8[4 + blk][2 * k] = dgt[0]; d8[4 + blk][2 * k + 1] = dgt[1];
       });
     });
     f32x4 dmv[1];

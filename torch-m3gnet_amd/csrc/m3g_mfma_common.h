@@ -58,6 +58,15 @@ __device__ __forceinline__ void silu_pair(f32x2 p, f32x2& act, f32x2& der) {
   der = act * (1.f - sg) + sg;
 }
 
+__device__ __forceinline__ f32x2 sigmoid_pair(f32x2 g) {
+#ifdef M3G_DIAG_CHEAP_ACT
+  return g * 0.25f + 0.5f;
+#else
+  const f32x2 t = g * -1.4426950408889634f;
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.f;
+  return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+#endif
+}
 // SiLU of a value pair / SiLU(p) * sigmoid(g) of two value pairs, the same way (fsilu, fgated)
 __device__ __forceinline__ f32x2 silu_pair(f32x2 p) {
 #ifdef M3G_DIAG_CHEAP_ACT
