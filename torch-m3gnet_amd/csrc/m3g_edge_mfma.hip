@@ -18,7 +18,7 @@
 //   * the 16 edge lanes are a DPP row and a centre's edges are consecutive, so sums over a centre's edges (messages in
 //     the forward kernel, dp1 rows in the reverse kernel) are segmented scans along the row (seg_scan).
 // Tile-SoA images ([tile][blk][64 lanes][4]) carry the edge features between blocks; nothing else is saved for the
-// reverse pass.  One persistent workgroup per CU (forward 16 waves, fused reverse 8 waves); workgroups sharing an XCD
+// reverse pass.  One persistent workgroup per CU (forward 12 waves in the f16x3 / bf16x3 modes, 16 in the fp32 mode; fused reverse 8); workgroups sharing an XCD
 // (blockIdx % 8) walk a contiguous edge range so their TA/TB rows stay in that XCD's L2.
 // Kernels: k_edge_block_mfma (forward), k_edge_rev_fused (reverse, one launch per block), and the earlier reverse pair
 // k_edge_rev_node_mlp / k_edge_rev_edge_mlp kept behind option rev_kernel = 0 for A/B tests.
