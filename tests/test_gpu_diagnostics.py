@@ -39,3 +39,28 @@ def test_stamped_fused_reverse_is_bit_identical_and_writes_stamps():
     out = model(g)
     for k, v in ref.items():
         assert torch.equal(out[k], v), k
+
+
+def test_readout_f16_option_agrees_with_the_exact_readout():
+    """f16x3 mode: the readout layers run on exact-fp32 chains by default; option readout_f16 = 1 moves them to scaled two-part fp16
+    chains (22-24 bits per product).  On a well-conditioned cell both give the same energies and forces to fp32 rounding."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.model.build import build_model
+
+    torch.manual_seed(0)
+    model = build_model(5.0, 4.0, 3, 3, 95, 64, 3).cuda()
+    model.engine.set_precision("f16x3")
+    g = fcc_cu_graph(3, 3, 4).to("cuda")
+    out = model(g)
+    e0, f0 = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone()
+    model.engine.set_option("readout_f16", 1)
+    try:
+        out = model(g)
+        e1, f1 = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone()
+    finally:
+        model.engine.set_option("readout_f16", 0)
+    assert not torch.equal(f0, f1)   # a different kernel really ran
+    assert float(((e1 - e0).abs() / e0.abs()).max()) < 2e-6
+    assert float((f1 - f0).abs().max() / f0.abs().max()) < 1e-5
+    out = model(g)
+    assert torch.equal(out[K.FORCES], f0)

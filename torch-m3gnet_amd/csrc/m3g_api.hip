@@ -377,6 +377,10 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->tb_moments = value != 0;
     return M3G_OK;
   }
+  if (strcmp(name, "readout_f16") == 0) {
+    plan->readout_f16 = value != 0;
+    return M3G_OK;
+  }
   if (strcmp(name, "stress_mode") == 0) {
     if (value != 0 && value != 1) { set_error("stress_mode must be 0 (reference: sum pos (x) F / V) or 1 (pair virial)"); return M3G_ERR_VALUE; }
     plan->stress_mode = value;
@@ -572,7 +576,7 @@ static int energy_forces_graph(const m3g_plan* plan, const m3g_io* io, void* wor
   memcpy(k, &workspace, sizeof(void*)); k += sizeof(void*);
   memcpy(k, &s, sizeof(void*)); k += sizeof(void*);
   memcpy(k, &workspace_bytes, sizeof(size_t)); k += sizeof(size_t);
-  const int opts[4] = {plan->edge_kernel, plan->rev_kernel + 2 * plan->save_p1 + 4 * plan->save_p2 + 8 * plan->tb_moments + 16 * plan->precision, plan->stress_mode, plan->overlap};
+  const int opts[4] = {plan->edge_kernel, plan->rev_kernel + 2 * plan->save_p1 + 4 * plan->save_p2 + 8 * plan->tb_moments + 16 * plan->precision + 64 * plan->readout_f16, plan->stress_mode, plan->overlap};
   memcpy(k, opts, sizeof(opts));
   for (auto& g : plan->graphs)
     if (g.key == key) { M3G_HIP_CHECK(hipGraphLaunch(g.exec, s)); return join(); }

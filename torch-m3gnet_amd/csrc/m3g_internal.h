@@ -215,6 +215,9 @@ struct m3g_plan {
   float* d_readout_img_h = nullptr; // the same layout as scaled two-part fp16 chain images (f16x3 mode), weights scaled by 1 / ro_w_scale_inv
   float ro_w_scale_inv = 1.f;
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
+  bool readout_f16 = false; // option "readout_f16": the readout layers on scaled two-part fp16 chains in the f16x3 mode (5 us faster at 10,000
+                            // atoms); default: exact-fp32 chains in every mode -- the per-atom energy can be the ill-conditioned remainder of its
+                            // last layer's terms, where 22 against 24 bits per product show (fuzz case 84)
   bool tb_moments = true;   // option "threebody_moments": per-atom moment sums where the partner lists are complete (m3g_threebody.hip)
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)

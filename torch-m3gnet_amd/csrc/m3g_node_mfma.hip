@@ -217,11 +217,12 @@ void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayo
   if (t.N > 0) {
     const int64_t tiles = (t.N + 15) / 16;
     const int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
-    if (plan->precision == kPrecF16x3)
+    if (plan->precision == kPrecF16x3 && plan->readout_f16)   // (option; default: exact-fp32 readout in every mode)
       hipLaunchKernelGGL(k_readout_mfma<kPrecF16x3>, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img_h, plan->ro_w_scale_inv,
                          plan->d_weights + wl.elemental, types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic,
                          want_grad ? w.dx : nullptr, scaled_total, t.S);
-    else   // fp32 mode, and bf16x3 (whose 2^-16 products here moved the Cu-32 virial from 4.5e-5 to 1.2e-4 of its fp64 value)
+    else   // every mode by default: this stage forms the energies and seeds the reverse pass (bf16x3 products here moved the Cu-32 virial from
+           // 4.5e-5 to 1.2e-4 of its fp64 value; f16x3 products put a six-atom structure's ill-conditioned energy 5.3e-5 off instead of 9e-6)
       hipLaunchKernelGGL(k_readout_mfma<kPrecF32>, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img, 1.f,
                          plan->d_weights + wl.elemental, types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic,
                          want_grad ? w.dx : nullptr, scaled_total, t.S);
