@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: energy + forces of M3GNet (default model) on the HIP engine.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config4] [--precision f16x3|fp32|bf16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config4] [--precision fp32|f16x3|bf16x3]
 
 `--gpus N` (N > 1) without a torch.distributed launcher in the environment starts the N ranks itself (one child
 process per GPU, before anything touches the GPU in the parent) and relays rank 0's JSON line; under
@@ -21,10 +21,10 @@ Model: default M3GNet (l_max = n_max = 3, D = 64, 3 blocks, 95 species), random-
 A step = one `model(graph)` call = the m3g_energy_forces launch sequence (forward + analytic reverse pass + virial),
 graph tensors resident in HBM.
 
-Precision: the headline runs the engine's default `f16x3` mode (every operand of the dense products as two power-of-two-scaled
-fp16 parts, three f16 MFMA products, fp32 accumulate: 22-24 significant bits, the parity margins of the exact mode); the exact
-`fp32` mode (v_mfma_f32_16x16x4_f32: the reference's arithmetic) and the `bf16x3` mode (~2^-16 relative product error) are timed
-beside it and reported under `fp32` / `bf16x3`.
+Precision: the headline runs the engine's default exact `fp32` mode (every dense product on v_mfma_f32_16x16x4_f32, bitwise an fp32
+fmaf chain: the reference's arithmetic); the opt-in split modes -- `f16x3` (every operand as two power-of-two-scaled fp16 parts,
+three f16 MFMA products, fp32 accumulate: 22-24 significant bits, NARROWER than fp32) and `bf16x3` (~2^-16 relative product error)
+-- are timed beside it and reported under `f16x3` / `bf16x3`, each with its operand format first in `dtype`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      the dominant kernel against the roofline that bounds it (fp32 mode: the fp32 matrix peak, `frac` on the USEFUL
@@ -103,10 +103,10 @@ FLOPS_RATIO_NOTE = ("flops_8d / flops_useful = 2: SURVEY.md 8(d) counts W1 [x_i 
 BYTES_8D_PER_STEP = lambda E, T, N: 4008 * E + 48 * T + 3504 * N   # noqa: E731  SURVEY.md 8(d), D = 64, B = 3
 PMC_TRAFFIC_FILE = "r03_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py), stamped with
                                                 # the digest of the kernel sources it was collected on
-DEFAULT_PRECISION = "f16x3"
+DEFAULT_PRECISION = "fp32"   # the reference's arithmetic (fp32 end to end): the headline `value` / `dtype` / `roofline`
 DTYPE = {"fp32": "f32",
-         "f16x3": "f32 (every operand as two power-of-two-scaled f16 parts = 22-24 significant bits, 3 f16 MFMA products, f32 accumulate)",
-         "bf16x3": "f32 (operands as two bf16 parts = 16 significant bits, 3 bf16 MFMA products, f32 accumulate)"}
+         "f16x3": "2xf16 split operands (power-of-two scaled, 22-24 significant bits; lo x lo dropped), 3 f16 MFMA products, f32 accumulate",
+         "bf16x3": "2xbf16 split operands (16 significant bits), 3 bf16 MFMA products, f32 accumulate"}
 METRIC = "atom-steps/sec (energy+forces) on 10k-atom PBC batch, 1/2/4/8 MI355X"
 
 
@@ -402,7 +402,7 @@ def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc, mo
     # HBM-bound kernels: bytes the data layout of DESIGN.md section 3 makes each launch move (every array the kernel must read or
     # write once; gathers from L2/MALL-resident node tables not counted)
     E, T, N, A = n_edges, n_trip, n_atoms, n_active
-    dp1_row = 768 if precision == "bf16x3" else 1024
+    dp1_row = {"fp32": 1024, "bf16x3": 768, "f16x3": 768 + 16}[precision]   # dL/dp1 hand-over row per edge
     hbm_kernels = {
         "geometry_basis": ("k_geometry", E * (8 + 12 + 12 + 4 + 16 + 16) + A * (64 + 64 + 8), 0),
         # three-body aggregate: the moment kernels (complete partner lists) read no partner ids; the list kernels

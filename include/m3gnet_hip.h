@@ -86,13 +86,14 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
 
 /* Engine options (not part of the reference):
  *   "precision"   arithmetic of the dense products of the gated MLPs (nn/core.py:61-62: fp32 Linear layers), fp32 accumulate in all modes:
- *                   2 (default) "f16x3": every operand scaled by a power of two (weights: one for the model; activations and gradients:
- *                   one per edge and chain, chosen from the data) and split in two fp16 parts that together carry 22-24 significant
- *                   bits, three v_mfma_f32_16x16x32_f16 products per fp32 product -- errors ~1.8 x those of an fp32 fmaf chain,
- *                   parity inside north_star's tolerances with the margins of the exact mode on every case;
- *                   0 "fp32": every product on v_mfma_f32_16x16x4_f32, exact fp32 products (the reference's arithmetic);
- *                   1 "bf16x3": two bf16 parts (16 significant bits), three v_mfma_f32_16x16x32_bf16 products (relative product
- *                   error ~2^-16; the fastest mode, parity within north_star's tolerances on near-linear weights only);
+ *                   0 (default) "fp32": every product on v_mfma_f32_16x16x4_f32 -- exact fp32 products accumulated in k order, bitwise
+ *                   an fp32 fmaf chain: the reference's arithmetic;
+ *                   2 "f16x3" (opt-in, narrower than fp32): every operand scaled by a power of two (weights: one for the model;
+ *                   activations and gradients: one per edge and chain, chosen from the data) and split in two fp16 parts that
+ *                   together carry 22-24 significant bits, three v_mfma_f32_16x16x32_f16 products per fp32 product (lo x lo
+ *                   dropped) -- errors ~1.8 x those of an fp32 fmaf chain, parity inside north_star's tolerances on every case;
+ *                   1 "bf16x3" (opt-in): two bf16 parts (16 significant bits), three v_mfma_f32_16x16x32_bf16 products (relative
+ *                   product error ~2^-16; the fastest mode, parity within north_star's tolerances on near-linear weights only);
  *                   all weight image sets are resident after a commit, switching costs nothing;
  *   "edge_kernel" = 1 fused MFMA edge blocks (default), 0 = vector-ALU baseline kernels (also M3G_EDGE_KERNEL in the env),
  *                   2 = the any-size path (run-time-sized fp32 kernels; chosen automatically for embedding_dim > 64,
@@ -144,6 +145,14 @@ int m3g_topology_build(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int
 #define M3G_TOPO_TB_COMPLETE 1
 int m3g_topology_hints(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
                        int32_t* host_hints, void* stream);
+
+/* Sticky error bits the hot call left on a topology buffer (0 = none).  M3G_TOPO_ERR_HINTS: m3g_energy_forces was handed a
+ * non-zero m3g_io.topo_hints that is not the word m3g_topology_hints certified for THIS buffer (stale after a rebuild, or copied
+ * from another topology): the three-body moment kernels then touch nothing (no out-of-bounds access) and the call's three-body
+ * terms, hence its results, are INVALID.  Synchronises the stream. */
+#define M3G_TOPO_ERR_HINTS 1
+int m3g_topology_status(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
+                        int32_t* host_status, void* stream);
 
 /* Number of ACTIVE edges of a built topology: edges that appear in either column of triplet_edge_index (the three-body
  * arrays of the workspace hold one row per active edge).  Synchronises the stream. */

@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (run on the GPU box): random small batches x random model shapes (l_max, n_max, blocks,
-cutoffs, scales) against the CPU oracle, with the tolerances of the test-suite (1e-5 energies, 1e-4 forces / stress)."""
+cutoffs, scales) against the CPU oracle, with the tolerances of the test-suite (1e-5 energies, 1e-4 forces / stress).
+
+    python tests/checkers/fuzz_parity.py [n_cases] [precision = fp32 | f16x3 | bf16x3]
+
+Energies are gated at the strict 1e-5 against the fp64 oracle.  ONE documented exception, by index: case 84 (a six-atom
+structure whose energy, 3.1e-5, is the remainder of readout terms of 1e-3) -- there the reference's own fp32 arithmetic (the
+fp32 oracle) is 1.3e-5 away from the fp64 value, and the gate is that measured distance + 1e-5.  `own` is printed for every
+case as a diagnostic only."""
 import sys
 from pathlib import Path
 
@@ -18,6 +25,8 @@ from torch_m3gnet.data.material_graph import Batch  # noqa: E402
 from torch_m3gnet.model.build import build_model  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+ILL_CONDITIONED = {84}   # documented exceptions to the strict energy gate (see the header)
 rng = np.random.default_rng(2024)
 worst = {"E": 0.0, "F": 0.0, "S": 0.0}
 fails = 0
@@ -39,20 +48,19 @@ for case in range(n_cases):
         box = float(rng.uniform(4.5, 9.0))
         n = int(rng.integers(1, max(2, min(40, int(box**3 / 14.0)))))   # keeps the random packing with dmin feasible
         graphs.append(random_cell_graph(n, box, seed=1000 * case + s, cutoff=cutoff, tb_cutoff=tb, dmin=1.4))
+    model.engine.set_precision(precision)
     g = model(Batch.from_data_list(graphs).to("cuda"))
     p, cfg, c, og = _oracle_inputs(model, g)
     o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
-    # Energies are gated at 1e-5 against the fp64 oracle, plus five times what the reference's OWN fp32 arithmetic (the fp32 oracle)
-    # is away from it: with random weights and a handful of atoms a structure's energy can be the ill-conditioned remainder of larger
-    # terms (case 84 of this sweep: E = 3e-5 from readout terms of 1e-3; the fp32 and fp64 oracles differ by 1.3e-5 of it, the
-    # engine's exact-fp32 mode by 1.3e-5, its f16x3 mode -- 22-24 significant bits per product against fp32's 24 -- by 5.3e-5)
     dbl = lambda t: t.double() if torch.is_tensor(t) and torch.is_floating_point(t) else t   # noqa: E731
     o64 = orc.energy_forces({k: dbl(v) for k, v in p.items()}, cfg, c, {k: dbl(v) for k, v in og.items()}, legendre_backward="exact")
     e64 = o64["total_energy"]
     own = (o["total_energy"].double() - e64).abs()
     err = (g[K.TOTAL_ENERGY].cpu().double() - e64).abs()
     e_err = float((err / e64.abs().clamp_min(1e-6)).max())
-    e_ok = bool((err <= 1e-5 * e64.abs().clamp_min(1e-6) + 5.0 * own).all())
+    slack = own if case in ILL_CONDITIONED else torch.zeros_like(own)
+    e_ok = bool((err <= 1e-5 * e64.abs().clamp_min(1e-6) + slack).all())
+    own_rel = float((own / e64.abs().clamp_min(1e-6)).max())
     fmax = float(o["forces"].abs().max())
     f_err = float((g[K.FORCES].cpu() - o["forces"]).abs().max()) / max(fmax, 1e-9)
     s_err = rel_err(g[K.STRESSES], o["stresses"]) if float(o["stresses"].abs().max()) > 0 else 0.0
@@ -60,5 +68,5 @@ for case in range(n_cases):
     fails += 0 if ok else 1
     worst = {"E": max(worst["E"], e_err), "F": max(worst["F"], f_err), "S": max(worst["S"], s_err)}
     print(f"case {case:3d} L={l_max} R={n_max} B={blocks} rc={cutoff:.2f} r3={tb:.2f} atoms={g[K.NUM_NODES]} E={g[K.NUM_EDGES]} "
-          f"T={g[K.NUM_TRIPLETS]}: E {e_err:.1e} F {f_err:.1e} S {s_err:.1e} {'ok' if ok else 'FAIL'}", flush=True)
-print("worst", worst, "failures", fails)
+          f"T={g[K.NUM_TRIPLETS]}: E {e_err:.1e} (fp32 oracle's own {own_rel:.1e}) F {f_err:.1e} S {s_err:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+print("precision", precision, "worst", worst, "failures", fails)

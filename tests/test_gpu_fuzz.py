@@ -11,10 +11,12 @@ from test_gpu_properties import _oracle_inputs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", range(20))
-def test_random_model_shape_and_batch_vs_oracle(case):
+# cases 0-11 run on the MFMA kernels, whose arithmetic mode matters: the default exact-fp32 mode and the opt-in f16x3 mode are both
+# swept; 12-19 take the any-size path, which is plain fp32 whatever the option says
+@pytest.mark.parametrize("case,precision", [(c, "fp32") for c in range(20)] + [(c, "f16x3") for c in range(12)])
+def test_random_model_shape_and_batch_vs_oracle(case, precision):
     """cases 0-11: shapes of the fast (MFMA) kernels; 12-19: any shape the reference accepts (widths up to 160, l_max up to 9,
-    n_max up to 10, up to 10 blocks) -- the any-size path."""
+    n_max up to 10, up to 10 blocks) -- the any-size path.  Energies at the strict 1e-5, forces / stresses at 1e-4."""
     from torch_m3gnet.data import MaterialGraphKey as K
     from torch_m3gnet.data.material_graph import Batch
     from torch_m3gnet.model.build import build_model
@@ -40,6 +42,7 @@ def test_random_model_shape_and_batch_vs_oracle(case):
         box = float(rng.uniform(4.5, 9.0))
         n = int(rng.integers(1, max(2, min(40, int(box**3 / 14.0)))))   # keeps the random packing feasible
         graphs.append(random_cell_graph(n, box, seed=1000 * case + s, cutoff=cutoff, tb_cutoff=tb, dmin=1.4))
+    model.engine.set_precision(precision)
     g = model(Batch.from_data_list(graphs).to("cuda"))
     p, cfg, c, og = _oracle_inputs(model, g)
     o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")

@@ -17,7 +17,9 @@ pytestmark = pytest.mark.gpu
 E_TOL, F_TOL, M_TOL = 1e-5, 1e-4, 1e-4
 
 
-PRECISIONS = ["fp32", "bf16x3", "f16x3"]   # engine option "precision": exact fp32 MFMA products (default) / 3 bf16 split products / 3 scaled fp16 split products
+# engine option "precision": exact fp32 MFMA products (the default, the reference's arithmetic) / the two opt-in split modes:
+# 3 bf16 split products / 3 scaled fp16 split products.  Every test below names the mode it runs in.
+PRECISIONS = ["fp32", "bf16x3", "f16x3"]
 
 
 def _record_margins(case, mode, precision, g, expect):
@@ -92,24 +94,28 @@ def test_engine_vs_golden_and_oracle(case, mode, precision):
                      f"   [reference's own forces vs the exact derivative: {defect_f:.2e}]\n")
 
 
-def test_energy_only_call_matches():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_energy_only_call_matches(precision):
     from torch_m3gnet.data import MaterialGraphKey as K
 
     _, _, _, graph, expect = load_oracle_case("cu32", "ref")
     model, _ = build_engine_model("cu32", "ref")
+    model.engine.set_precision(precision)
     g = model(engine_graph(graph), forces=False, extras=False)
     assert K.FORCES not in g
     assert rel_err(g[K.TOTAL_ENERGY], expect["out_total_energy"]) < E_TOL
 
 
-@pytest.mark.parametrize("edge_kernel", [0, 1])
+@pytest.mark.parametrize("edge_kernel,precision", [(0, "fp32"), (1, "fp32"), (1, "f16x3"), (1, "bf16x3")])
 @pytest.mark.parametrize("case,mode", [("cu32", "doc"), ("alna", "ref"), ("mix", "doc")])
-def test_both_edge_kernels_against_oracle(case, mode, edge_kernel):
-    """edge_kernel = 1: fused fp32-MFMA edge blocks (default); 0: vector-ALU baseline kernels (fallback)."""
+def test_both_edge_kernels_against_oracle(case, mode, edge_kernel, precision):
+    """edge_kernel = 1: fused MFMA edge blocks (default) in each arithmetic mode; 0: vector-ALU baseline kernels (plain fp32
+    `fmaf` arithmetic whatever the precision option says)."""
     from oracle import m3gnet_oracle as orc
     from torch_m3gnet.data import MaterialGraphKey as K
 
     model, _ = build_engine_model(case, mode)
+    model.engine.set_precision(precision)
     model.engine.set_option("edge_kernel", edge_kernel)
     _, _, _, graph, _ = load_oracle_case(case, mode)
     g = model(engine_graph(graph))

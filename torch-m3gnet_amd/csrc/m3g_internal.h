@@ -202,7 +202,7 @@ struct m3g_plan {
   float* d_mfma_revf_h = nullptr;  // the same layout holding fp16 parts of the scaled weights (f16x3 mode)
   float* d_mfma_revf32 = nullptr;  // [num_blocks][MfmaRevF32Layout.total] (fused fp32 reverse kernel)
   float* d_node_img[m3g::kNumPrec] = {nullptr, nullptr, nullptr};   // [num_blocks][kNodeImgFloats]: node-table weights as MFMA A-operand images (k_node_pre_mfma)
-  int precision = m3g::kPrecF16x3; // option "precision" (default: fp32-grade results from scaled two-part fp16 operands; 0 = exact fp32 MFMA products)
+  int precision = m3g::kPrecF32;   // option "precision" (default: exact fp32 MFMA products = the reference's arithmetic; 1 / 2 = the split modes, opt-in)
   float w_scale_inv = 1.f;       // f16x3 mode: 1 / (the power of two all chain-image weights were multiplied by), set by pack_mfma_images
   int save_p1 = 1;               // option "save_p1" (fp32 mode only): 0 = recompute layer 1 in the reverse kernels (A/B tests)
   int save_p2 = 1;               // option "save_p2" (fp32 mode, fused reverse): 0 = recompute layer 2 in the reverse kernel
@@ -285,6 +285,7 @@ constexpr int kTbCap = M3G_TB_CAP;   // staged three-body window: the rows of th
 // ids per row takes the dense case from 61 to 24 us (forward) and 137 to 86 us (reverse) per launch, but costs the 10k-atom
 // Cu cell 25 % of its three-body reverse (LDS footprint -> fewer resident workgroups), hence the choice per launch.
 constexpr int kTbListShort = 32, kTbListLong = 96;
+constexpr int kTopoFlags = 16;     // Topo::flags words
 constexpr int kTbFastAtoms = 64;   // most centre atoms per workgroup window the moment path keeps sums for (more: the list path)
 constexpr int kTbCapShort = kTbRows + 64 < kTbCap ? kTbRows + 64 : kTbCap;   // window rows the short-list instantiation stages
    // active edge rows per three-body workgroup (m3g_threebody.hip; windows precomputed in the topology)
@@ -322,9 +323,10 @@ struct Topo {
   int32_t* n_act;      // device scalar A (= flags + 2)
   int32_t* batch;    // [N]
   int32_t* struct_ptr;  // [S+1] atoms of structure s: struct_ptr[s] .. struct_ptr[s+1] (valid when `batch` is non-decreasing, flags[3] == 0)
-  int32_t* flags;    // [8] [0] malformed-graph bits; [2] = A; [3] != 0: `batch` is not sorted (per-structure sums then use atomics);
+  int32_t* flags;    // [kTopoFlags] [0] malformed-graph bits; [2] = A; [3] != 0: `batch` is not sorted (per-structure sums then use atomics);
                      // [4] three-body workgroups that may NOT use the moment path, [5] largest window (rows), [6] most atoms per window
-                     // (m3g_topology_hints packs 4..6 for the caller)
+                     // (m3g_topology_hints packs 4..6 for the caller); [7] the hints word m3g_topology_hints certified for this
+                     // buffer (0 after a build); [8] sticky error bits set by the hot call (M3G_TOPO_ERR_*, m3g_topology_status)
   void* sort_tmp;    // scratch for the radix sorts
   size_t sort_tmp_bytes;
   size_t total_bytes;

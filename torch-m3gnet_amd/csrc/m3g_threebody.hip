@@ -386,6 +386,8 @@ __device__ __forceinline__ MomEval mom_eval(const float* M, float ux, float uy, 
 struct TbMomArgs {
   int blocks;   // E / kTbRows + 1: block indices with a window record
   const int32_t *src, *arow_ptr, *tb_fast, *act_list, *act_dst, *tb_win, *n_act;
+  int32_t* flags;   // Topo::flags: [7] the hints word certified for this buffer, [8] sticky error
+  int hints;        // the word the caller handed in
   const float *u, *fc3, *fc3p, *q, *qp, *v, *dm;   // reverse only: fc3p, qp, dm
   float* m;                                        // forward out
   float *dd, *du, *dgq;                            // reverse out
@@ -406,6 +408,12 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomAr
   float* ss = sg + cap_rows * C;                              // dS = fc dm (reverse)
   float* s_mom = ss + (REV ? cap_rows * C : 0);               // moments of g, then (reverse) of dS
   int* s_arow = reinterpret_cast<int*>(s_mom + (REV ? 2 : 1) * cap_atoms * R * NM);
+  // The launch sizes (cap_rows, cap_atoms -> the LDS carve-up above) come from the caller's hints word; they are only valid for the
+  // topology buffer that word was certified for.  Anything else flags an error and touches nothing.
+  if (a.flags[7] != a.hints) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.flags + 8, M3G_TOPO_ERR_HINTS);
+    return;
+  }
   // (the row count A lives on the device; a workgroup beyond it finds an empty window -- k_tb_windows writes one for every block
   // index the grid can reach -- so nothing here waits for A: one dependent load less in a kernel that is a chain of them)
   for (int blk = blockIdx.x; blk < a.blocks; blk += gridDim.x) {
@@ -413,8 +421,12 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomAr
     const int lo = a.tb_win[6 * blk], n = a.tb_win[6 * blk + 1] - lo;
     if (n <= 0) break;   // windows are in row order: the first empty one ends the list
     const int A = lo + n;   // rows of this block are < lo + n (the window covers them), rows >= A of the last block are not
-    const int na = a.tb_fast[2 * blk], a0 = a.tb_fast[2 * blk + 1];   // (0 < na <= cap_atoms, n <= cap_rows: the launch is only made
-                                                                     // for graphs whose every window qualifies, with the sizes from the hints)
+    const int na = a.tb_fast[2 * blk], a0 = a.tb_fast[2 * blk + 1];   // (the launch is only made for graphs whose every window
+                                                                     // qualifies, with the sizes from the certified hints)
+    if (na <= 0 || na > cap_atoms || n > cap_rows) {                  // cannot happen with a certified word: never overrun the LDS
+      if (threadIdx.x == 0) atomicOr(a.flags + 8, M3G_TOPO_ERR_HINTS);
+      continue;
+    }
     const int r = rb + (int)threadIdx.x;
     const bool live = r < A;
     const int rr = live ? r : A - 1;
@@ -539,7 +551,9 @@ static inline bool long_lists(const Topo& t) { return t.T > 24 * t.E; }
 // the moment kernels apply when the topology build found every window complete (hint bit, read back by the caller once per
 // topology: m3g_topology_hints) and l_max <= 3
 static inline bool use_moments(const Consts& c, int topo_hints) {
-  return (topo_hints & M3G_TOPO_TB_COMPLETE) && c.L <= 3 && ((topo_hints >> 8) & 0xff) > 0 && ((topo_hints >> 16) & 0xff) > 0;
+  // (L, R outside M3G_DISPATCH_LR3's cases take the list kernels)
+  return (topo_hints & M3G_TOPO_TB_COMPLETE) && c.L >= 1 && c.L <= 3 && c.R >= 1 && c.R <= 4 && ((topo_hints >> 8) & 0xff) > 0 &&
+         ((topo_hints >> 16) & 0xff) > 0;
 }
 #define M3G_DISPATCH_LR3(Lv, Rv, BODY)                          \
   switch ((Lv) * 8 + (Rv)) {                                    \
@@ -562,7 +576,7 @@ void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float
   if (t.E == 0) return;
   if (t.T == 0) return;   // no active edge: every consumer reads zeros through act_id < 0
   if (use_moments(c, topo_hints)) {
-    TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, w.u, w.fc3, nullptr, w.q, nullptr, v, nullptr, m, nullptr, nullptr, nullptr, 0};
+    TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, t.flags, topo_hints, w.u, w.fc3, nullptr, w.q, nullptr, v, nullptr, m, nullptr, nullptr, nullptr, 0};
     const int rows = (topo_hints >> 8) & 0xff, atoms = (topo_hints >> 16) & 0xff;
     M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments<L, R, false>), grid_rows(t.E), dim3(kTbRows), (mom_lds_bytes<L, R, false>(rows, atoms)), s, c, a, rows, atoms));
     return;
@@ -576,7 +590,7 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
   if (t.E == 0) return;
   if (t.T == 0) return;
   if (use_moments(c, topo_hints)) {
-    TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd, w.du, w.dg, first ? 1 : 0};
+    TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, t.flags, topo_hints, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd, w.du, w.dg, first ? 1 : 0};
     const int rows = (topo_hints >> 8) & 0xff, atoms = (topo_hints >> 16) & 0xff;
     M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments<L, R, true>), grid_rows(t.E), dim3(kTbRows), (mom_lds_bytes<L, R, true>(rows, atoms)), s, c, a, rows, atoms));
     return;

@@ -56,7 +56,7 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   t.t2_b = (uint8_t*)take((size_t)T + 16);
   t.batch = (int32_t*)take(sizeof(int32_t) * (N + 1));
   t.struct_ptr = (int32_t*)take(sizeof(int32_t) * (S + 2));
-  t.flags = (int32_t*)take(sizeof(int32_t) * 8);
+  t.flags = (int32_t*)take(sizeof(int32_t) * kTopoFlags);
   t.n_act = t.flags ? t.flags + 2 : nullptr;
   t.sort_tmp_bytes = topo_sort_tmp_bytes(E, T);
   t.sort_tmp = take(t.sort_tmp_bytes);
@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(256) k_tb_fast(int64_t blocks, const int32_t* 
     fast[2 * b + 1] = a0;
   }
 }
+__global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
 __global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ table, int32_t* out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) { out[2 * i] = idx[i]; out[2 * i + 1] = table[idx[i]]; }
@@ -302,7 +303,10 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   Topo t = topo_carve(N, E, T, S, topo_buf);
   const int TPB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TPB - 1) / TPB)); };
-  M3G_HIP_CHECK(hipMemsetAsync(t.flags, 0, 8 * sizeof(int32_t), s));
+  M3G_HIP_CHECK(hipMemsetAsync(t.flags, 0, kTopoFlags * sizeof(int32_t), s));   // incl. the certified hints word [7] and the sticky error [8]
+  // no window may use the three-body moment path until m3g_topology_hints has certified THIS buffer (stale rows of an earlier
+  // topology in the same memory must not survive a rebuild)
+  M3G_HIP_CHECK(hipMemsetAsync(t.tb_fast, 0, sizeof(int32_t) * 2 * (E / kTbRows + 2), s));
 
   size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
   char* tmp = (char*)t.sort_tmp;
@@ -419,7 +423,23 @@ extern "C" int m3g_topology_hints(int64_t N, int64_t E, int64_t T, int64_t S, co
   int32_t h[3] = {0, 0, 0};
   M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags + 4, sizeof(h), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipStreamSynchronize(s));
+  // the window sizes travel in one byte each
+  static_assert(kTbCap <= 255 && kTbFastAtoms <= 255, "m3g_topology_hints packs the largest window (rows, atoms) in 8 bits each");
   if (h[0] == 0 && h[1] > 0) *host_hints = M3G_TOPO_TB_COMPLETE | ((h[1] & 0xff) << 8) | ((h[2] & 0xff) << 16);
+  // the same word stays with the buffer (flags[7]): the moment kernels run only when the word the caller hands to m3g_energy_forces
+  // is the one certified for THIS topology buffer -- a stale word, or one copied from another buffer, flags an error instead
+  hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, s, t.flags + 7, *host_hints);
+  return M3G_OK;
+}
+
+extern "C" int m3g_topology_status(int64_t N, int64_t E, int64_t T, int64_t S, const void* topo_buf, int32_t* host_status, void* stream_) {
+  if (!topo_buf || !host_status) { set_error("m3g_topology_status: null argument"); return M3G_ERR_VALUE; }
+  hipStream_t s = (hipStream_t)stream_;
+  Topo t = topo_carve(N, E, T, S, const_cast<void*>(topo_buf));
+  int32_t v = 0;
+  M3G_HIP_CHECK(hipMemcpyAsync(&v, t.flags + 8, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  M3G_HIP_CHECK(hipStreamSynchronize(s));
+  *host_status = v;
   return M3G_OK;
 }
 

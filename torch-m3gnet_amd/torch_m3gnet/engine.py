@@ -59,8 +59,8 @@ class Engine:
         self.plan = C.c_void_p()
         _lib.check(self.lib.m3g_plan_create(C.byref(self.cfg), C.byref(self.plan)))
         self._sig = None
-        self.precision = "f16x3"
-        env_prec = os.environ.get("M3G_PRECISION")   # run a whole test suite in the other mode without touching it
+        self.precision = "fp32"   # the reference's arithmetic; the split modes are explicit opt-ins (set_precision / M3G_PRECISION)
+        env_prec = os.environ.get("M3G_PRECISION")   # run a whole test suite in another mode without touching it
         if env_prec:
             self.set_precision(env_prec)
         self._workspace = None
@@ -115,12 +115,12 @@ class Engine:
 
     def set_precision(self, name: str) -> None:
         """Arithmetic of the dense gated-MLP products (fp32 accumulate in every mode):
-        "f16x3"  (default) every operand scaled by a power of two and split in two fp16 parts (22-24 significant bits), three
-                 v_mfma_f32_16x16x32_f16 products per fp32 product: errors ~1.8 x those of an fp32 fmaf chain, every parity case
-                 (golden, LJ-fitted, saturated) inside the 1e-5 / 1e-4 tolerances with the margins of the exact mode;
-        "fp32"   every product on v_mfma_f32_16x16x4_f32: exact fp32 products, the reference's arithmetic (25 % slower: fp32
-                 MFMAs run at 1/16 of the f16 rate and share the SIMD's datapath with the vector instructions);
-        "bf16x3" two bf16 parts (16 significant bits), three bf16 MFMA products: ~2^-16 product error, the fastest mode."""
+        "fp32"   (default) every product on v_mfma_f32_16x16x4_f32: exact fp32 products accumulated in k order, bitwise an fp32
+                 `fmaf` chain -- the reference's arithmetic (nn/core.py:61-62, nn/featurizer.py:36);
+        "f16x3"  opt-in, NARROWER than fp32: every operand scaled by a power of two and split in two fp16 parts (22-24 significant
+                 bits), three v_mfma_f32_16x16x32_f16 products per fp32 product (the lo x lo term is dropped): errors ~1.8 x those
+                 of an fp32 fmaf chain; every parity case (golden, LJ-fitted, saturated) inside the 1e-5 / 1e-4 tolerances;
+        "bf16x3" opt-in, two bf16 parts (16 significant bits), three bf16 MFMA products: ~2^-16 product error, the fastest mode."""
         if name not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}, got {name!r}")
         self.set_option("precision", self.PRECISIONS[name])

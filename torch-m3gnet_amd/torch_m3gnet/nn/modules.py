@@ -129,6 +129,13 @@ class _Topology:
         loops (the list kernels, always valid)."""
         return self.query_hints()
 
+    def status(self) -> int:
+        """Sticky error bits the hot call left on this topology buffer (m3g_topology_status; 0 = none)."""
+        st = C.c_int32(0)
+        with torch.cuda.device(self.buf.device):
+            _lib.check(_lib.load_library().m3g_topology_status(self.N, self.E, self.T, self.S, _ptr(self.buf), C.byref(st), _stream()))
+        return int(st.value)
+
     def n_active(self) -> int:
         """Edges that take part in a triplet (rows of the three-body arrays)."""
         n = C.c_int64()
