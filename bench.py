@@ -101,7 +101,11 @@ FLOPS_RATIO_NOTE = ("flops_8d / flops_useful = 2: SURVEY.md 8(d) counts W1 [x_i 
                     "factorisation TA[i] + TB[j] + W1c e, whose x_i / x_j parts are per-node tables (k_node_pre_mfma, 65,536 FLOP "
                     "per atom and block, 42 x fewer rows than edges)")
 BYTES_8D_PER_STEP = lambda E, T, N: 4008 * E + 48 * T + 3504 * N   # noqa: E731  SURVEY.md 8(d), D = 64, B = 3
-PMC_TRAFFIC_FILE = "r03_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py), stamped with
+PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16 MFMA peak (same rate as bf16)
+PMC_SQ_FILE = "r04_pmc_sq_counters.json"        # profiles/: per-kernel SQ counters (tools/pmc_sq_json.py), stamped like the traffic set
+# kernels one launch of a stage consists of (csrc/m3g_api.hip: m3g_energy_forces), for `launches_per_step`
+KERNELS_PER_STAGE = {"readout": 2, "geometry_rev_forces": 3}
+PMC_TRAFFIC_FILE = "r04_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py), stamped with
                                                 # the digest of the kernel sources it was collected on
 DEFAULT_PRECISION = "fp32"   # the reference's arithmetic (fp32 end to end): the headline `value` / `dtype` / `roofline`
 DTYPE = {"fp32": "f32",
@@ -331,6 +335,61 @@ class Job:
             self.dist.destroy_process_group()
 
 
+def series_and_clock(step, steps):
+    """A pass of `steps` further steps AFTER the timed region (which stays untouched): every step bracketed by HIP events on the
+    launch stream -> min / median / max step time, and the shader clock sampled from the SMU on a second thread while the steps
+    run (torch.cuda.clock_rate -> amdsmi: MHz of the current device).  Tells a slow box / a throttled clock from warm-up ramp."""
+    import statistics
+    import threading
+
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                samples.append(int(torch.cuda.clock_rate()))
+            except Exception:
+                return
+            stop.wait(0.004)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize()
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=2.0)
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    rec = {"ms_per_step_min": min(ms), "ms_per_step_median": statistics.median(ms), "ms_per_step_max": max(ms), "steps": steps,
+           "how": "a second pass of the same steps, each bracketed by HIP events on the launch stream (the timed region itself carries no events)"}
+    busy = [c for c in samples if c > 0]
+    if busy:
+        rec["clock_mhz"] = {"median": statistics.median(busy), "min": min(busy), "max": max(busy), "samples": len(busy),
+                            "source": "torch.cuda.clock_rate() (amdsmi current sclk) sampled every ~4 ms during that pass"}
+    return rec
+
+
+def load_stamped(name, digest, cells):
+    """A profile set under profiles/ that carries the digest of the kernel sources it was collected on; ({}, source record)."""
+    path = ROOT / "profiles" / name
+    source = {"file": f"profiles/{name}", "csrc_sha256_of_this_build": digest, "valid": False}
+    if path.exists() and tuple(cells) == (10, 10, 25):
+        loaded = json.loads(path.read_text())
+        src = loaded.get("_source", {})
+        source.update({k: src.get(k) for k in ("csrc_sha256", "git_commit", "command")})
+        if src.get("csrc_sha256") == digest:
+            source["valid"] = True
+            return loaded, source
+        source["note"] = "profile set collected on other kernel sources than this build: fields taken from it are null"
+    else:
+        source["note"] = "no profile set for this workload"
+    return {}, source
+
+
 def stage_times(model, call, steps):
     """{stage: (ms per launch, launches per step)} from HIP events recorded on the launch stream inside the library."""
     eng = model.engine
@@ -384,21 +443,25 @@ def rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc, mo
                          "frac": t_useful / PEAK_F32_MFMA_TFLOPS, "executed_mfma_tflops": t_exe,
                          "executed_mfma_frac": t_exe / PEAK_F32_MFMA_TFLOPS, "flops_note": FLOPS_RATIO_NOTE}
             views[stage] = dict(common, **mfma_view, other_view=hbm_view)
-        elif precision == "f16x3":
-            # fp32-grade results from two-part f16 operands: priced like the fp32 mode -- USEFUL fp32 FLOPs against the fp32 matrix peak,
-            # the rate a native fp32 MFMA kernel could at best reach -- with the f16 pipe's own view beside it: the three products per
-            # fp32 product execute on the f16 matrix pipe, which (unlike the fp32 MFMA) co-executes with the vector instructions; the
-            # kernel is bound by its vector instruction issue (operand scaling / splitting, activations), not by either pipe.
+        else:
+            # split modes: the products execute on the f16 / bf16 matrix pipe, which (unlike the fp32 MFMA) co-executes with the
+            # vector instructions -- `frac` is priced against THAT pipe on the EXECUTED FLOPs (3 part products per fp32 product, zero
+            # padding included), the HBM view on PMC traffic beside it (`hbm_traffic_view`; falls back to the algorithmic bytes when
+            # no profile set matches this build), and the useful fp32 FLOPs against the fp32 matrix peak only as a yardstick
+            # (`useful_vs_fp32_peak`: that peak does not bound a kernel on the f16 pipe).  Neither pipe bounds these kernels: they
+            # are bound by their vector instruction stream (operand scaling / splitting, activations) -- `valu_per_mfma`,
+            # `valu_active_frac` from the SQ counter set say so in the line.
             t_useful, t_exe = useful / sec / 1e12, exe_flops / sec / 1e12
-            mfma_view = {"bound": "mfma", "achieved": t_useful, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": t_useful / PEAK_F32_MFMA_TFLOPS, "peak_is": "fp32 matrix peak (the arithmetic this mode reproduces)",
-                         "f16_pipe_view": {"executed_tflops": t_exe, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": t_exe / PEAK_BF16_MFMA_TFLOPS},
+            peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_BF16_MFMA_TFLOPS
+            traffic_rate = (traffic / sec / 1e9) if traffic else None
+            mfma_view = {"bound": "mfma", "achieved": t_exe, "peak": peak, "unit": "TFLOP/s", "frac": t_exe / peak,
+                         "frac_is": "executed MFMA FLOPs (incl. the 3x of the split and zero padding) / dense %s peak" % ("f16" if precision == "f16x3" else "bf16"),
+                         "useful_vs_fp32_peak": t_useful / PEAK_F32_MFMA_TFLOPS, "useful_tflops": t_useful,
+                         "hbm_traffic_view": {"achieved": traffic_rate if traffic_rate else hbm_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                              "frac": (traffic_rate if traffic_rate else hbm_rate) / PEAK_HBM_GBS,
+                                              "bytes_basis": "PMC traffic (2 x FETCH_SIZE + WRITE_SIZE)" if traffic_rate else "algorithmic_bytes_8d"},
                          "flops_note": FLOPS_RATIO_NOTE}
             views[stage] = dict(common, **mfma_view, other_view=hbm_view)
-        else:
-            views[stage] = dict(common, **hbm_view,
-                                mfma_view={"useful_tflops": useful / sec / 1e12, "executed_tflops": exe_flops / sec / 1e12,
-                                           "executed_frac_of_bf16_peak": exe_flops / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS})
     # HBM-bound kernels: bytes the data layout of DESIGN.md section 3 makes each launch move (every array the kernel must read or
     # write once; gathers from L2/MALL-resident node tables not counted)
     E, T, N, A = n_edges, n_trip, n_atoms, n_active
@@ -603,20 +666,9 @@ def main():
 
     # PMC traffic is a property of a build: the profile set carries the digest of the kernel sources it was collected on
     # (tools/pmc_traffic.py); a set from other sources than the ones being timed yields `traffic: null`
-    pmc_path = ROOT / "profiles" / PMC_TRAFFIC_FILE
-    pmc_all, digest = {}, csrc_digest()
-    traffic_source = {"file": f"profiles/{PMC_TRAFFIC_FILE}", "csrc_sha256_of_this_build": digest, "valid": False}
-    if pmc_path.exists() and tuple(args.cells) == (10, 10, 25):
-        loaded = json.loads(pmc_path.read_text())
-        src = loaded.get("_source", {})
-        traffic_source.update({k: src.get(k) for k in ("csrc_sha256", "git_commit", "command")})
-        if src.get("csrc_sha256") == digest:
-            pmc_all = loaded
-            traffic_source["valid"] = True
-        else:
-            traffic_source["note"] = "profile set collected on other kernel sources than this build: traffic fields are null"
-    else:
-        traffic_source["note"] = "no profile set for this workload"
+    digest = csrc_digest()
+    pmc_all, traffic_source = load_stamped(PMC_TRAFFIC_FILE, digest, args.cells)
+    sq_all, sq_source = load_stamped(PMC_SQ_FILE, digest, args.cells)
 
     def record(precision, ms_step):
         """Roofline objects of one precision mode from live stage timers (the mode must be the engine's current one)."""
@@ -627,6 +679,16 @@ def main():
         dom = max(edge, key=lambda k: edge[k]["avg_launch_ms"] * per_launch[k][1])   # dominant kernel = largest share of the step
         stage_ms = {k: round(ms * cnt, 4) for k, (ms, cnt) in per_launch.items()}
         views[dom]["traffic_source"] = traffic_source
+        # vector instructions per MFMA and the share of SIMD cycles the vector ALU is active, from the SQ counter set of this build
+        # (tools/collect_sq_counters.sh + tools/pmc_sq_json.py): SQ_ACTIVE_INST_VALU counts units of 4 cycles summed over SIMDs,
+        # SQ_BUSY_CU_CYCLES cycles summed over CUs (4 SIMDs each) -> active share = ACTIVE_INST_VALU / BUSY_CU_CYCLES
+        kname = views[dom]["kernel"].split(" ")[0]
+        sq = sq_all.get(precision, {}).get(kname)
+        views[dom]["sq_counters"] = ({"valu_per_mfma": sq["SQ_INSTS_VALU"] / max(sq["SQ_INSTS_MFMA"], 1.0),
+                                      "valu_active_frac": sq["SQ_ACTIVE_INST_VALU"] / max(sq["SQ_BUSY_CU_CYCLES"], 1.0),
+                                      "mfma_busy_frac": sq["SQ_VALU_MFMA_BUSY_CYCLES"] / max(4.0 * sq["SQ_BUSY_CU_CYCLES"], 1.0),
+                                      "insts_valu_per_launch": sq["SQ_INSTS_VALU"], "insts_mfma_per_launch": sq["SQ_INSTS_MFMA"],
+                                      "source": sq_source} if sq else {"valu_per_mfma": None, "valu_active_frac": None, "source": sq_source})
         pm = pmc_all.get(precision, {})
         # (kernels that run less than once per step belong to the topology build of the first call, not to the step)
         total = sum(r["launches_per_step"] * (2.0 * r["fetch_kb"] + r["write_kb"]) * 1024.0 for r in pm.values()
@@ -634,10 +696,13 @@ def main():
         ideal = BYTES_8D_PER_STEP(n_edges, n_trip, n_atoms)
         step_bytes = {"traffic": total, "algorithmic_bytes_8d": ideal, "traffic_over_algorithmic": (total / ideal) if total else None,
                       "source": traffic_source["file"] if total else None}
-        return views[dom], [v for k, v in views.items() if k != dom], stage_ms, step_bytes
+        launches = sum(cnt * KERNELS_PER_STAGE.get(k, 1) for k, (ms, cnt) in per_launch.items() if ms * cnt > 0.006)   # (empty stages: two bare events, ~5 us)
+        return views[dom], [v for k, v in views.items() if k != dom], stage_ms, step_bytes, launches
 
-    roofline, others, stage_ms, step_bytes = record(args.precision, ms_per_step)
-    out.update(value=value, ms_per_step=ms_per_step, roofline=roofline, roofline_other_kernels=others, step_traffic_bytes=step_bytes,
+    timing = series_and_clock(step, args.steps)
+    roofline, others, stage_ms, step_bytes, launches = record(args.precision, ms_per_step)
+    out.update(value=value, ms_per_step=ms_per_step, ms_per_step_min=timing["ms_per_step_min"], ms_per_step_median=timing["ms_per_step_median"],
+               clock_mhz=(timing.get("clock_mhz") or {}).get("median"), step_timing=timing, kernel_launches_per_step=launches, roofline=roofline, roofline_other_kernels=others, step_traffic_bytes=step_bytes,
                config={"workload": f"single {n_atoms}-atom fcc Cu PBC supercell per GPU ({'x'.join(map(str, args.cells))} cells, "
                                    "a=3.61 A, jitter 0.025 A), r_cut 5 A / 3-body 4 A, default M3GNet (l_max=n_max=3, D=64, "
                                    "3 blocks), energy+forces+stress",
@@ -652,8 +717,11 @@ def main():
             model.engine.set_precision(other)
             step()
             el2 = job.timed(step, args.steps, args.warmup)
-            r2, o2, st2, sb2 = record(other, el2 / args.steps * 1e3)
+            t2 = series_and_clock(step, args.steps)
+            r2, o2, st2, sb2, _ = record(other, el2 / args.steps * 1e3)
             out[other] = {"value": world * n_atoms * args.steps / el2, "unit": "atom-steps/s", "ms_per_step": el2 / args.steps * 1e3,
+                          "ms_per_step_min": t2["ms_per_step_min"], "ms_per_step_median": t2["ms_per_step_median"],
+                          "clock_mhz": (t2.get("clock_mhz") or {}).get("median"),
                           "dtype": DTYPE[other], "roofline": r2, "stage_ms_per_step": st2, "step_traffic_bytes": sb2}
             log(f"{other}: {el2 / args.steps * 1e3:.3f} ms/step")
         model.engine.set_precision(args.precision)

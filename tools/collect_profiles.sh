@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_$tag/
 echo "[collect] write pass done"
 {
   echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 3 --warmup 1 --no-cpu-baseline, $tag build"
-  mode=$(echo "$extra" | sed -n 's/.*--precision \([a-z0-9]*\).*/\1/p'); mode=${mode:-f16x3}   # bench.py's default mode
+  mode=$(echo "$extra" | sed -n 's/.*--precision \([a-z0-9]*\).*/\1/p'); mode=${mode:-fp32}   # bench.py's default mode
   # merged into one stamped file per round (both modes), which bench.py reads: $root/gpurun_out/pmc_hbm_traffic.json
   python3 $root/tools/pmc_traffic.py $(find /tmp/prof_$tag/fetch -name '*counter_collection.csv' | head -1) $(find /tmp/prof_$tag/write -name '*counter_collection.csv' | head -1) $root/gpurun_out/pmc_hbm_traffic.json $mode
 } > $out/pmc_hbm_traffic.txt

@@ -23,4 +23,7 @@ echo "[sq] pass 2 done"
   python3 $root/tools/pmc_report.py $(find /tmp/sq_$tag/p1 -name '*counter_collection.csv' | head -1) k_ | grep -v "k_convert\|k_low\|k_lower\|k_active\|k_tb_win\|k_pair\|k_compact\|k_partner"
   python3 $root/tools/pmc_report.py $(find /tmp/sq_$tag/p2 -name '*counter_collection.csv' | head -1) k_ | grep -v "k_convert\|k_low\|k_lower\|k_active\|k_tb_win\|k_pair\|k_compact\|k_partner"
 } > $out/pmc_sq_counters.txt
+mode=$(echo "$extra" | sed -n 's/.*--precision \([a-z0-9]*\).*/\1/p'); mode=${mode:-fp32}   # bench.py's default mode
+# merged into one stamped file per round (all modes), which bench.py reads: $root/gpurun_out/pmc_sq_counters.json
+python3 $root/tools/pmc_sq_json.py $(find /tmp/sq_$tag/p1 -name '*counter_collection.csv' | head -1) $(find /tmp/sq_$tag/p2 -name '*counter_collection.csv' | head -1) $root/gpurun_out/pmc_sq_counters.json $mode | tee -a $out/pmc_sq_counters.txt
 echo "[sq] done"

@@ -3,7 +3,9 @@
 k_geometry<> launches, with its duration and the gap to the previous dispatch's end (us).
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/seq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
-    python tools/step_sequence.py gpurun_out/seq
+    python tools/step_sequence.py gpurun_out/seq [k]     (k: which step, counted from the end; default 1 = the last one.  bench.py
+                                                          ends with `--steps` PROFILED steps -- stage events between the kernels --,
+                                                          so k = steps + 1 is the last step of the timed region)
 """
 import csv
 import glob
@@ -20,7 +22,11 @@ def main():
     if len(geo) < 2:
         print("fewer than two steps in the trace")
         return
-    a, b = geo[-2], geo[-1]
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(geo) < k + 1:
+        print("fewer steps in the trace than asked for")
+        return
+    a, b = geo[-k - 1], geo[-k]
     prev_end = None
     total = 0.0
     for r in rows[a:b]:
