@@ -36,7 +36,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   roofline_other_kernels   every other kernel of the step with its bound, bytes and achieved rate
   step_traffic_bytes       PMC traffic of one whole step against SURVEY.md 8(d)'s ideal-fusion bytes
   beside        (n_gpus = 1, default run) step latency of the 32-atom Cu cell of BASELINE configs[0] and one MD-style iteration on
-                the headline cell: GPU neighbour list + triplets + topology + step from fresh positions
+                the headline cell with device-resident positions: skin-list test (lists reused) or full rebuild, then the step
   cpu_baseline  the CPU oracle (oracle/m3gnet_oracle.py, a plain-torch port of the reference) timed on the host cores ON THE
                 HEADLINE CONFIGURATION ITSELF (the 10,000-atom cell; 1 warm-up + 3 steps at all cores, 1 step at 1 thread,
                 ~25 s), rank 0, N = 1 only.  `vs_cpu_baseline` = value / cpu_baseline.value (`vs_baseline` stays null:
@@ -527,11 +527,16 @@ def measure_config4(job, model, steps, warmup):
 
 
 def measure_beside(model, device):
-    """Two figures beside the throughput headline (n_gpus = 1 only): the step latency of BASELINE configs[0]'s 32-atom Cu cell and
-    one MD-style iteration on the headline cell -- fresh positions -> GPU neighbour list + triplets -> topology -> energies and
-    forces (tools/time_small_systems.py, tools/profile_graph_build.py)."""
+    """Figures beside the throughput headline (n_gpus = 1 only): the step latency of BASELINE configs[0]'s 32-atom Cu cell, and one
+    MD-style iteration on the headline cell with the positions RESIDENT ON THE DEVICE (torch_m3gnet.data.md.VerletGraph over the
+    C ABI's m3g_verlet_*): fresh jittered positions every iteration -> skin-list test -> energies and forces.
+      reuse    the lists are unchanged (the jitter moves no shell across 5 A / 4 A): index tensors, CSR topology and its
+               certificate are reused, only the positions are new -- bit-identical to a fresh build (tests/test_gpu_md.py);
+      rebuild  the same iteration forced through a new candidate search (cutoff + skin), list fill, triplets, topology and
+               certificate: what a step costs when an atom has moved further than skin / 2.
+    Both in the headline's arithmetic mode and in the opt-in f16x3 mode."""
     import numpy as np
-    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.md import VerletGraph
     from torch_m3gnet.data.synthetic import fcc_cu_graph
 
     def per_call(fn, reps, warm=3):
@@ -549,43 +554,45 @@ def measure_beside(model, device):
     a = 3.61
     base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
     gi = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(25), indexing="ij"), -1)
-    pos0 = (gi.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a
+    pos0 = torch.tensor((gi.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a, device=device)   # fp64, on the device
     lat = np.diag([10 * a, 10 * a, 25 * a]).astype(float)
-    z = np.full(len(pos0), 29)
-    rng = np.random.default_rng(0)
-    t_build = [0.0]
+    z = np.full(pos0.size(0), 29)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    vg = VerletGraph([lat], [z], 5.0, 4.0, skin=0.5, device=device)
+    t_graph = [0.0]
 
-    def iteration():
-        pos = pos0 + rng.uniform(-0.025, 0.025, pos0.shape)
+    def iteration(force=None):
+        pos = pos0 + (torch.rand(pos0.shape, generator=gen, device=device, dtype=torch.float64) - 0.5) * 0.05   # +-0.025 A, on the device
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        g = batch_from_arrays([lat], [pos], [z], 5.0, 4.0, device=device)
+        g = vg.update(pos, force=force)
         torch.cuda.synchronize()
-        t_build[0] += time.perf_counter() - t0
+        t_graph[0] += time.perf_counter() - t0
         model(g, forces=True, extras=False)
 
-    def md_loop():
+    def md_loop(force, reps=10):
         for _ in range(3):
-            iteration()
+            iteration(force)
         torch.cuda.synchronize()
-        t_build[0] = 0.0
+        t_graph[0] = 0.0
         t0 = time.perf_counter()
-        for _ in range(10):
-            iteration()
+        for _ in range(reps):
+            iteration(force)
         torch.cuda.synchronize()
-        total = (time.perf_counter() - t0) / 10 * 1e3
-        return {"graph_build_from_host_positions": t_build[0] / 10 * 1e3, "topology_and_step": total - t_build[0] / 10 * 1e3,
-                "total_incl_position_jitter_on_host": total}
+        total = (time.perf_counter() - t0) / reps * 1e3
+        return {"graph_update": t_graph[0] / reps * 1e3, "topology_and_step": total - t_graph[0] / reps * 1e3, "total": total}
 
-    # every iteration has a NEW topology: the triplet-list certificate (m3g_topology_hints) costs such a loop more than the
-    # three-body moment kernels return on this cell, so it runs with the engine's switch for exactly this case off; the figure
-    # with the default (certificate before the first call with every topology) beside it
-    model.engine.topology_hints = False
-    try:
-        rec["md_iteration_ms_10k_atom_cell"] = dict(md_loop(), engine_topology_hints=False)
-    finally:
-        model.engine.topology_hints = True
-    rec["md_iteration_ms_10k_atom_cell"]["with_topology_hints_total"] = md_loop()["total_incl_position_jitter_on_host"]
+    md = {}
+    current = model.engine.precision
+    for mode in dict.fromkeys((current, "f16x3")):
+        model.engine.set_precision(mode)
+        md[mode] = {"reuse": md_loop(None), "rebuild": md_loop("search")}
+    model.engine.set_precision(current)
+    md["paths_taken"] = dict(vg.stats)
+    md["note"] = ("positions generated and kept on the device; `total` includes the jitter kernel and two waits for the device per "
+                  "iteration (one inside the skin-list test, one for the timer)")
+    rec["md_iteration_ms_10k_atom_cell"] = md
     return rec
 
 

@@ -243,7 +243,8 @@ int m3g_readout(int32_t embedding_dim, int64_t n_atoms, int64_t n_structs, const
 /* ---- graph construction on the GPU -------------------------------------
  * Periodic neighbour list: replaces get_all_neighbors_with_cell_shifts (data/material_graph.py:168-193, pymatgen
  * Structure.get_all_neighbors).  pos [N,3] and lattice [S,3,3] are DEVICE fp64 (pymatgen works in double), batch
- * [N] int64 sorted.  Output order: centre atom, image shift lexicographic, neighbour index.  Two phases because the
+ * [N] int64 sorted.  Output order: centre atom, edge cell shift (sx, sy, sz) lexicographic, neighbour index
+ * (the shift refers to the given coordinates: the order does not depend on which atoms sit outside the home cell).  Two phases because the
  * edge count is data dependent: *_count synchronises the stream and returns E, the caller allocates, *_fill writes.
  * max_images >= (2rx+1)(2ry+1)(2rz+1) of every structure, r_p = ceil((cutoff+1e-8) |a_q x a_r| / V). */
 int m3g_neighbor_scratch_bytes(int64_t n_atoms, int64_t n_structs, int64_t max_images, size_t* bytes);
@@ -272,6 +273,34 @@ int m3g_threebody_fill(int64_t n_atoms, int64_t n_edges, const int64_t* edge_ind
 int m3g_threebody_build(int64_t n_atoms, int64_t n_edges, const int64_t* edge_index, const float* distances, float threebody_cutoff,
                         void* scratch, size_t scratch_bytes, int64_t n_triplets, int64_t* triplet_edge_index /* [2,T] */,
                         int64_t* num_triplet_i /* [N] */, int32_t* num_triplet_ij /* [E] */, void* stream);
+
+/* ---- skin ("Verlet") list: repeated evaluation along an MD trajectory without a search per step --------------------
+ * The reference rebuilds everything for every structure it sees, in Python (data/material_graph.py:133-254).  For a trajectory
+ * the caller keeps CANDIDATES -- the list m3g_neighbor_count/fill return for cutoff + skin at reference positions -- on the
+ * device, with their row pointers (m3g_verlet_rows) and one membership byte per candidate.  While no atom has moved by more than
+ * skin / 2 since the reference, the candidates that pass d <= cutoff, in candidate order, are EXACTLY the list a fresh search at
+ * the current positions returns (same edges, order, shifts, hence the same triplets): the canonical order does not depend on the
+ * positions, and every distance is formed by the search's own arithmetic.
+ *   m3g_verlet_update   one pass over atoms and candidates at the current positions (DEVICE fp64, unwrapped like pos_ref): the
+ *                       largest displacement since pos_ref, whether any candidate's membership (bit 0: in the list; bit 1: fp32
+ *                       length within the three-body cutoff) differs from cand_state -- the membership the caller's current lists
+ *                       were filled with --, and the sizes E, T the lists have now.  Waits for the stream once.  changed == 0 and
+ *                       max_disp < skin / 2: the current edge_index / edge_cell_shift / triplets / topology / hints stay valid,
+ *                       only the positions of the next m3g_energy_forces call are new.
+ *   m3g_verlet_fill     (changed != 0, max_disp < skin / 2) writes the new list from the candidates and updates cand_state; follow
+ *                       with m3g_threebody_build (n_triplets from the update) and m3g_topology_build.  No wait.
+ * max_disp >= skin / 2 (or a changed lattice): search again with cutoff + skin, pos_ref = pos, cand_state = 0, then update + fill.
+ * cand_row_ptr: int32 [N + 2] (N + 1 pointers and one scratch word). */
+int m3g_verlet_scratch_bytes(int64_t n_atoms, int64_t n_candidates, size_t* bytes);
+int m3g_verlet_rows(int64_t n_atoms, int64_t n_candidates, const int64_t* cand_edge_index /* [2,Ec] */, int32_t* cand_row_ptr, void* stream);
+int m3g_verlet_update(int64_t n_atoms, int64_t n_structs, int64_t n_candidates, const double* pos, const double* pos_ref,
+                      const double* lattice, const int64_t* batch, const int64_t* cand_edge_index, const int32_t* cand_shift,
+                      const int32_t* cand_row_ptr, double cutoff, float threebody_cutoff, const uint8_t* cand_state, void* scratch,
+                      size_t scratch_bytes, double* host_max_disp, int32_t* host_changed, int64_t* host_n_edges,
+                      int64_t* host_n_triplets, void* stream);
+int m3g_verlet_fill(int64_t n_atoms, int64_t n_candidates, int64_t n_edges, void* scratch, const int64_t* cand_edge_index,
+                    const int32_t* cand_shift, const int32_t* cand_row_ptr, int64_t* edge_index /* [2,E] */,
+                    int32_t* edge_cell_shift /* [E,3] */, double* distances /* [E] */, uint8_t* cand_state /* [Ec] out */, void* stream);
 
 /* ---- measurement: per-stage device time from HIP events recorded on the call's own stream ---------
  * m3g_profile_enable(plan, 1) makes every following m3g_energy_forces record an event pair around each

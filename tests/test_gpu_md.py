@@ -1,0 +1,133 @@
+"""GPU: the device-resident trajectory graph (torch_m3gnet.data.md.VerletGraph over the C ABI's m3g_verlet_*).
+
+The contract: for ANY positions, `VerletGraph.update(pos)` is the graph a fresh build at those positions returns -- same
+edges, order, shifts and triplets -- and the engine's results on it are BIT-identical to the fresh build's, whichever of its
+three paths (reuse / refill from the skin list / new search) produced it.  Reference behaviour preserved: the edge set and
+the triplet set of data/material_graph.py:168-254 (everything within the cutoffs, rebuilt from the positions alone)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_cell_arrays
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _K():
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    return K
+
+
+def _model():
+    from torch_m3gnet.model.build import build_model
+
+    torch.manual_seed(0)
+    model = build_model(cutoff=5.0, threebody_cutoff=4.0, l_max=3, n_max=3, num_types=95, embedding_dim=64, num_blocks=3)
+    for m in model.model:
+        if type(m).__name__ == "ThreeBodyInteration":
+            m.nsb.factors = m.nsb.documented_factors()
+    return model
+
+
+def _same_graph(a, b):
+    K = _K()
+    for key in (K.EDGE_INDEX, K.EDGE_CELL_SHIFT, K.TRIPLET_EDGE_INDEX, K.NUM_TRIPLET_I, K.NUM_TRIPLET_IJ, K.BATCH, K.ATOM_TYPES):
+        assert a[key].shape == b[key].shape and torch.equal(a[key], b[key]), key
+    assert torch.equal(a[K.POS], b[K.POS]) and torch.equal(a[K.LATTICE], b[K.LATTICE])
+
+
+def test_edge_order_does_not_depend_on_which_side_of_a_cell_face_an_atom_sits():
+    """The canonical order sorts a centre's edges by the shift relative to the GIVEN coordinates: an atom that drifts across a
+    cell face (fractional coordinate -0.002 -> +0.002) changes neither the shifts nor the order of any edge -- the property the
+    skin list rests on.  Host builder (torch_m3gnet/data/neighbors.py) and GPU builder alike, element by element."""
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.material_graph import MaterialGraph
+
+    K = _K()
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    gi = np.stack(np.meshgrid(np.arange(2), np.arange(2), np.arange(2), indexing="ij"), -1)
+    pos = (gi.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a + np.random.default_rng(3).uniform(0.03, 0.06, (32, 3))
+    lat = np.eye(3) * 2 * a
+    z = np.full(32, 29)
+    graphs = []
+    for dx in (-0.002, +0.002):
+        p = pos.copy()
+        p[0] = [dx * 2 * a, 0.04, -0.001 if dx < 0 else 0.001]   # the atom at the origin, just outside / just inside two faces
+        p[5, 1] += 2 * a                                          # and one atom a whole cell away from home in both builds
+        graphs.append((batch_from_arrays([lat], [p], [z], 5.0, 4.0, device=DEV), MaterialGraph.from_arrays(lat, p, z, 5.0, 4.0)))
+    (g0, h0), (g1, h1) = graphs
+    for key in (K.EDGE_INDEX, K.EDGE_CELL_SHIFT, K.TRIPLET_EDGE_INDEX):
+        assert torch.equal(g0[key], g1[key]), key                        # GPU builder: same lists on both sides of the face
+        assert torch.equal(g0[key].cpu(), h0[key]) and torch.equal(g1[key].cpu(), h1[key]), key   # and equal to the host builder's
+
+
+def test_verlet_graph_is_the_fresh_build_along_a_trajectory():
+    """A random walk of three batched cells (random species; one of them smaller than the cutoff, i.e. with self-images): every
+    step compared with a fresh build at the same positions -- index tensors equal, energies / forces / stresses bit-identical --
+    and all three paths taken."""
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.md import VerletGraph
+
+    K = _K()
+    model = _model()
+    cells = [random_cell_arrays(40, 8.0, 11), random_cell_arrays(25, 7.0, 12), random_cell_arrays(6, 4.2, 13, dmin=1.8)]
+    lats, pos0, zs = zip(*cells)
+    sizes = [len(p) for p in pos0]
+    vg = VerletGraph(lats, zs, 5.0, 4.0, skin=0.4, device=DEV)
+    rng = np.random.default_rng(5)
+    pos = np.concatenate(pos0)
+    for step in range(24):
+        # small thermal-like moves; every 8th step one atom jumps by a lattice vector (a wrapped coordinate) -> search path
+        # (every 4th step moves nothing to speak of: in a disordered cell some pair crosses a cutoff on any real move, so this
+        # is where the reuse path runs)
+        pos = pos + rng.normal(0.0, 1e-9 if step % 4 == 2 else 0.02, pos.shape)
+        if step % 8 == 7:
+            pos[3] += lats[0][1]
+        g = vg.update(torch.tensor(pos, device=DEV))
+        split = np.split(pos, np.cumsum(sizes)[:-1])
+        fresh = batch_from_arrays(lats, split, zs, 5.0, 4.0, device=DEV)
+        _same_graph(g, fresh)
+        out = model(g, extras=False)
+        e, f, s = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone(), out[K.STRESSES].clone()
+        ref = model(fresh, extras=False)
+        assert torch.equal(e, ref[K.TOTAL_ENERGY]) and torch.equal(f, ref[K.FORCES]) and torch.equal(s, ref[K.STRESSES]), step
+    assert vg.stats["reuse"] > 0 and vg.stats["refill"] > 1 and vg.stats["search"] >= 3, vg.stats
+
+
+def test_verlet_graph_reuses_everything_on_the_headline_cell():
+    """BASELINE config 3's cell under the bench's MD-style jitter (+-0.025 A around the lattice sites: no shell crosses 5 A or
+    4 A): after the first step every update takes the reuse path -- same graph object, same tensors, the engine's cached topology
+    and certificate -- and the results are bit-identical to a fresh build's."""
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.md import VerletGraph
+    from torch_m3gnet.nn.modules import _Topology
+
+    K = _K()
+    model = _model()
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    gi = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(25), indexing="ij"), -1)
+    pos0 = (gi.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a
+    lat = np.diag([10 * a, 10 * a, 25 * a]).astype(float)
+    z = np.full(len(pos0), 29)
+    vg = VerletGraph([lat], [z], 5.0, 4.0, skin=0.5, device=DEV)
+    rng = np.random.default_rng(0)
+    first, topo = None, None
+    for step in range(4):
+        pos = pos0 + rng.uniform(-0.025, 0.025, pos0.shape)
+        g = vg.update(torch.tensor(pos, device=DEV))
+        out = model(g, extras=False)
+        e, f = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone()
+        if step == 0:
+            first, topo = g, _Topology.of(g)
+            assert g[K.NUM_EDGES] == 420_000 and g[K.NUM_TRIPLETS] == 3_060_000
+        else:
+            assert g is first and _Topology.of(g) is topo      # nothing was rebuilt
+        fresh = batch_from_arrays([lat], [pos], [z], 5.0, 4.0, device=DEV)
+        _same_graph(g, fresh)
+        ref = model(fresh, extras=False)
+        assert torch.equal(e, ref[K.TOTAL_ENERGY]) and torch.equal(f, ref[K.FORCES]), step
+    assert vg.stats == {"reuse": 3, "refill": 1, "search": 1}, vg.stats

@@ -5,9 +5,11 @@
 //   * m3g_threebody_*  replaces compute_threebody (data/material_graph.py:196-254, an O(T) Python loop):
 //                      every ordered pair (e1, e2), e1 != e2, of edges with d <= threebody_cutoff sharing a centre,
 //                      in exactly the reference's order.
-// Canonical edge order (the reference leaves the order inside a centre unspecified): centre atom, then image shift
-// (sx, sy, sz) lexicographic, then neighbour index -- the same order torch_m3gnet/data/neighbors.py produces, so
-// both builders can be compared element by element.
+// Canonical edge order (the reference leaves the order inside a centre unspecified): centre atom, then the edge's cell shift
+// (sx, sy, sz) lexicographic -- the shift that refers to the GIVEN coordinates, so the order does not depend on which atoms sit
+// outside the home cell: an unwrapped MD trajectory keeps its edge order while atoms cross cell faces, which is what lets a
+// skin list (m3g_verlet_*) reproduce a fresh build bit for bit --, then neighbour index: the same order
+// torch_m3gnet/data/neighbors.py produces, so both builders can be compared element by element.
 // Geometry in fp64 like pymatgen (inclusion d <= cutoff is decided in double; the stored tensors are narrowed by
 // the caller).  Linked cells: atoms are radix-sorted (hipCUB) into bins at least one cutoff wide, and one wave per atom
 // walks its periodic images, testing only the bins of an image within reach -- O(N) pair tests for large cells, and
@@ -20,6 +22,52 @@
 namespace m3g {
 
 static inline size_t align_up_g(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Geometry shared by the search and by the skin-list update (m3g_verlet_*): the update must classify a pair exactly as a fresh
+// search would, so both go through these functions, compiled WITHOUT floating-point contraction (an fma formed in one caller and
+// not in the other would let the two disagree on a pair that sits on the cutoff sphere to within rounding).
+struct LatticeFrame { double lat[9], inv[9], cross[9], det; };
+__device__ __forceinline__ LatticeFrame lattice_frame(const double* L) {
+#pragma clang fp contract(off)
+  LatticeFrame f;
+  for (int k = 0; k < 9; ++k) f.lat[k] = L[k];
+  f.cross[0] = L[4] * L[8] - L[5] * L[7]; f.cross[1] = L[5] * L[6] - L[3] * L[8]; f.cross[2] = L[3] * L[7] - L[4] * L[6];  // a1 x a2
+  f.cross[3] = L[7] * L[2] - L[8] * L[1]; f.cross[4] = L[8] * L[0] - L[6] * L[2]; f.cross[5] = L[6] * L[1] - L[7] * L[0];  // a2 x a0
+  f.cross[6] = L[1] * L[5] - L[2] * L[4]; f.cross[7] = L[2] * L[3] - L[0] * L[5]; f.cross[8] = L[0] * L[4] - L[1] * L[3];  // a0 x a1
+  f.det = L[0] * f.cross[0] + L[1] * f.cross[1] + L[2] * f.cross[2];
+  // inverse: columns are the cross products / det  (frac_p = cart . inv[:, p])
+  f.inv[0] = f.cross[0] / f.det; f.inv[3] = f.cross[1] / f.det; f.inv[6] = f.cross[2] / f.det;
+  f.inv[1] = f.cross[3] / f.det; f.inv[4] = f.cross[4] / f.det; f.inv[7] = f.cross[5] / f.det;
+  f.inv[2] = f.cross[6] / f.det; f.inv[5] = f.cross[7] / f.det; f.inv[8] = f.cross[8] / f.det;
+  return f;
+}
+// fractional coordinates of (x, y, z): integer part `w` (the wrap), remainder `f`, and the wrapped cartesian position `pw`
+__device__ __forceinline__ void wrap_point(const double* lat, const double* inv, double x, double y, double z, double (&f)[3], double (&w)[3], double (&pw)[3]) {
+#pragma clang fp contract(off)
+  for (int p = 0; p < 3; ++p) {
+    f[p] = x * inv[0 + p] + y * inv[3 + p] + z * inv[6 + p];
+    w[p] = floor(f[p]);
+    f[p] -= w[p];
+  }
+  for (int c = 0; c < 3; ++c) pw[c] = f[0] * lat[0 + c] + f[1] * lat[3 + c] + f[2] * lat[6 + c];
+}
+// displacement of image `sh` of the cell minus the wrapped position of the centre: |pos_w[j] + o| is the pair distance
+__device__ __forceinline__ void image_offset(const double* lat, const int (&sh)[3], const double* pos_w_i, double& ox, double& oy, double& oz) {
+#pragma clang fp contract(off)
+  ox = sh[0] * lat[0] + sh[1] * lat[3] + sh[2] * lat[6] - pos_w_i[0];
+  oy = sh[0] * lat[1] + sh[1] * lat[4] + sh[2] * lat[7] - pos_w_i[1];
+  oz = sh[0] * lat[2] + sh[1] * lat[5] + sh[2] * lat[8] - pos_w_i[2];
+}
+__device__ __forceinline__ double pair_d2(const double* pos_w_j, double ox, double oy, double oz) {
+#pragma clang fp contract(off)
+  const double dx = pos_w_j[0] + ox, dy = pos_w_j[1] + oy, dz = pos_w_j[2] + oz;
+  return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ bool pair_hit(double d2, double c2) { return d2 <= c2 && d2 > 1e-16; }
+__device__ __forceinline__ double cutoff_sq(double cutoff) {
+#pragma clang fp contract(off)
+  return (cutoff + 1e-8) * (cutoff + 1e-8);
+}
 
 struct StructInfo {   // per structure, device
   double lat[9];      // rows
@@ -88,16 +136,12 @@ __global__ void k_struct_info(int64_t N, int64_t S, const double* __restrict__ l
   if (s >= S) return;
   StructInfo si;
   const double* L = lattice + s * 9;
-  for (int k = 0; k < 9; ++k) si.lat[k] = L[k];
-  const double c0x = L[4] * L[8] - L[5] * L[7], c0y = L[5] * L[6] - L[3] * L[8], c0z = L[3] * L[7] - L[4] * L[6];  // a1 x a2
-  const double c1x = L[7] * L[2] - L[8] * L[1], c1y = L[8] * L[0] - L[6] * L[2], c1z = L[6] * L[1] - L[7] * L[0];  // a2 x a0
-  const double c2x = L[1] * L[5] - L[2] * L[4], c2y = L[2] * L[3] - L[0] * L[5], c2z = L[0] * L[4] - L[1] * L[3];  // a0 x a1
-  const double det = L[0] * c0x + L[1] * c0y + L[2] * c0z;
+  const LatticeFrame fr = lattice_frame(L);
+  for (int k = 0; k < 9; ++k) { si.lat[k] = fr.lat[k]; si.inv[k] = fr.inv[k]; }
+  const double c0x = fr.cross[0], c0y = fr.cross[1], c0z = fr.cross[2], c1x = fr.cross[3], c1y = fr.cross[4], c1z = fr.cross[5],
+               c2x = fr.cross[6], c2y = fr.cross[7], c2z = fr.cross[8];
+  const double det = fr.det;
   const double vol = fabs(det);
-  // inverse: columns are the cross products / det  (frac_p = cart . inv[:, p])
-  si.inv[0] = c0x / det; si.inv[3] = c0y / det; si.inv[6] = c0z / det;
-  si.inv[1] = c1x / det; si.inv[4] = c1y / det; si.inv[7] = c1z / det;
-  si.inv[2] = c2x / det; si.inv[5] = c2y / det; si.inv[8] = c2z / det;
   // atom range by binary search on the sorted batch vector
   int64_t lo = 0, hi = N;
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (batch[mid] < s) lo = mid + 1; else hi = mid; }
@@ -136,17 +180,15 @@ __global__ void k_wrap_positions(int64_t N, int64_t S, const double* __restrict_
   if (s < 0 || s >= S || (a > 0 && batch[a - 1] > s)) { atomicOr(flags, 2); s = 0; }
   const StructInfo& si = info[s];
   const double x = pos[a * 3], y = pos[a * 3 + 1], z = pos[a * 3 + 2];
-  double f[3], w[3];
+  double f[3], w[3], pw[3];
   int b[3];
+  wrap_point(si.lat, si.inv, x, y, z, f, w, pw);
   for (int p = 0; p < 3; ++p) {
-    f[p] = x * si.inv[0 + p] + y * si.inv[3 + p] + z * si.inv[6 + p];
-    w[p] = floor(f[p]);
     wrap[a * 3 + p] = (int32_t)w[p];
-    f[p] -= w[p];
     b[p] = min(si.nb[p] - 1, max(0, (int)(f[p] * si.nb[p])));
     binc[a * 3 + p] = b[p];
   }
-  for (int c = 0; c < 3; ++c) pos_w[a * 3 + c] = f[0] * si.lat[0 + c] + f[1] * si.lat[3 + c] + f[2] * si.lat[6 + c];
+  for (int c = 0; c < 3; ++c) pos_w[a * 3 + c] = pw[c];
   bin_key[a] = (int32_t)(bin_off[s] + ((int64_t)b[0] * si.nb[1] + b[1]) * si.nb[2] + b[2]);
   iota[a] = (int32_t)a;
 }
@@ -193,10 +235,7 @@ __device__ __forceinline__ NbImage nb_image(const StructInfo& si, int img, const
     im.hi[p] = min(si.nb[p] - 1, b + si.reach[p] - im.sh[p] * si.nb[p]);
     im.any = im.any && im.lo[p] <= im.hi[p];
   }
-  // image displacement minus this atom's wrapped position: |pos_w[j] + o| is the pair distance
-  im.ox = im.sh[0] * si.lat[0] + im.sh[1] * si.lat[3] + im.sh[2] * si.lat[6] - pos_w_i[0];
-  im.oy = im.sh[0] * si.lat[1] + im.sh[1] * si.lat[4] + im.sh[2] * si.lat[7] - pos_w_i[1];
-  im.oz = im.sh[0] * si.lat[2] + im.sh[1] * si.lat[5] + im.sh[2] * si.lat[8] - pos_w_i[2];
+  image_offset(si.lat, im.sh, pos_w_i, im.ox, im.oy, im.oz);
   return im;
 }
 
@@ -216,7 +255,7 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
   if (i >= N) return;
   const int s = (int)batch[i];
   const StructInfo& si = info[s];
-  const double c2 = (cutoff + 1e-8) * (cutoff + 1e-8);
+  const double c2 = cutoff_sq(cutoff);
   const int64_t b0 = bin_off[s];
   // A cell smaller than the cutoff is one bin and has many images with at most `count` candidates each: the wave then works
   // on G = 64 / W images at a time, W lanes per image.
@@ -246,9 +285,8 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
             bool hit = false;
             double d2 = 0.0;
             if (k < k1) {
-              const double dx = pos_s[(int64_t)k * 3] + im.ox, dy = pos_s[(int64_t)k * 3 + 1] + im.oy, dz = pos_s[(int64_t)k * 3 + 2] + im.oz;
-              d2 = dx * dx + dy * dy + dz * dz;
-              hit = d2 <= c2 && d2 > 1e-16;
+              d2 = pair_d2(pos_s + (int64_t)k * 3, im.ox, im.oy, im.oz);
+              hit = pair_hit(d2, c2);
               if (!FILL && tri && hit && (float)sqrt(d2) <= tb_cutoff) ++my3;   // as the reference thresholds the narrowed lengths
             }
             const unsigned long long m = (__ballot(hit) >> (g * W)) & group_bits;   // this group's lanes (all in this iteration together)
@@ -282,9 +320,8 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
           const int64_t g0 = b0 + ((int64_t)bx * si.nb[1] + by) * si.nb[2];
           const int k0 = bin_start[g0 + im.lo[2]], k1 = bin_start[g0 + im.hi[2] + 1];
           for (int k = k0; k < k1; ++k) {
-            const double dx = pos_s[(int64_t)k * 3] + im.ox, dy = pos_s[(int64_t)k * 3 + 1] + im.oy, dz = pos_s[(int64_t)k * 3 + 2] + im.oz;
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 <= c2 && d2 > 1e-16) {
+            const double d2 = pair_d2(pos_s + (int64_t)k * 3, im.ox, im.oy, im.oz);
+            if (pair_hit(d2, c2)) {
               if (out < E) { edge_index[E + out] = perm[k]; dist[out] = sqrt(d2); }
               ++out;
             }
@@ -309,6 +346,208 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
   if (!FILL && tri) {
     const int64_t d = __reduce_add_sync(~0ull, my3);
     if (lane == 0) tri[i] = d * (d - 1);
+  }
+}
+
+// The search above emits a centre's edges by image of the WRAPPED cell; the canonical order is by the shift relative to the given
+// coordinates, shift = image - wrap[j] + wrap[i].  The two differ only in rows that hold a neighbour outside the home cell (wrap[j]
+// != 0; wrap[i] moves all shifts of a row alike).  One wave per centre: rows without such a neighbour return at once, the others
+// are re-ranked by (shift, j) -- unique per row -- from an LDS copy (rows longer than the stage: insertion sort by one lane).
+constexpr int kCanonStage = 512;   // edges per wave (4 waves x 24 B: 48 KB of LDS)
+__device__ __forceinline__ bool canon_less(int ax, int ay, int az, int aj, int bx, int by, int bz, int bj) {
+  if (ax != bx) return ax < bx;
+  if (ay != by) return ay < by;
+  if (az != bz) return az < bz;
+  return aj < bj;
+}
+__global__ void __launch_bounds__(256) k_rows_canonical(int64_t N, int64_t M, const int64_t* __restrict__ offsets, const int32_t* __restrict__ wrap,
+                                                        int64_t E, int64_t* __restrict__ edge_index, int32_t* __restrict__ shift,
+                                                        double* __restrict__ dist) {
+  __shared__ int32_t s_j[4 * kCanonStage], s_x[4 * kCanonStage], s_y[4 * kCanonStage], s_z[4 * kCanonStage];
+  __shared__ double s_d[4 * kCanonStage];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + wave;   // wave-uniform
+  if (i >= N) return;
+  const int64_t b = offsets[i * M], e = offsets[(i + 1) * M];
+  const int n = (int)(e - b);
+  if (n < 2 || e > E) return;
+  bool moved = false;
+  for (int k = lane; k < n; k += 64) {
+    const int64_t j = edge_index[E + b + k];
+    moved = moved || wrap[j * 3] != 0 || wrap[j * 3 + 1] != 0 || wrap[j * 3 + 2] != 0;
+  }
+  if (!__any(moved)) return;
+  if (n <= kCanonStage) {
+    int32_t *sj = s_j + wave * kCanonStage, *sx = s_x + wave * kCanonStage, *sy = s_y + wave * kCanonStage, *sz = s_z + wave * kCanonStage;
+    double* sd = s_d + wave * kCanonStage;
+    for (int k = lane; k < n; k += 64) {
+      sj[k] = (int32_t)edge_index[E + b + k];
+      sx[k] = shift[(b + k) * 3]; sy[k] = shift[(b + k) * 3 + 1]; sz[k] = shift[(b + k) * 3 + 2];
+      sd[k] = dist[b + k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int k = lane; k < n; k += 64) {
+      const int x = sx[k], y = sy[k], z = sz[k], j = sj[k];
+      int rank = 0;
+      for (int f = 0; f < n; ++f) rank += canon_less(sx[f], sy[f], sz[f], sj[f], x, y, z, j) ? 1 : 0;
+      const int64_t a = b + rank;
+      edge_index[E + a] = j;
+      shift[a * 3] = x; shift[a * 3 + 1] = y; shift[a * 3 + 2] = z;
+      dist[a] = sd[k];
+    }
+  } else if (lane == 0) {   // very long rows (a tiny cell under a large cutoff): in place
+    for (int64_t a = b + 1; a < e; ++a) {
+      const int64_t j = edge_index[E + a];
+      const int x = shift[a * 3], y = shift[a * 3 + 1], z = shift[a * 3 + 2];
+      const double d = dist[a];
+      int64_t c = a;
+      while (c > b && canon_less(x, y, z, (int)j, shift[(c - 1) * 3], shift[(c - 1) * 3 + 1], shift[(c - 1) * 3 + 2], (int)edge_index[E + c - 1])) {
+        edge_index[E + c] = edge_index[E + c - 1];
+        shift[c * 3] = shift[(c - 1) * 3]; shift[c * 3 + 1] = shift[(c - 1) * 3 + 1]; shift[c * 3 + 2] = shift[(c - 1) * 3 + 2];
+        dist[c] = dist[c - 1];
+        --c;
+      }
+      edge_index[E + c] = j;
+      shift[c * 3] = x; shift[c * 3 + 1] = y; shift[c * 3 + 2] = z;
+      dist[c] = d;
+    }
+  }
+}
+
+// ---- skin ("Verlet") list: the lists of an MD trajectory without a search per step ------------------------------------
+// CANDIDATES are the neighbour list built with cutoff + skin at reference positions.  While no atom has moved by more than skin / 2
+// since, every pair within `cutoff` is among them; the candidates are in canonical order and that order does not depend on the
+// positions (centre, shift relative to the given coordinates, neighbour), so the candidates that pass d <= cutoff, in candidate
+// order, ARE the list a fresh search would return -- same edges, same order, same shifts, and with them the same triplets.  Every
+// distance goes through the search's own functions (wrap_point / image_offset / pair_d2, no contraction): the update classifies a
+// pair exactly as the search does.
+struct VerletScratch {
+  double* pos_w;       // [N,3] wrapped positions (as the search forms them)
+  int32_t* wrap;       // [N,3]
+  uint8_t* state;      // [Ec] membership at the current positions: bit 0 in the list, bit 1 within the three-body cutoff
+  double* dist;        // [Ec] pair distance at the current positions
+  int32_t* row_keep;   // [N+1] kept candidates per centre, then exclusive offsets
+  void* scan_tmp;
+  size_t scan_tmp_bytes;
+  unsigned long long* acc;   // [4] max displacement^2 (bits of a non-negative double), changed flag, E, T
+  size_t total;
+};
+static VerletScratch verlet_carve(int64_t N, int64_t Ec, void* base) {
+  VerletScratch w{};
+  char* p = (char*)base;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { void* r = p ? (void*)(p + off) : nullptr; off += align_up_g(bytes); return r; };
+  w.pos_w = (double*)take(sizeof(double) * 3 * (size_t)(N + 1));
+  w.wrap = (int32_t*)take(sizeof(int32_t) * 3 * (size_t)(N + 1));
+  w.state = (uint8_t*)take((size_t)Ec + 16);
+  w.dist = (double*)take(sizeof(double) * (size_t)(Ec + 1));
+  w.row_keep = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 2));
+  size_t tmp = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(N + 1));
+  w.scan_tmp_bytes = tmp;
+  w.scan_tmp = take(tmp);
+  w.acc = (unsigned long long*)take(sizeof(unsigned long long) * 4);
+  w.total = off;
+  return w;
+}
+
+// one thread per atom: wrapped position and wrap exactly as the search forms them; largest displacement since the reference
+__global__ void k_verlet_prep(int64_t N, int64_t S, const double* __restrict__ pos, const double* __restrict__ pos_ref,
+                              const double* __restrict__ lattice, const int64_t* __restrict__ batch, double* pos_w, int32_t* wrap,
+                              unsigned long long* acc) {
+  const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  int64_t s = batch[a];
+  if (s < 0 || s >= S) s = 0;
+  const LatticeFrame fr = lattice_frame(lattice + s * 9);
+  const double x = pos[a * 3], y = pos[a * 3 + 1], z = pos[a * 3 + 2];
+  double f[3], w[3], pw[3];
+  wrap_point(fr.lat, fr.inv, x, y, z, f, w, pw);
+  for (int c = 0; c < 3; ++c) { pos_w[a * 3 + c] = pw[c]; wrap[a * 3 + c] = (int32_t)w[c]; }
+  const double dx = x - pos_ref[a * 3], dy = y - pos_ref[a * 3 + 1], dz = z - pos_ref[a * 3 + 2];
+  double m = dx * dx + dy * dy + dz * dz;
+  if (!(m >= 0.0)) m = 1e300;   // NaN positions: force the rebuild path (which reports them)
+  // wave maximum first: one atomic per wave (non-negative doubles order like their bit patterns)
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(acc, (unsigned long long)__double_as_longlong(m));
+}
+
+// one wave per centre over its candidate row: membership and distance of every candidate at the current positions, compared with
+// the membership the caller's lists were built with; kept edges and triplets of the row
+__global__ void __launch_bounds__(256) k_verlet_rows(int64_t N, int64_t S, int64_t Ec, const int64_t* __restrict__ batch,
+                                                     const double* __restrict__ lattice, const int64_t* __restrict__ cand_ei,
+                                                     const int32_t* __restrict__ cand_shift, const int32_t* __restrict__ row_ptr,
+                                                     const double* __restrict__ pos_w, const int32_t* __restrict__ wrap, double cutoff,
+                                                     float tb_cutoff, const uint8_t* __restrict__ old_state, uint8_t* state,
+                                                     double* dist, int32_t* row_keep, unsigned long long* acc) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);   // wave-uniform
+  if (i >= N) return;
+  int64_t s = batch[i];
+  if (s < 0 || s >= S) s = 0;
+  const double* lat = lattice + s * 9;
+  const double c2 = cutoff_sq(cutoff);
+  const int r0 = row_ptr[i], r1 = row_ptr[i + 1];
+  int n2 = 0, n3 = 0;
+  bool changed = false;
+  for (int base = r0; base < r1; base += 64) {
+    const int c = base + lane;
+    bool in2 = false, in3 = false;
+    if (c < r1) {
+      const int64_t j = cand_ei[Ec + c];
+      // the image of the wrapped cell this edge belongs to: shift = image - wrap[j] + wrap[i]
+      int sh[3];
+      for (int p = 0; p < 3; ++p) sh[p] = cand_shift[(int64_t)c * 3 + p] + wrap[j * 3 + p] - wrap[i * 3 + p];
+      double ox, oy, oz;
+      image_offset(lat, sh, pos_w + i * 3, ox, oy, oz);
+      const double d2 = pair_d2(pos_w + j * 3, ox, oy, oz);
+      const double d = sqrt(d2);
+      in2 = pair_hit(d2, c2);
+      in3 = in2 && (float)d <= tb_cutoff;   // as the reference thresholds the narrowed lengths
+      const uint8_t st = (uint8_t)((in2 ? 1 : 0) | (in3 ? 2 : 0));
+      state[c] = st;
+      dist[c] = d;
+      changed = changed || st != old_state[c];
+    }
+    n2 += __popcll(__ballot(in2));
+    n3 += __popcll(__ballot(in3));
+  }
+  const bool any_changed = __any(changed);
+  if (lane == 0) {
+    row_keep[i] = n2;
+    if (any_changed) atomicOr(acc + 1, 1ull);
+    atomicAdd(acc + 2, (unsigned long long)n2);
+    atomicAdd(acc + 3, (unsigned long long)n3 * (unsigned long long)(n3 > 0 ? n3 - 1 : 0));
+  }
+}
+
+// one wave per centre: its kept candidates, in candidate order, to the slots the scan assigned to the row
+__global__ void __launch_bounds__(256) k_verlet_fill(int64_t N, int64_t Ec, int64_t E, const int64_t* __restrict__ cand_ei,
+                                                     const int32_t* __restrict__ cand_shift, const int32_t* __restrict__ row_ptr,
+                                                     const int32_t* __restrict__ row_off, const uint8_t* __restrict__ state,
+                                                     const double* __restrict__ dist_c, int64_t* __restrict__ edge_index,
+                                                     int32_t* __restrict__ shift, double* __restrict__ dist, uint8_t* cand_state) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int r0 = row_ptr[i], r1 = row_ptr[i + 1];
+  int64_t out = row_off[i];
+  for (int base = r0; base < r1; base += 64) {
+    const int c = base + lane;
+    const uint8_t st = c < r1 ? state[c] : (uint8_t)0;
+    const bool keep = (st & 1) != 0;
+    const unsigned long long m = __ballot(keep);
+    if (c < r1) cand_state[c] = st;
+    if (keep) {
+      const int64_t a = out + __popcll(m & ((1ull << lane) - 1ull));
+      if (a < E) {
+        edge_index[a] = i;
+        edge_index[E + a] = cand_ei[Ec + c];
+        for (int p = 0; p < 3; ++p) shift[a * 3 + p] = cand_shift[(int64_t)c * 3 + p];
+        dist[a] = dist_c[c];
+      }
+    }
+    out += __popcll(m);
   }
 }
 
@@ -493,6 +732,79 @@ extern "C" int m3g_neighbor_fill(int64_t N, int64_t S, int64_t max_images, const
   NbScratch w = nb_carve(N, S, max_images, scratch);
   hipLaunchKernelGGL((k_neighbors<true>), g_for(N * 64), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm,
                      w.pos_s, w.pos_w, w.binc, w.wrap, cutoff, w.counts, n_edges, edge_index, edge_cell_shift, distances, 0.f, nullptr);
+  // canonical order inside a centre: by the shift relative to the given coordinates (rows with a neighbour outside the home cell)
+  hipLaunchKernelGGL(k_rows_canonical, g_for(N * 64), dim3(256), 0, s, N, max_images, w.counts, w.wrap, n_edges, edge_index, edge_cell_shift, distances);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+
+// ---- skin list, host entries (include/m3gnet_hip.h) -----------------------------------------------------------------
+extern "C" int m3g_verlet_scratch_bytes(int64_t N, int64_t n_candidates, size_t* bytes) {
+  if (!bytes || N < 0 || n_candidates < 0) { set_error("m3g_verlet_scratch_bytes: bad argument"); return M3G_ERR_VALUE; }
+  if (n_candidates >= (int64_t(1) << 31) - 2) { set_error("too many candidate pairs for int32 row pointers"); return M3G_ERR_UNSUPPORTED; }
+  *bytes = verlet_carve(N, n_candidates, nullptr).total + 256;
+  return M3G_OK;
+}
+
+extern "C" int m3g_verlet_rows(int64_t N, int64_t n_candidates, const int64_t* cand_edge_index, int32_t* cand_row_ptr, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!cand_row_ptr || (n_candidates > 0 && !cand_edge_index)) { set_error("m3g_verlet_rows: null argument"); return M3G_ERR_VALUE; }
+  int* flags = (int*)(cand_row_ptr + N + 1);   // one spare word behind the row pointers (the caller allocates N + 2)
+  M3G_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_rows_from_sorted, g_for(N + 1), dim3(256), 0, s, N, n_candidates, cand_edge_index, cand_row_ptr, flags);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+
+extern "C" int m3g_verlet_update(int64_t N, int64_t S, int64_t Ec, const double* pos, const double* pos_ref, const double* lattice,
+                                 const int64_t* batch, const int64_t* cand_edge_index, const int32_t* cand_shift, const int32_t* cand_row_ptr,
+                                 double cutoff, float threebody_cutoff, const uint8_t* cand_state, void* scratch, size_t scratch_bytes,
+                                 double* host_max_disp, int32_t* host_changed, int64_t* host_n_edges, int64_t* host_n_triplets, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  size_t need = 0;
+  int rc = m3g_verlet_scratch_bytes(N, Ec, &need);
+  if (rc) return rc;
+  if (!scratch || scratch_bytes < need || !host_max_disp || !host_changed || !host_n_edges || !host_n_triplets) {
+    set_error("m3g_verlet_update: scratch too small or null argument");
+    return M3G_ERR_SIZE;
+  }
+  *host_max_disp = 0.0; *host_changed = 0; *host_n_edges = 0; *host_n_triplets = 0;
+  if (N == 0) return M3G_OK;
+  if (!pos || !pos_ref || !lattice || !batch || !cand_row_ptr || (Ec > 0 && (!cand_edge_index || !cand_shift || !cand_state))) {
+    set_error("m3g_verlet_update: null argument");
+    return M3G_ERR_VALUE;
+  }
+  VerletScratch w = verlet_carve(N, Ec, scratch);
+  M3G_HIP_CHECK(hipMemsetAsync(w.acc, 0, sizeof(unsigned long long) * 4, s));
+  hipLaunchKernelGGL(k_verlet_prep, g_for(N), dim3(256), 0, s, N, S, pos, pos_ref, lattice, batch, w.pos_w, w.wrap, w.acc);
+  hipLaunchKernelGGL(k_verlet_rows, g_for(N * 64), dim3(256), 0, s, N, S, Ec, batch, lattice, cand_edge_index, cand_shift, cand_row_ptr, w.pos_w,
+                     w.wrap, cutoff, threebody_cutoff, cand_state, w.state, w.dist, w.row_keep, w.acc);
+  unsigned long long h[4] = {0, 0, 0, 0};
+  M3G_HIP_CHECK(hipMemcpyAsync(h, w.acc, sizeof(h), hipMemcpyDeviceToHost, s));
+  M3G_HIP_CHECK(hipStreamSynchronize(s));
+  double m2;
+  memcpy(&m2, &h[0], sizeof(double));
+  *host_max_disp = sqrt(m2);
+  *host_changed = h[1] ? 1 : 0;
+  *host_n_edges = (int64_t)h[2];
+  *host_n_triplets = (int64_t)h[3];
+  return M3G_OK;
+}
+
+extern "C" int m3g_verlet_fill(int64_t N, int64_t Ec, int64_t n_edges, void* scratch, const int64_t* cand_edge_index, const int32_t* cand_shift,
+                               const int32_t* cand_row_ptr, int64_t* edge_index, int32_t* edge_cell_shift, double* distances,
+                               uint8_t* cand_state, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (N == 0) return M3G_OK;
+  if (!scratch || !cand_row_ptr || !cand_state || (n_edges > 0 && (!edge_index || !edge_cell_shift || !distances))) {
+    set_error("m3g_verlet_fill: null argument");
+    return M3G_ERR_VALUE;
+  }
+  VerletScratch w = verlet_carve(N, Ec, scratch);
+  M3G_HIP_CHECK(hipMemsetAsync(w.row_keep + N, 0, sizeof(int32_t), s));
+  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, w.scan_tmp_bytes, w.row_keep, w.row_keep, (int)(N + 1), s));
+  hipLaunchKernelGGL(k_verlet_fill, g_for(N * 64), dim3(256), 0, s, N, Ec, n_edges, cand_edge_index, cand_shift, cand_row_ptr, w.row_keep, w.state,
+                     w.dist, edge_index, edge_cell_shift, distances, cand_state);
   M3G_HIP_CHECK(hipGetLastError());
   return M3G_OK;
 }

@@ -1,0 +1,137 @@
+"""Device-resident graph of a batch of periodic structures along a trajectory (MD, relaxation): positions stay on the GPU, the
+neighbour / triplet lists, the CSR topology and its certificate are REUSED while the lists are provably unchanged.
+
+The reference rebuilds the whole graph for every structure it sees, on the host (data/material_graph.py:133-254: pymatgen
+neighbour search + an O(T) Python triplet loop).  `VerletGraph.update(pos)` returns, for the positions given, exactly the
+`MaterialGraph` batch a fresh build (`graph_gpu.batch_from_arrays`, or the reference's own construction in canonical order)
+would return -- same edges, same order, same shifts, same triplets, hence bit-identical energies and forces -- at the cost of
+one small pass over a skin list (C ABI: m3g_verlet_*, csrc/m3g_graph_build.hip):
+
+  reuse    no candidate pair crossed the cutoff or the three-body cutoff and no atom moved further than skin / 2 since the
+           candidates were searched: the index tensors, the engine's topology (cached on the graph) and its hints word stay as
+           they are, only `pos` is new (written in place: the storage of every tensor of the graph is unchanged);
+  refill   some pair crossed a cutoff: the lists are re-derived from the candidates (no search), the engine rebuilds its topology;
+  search   an atom moved further than skin / 2 (or the caller asks): a new candidate search with cutoff + skin.
+
+Positions are the trajectory's own, UNWRAPPED coordinates (an atom that crosses a cell face keeps going; wrapping it back by a
+lattice vector reads as a jump and takes the search path, which is correct, just slower).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import MaterialGraphKey as K
+from .graph_gpu import _ptr, _stream, neighbor_list_gpu
+from .material_graph import Batch
+
+
+class VerletGraph:
+    def __init__(self, lattices: Sequence, atomic_numbers: Sequence, cutoff: float, threebody_cutoff: float, skin: float = 0.5,
+                 device="cuda"):
+        """lattices: list of [3,3] arrays (rows = lattice vectors), atomic_numbers: list of [n_s] arrays (one per structure);
+        cutoff / threebody_cutoff as `MaterialGraph.from_structure`; skin in the same length unit."""
+        if threebody_cutoff > cutoff:
+            raise ValueError("Three body cutoff raidus should be smaller than two body.")
+        self.cutoff, self.threebody_cutoff, self.skin = float(cutoff), float(threebody_cutoff), float(skin)
+        self.device = torch.device(device)
+        self.lib = _lib.load_library()
+        lat = np.stack([np.asarray(L, dtype=np.float64).reshape(3, 3) for L in lattices])
+        sizes = [len(np.asarray(z).reshape(-1)) for z in atomic_numbers]
+        z = np.concatenate([np.asarray(a).reshape(-1) for a in atomic_numbers])
+        self._host_lattice = lat
+        self.lattice = torch.tensor(lat, device=self.device)                                    # fp64, as the search works
+        self.batch = torch.tensor(np.repeat(np.arange(len(sizes)), sizes), dtype=torch.int64, device=self.device)
+        self.atom_types = torch.tensor(z - 1, dtype=torch.long, device=self.device)
+        self.lattice32 = self.lattice.to(torch.float)
+        self.N, self.S = int(len(z)), len(sizes)
+        self.graph = None
+        self._cand = None            # (edge_index [2,Ec], shift [Ec,3], row_ptr [N+2], state [Ec] u8, pos_ref [N,3] f64, scratch)
+        self.stats = {"reuse": 0, "refill": 0, "search": 0}
+
+    # ------------------------------------------------------------------------------------------------ candidates
+    def _search(self, pos: torch.Tensor) -> None:
+        ei, shift, _ = neighbor_list_gpu(self.lattice, pos, self.batch, self.cutoff + self.skin, host_lattice=self._host_lattice)
+        ec = int(ei.size(1))
+        rows = torch.empty(self.N + 2, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.m3g_verlet_rows(self.N, ec, _ptr(ei), _ptr(rows), _stream()))
+        nbytes = C.c_size_t()
+        _lib.check(self.lib.m3g_verlet_scratch_bytes(self.N, ec, C.byref(nbytes)))
+        scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        state = torch.zeros(ec + 16, dtype=torch.uint8, device=self.device)
+        self._cand = (ei, shift, rows, state, pos.clone(), scratch)
+        self.stats["search"] += 1
+
+    def _update(self, pos: torch.Tensor):
+        ei, shift, rows, state, pos_ref, scratch = self._cand
+        disp, changed, n_e, n_t = C.c_double(), C.c_int32(), C.c_int64(), C.c_int64()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.m3g_verlet_update(self.N, self.S, int(ei.size(1)), _ptr(pos), _ptr(pos_ref), _ptr(self.lattice), _ptr(self.batch),
+                                                  _ptr(ei), _ptr(shift), _ptr(rows), self.cutoff, self.threebody_cutoff, _ptr(state),
+                                                  _ptr(scratch), scratch.numel(), C.byref(disp), C.byref(changed), C.byref(n_e),
+                                                  C.byref(n_t), _stream()))
+        return float(disp.value), bool(changed.value), int(n_e.value), int(n_t.value)
+
+    def _fill(self, pos: torch.Tensor, n_e: int, n_t: int) -> None:
+        """New index tensors from the candidates at `pos` (m3g_verlet_update has just run on them) -> a NEW graph object (the
+        engine's topology cache lives on the graph and is keyed by the tensors' storage)."""
+        c_ei, c_shift, rows, state, _, scratch = self._cand
+        dev, N = self.device, self.N
+        ei = torch.empty(2, n_e, dtype=torch.int64, device=dev)
+        shift = torch.empty(n_e, 3, dtype=torch.int32, device=dev)
+        dist = torch.empty(n_e, dtype=torch.float64, device=dev)
+        tei = torch.empty(2, n_t, dtype=torch.int64, device=dev)
+        nti = torch.empty(N, dtype=torch.int64, device=dev)
+        ntij = torch.empty(n_e, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.m3g_verlet_fill(N, int(c_ei.size(1)), n_e, _ptr(scratch), _ptr(c_ei), _ptr(c_shift), _ptr(rows), _ptr(ei),
+                                                _ptr(shift), _ptr(dist), _ptr(state), _stream()))
+            d32 = dist.to(torch.float32)
+            tb_bytes = C.c_size_t()
+            _lib.check(self.lib.m3g_threebody_scratch_bytes(N, n_e, C.byref(tb_bytes)))
+            tb_scratch = torch.empty(tb_bytes.value, dtype=torch.uint8, device=dev)
+            _lib.check(self.lib.m3g_threebody_build(N, n_e, _ptr(ei), _ptr(d32), float(self.threebody_cutoff), _ptr(tb_scratch),
+                                                    tb_bytes.value, n_t, _ptr(tei), _ptr(nti), _ptr(ntij), _stream()))
+        g = Batch.__new__(Batch)
+        dict.__init__(g)
+        g[K.POS] = pos.to(torch.float)
+        g[K.ATOM_TYPES] = self.atom_types
+        g[K.NUM_TRIPLET_I] = nti
+        g[K.EDGE_INDEX] = ei
+        g[K.EDGE_CELL_SHIFT] = shift
+        g[K.NUM_TRIPLET_IJ] = ntij
+        g[K.TRIPLET_EDGE_INDEX] = tei
+        g[K.LATTICE] = self.lattice32
+        g[K.BATCH] = self.batch
+        g[K.NUM_NODES] = N
+        g[K.NUM_EDGES] = n_e
+        g[K.NUM_TRIPLETS] = n_t
+        g["num_graphs"] = self.S
+        self.graph = g
+
+    # ------------------------------------------------------------------------------------------------ the per-step call
+    def update(self, pos: torch.Tensor, force: str | None = None) -> Batch:
+        """The graph at positions `pos` ([N,3] device tensor, fp64 or fp32, unwrapped).  `force="search"` / `"refill"` take that
+        path whatever the skin test says (benchmarks, tests).  The returned object is `self.graph`; on the reuse path it is the
+        SAME object with the same tensors, its `pos` overwritten in place."""
+        if pos.device != self.device or tuple(pos.shape) != (self.N, 3):
+            raise ValueError(f"pos must be a [{self.N}, 3] tensor on {self.device}")
+        pos = pos.detach().to(torch.float64).contiguous()
+        if self._cand is None or force == "search" or self.skin <= 0.0:
+            self._search(pos)
+        disp, changed, n_e, n_t = self._update(pos)
+        if disp >= 0.5 * self.skin and not (disp == 0.0):
+            self._search(pos)
+            disp, changed, n_e, n_t = self._update(pos)
+        if changed or self.graph is None or force == "refill":
+            self._fill(pos, n_e, n_t)
+            self.stats["refill"] += 1
+        else:
+            self.graph[K.POS].copy_(pos)   # fp64 -> fp32 in place: every tensor of the graph keeps its storage
+            self.stats["reuse"] += 1
+        return self.graph

@@ -38,7 +38,9 @@ def neighbor_list(lattice, cart_coords, cutoff: float, tol: float = 1e-8):
     """Full periodic neighbour list.
 
     Returns (edge_index [2,E] int64 (row 0 = centre i, row 1 = neighbour j; sorted by i, then by the
-    periodic image (sx, sy, sz) of the wrapped cell lexicographically, then by j -- the canonical order
+    edge's cell shift (sx, sy, sz) lexicographically -- the shift that refers to the GIVEN coordinates, so
+    the order does not depend on which atoms happen to sit outside the home cell (an unwrapped MD
+    trajectory keeps its edge order while atoms cross cell faces) --, then by j: the canonical order
     shared with the GPU builder, csrc/m3g_graph_build.hip), edge_cell_shift [E,3] int32, distances [E] float64).
     A pair is kept when 1e-8 < d <= cutoff + tol (pymatgen semantics: self at zero distance is
     dropped, periodic self-images are kept)."""
@@ -85,7 +87,7 @@ def neighbor_list(lattice, cart_coords, cutoff: float, tol: float = 1e-8):
     img = all_img[col]
     # shift such that r = pos[dst] + shift @ lattice - pos[src] for the *given* (unwrapped) coords
     shift = img - wrap[dst] + wrap[src]
-    order = np.lexsort((dst, img[:, 2], img[:, 1], img[:, 0], src))
+    order = np.lexsort((dst, shift[:, 2], shift[:, 1], shift[:, 0], src))
     src, dst, dist, shift = src[order], dst[order], dist[order], shift[order]
     edge_index = np.stack([src, dst]).astype(np.int64)
     return edge_index, shift.astype(np.int32), dist
