@@ -39,6 +39,8 @@ class VerletGraph:
             raise ValueError("Three body cutoff raidus should be smaller than two body.")
         self.cutoff, self.threebody_cutoff, self.skin = float(cutoff), float(threebody_cutoff), float(skin)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.load_library()
         lat = np.stack([np.asarray(L, dtype=np.float64).reshape(3, 3) for L in lattices])
         sizes = [len(np.asarray(z).reshape(-1)) for z in atomic_numbers]
