@@ -532,6 +532,8 @@ def measure_beside(model, device):
     C ABI's m3g_verlet_*): fresh jittered positions every iteration -> skin-list test -> energies and forces.
       reuse    the lists are unchanged (the jitter moves no shell across 5 A / 4 A): index tensors, CSR topology and its
                certificate are reused, only the positions are new -- bit-identical to a fresh build (tests/test_gpu_md.py);
+               `reuse_verdict_read_after_the_step`: the same with the evaluation queued behind the skin test before its verdict
+               is read (VerletGraph.evaluate: no wait in front of the step; a changed list would re-run the step);
       rebuild  the same iteration forced through a new candidate search (cutoff + skin), list fill, triplets, topology and
                certificate: what a step costs when an atom has moved further than skin / 2.
     Both in the headline's arithmetic mode and in the opt-in f16x3 mode."""
@@ -564,6 +566,9 @@ def measure_beside(model, device):
 
     def iteration(force=None):
         pos = pos0 + (torch.rand(pos0.shape, generator=gen, device=device, dtype=torch.float64) - 0.5) * 0.05   # +-0.025 A, on the device
+        if force == "no_wait":   # the skin test queued in front of the evaluation, its verdict read afterwards (VerletGraph.evaluate)
+            vg.evaluate(model, pos, forces=True, extras=False)
+            return
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         g = vg.update(pos, force=force)
@@ -587,7 +592,8 @@ def measure_beside(model, device):
     current = model.engine.precision
     for mode in dict.fromkeys((current, "f16x3")):
         model.engine.set_precision(mode)
-        md[mode] = {"reuse": md_loop(None), "rebuild": md_loop("search")}
+        md[mode] = {"reuse": md_loop(None), "reuse_verdict_read_after_the_step": {"total": md_loop("no_wait", reps=20)["total"]},
+                    "rebuild": md_loop("search")}
     model.engine.set_precision(current)
     md["paths_taken"] = dict(vg.stats)
     md["note"] = ("positions generated and kept on the device; `total` includes the jitter kernel and two waits for the device per "

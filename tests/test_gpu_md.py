@@ -86,12 +86,19 @@ def test_verlet_graph_is_the_fresh_build_along_a_trajectory():
         pos = pos + rng.normal(0.0, 1e-9 if step % 4 == 2 else 0.02, pos.shape)
         if step % 8 == 7:
             pos[3] += lats[0][1]
-        g = vg.update(torch.tensor(pos, device=DEV))
+        # odd steps: the skin test's verdict is read AFTER the evaluation was queued (evaluate = begin / model / confirm, re-run
+        # when the lists had to be rebuilt); even steps wait for it first
+        if step % 2:
+            out = vg.evaluate(model, torch.tensor(pos, device=DEV), extras=False)
+            g = vg.graph
+            assert out is g
+        else:
+            g = vg.update(torch.tensor(pos, device=DEV))
+            out = model(g, extras=False)
+        e, f, s = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone(), out[K.STRESSES].clone()
         split = np.split(pos, np.cumsum(sizes)[:-1])
         fresh = batch_from_arrays(lats, split, zs, 5.0, 4.0, device=DEV)
         _same_graph(g, fresh)
-        out = model(g, extras=False)
-        e, f, s = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone(), out[K.STRESSES].clone()
         ref = model(fresh, extras=False)
         assert torch.equal(e, ref[K.TOTAL_ENERGY]) and torch.equal(f, ref[K.FORCES]) and torch.equal(s, ref[K.STRESSES]), step
     assert vg.stats["reuse"] > 0 and vg.stats["refill"] > 1 and vg.stats["search"] >= 3, vg.stats
@@ -118,8 +125,12 @@ def test_verlet_graph_reuses_everything_on_the_headline_cell():
     first, topo = None, None
     for step in range(4):
         pos = pos0 + rng.uniform(-0.025, 0.025, pos0.shape)
-        g = vg.update(torch.tensor(pos, device=DEV))
-        out = model(g, extras=False)
+        if step == 3:   # the last step without waiting for the verdict first
+            out = vg.evaluate(model, torch.tensor(pos, device=DEV), extras=False)
+            g = vg.graph
+        else:
+            g = vg.update(torch.tensor(pos, device=DEV))
+            out = model(g, extras=False)
         e, f = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone()
         if step == 0:
             first, topo = g, _Topology.of(g)

@@ -3,7 +3,8 @@
 k_geometry<> launches, with its duration and the gap to the previous dispatch's end (us).
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/seq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
-    python tools/step_sequence.py gpurun_out/seq [k]     (k: which step, counted from the end; default 1 = the last one.  bench.py
+    python tools/step_sequence.py gpurun_out/seq [k [marker]]     (marker: substring of the kernel that starts an iteration, default
+                                                          k_geometry<; k: which step, counted from the end; default 1 = the last one.  bench.py
                                                           ends with `--steps` PROFILED steps -- stage events between the kernels --,
                                                           so k = steps + 1 is the last step of the timed region)
 """
@@ -18,7 +19,8 @@ def main():
     for p in paths:
         rows += list(csv.DictReader(open(p)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    geo = [i for i, r in enumerate(rows) if "k_geometry<" in r["Kernel_Name"]]
+    marker = sys.argv[3] if len(sys.argv) > 3 else "k_geometry<"   # a kernel that runs once per iteration, first
+    geo = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
     if len(geo) < 2:
         print("fewer than two steps in the trace")
         return

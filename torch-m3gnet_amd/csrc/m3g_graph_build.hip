@@ -427,6 +427,7 @@ struct VerletScratch {
   uint8_t* state;      // [Ec] membership at the current positions: bit 0 in the list, bit 1 within the three-body cutoff
   double* dist;        // [Ec] pair distance at the current positions
   int32_t* row_keep;   // [N+1] kept candidates per centre, then exclusive offsets
+  int64_t* row_tri;    // [N] triplets per centre
   void* scan_tmp;
   size_t scan_tmp_bytes;
   unsigned long long* acc;   // [4] max displacement^2 (bits of a non-negative double), changed flag, E, T
@@ -442,6 +443,7 @@ static VerletScratch verlet_carve(int64_t N, int64_t Ec, void* base) {
   w.state = (uint8_t*)take((size_t)Ec + 16);
   w.dist = (double*)take(sizeof(double) * (size_t)(Ec + 1));
   w.row_keep = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 2));
+  w.row_tri = (int64_t*)take(sizeof(int64_t) * (size_t)(N + 1));
   size_t tmp = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(N + 1));
   w.scan_tmp_bytes = tmp;
@@ -479,7 +481,7 @@ __global__ void __launch_bounds__(256) k_verlet_rows(int64_t N, int64_t S, int64
                                                      const int32_t* __restrict__ cand_shift, const int32_t* __restrict__ row_ptr,
                                                      const double* __restrict__ pos_w, const int32_t* __restrict__ wrap, double cutoff,
                                                      float tb_cutoff, const uint8_t* __restrict__ old_state, uint8_t* state,
-                                                     double* dist, int32_t* row_keep, unsigned long long* acc) {
+                                                     double* dist, int32_t* row_keep, int64_t* row_tri, unsigned long long* acc) {
   const int lane = threadIdx.x & 63;
   const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);   // wave-uniform
   if (i >= N) return;
@@ -513,11 +515,27 @@ __global__ void __launch_bounds__(256) k_verlet_rows(int64_t N, int64_t S, int64
     n3 += __popcll(__ballot(in3));
   }
   const bool any_changed = __any(changed);
-  if (lane == 0) {
+  if (lane == 0) {   // (no per-row atomics on shared totals: 10,000 waves on one address serialise -- k_verlet_totals adds the rows up)
     row_keep[i] = n2;
-    if (any_changed) atomicOr(acc + 1, 1ull);
-    atomicAdd(acc + 2, (unsigned long long)n2);
-    atomicAdd(acc + 3, (unsigned long long)n3 * (unsigned long long)(n3 > 0 ? n3 - 1 : 0));
+    row_tri[i] = (int64_t)n3 * (n3 > 0 ? n3 - 1 : 0);
+    // rare along a trajectory; right after a search EVERY row differs from the zeroed membership bytes, and 10,000 atomics on one
+    // address serialise (measured: 118 us) -- so look first, and only the first few waves write
+    if (any_changed && __atomic_load_n(acc + 1, __ATOMIC_RELAXED) == 0ull) atomicOr(acc + 1, 1ull);
+  }
+}
+// one workgroup: E = sum of the rows' kept candidates, T = sum of their triplets (fixed order: integers anyway)
+__global__ void __launch_bounds__(1024) k_verlet_totals(int64_t N, const int32_t* __restrict__ row_keep, const int64_t* __restrict__ row_tri,
+                                                        unsigned long long* acc) {
+  __shared__ unsigned long long se[16], st[16];
+  unsigned long long e = 0, t = 0;
+  for (int64_t i = threadIdx.x; i < N; i += blockDim.x) { e += (unsigned long long)row_keep[i]; t += (unsigned long long)row_tri[i]; }
+  for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); t += __shfl_xor(t, o); }
+  if ((threadIdx.x & 63) == 0) { se[threadIdx.x >> 6] = e; st[threadIdx.x >> 6] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    e = 0; t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { e += se[k]; t += st[k]; }
+    acc[2] = e; acc[3] = t;
   }
 }
 
@@ -756,20 +774,19 @@ extern "C" int m3g_verlet_rows(int64_t N, int64_t n_candidates, const int64_t* c
   return M3G_OK;
 }
 
-extern "C" int m3g_verlet_update(int64_t N, int64_t S, int64_t Ec, const double* pos, const double* pos_ref, const double* lattice,
-                                 const int64_t* batch, const int64_t* cand_edge_index, const int32_t* cand_shift, const int32_t* cand_row_ptr,
-                                 double cutoff, float threebody_cutoff, const uint8_t* cand_state, void* scratch, size_t scratch_bytes,
-                                 double* host_max_disp, int32_t* host_changed, int64_t* host_n_edges, int64_t* host_n_triplets, void* stream_) {
+// The pass itself, queued on the stream with its 32-byte result copy: host_out[0] = bits of the largest squared displacement
+// (a non-negative double), [1] = changed flag, [2] = E, [3] = T.  No wait: a caller with PINNED host memory can queue the
+// evaluation behind it and look at the verdict afterwards (torch_m3gnet.data.md.VerletGraph.begin / confirm).
+extern "C" int m3g_verlet_update_async(int64_t N, int64_t S, int64_t Ec, const double* pos, const double* pos_ref, const double* lattice,
+                                       const int64_t* batch, const int64_t* cand_edge_index, const int32_t* cand_shift,
+                                       const int32_t* cand_row_ptr, double cutoff, float threebody_cutoff, const uint8_t* cand_state,
+                                       void* scratch, size_t scratch_bytes, uint64_t* host_out, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   size_t need = 0;
   int rc = m3g_verlet_scratch_bytes(N, Ec, &need);
   if (rc) return rc;
-  if (!scratch || scratch_bytes < need || !host_max_disp || !host_changed || !host_n_edges || !host_n_triplets) {
-    set_error("m3g_verlet_update: scratch too small or null argument");
-    return M3G_ERR_SIZE;
-  }
-  *host_max_disp = 0.0; *host_changed = 0; *host_n_edges = 0; *host_n_triplets = 0;
-  if (N == 0) return M3G_OK;
+  if (!scratch || scratch_bytes < need || !host_out) { set_error("m3g_verlet_update: scratch too small or null argument"); return M3G_ERR_SIZE; }
+  if (N == 0) { host_out[0] = host_out[1] = host_out[2] = host_out[3] = 0; return M3G_OK; }
   if (!pos || !pos_ref || !lattice || !batch || !cand_row_ptr || (Ec > 0 && (!cand_edge_index || !cand_shift || !cand_state))) {
     set_error("m3g_verlet_update: null argument");
     return M3G_ERR_VALUE;
@@ -778,10 +795,22 @@ extern "C" int m3g_verlet_update(int64_t N, int64_t S, int64_t Ec, const double*
   M3G_HIP_CHECK(hipMemsetAsync(w.acc, 0, sizeof(unsigned long long) * 4, s));
   hipLaunchKernelGGL(k_verlet_prep, g_for(N), dim3(256), 0, s, N, S, pos, pos_ref, lattice, batch, w.pos_w, w.wrap, w.acc);
   hipLaunchKernelGGL(k_verlet_rows, g_for(N * 64), dim3(256), 0, s, N, S, Ec, batch, lattice, cand_edge_index, cand_shift, cand_row_ptr, w.pos_w,
-                     w.wrap, cutoff, threebody_cutoff, cand_state, w.state, w.dist, w.row_keep, w.acc);
-  unsigned long long h[4] = {0, 0, 0, 0};
-  M3G_HIP_CHECK(hipMemcpyAsync(h, w.acc, sizeof(h), hipMemcpyDeviceToHost, s));
-  M3G_HIP_CHECK(hipStreamSynchronize(s));
+                     w.wrap, cutoff, threebody_cutoff, cand_state, w.state, w.dist, w.row_keep, w.row_tri, w.acc);
+  hipLaunchKernelGGL(k_verlet_totals, dim3(1), dim3(1024), 0, s, N, w.row_keep, w.row_tri, w.acc);
+  M3G_HIP_CHECK(hipMemcpyAsync(host_out, w.acc, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, s));
+  return M3G_OK;
+}
+
+extern "C" int m3g_verlet_update(int64_t N, int64_t S, int64_t Ec, const double* pos, const double* pos_ref, const double* lattice,
+                                 const int64_t* batch, const int64_t* cand_edge_index, const int32_t* cand_shift, const int32_t* cand_row_ptr,
+                                 double cutoff, float threebody_cutoff, const uint8_t* cand_state, void* scratch, size_t scratch_bytes,
+                                 double* host_max_disp, int32_t* host_changed, int64_t* host_n_edges, int64_t* host_n_triplets, void* stream_) {
+  if (!host_max_disp || !host_changed || !host_n_edges || !host_n_triplets) { set_error("m3g_verlet_update: null argument"); return M3G_ERR_VALUE; }
+  uint64_t h[4] = {0, 0, 0, 0};
+  int rc = m3g_verlet_update_async(N, S, Ec, pos, pos_ref, lattice, batch, cand_edge_index, cand_shift, cand_row_ptr, cutoff, threebody_cutoff,
+                                   cand_state, scratch, scratch_bytes, h, stream_);
+  if (rc) return rc;
+  M3G_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
   double m2;
   memcpy(&m2, &h[0], sizeof(double));
   *host_max_disp = sqrt(m2);

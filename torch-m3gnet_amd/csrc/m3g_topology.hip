@@ -78,6 +78,10 @@ __global__ void k_convert_edges(int64_t N, int64_t E, const int64_t* __restrict_
   if (bad) atomicOr(flags, bad);
 }
 
+__global__ void k_iota32(int64_t n, int32_t* out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)i;
+}
 __global__ void k_convert_batch(int64_t N, int64_t S, const int64_t* __restrict__ batch, int32_t* out, int32_t* flags) {
   int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (a >= N) return;
@@ -117,6 +121,45 @@ __global__ void k_check_symmetric(int64_t T, const uint64_t* __restrict__ sorted
     if (sorted_keys[mid] < want) lo = mid + 1; else hi = mid;
   }
   if (lo >= end || sorted_keys[lo] != want) atomicOr(order, 2);
+}
+
+// Incoming-edge lists without a sort, for SYMMETRIC edge lists (every i -> j has its j -> i, with multiplicity: what any full
+// neighbour list is): atom j's incoming edges are the mirrors of its outgoing ones, so in_ptr == row_ptr, and one wave per atom
+// finds, for its k-th outgoing edge j -> i, the matching entry of row i (the d-th entry with neighbour j for the d-th outgoing
+// edge to the same i), then writes the found edge ids in ascending order -- exactly what the stable sort on the neighbour index
+// produces.  A mirror that does not exist, or a row longer than the stage, raises flags[0] bit 3 and the caller sorts instead.
+constexpr int kInStage = 512;   // outgoing edges per atom handled here
+__global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
+                                                            int32_t* in_ptr, int32_t* in_edge, int32_t* flags) {
+  __shared__ int32_t s_e[4 * kInStage];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j = blockIdx.x * (int64_t)(blockDim.x >> 6) + wave;   // wave-uniform
+  if (j > N) return;
+  if (lane == 0) in_ptr[j] = row_ptr[j];
+  if (j == N) return;
+  const int r0 = row_ptr[j], r1 = row_ptr[j + 1], n = r1 - r0;
+  if (n == 0) return;
+  if (n > kInStage) { if (lane == 0) atomicOr(flags, 8); return; }
+  int32_t* se = s_e + wave * kInStage;
+  bool missing = false;
+  for (int k = lane; k < n; k += 64) {
+    const int i = dst[r0 + k];
+    int dup = 0;
+    for (int f = 0; f < k; ++f) dup += dst[r0 + f] == i ? 1 : 0;
+    int found = -1;
+    for (int q = row_ptr[i], q1 = row_ptr[i + 1]; q < q1; ++q)
+      if (dst[q] == (int)j && dup-- == 0) { found = q; break; }
+    missing = missing || found < 0;
+    se[k] = found;
+  }
+  if (__any(missing)) { if (lane == 0) atomicOr(flags, 8); return; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int k = lane; k < n; k += 64) {
+    const int e = se[k];
+    int rank = 0;
+    for (int f = 0; f < n; ++f) rank += se[f] < e ? 1 : 0;
+    in_edge[r0 + rank] = e;
+  }
 }
 
 // ptr[r] = first position whose key (high word of keys64, or keys32[pos]) >= r, for r = 0..rows
@@ -316,17 +359,25 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   size_t cub_bytes = t.sort_tmp_bytes - 2 * align_up(m * sizeof(uint64_t));
 
   if (N > 0) hipLaunchKernelGGL(k_convert_batch, grid(N), dim3(TPB), 0, s, N, S, batch, t.batch, t.flags);
-  // incoming-edge lists: edges ordered by (neighbour atom, edge id) = a STABLE sort of the edge ids on the neighbour index alone
-  // (bits_for(N) key bits: 2 radix passes for 10k atoms, where sorting the 64-bit (neighbour, edge) keys took 6)
+  // incoming-edge lists: edges ordered by (neighbour atom, edge id).  A symmetric edge list (any full neighbour list) gets them
+  // from the mirrors of each atom's own row in ONE kernel (k_in_edges_symmetric; it raises flags[0] bit 3 when the list is not
+  // symmetric); otherwise -- and for graphs without triplets, which have no host read-back to learn the verdict from -- a STABLE
+  // radix sort of the edge ids on the neighbour index (bits_for(N) key bits).
   int32_t* dst_sorted = (int32_t*)keysA;
   int32_t* edge_ids = (int32_t*)keysB;
-  if (E > 0) {
-    hipLaunchKernelGGL(k_convert_edges, grid(E), dim3(TPB), 0, s, N, E, edge_index, t.src, t.dst, edge_ids, t.flags);
+  auto sort_in_edges = [&]() -> int {
+    hipLaunchKernelGGL(k_iota32, grid(E), dim3(TPB), 0, s, E, edge_ids);
     M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, t.dst, dst_sorted, edge_ids, t.in_edge, (int)E, 0, bits_for(N + 1), s));
-  }
+    hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, dst_sorted, t.in_ptr);
+    return M3G_OK;
+  };
+  if (E > 0) hipLaunchKernelGGL(k_convert_edges, grid(E), dim3(TPB), 0, s, N, E, edge_index, t.src, t.dst, edge_ids, t.flags);
   hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, t.src, t.row_ptr);
   hipLaunchKernelGGL(k_lower_bound32, grid(S + 1), dim3(TPB), 0, s, S, N, t.batch, t.struct_ptr);
-  hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, dst_sorted, t.in_ptr);
+  const bool try_mirrors = E > 0 && T > 0;
+  if (try_mirrors) hipLaunchKernelGGL(k_in_edges_symmetric, grid((N + 1) * 64), dim3(TPB), 0, s, N, t.row_ptr, t.dst, t.in_ptr, t.in_edge, t.flags);
+  else if (E > 0) { int rc2 = sort_in_edges(); if (rc2) return rc2; }
+  else hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, t.dst, t.in_ptr);
   // Triplet lists grouped by first edge (t1) and by second edge (t2), each in canonical (sorted) order.  The list the graph
   // builders emit (compute_threebody's order, data/material_graph.py:239-248) is already sorted by (e1, e2) and symmetric
   // (every ordered pair of a centre's edges): then t1 needs no sort and t2 IS t1.  Both properties are checked on the device
@@ -344,6 +395,14 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
     M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     M3G_HIP_CHECK(hipStreamSynchronize(s));
     flags_read = true;   // every kernel that can flag a malformed graph has run
+    if (try_mirrors && (h[0] & 8)) {   // not a symmetric edge list (or very long rows): the sort after all.  Its buffers (keysA /
+      // keysB) hold the triplet keys of the optimistic pass, so it runs in the spare half of the sort scratch... which does not
+      // exist: redo the optimistic triplet pass afterwards instead (this path is the exception).
+      int rc2 = sort_in_edges();
+      if (rc2) return rc2;
+      hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, 0, t.flags, order);
+    }
+    h[0] &= ~8;
     uint64_t* sorted = keysA;
     if (h[1] & 1) {      // not sorted: radix sort, then rows, partners and the mirror check again
       M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)T, 0, 32 + bits_for(E + 1), s));

@@ -78,6 +78,8 @@ SYMBOLS = {
     "m3g_verlet_update": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_double, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    "m3g_verlet_update_async": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_double, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "m3g_verlet_fill": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "m3g_neighbor_scratch_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),

@@ -13,6 +13,11 @@ one small pass over a skin list (C ABI: m3g_verlet_*, csrc/m3g_graph_build.hip):
   refill   some pair crossed a cutoff: the lists are re-derived from the candidates (no search), the engine rebuilds its topology;
   search   an atom moved further than skin / 2 (or the caller asks): a new candidate search with cutoff + skin.
 
+`update(pos)` waits for the skin test's verdict (32 bytes) before it returns.  `evaluate(model, pos)` does not: it queues the
+test, writes the positions into the current graph, queues the evaluation behind it ON THE ASSUMPTION that nothing changed, and
+reads the verdict afterwards -- the common case costs two small kernels and no wait; when the verdict says otherwise the lists
+are rebuilt and the evaluation runs again (its first results are overwritten).
+
 Positions are the trajectory's own, UNWRAPPED coordinates (an atom that crosses a cell face keeps going; wrapping it back by a
 lattice vector reads as a jump and takes the search path, which is correct, just slower).
 """
@@ -54,6 +59,9 @@ class VerletGraph:
         self.graph = None
         self._cand = None            # (edge_index [2,Ec], shift [Ec,3], row_ptr [N+2], state [Ec] u8, pos_ref [N,3] f64, scratch)
         self.stats = {"reuse": 0, "refill": 0, "search": 0}
+        self._verdict = torch.zeros(4, dtype=torch.int64).pin_memory()   # m3g_verlet_update_async: max disp^2 (bits), changed, E, T
+        self._verdict_ready = torch.cuda.Event()
+        self._pending = None         # positions of a begin() whose verdict has not been read
 
     # ------------------------------------------------------------------------------------------------ candidates
     def _search(self, pos: torch.Tensor) -> None:
@@ -69,15 +77,24 @@ class VerletGraph:
         self._cand = (ei, shift, rows, state, pos.clone(), scratch)
         self.stats["search"] += 1
 
-    def _update(self, pos: torch.Tensor):
+    def _queue_test(self, pos: torch.Tensor) -> None:
+        """The skin test at `pos`, queued on the current stream together with the copy of its verdict to pinned host memory."""
         ei, shift, rows, state, pos_ref, scratch = self._cand
-        disp, changed, n_e, n_t = C.c_double(), C.c_int32(), C.c_int64(), C.c_int64()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.m3g_verlet_update(self.N, self.S, int(ei.size(1)), _ptr(pos), _ptr(pos_ref), _ptr(self.lattice), _ptr(self.batch),
-                                                  _ptr(ei), _ptr(shift), _ptr(rows), self.cutoff, self.threebody_cutoff, _ptr(state),
-                                                  _ptr(scratch), scratch.numel(), C.byref(disp), C.byref(changed), C.byref(n_e),
-                                                  C.byref(n_t), _stream()))
-        return float(disp.value), bool(changed.value), int(n_e.value), int(n_t.value)
+            _lib.check(self.lib.m3g_verlet_update_async(self.N, self.S, int(ei.size(1)), _ptr(pos), _ptr(pos_ref), _ptr(self.lattice),
+                                                        _ptr(self.batch), _ptr(ei), _ptr(shift), _ptr(rows), self.cutoff, self.threebody_cutoff,
+                                                        _ptr(state), _ptr(scratch), scratch.numel(), C.c_void_p(self._verdict.data_ptr()), _stream()))
+            self._verdict_ready.record()
+
+    def _read_verdict(self):
+        self._verdict_ready.synchronize()
+        v = self._verdict
+        disp = float(np.sqrt(np.frombuffer(np.int64(int(v[0])).tobytes(), dtype=np.float64)[0]))
+        return disp, bool(int(v[1])), int(v[2]), int(v[3])
+
+    def _update(self, pos: torch.Tensor):
+        self._queue_test(pos)
+        return self._read_verdict()
 
     def _fill(self, pos: torch.Tensor, n_e: int, n_t: int) -> None:
         """New index tensors from the candidates at `pos` (m3g_verlet_update has just run on them) -> a NEW graph object (the
@@ -114,6 +131,9 @@ class VerletGraph:
         g[K.NUM_EDGES] = n_e
         g[K.NUM_TRIPLETS] = n_t
         g["num_graphs"] = self.S
+        # the species check of the engine is a property of `atom_types`, which every graph of this trajectory shares
+        if self.graph is not None and "_m3g_species_ok" in self.graph:
+            dict.__setitem__(g, "_m3g_species_ok", self.graph["_m3g_species_ok"])
         self.graph = g
 
     # ------------------------------------------------------------------------------------------------ the per-step call
@@ -121,12 +141,19 @@ class VerletGraph:
         """The graph at positions `pos` ([N,3] device tensor, fp64 or fp32, unwrapped).  `force="search"` / `"refill"` take that
         path whatever the skin test says (benchmarks, tests).  The returned object is `self.graph`; on the reuse path it is the
         SAME object with the same tensors, its `pos` overwritten in place."""
-        if pos.device != self.device or tuple(pos.shape) != (self.N, 3):
-            raise ValueError(f"pos must be a [{self.N}, 3] tensor on {self.device}")
-        pos = pos.detach().to(torch.float64).contiguous()
+        pos = self._check_pos(pos)
+        self._pending = None
         if self._cand is None or force == "search" or self.skin <= 0.0:
             self._search(pos)
         disp, changed, n_e, n_t = self._update(pos)
+        return self._settle(pos, disp, changed, n_e, n_t, force)
+
+    def _check_pos(self, pos: torch.Tensor) -> torch.Tensor:
+        if pos.device != self.device or tuple(pos.shape) != (self.N, 3):
+            raise ValueError(f"pos must be a [{self.N}, 3] tensor on {self.device}")
+        return pos.detach().to(torch.float64).contiguous()
+
+    def _settle(self, pos, disp, changed, n_e, n_t, force=None) -> Batch:
         if disp >= 0.5 * self.skin and not (disp == 0.0):
             self._search(pos)
             disp, changed, n_e, n_t = self._update(pos)
@@ -137,3 +164,35 @@ class VerletGraph:
             self.graph[K.POS].copy_(pos)   # fp64 -> fp32 in place: every tensor of the graph keeps its storage
             self.stats["reuse"] += 1
         return self.graph
+
+    # ------------------------------------------------------------------------------------------------ without the wait
+    def begin(self, pos: torch.Tensor) -> Batch:
+        """Queue the skin test at `pos` and return the CURRENT graph with `pos` written into it, on the assumption that the lists
+        are unchanged; `confirm()` says whether that held.  (No graph yet: falls back to `update`.)"""
+        if self._cand is None or self.graph is None or self.skin <= 0.0:
+            return self.update(pos)
+        pos = self._check_pos(pos)
+        self._queue_test(pos)
+        self.graph[K.POS].copy_(pos)
+        self._pending = pos
+        return self.graph
+
+    def confirm(self) -> bool:
+        """True: the graph `begin` returned was the right one (whatever was evaluated on it stands).  False: the lists had to be
+        rebuilt -- `self.graph` is the right graph now, evaluate again."""
+        if self._pending is None:
+            return True
+        pos, self._pending = self._pending, None
+        disp, changed, n_e, n_t = self._read_verdict()
+        if not changed and (disp < 0.5 * self.skin or disp == 0.0):
+            self.stats["reuse"] += 1
+            return True
+        self._settle(pos, disp, changed, n_e, n_t)
+        return False
+
+    def evaluate(self, model, pos: torch.Tensor, **kwargs):
+        """model(graph at `pos`) without waiting for the skin test first (see the module text)."""
+        out = model(self.begin(pos), **kwargs)
+        if not self.confirm():
+            out = model(self.graph, **kwargs)
+        return out
