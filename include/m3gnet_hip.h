@@ -289,7 +289,8 @@ int m3g_threebody_build(int64_t n_atoms, int64_t n_edges, const int64_t* edge_in
  *                       only the positions of the next m3g_energy_forces call are new.
  *   m3g_verlet_fill     (changed != 0, max_disp < skin / 2) writes the new list from the candidates and updates cand_state; follow
  *                       with m3g_threebody_build (n_triplets from the update) and m3g_topology_build.  No wait.
- * max_disp >= skin / 2 (or a changed lattice): search again with cutoff + skin, pos_ref = pos, cand_state = 0, then update + fill.
+ * max_disp >= skin / 2 (or a changed lattice): search again with cutoff + skin, pos_ref = pos, then update with cand_state = NULL
+ * (fresh candidates: reported as changed) + fill.
  * cand_row_ptr: int32 [N + 2] (N + 1 pointers and one scratch word). */
 int m3g_verlet_scratch_bytes(int64_t n_atoms, int64_t n_candidates, size_t* bytes);
 int m3g_verlet_rows(int64_t n_atoms, int64_t n_candidates, const int64_t* cand_edge_index /* [2,Ec] */, int32_t* cand_row_ptr, void* stream);

@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(256) k_verlet_rows(int64_t N, int64_t S, int64
       const uint8_t st = (uint8_t)((in2 ? 1 : 0) | (in3 ? 2 : 0));
       state[c] = st;
       dist[c] = d;
-      changed = changed || st != old_state[c];
+      changed = changed || (old_state && st != old_state[c]);
     }
     n2 += __popcll(__ballot(in2));
     n3 += __popcll(__ballot(in3));
@@ -787,12 +787,14 @@ extern "C" int m3g_verlet_update_async(int64_t N, int64_t S, int64_t Ec, const d
   if (rc) return rc;
   if (!scratch || scratch_bytes < need || !host_out) { set_error("m3g_verlet_update: scratch too small or null argument"); return M3G_ERR_SIZE; }
   if (N == 0) { host_out[0] = host_out[1] = host_out[2] = host_out[3] = 0; return M3G_OK; }
-  if (!pos || !pos_ref || !lattice || !batch || !cand_row_ptr || (Ec > 0 && (!cand_edge_index || !cand_shift || !cand_state))) {
+  if (!pos || !pos_ref || !lattice || !batch || !cand_row_ptr || (Ec > 0 && (!cand_edge_index || !cand_shift))) {
     set_error("m3g_verlet_update: null argument");
     return M3G_ERR_VALUE;
   }
   VerletScratch w = verlet_carve(N, Ec, scratch);
   M3G_HIP_CHECK(hipMemsetAsync(w.acc, 0, sizeof(unsigned long long) * 4, s));
+  // cand_state == NULL: fresh candidates, no lists built from them yet -- everything counts as changed (and no row has to say so)
+  if (!cand_state) M3G_HIP_CHECK(hipMemsetAsync(w.acc + 1, 1, 1, s));
   hipLaunchKernelGGL(k_verlet_prep, g_for(N), dim3(256), 0, s, N, S, pos, pos_ref, lattice, batch, w.pos_w, w.wrap, w.acc);
   hipLaunchKernelGGL(k_verlet_rows, g_for(N * 64), dim3(256), 0, s, N, S, Ec, batch, lattice, cand_edge_index, cand_shift, cand_row_ptr, w.pos_w,
                      w.wrap, cutoff, threebody_cutoff, cand_state, w.state, w.dist, w.row_keep, w.row_tri, w.acc);

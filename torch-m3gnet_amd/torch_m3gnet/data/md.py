@@ -62,6 +62,7 @@ class VerletGraph:
         self._verdict = torch.zeros(4, dtype=torch.int64).pin_memory()   # m3g_verlet_update_async: max disp^2 (bits), changed, E, T
         self._verdict_ready = torch.cuda.Event()
         self._pending = None         # positions of a begin() whose verdict has not been read
+        self._state_valid = False    # the candidates' membership bytes describe the current lists
 
     # ------------------------------------------------------------------------------------------------ candidates
     def _search(self, pos: torch.Tensor) -> None:
@@ -73,8 +74,9 @@ class VerletGraph:
         nbytes = C.c_size_t()
         _lib.check(self.lib.m3g_verlet_scratch_bytes(self.N, ec, C.byref(nbytes)))
         scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
-        state = torch.zeros(ec + 16, dtype=torch.uint8, device=self.device)
+        state = torch.empty(ec + 16, dtype=torch.uint8, device=self.device)   # written by the first fill
         self._cand = (ei, shift, rows, state, pos.clone(), scratch)
+        self._state_valid = False
         self.stats["search"] += 1
 
     def _queue_test(self, pos: torch.Tensor) -> None:
@@ -83,7 +85,8 @@ class VerletGraph:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.m3g_verlet_update_async(self.N, self.S, int(ei.size(1)), _ptr(pos), _ptr(pos_ref), _ptr(self.lattice),
                                                         _ptr(self.batch), _ptr(ei), _ptr(shift), _ptr(rows), self.cutoff, self.threebody_cutoff,
-                                                        _ptr(state), _ptr(scratch), scratch.numel(), C.c_void_p(self._verdict.data_ptr()), _stream()))
+                                                        _ptr(state) if self._state_valid else None, _ptr(scratch), scratch.numel(),
+                                                        C.c_void_p(self._verdict.data_ptr()), _stream()))
             self._verdict_ready.record()
 
     def _read_verdict(self):
@@ -110,6 +113,7 @@ class VerletGraph:
         with torch.cuda.device(dev):
             _lib.check(self.lib.m3g_verlet_fill(N, int(c_ei.size(1)), n_e, _ptr(scratch), _ptr(c_ei), _ptr(c_shift), _ptr(rows), _ptr(ei),
                                                 _ptr(shift), _ptr(dist), _ptr(state), _stream()))
+            self._state_valid = True
             d32 = dist.to(torch.float32)
             tb_bytes = C.c_size_t()
             _lib.check(self.lib.m3g_threebody_scratch_bytes(N, n_e, C.byref(tb_bytes)))
