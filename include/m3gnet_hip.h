@@ -328,7 +328,8 @@ int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
  * event pool).  They are bound to the plan's device: a commit that moves the plan to another device releases all of them. */
 int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out);
 
-#define M3G_ABI_VERSION 2   /* 2: m3g_io.topo_hints, m3g_topology_hints */
+#define M3G_ABI_VERSION 3   /* 2: m3g_io.topo_hints, m3g_topology_hints; 3: m3g_verlet_*, m3g_topology_status, hints word certified on the buffer,
+                             * canonical edge order by the shift relative to the given coordinates, default precision fp32 */
 
 #ifdef __cplusplus
 }

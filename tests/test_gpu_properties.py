@@ -358,6 +358,49 @@ def test_one_sided_and_filtered_triplet_lists():
             assert rel_err(out[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) < m_tol, (name, b)
 
 
+def test_asymmetric_edge_lists_take_the_sorted_incoming_lists():
+    """The incoming-edge lists of a SYMMETRIC edge list come from the mirrors of each atom's own row (k_in_edges_symmetric, round 4);
+    the reference's modules accept any centre-sorted edge list (`edge_index` is only ever gathered from and scattered by,
+    nn/conv.py:63-97), so a list with edges removed on one side -- i -> j kept, j -> i dropped -- must fall back to the stable
+    sort and still match the oracle.  Also: the same graph evaluated with a symmetric list afterwards (mirror path) agrees with
+    the oracle too, and a multigraph cell (several images of the same neighbour) runs the mirror path on duplicate (i, j) pairs."""
+    from oracle import m3gnet_oracle as orc
+    from torch_m3gnet.data.material_graph import Batch
+    from torch_m3gnet.data.neighbors import threebody_index
+
+    K = _K()
+    model = _default_model(seed=4, energy_scale=1.5)
+    cases = {"thinned": random_cell_graph(24, 7.0, 21), "multigraph": random_cell_graph(5, 3.9, 22, dmin=1.8)}
+    for name, cell in cases.items():
+        base = Batch.from_data_list([cell])
+        ei, shift = base[K.EDGE_INDEX], base[K.EDGE_CELL_SHIFT]
+        variants = {"symmetric": torch.ones(ei.size(1), dtype=torch.bool)}
+        if name == "thinned":
+            keep = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(1)) < 0.85   # drops one direction of many pairs
+            variants["asymmetric"] = keep
+        for vname, keep in variants.items():
+            g = base.clone()
+            g[K.EDGE_INDEX] = ei[:, keep].contiguous()
+            g[K.EDGE_CELL_SHIFT] = shift[keep].contiguous()
+            # triplets of the remaining edges (distances from the positions, as the builders form them)
+            pos, lat = base[K.POS].double(), base[K.LATTICE][0].double()
+            src, dst = g[K.EDGE_INDEX]
+            d = (pos[dst] + g[K.EDGE_CELL_SHIFT].double() @ lat - pos[src]).norm(dim=1)
+            tei, nti, ntij = threebody_index(int(pos.size(0)), g[K.EDGE_INDEX].numpy(), d.float().numpy(), 4.0)
+            g[K.TRIPLET_EDGE_INDEX] = torch.from_numpy(tei)
+            g[K.NUM_TRIPLET_I], g[K.NUM_TRIPLET_IJ] = torch.from_numpy(nti), torch.from_numpy(ntij)
+            g[K.NUM_EDGES], g[K.NUM_TRIPLETS] = int(g[K.EDGE_INDEX].size(1)), int(tei.shape[1])
+            out = model(g.to(DEV))
+            p, cfg, c, og = _oracle_inputs(model, out)
+            p = {k: v.double() for k, v in p.items()}
+            c = orc.make_constants(cfg, model.model[1].elemental_energies.cpu(), dtype=torch.float64)
+            c.factors = model.model[6].nsb.factors.double()
+            o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+            assert float(((out[K.TOTAL_ENERGY].cpu().double() - o["total_energy"]).abs() / o["total_energy"].abs()).max()) < 1e-5, (name, vname)
+            assert rel_err(out[K.FORCES], o["forces"]) < 1e-4, (name, vname)
+            assert rel_err(out[K.NODE_FEATURES], o["x"]) < 1e-5, (name, vname)
+
+
 def test_topology_hints_tell_complete_lists_from_the_rest():
     """m3g_topology_hints (include/m3gnet_hip.h): bit 0 is set exactly when every centre's triplet list holds each ordered
     pair of its active edges once -- what compute_threebody emits (data/material_graph.py:196-254) -- and then the word also

@@ -10,7 +10,7 @@ _PKG_ROOT = Path(__file__).resolve().parent.parent  # .../torch-m3gnet_amd
 LIB_PATH = _PKG_ROOT / "lib" / "libm3gnet_hip.so"
 
 M3G_OK, M3G_ERR_VALUE, M3G_ERR_STATE, M3G_ERR_SIZE, M3G_ERR_HIP, M3G_ERR_UNSUPPORTED = range(6)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class M3GConfig(C.Structure):
