@@ -714,6 +714,12 @@ def main():
 
     timing = series_and_clock(step, args.steps)
     roofline, others, stage_ms, step_bytes, launches = record(args.precision, ms_per_step)
+    roofline["formula"] = ("achieved = algorithmic_flops (fp32) or executed_mfma_flops (split modes) / avg_launch_ms; frac = achieved / peak; "
+                           "avg_launch_ms = HIP events around the kernel's launches on the launch stream, inside the library (m3g_profile_*), "
+                           "which the rocprofv3 average of profiles/r04_<mode>_kernel_stats.csv must agree with")
+    clk = (timing.get("clock_mhz") or {}).get("median")
+    if clk:   # the peaks of MI355X_MICROARCH.md are quoted at 2,400 MHz; the card holds less under this load
+        roofline["frac_at_measured_clock"] = roofline["frac"] * 2400.0 / clk
     out.update(value=value, ms_per_step=ms_per_step, ms_per_step_min=timing["ms_per_step_min"], ms_per_step_median=timing["ms_per_step_median"],
                clock_mhz=(timing.get("clock_mhz") or {}).get("median"), step_timing=timing, kernel_launches_per_step=launches, roofline=roofline, roofline_other_kernels=others, step_traffic_bytes=step_bytes,
                config={"workload": f"single {n_atoms}-atom fcc Cu PBC supercell per GPU ({'x'.join(map(str, args.cells))} cells, "

@@ -1,6 +1,6 @@
 """GPU graph construction against the host builder, element by element.
 
-Both builders emit the canonical order (centre, periodic image lexicographic, neighbour), so index tensors must
+Both builders emit the canonical order (centre, cell shift relative to the given coordinates lexicographic, neighbour), so index tensors must
 be IDENTICAL (integer work: bit-exact); distances are fp64 on both sides and compared to 1e-12 relative.
 Counts pinned by the reference's own fixtures: Al/Na 132 edges at r_c = 5... are in tests/golden (case_alna)."""
 import numpy as np
@@ -225,3 +225,24 @@ def test_graphs_without_edges_or_triplets_run_end_to_end():
     assert g[K.NUM_EDGES] == 4 * 42 and g[K.NUM_TRIPLET_I].tolist() == [0] + [18 * 17] * 4
     out = model(g)
     assert torch.isfinite(out[K.TOTAL_ENERGY]).all() and float(out[K.FORCES][0].abs().max()) == 0.0
+
+
+def test_long_rows_with_atoms_outside_the_home_cell_are_ordered_canonically():
+    """The canonical order sorts a centre's edges by the shift relative to the GIVEN coordinates.  The search emits them by image
+    of the wrapped cell, so rows that hold a neighbour outside the home cell are re-ranked (k_rows_canonical): from an LDS stage
+    for rows of up to 512 edges, in place by one lane beyond -- a 7-atom cell of 3.3 A under a 9 A cutoff has ~590 edges per
+    centre, and half of the atoms are moved out of the home cell by lattice vectors.  Against the host builder, element by
+    element."""
+    rng = np.random.default_rng(17)
+    lat = np.array([[3.3, 0.2, 0.0], [-0.3, 3.4, 0.1], [0.2, -0.1, 3.2]])
+    frac = rng.uniform(0, 1, (7, 3))
+    frac[::2] += rng.integers(-2, 3, (4, 3))           # every other atom outside the home cell
+    pos = frac @ lat
+    host = _host(lat, pos, 9.0, 3.0)
+    deg = np.bincount(host[0][0], minlength=7)
+    assert deg.max() > 512 and (np.abs(np.floor(frac)).sum() > 0)
+    _assert_same(host, _gpu([lat], [pos], 9.0, 3.0))
+    # and a moderate case through the LDS stage (rows of ~150 edges)
+    host = _host(lat, pos, 5.5, 4.0)
+    assert 64 < np.bincount(host[0][0], minlength=7).max() <= 512
+    _assert_same(host, _gpu([lat], [pos], 5.5, 4.0))
