@@ -142,3 +142,65 @@ def test_verlet_graph_reuses_everything_on_the_headline_cell():
         ref = model(fresh, extras=False)
         assert torch.equal(e, ref[K.TOTAL_ENERGY]) and torch.equal(f, ref[K.FORCES]), step
     assert vg.stats == {"reuse": 3, "refill": 1, "search": 1}, vg.stats
+
+
+def test_nve_trajectory_conserves_energy_across_list_updates():
+    """Physics-level check of the whole trajectory path: velocity-Verlet NVE dynamics of a 108-atom Cu cell on the LJ-FITTED weights
+    (trained by the reference's own code, tests/golden/model_fitted_lj.npz), positions resident on the device, lists maintained by
+    VerletGraph.evaluate (no wait in front of the step).  Forces that were not the exact gradient of the energy, a stale or
+    mis-ordered list after a refill, or a pair missed by the skin list would show as a drift of the total energy that does not
+    shrink with the time step; here the error is the integrator's own: it falls by ~4 when dt is halved.
+
+    The REFERENCE MODEL's energy is discontinuous where a pair crosses the two-body cutoff (its radial basis does not vanish
+    there: tools/nve_probe.py, 5.5 meV per pair on these weights -- reproduced faithfully, oracle and engine alike), so the test
+    keeps the cutoff in a gap of the fcc shells (4.42 A < 4.76 A < 5.10 A) and the amplitude small: no pair crosses it, while
+    pairs cross the three-body cutoff (4.38 A, next to the 4.42 A shell) on most steps -- in the `ref` mode of `factors` the
+    three-body term is ~1e-9 of the energy, so those crossings rebuild the triplet lists and the topology without a jump."""
+    from helpers import CASE_MODEL, GOLDEN
+    from oracle import m3gnet_oracle as orc
+    from torch_m3gnet.data.md import VerletGraph
+    from torch_m3gnet.model.build import build_model
+
+    K = _K()
+    rc, r3 = 4.76, 4.38
+    params, cfg, elemental = orc.load_model_npz(GOLDEN / f"{CASE_MODEL['cu32fit']}.npz")
+    model = build_model(rc, r3, cfg.l_max, cfg.n_max, cfg.num_types, cfg.embedding_dim, cfg.num_blocks, elemental_energies=elemental,
+                        energy_scale=cfg.energy_scale, length_scale=cfg.length_scale)
+    model.load_state_dict({k: v for k, v in params.items()})
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    gi = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(3), indexing="ij"), -1)
+    lat = np.eye(3) * 3 * a
+    mass, kB, acc_unit = 63.546, 8.617333e-5, 9.64853e-3       # amu, eV/K, (eV/A/amu) -> A/fs^2
+
+    def run(dt, n_steps):
+        rng = np.random.default_rng(9)
+        pos = torch.tensor((gi.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a + rng.normal(0, 0.01, (108, 3)), device=DEV)
+        vel = torch.tensor(rng.normal(0, np.sqrt(kB * 50.0 / mass * acc_unit), (108, 3)), device=DEV)   # ~50 K, A/fs
+        vel -= vel.mean(0, keepdim=True)
+        vg = VerletGraph([lat], [np.full(108, 29)], rc, r3, skin=0.3, device=DEV)
+
+        def energy_forces(p):
+            out = vg.evaluate(model, p, extras=False)
+            return out[K.TOTAL_ENERGY].double().sum(), out[K.FORCES].double().clone()
+
+        e_pot, f = energy_forces(pos)
+        totals, pots, sizes = [], [], set()
+        for _ in range(n_steps):
+            vel = vel + 0.5 * dt * acc_unit / mass * f
+            pos = pos + dt * vel
+            e_pot, f = energy_forces(pos)
+            vel = vel + 0.5 * dt * acc_unit / mass * f
+            totals.append(float(e_pot + 0.5 * mass / acc_unit * (vel * vel).sum()))
+            pots.append(float(e_pot))
+            sizes.add((int(vg.graph[K.NUM_EDGES]), int(vg.graph[K.NUM_TRIPLETS])))
+        totals, pots = np.array(totals), np.array(pots)
+        return np.abs(totals - totals[0]).max(), pots.max() - pots.min(), sizes, vg.stats
+
+    drift1, swing, sizes, stats = run(1.0, 300)
+    drift2, _, _, _ = run(2.0, 150)
+    print(f"NVE 300 fs: potential energy swings {swing:.3f} eV; total energy within {drift1:.1e} eV at dt = 1 fs, {drift2:.1e} eV at 2 fs; paths {stats}")
+    assert len({e for e, _ in sizes}) == 1 and len({t for _, t in sizes}) > 50     # no pair crossed the cutoff, triplets changed all the time
+    assert stats["refill"] > 100 and stats["search"] >= 2
+    assert swing > 0.2 and drift1 < 3e-4 and drift1 < 1e-3 * swing, (drift1, swing)
+    assert 2.0 < drift2 / drift1 < 8.0, (drift1, drift2)                            # second-order integrator error, nothing else
