@@ -145,6 +145,12 @@ int m3g_topology_build(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int
 #define M3G_TOPO_TB_COMPLETE 1
 int m3g_topology_hints(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
                        int32_t* host_hints, void* stream);
+/* m3g_topology_build + m3g_topology_hints with ONE wait for the device: for the lists the graph builders emit (triplets sorted by
+ * (e1, e2) and symmetric, symmetric edge list) the whole build and the certificate are queued on that assumption and a single
+ * read-back confirms it; other lists redo the affected parts.  host_hints may be NULL (then exactly m3g_topology_build). */
+int m3g_topology_build_hints(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
+                             const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
+                             void* topo, size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream);
 
 /* Sticky error bits the hot call left on a topology buffer (0 = none).  M3G_TOPO_ERR_HINTS: m3g_energy_forces was handed a
  * non-zero m3g_io.topo_hints that is not the word m3g_topology_hints certified for THIS buffer (stale after a rebuild, or copied

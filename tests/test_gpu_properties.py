@@ -453,8 +453,12 @@ def test_hints_word_of_another_topology_is_refused_not_trusted():
     # a fresh topology of the same graph whose certificate was never formed, called with the (plausible) word of the other one
     g2 = g.clone()
     g2[K.EDGE_INDEX] = g2[K.EDGE_INDEX].clone()
-    topo2 = _Topology.of(g2)
-    assert topo2 is not topo
+    _Topology.WITH_HINTS = False          # a plain m3g_topology_build, as a C-ABI caller that never asks for the certificate makes it
+    try:
+        topo2 = _Topology.of(g2)
+    finally:
+        _Topology.WITH_HINTS = True
+    assert topo2 is not topo and topo2._hints is None
     topo2._hints = topo.query_hints()
     model(g2)
     torch.cuda.synchronize()

@@ -139,7 +139,11 @@ __global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int
   if (j == N) return;
   const int r0 = row_ptr[j], r1 = row_ptr[j + 1], n = r1 - r0;
   if (n == 0) return;
-  if (n > kInStage) { if (lane == 0) atomicOr(flags, 8); return; }
+  if (n > kInStage) {
+    if (lane == 0) atomicOr(flags, 8);
+    for (int k = lane; k < n; k += 64) in_edge[r0 + k] = 0;   // defined until the sort replaces the list
+    return;
+  }
   int32_t* se = s_e + wave * kInStage;
   bool missing = false;
   for (int k = lane; k < n; k += 64) {
@@ -152,7 +156,11 @@ __global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int
     missing = missing || found < 0;
     se[k] = found;
   }
-  if (__any(missing)) { if (lane == 0) atomicOr(flags, 8); return; }
+  if (__any(missing)) {
+    if (lane == 0) atomicOr(flags, 8);
+    for (int k = lane; k < n; k += 64) in_edge[r0 + k] = 0;
+    return;
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (int k = lane; k < n; k += 64) {
     const int e = se[k];
@@ -280,9 +288,15 @@ __global__ void __launch_bounds__(256) k_tb_fast(int64_t blocks, const int32_t* 
   }
 }
 __global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
+// (idx may hold anything while a build runs ahead of its own verdict -- an edge list that turns out not to be symmetric leaves
+// rows of in_edge unwritten until the sort replaces them --, so the lookup is bounded: never an out-of-range read)
 __global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ table, int32_t* out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) { out[2 * i] = idx[i]; out[2 * i + 1] = table[idx[i]]; }
+  if (i >= n) return;
+  const int32_t e = idx[i];
+  const bool ok = e >= 0 && (int64_t)e < n;
+  out[2 * i] = ok ? e : 0;
+  out[2 * i + 1] = ok ? table[e] : -1;
 }
 // byte-sized partner ids: for triplet slot t of list (t_ptr, t_other_c), the row it belongs to fixes the workgroup and so the
 // staged window [lo, lo + n); the partner is stored relative to lo, 255 when it falls outside.  The row is the high word of the
@@ -335,19 +349,45 @@ extern "C" int m3g_topology_bytes(int64_t N, int64_t E, int64_t T, int64_t S, si
   return M3G_OK;
 }
 
-extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
-                                  const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
-                                  size_t topo_bytes, int32_t* host_flags, void* stream_) {
+// The certificate kernels of m3g_topology_hints (row flags in the sort scratch of the buffer, which nothing reads after the build);
+// false when the scratch is too small for the row flags (never for buffers sized by m3g_topology_bytes)
+static bool launch_hint_kernels(const Topo& t, hipStream_t s) {
+  const int64_t E = t.E, T = t.T;
+  size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
+  char* tmp = (char*)t.sort_tmp;
+  uint8_t* row_ok = (uint8_t*)(tmp + 2 * align_up(m * sizeof(uint64_t)));
+  if (t.sort_tmp_bytes < 2 * align_up(m * sizeof(uint64_t)) + (size_t)E + 1) return false;
+  const int TPB = 256;
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + TPB - 1) / TPB)); };
+  hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok,
+                     t.flags + 4);
+  hipLaunchKernelGGL(k_tb_fast, grid((E / kTbRows + 1) * 64), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
+  return true;
+}
+static int32_t hints_word(const int32_t (&h)[3]) {
+  // the window sizes travel in one byte each
+  static_assert(kTbCap <= 255 && kTbFastAtoms <= 255, "m3g_topology_hints packs the largest window (rows, atoms) in 8 bits each");
+  return (h[0] == 0 && h[1] > 0) ? (M3G_TOPO_TB_COMPLETE | ((h[1] & 0xff) << 8) | ((h[2] & 0xff) << 16)) : 0;
+}
+
+// host_hints != NULL: also form the certificate of m3g_topology_hints and return its word.  For the lists the graph builders emit
+// (triplets sorted by (e1, e2) and symmetric, edge list symmetric) the WHOLE build -- rows, partner lists, active-edge compaction,
+// windows, certificate -- is queued on that assumption and ONE read-back (malformed-graph bits, order / symmetry verdicts, the
+// certificate's statistics) confirms it; any other list redoes the affected parts with the radix sorts (the round-3 path).
+extern "C" int m3g_topology_build_hints(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
+                                        const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
+                                        size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   size_t need = 0;
   int rc = m3g_topology_bytes(N, E, T, S, &need);
   if (rc) return rc;
   if (!topo_buf || topo_bytes < need) { set_error("topology buffer too small: %zu < %zu", topo_bytes, need); return M3G_ERR_SIZE; }
+  if (host_hints) *host_hints = 0;
   Topo t = topo_carve(N, E, T, S, topo_buf);
   const int TPB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TPB - 1) / TPB)); };
   M3G_HIP_CHECK(hipMemsetAsync(t.flags, 0, kTopoFlags * sizeof(int32_t), s));   // incl. the certified hints word [7] and the sticky error [8]
-  // no window may use the three-body moment path until m3g_topology_hints has certified THIS buffer (stale rows of an earlier
+  // no window may use the three-body moment path until the certificate has been formed for THIS buffer (stale rows of an earlier
   // topology in the same memory must not survive a rebuild)
   M3G_HIP_CHECK(hipMemsetAsync(t.tb_fast, 0, sizeof(int32_t) * 2 * (E / kTbRows + 2), s));
 
@@ -378,77 +418,119 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   if (try_mirrors) hipLaunchKernelGGL(k_in_edges_symmetric, grid((N + 1) * 64), dim3(TPB), 0, s, N, t.row_ptr, t.dst, t.in_ptr, t.in_edge, t.flags);
   else if (E > 0) { int rc2 = sort_in_edges(); if (rc2) return rc2; }
   else hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, t.dst, t.in_ptr);
+
+  // everything downstream of the triplet rows: active-edge compaction (act_scan doubles as the flag array before the scan),
+  // windows, compacted partner lists, byte-sized partner ids
+  auto downstream = [&](bool symmetric, const uint64_t* t1_keys) -> int {
+    hipLaunchKernelGGL(k_active_flags, grid(E + 1), dim3(TPB), 0, s, E, t.t1_ptr, t.t2_ptr, t.act_scan);
+    M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, t.act_scan, t.act_scan, (int)(E + 1), s));
+    hipLaunchKernelGGL(k_active_scatter, grid(std::max(E, N) + 1), dim3(TPB), 0, s, N, E, t.t1_ptr, t.t2_ptr, t.act_scan, t.row_ptr, t.dst, t.act_list,
+                       t.act_dst, t.act_id, t.arow_ptr, t.n_act);
+    hipLaunchKernelGGL(k_tb_windows, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t2_ptr,
+                       t.tb_win);
+    if (E > 0) hipLaunchKernelGGL(k_pair_with_lookup, grid(E), dim3(TPB), 0, s, E, t.in_edge, t.act_id, t.in_pair);
+    if (T > 0) {
+      hipLaunchKernelGGL(k_compact_partners, grid(T), dim3(TPB), 0, s, T, t.act_scan, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c);
+      if (symmetric) {   // one list serves both roles
+        hipLaunchKernelGGL(k_partner_bytes<true>, grid(T), dim3(TPB), 0, s, E, T, t.t1_ptr, t1_keys, t.act_id, t.tb_win, t.t1_e2c, t.t1_b);
+        M3G_HIP_CHECK(hipMemcpyAsync(t.t2_b, t.t1_b, (size_t)T, hipMemcpyDeviceToDevice, s));
+      } else {
+        hipLaunchKernelGGL(k_partner_bytes<false>, grid(T), dim3(TPB), 0, s, E, T, t.t1_ptr, nullptr, t.act_id, t.tb_win, t.t1_e2c, t.t1_b);
+        hipLaunchKernelGGL(k_partner_bytes<false>, grid(T), dim3(TPB), 0, s, E, T, t.t2_ptr, nullptr, t.act_id, t.tb_win, t.t2_e1c, t.t2_b);
+      }
+    }
+    return M3G_OK;
+  };
+  auto mirror_lists = [&]() -> int {   // symmetric triplet list: the partners of e as second edge are its partners as first edge
+    M3G_HIP_CHECK(hipMemcpyAsync(t.t2_ptr, t.t1_ptr, sizeof(int32_t) * (E + 1), hipMemcpyDeviceToDevice, s));
+    M3G_HIP_CHECK(hipMemcpyAsync(t.t2_e1, t.t1_e2, sizeof(int32_t) * T, hipMemcpyDeviceToDevice, s));
+    return M3G_OK;
+  };
+
   // Triplet lists grouped by first edge (t1) and by second edge (t2), each in canonical (sorted) order.  The list the graph
   // builders emit (compute_threebody's order, data/material_graph.py:239-248) is already sorted by (e1, e2) and symmetric
-  // (every ordered pair of a centre's edges): then t1 needs no sort and t2 IS t1.  Both properties are checked on the device
-  // (one small host read-back); any other list -- permuted, one-sided, filtered -- takes the radix sorts.
+  // (every ordered pair of a centre's edges): then t1 needs no sort and t2 IS t1.  Both properties are checked on the device.
   int32_t* order = t.flags + 1;   // flags[1] (otherwise unused): bit 0 "not sorted", bit 1 "not symmetric"
-  bool symmetric = false, flags_read = false;
-  const uint64_t* t1_keys = nullptr;   // sorted (e1, e2) keys while they are still in the sort buffers
+  bool flags_read = false;
   int32_t h[2] = {0, 0};               // flags[0] (malformed graph), flags[1] (order)
   if (T > 0) {
-    // optimistic pass: rows and partners as if the list were sorted, and the mirror check on it -- ONE host read-back decides
+    // optimistic pass: rows and partners as if the list were sorted and symmetric, the mirror check on it, and -- on the same
+    // assumption -- everything downstream and the certificate; ONE host read-back decides
     hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, 0, t.flags, order);
     hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, keysA, t.t1_e2);
     hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, keysA, t.t1_ptr);
     hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, keysA, t.t1_ptr, order);
+    { int r = mirror_lists(); if (r) return r; }
+    { int r = downstream(true, keysA); if (r) return r; }
+    const bool hinted = host_hints && E > 0 && launch_hint_kernels(t, s);
+    int32_t hs[3] = {0, 0, 0};
     M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (hinted) M3G_HIP_CHECK(hipMemcpyAsync(hs, t.flags + 4, sizeof(hs), hipMemcpyDeviceToHost, s));
     M3G_HIP_CHECK(hipStreamSynchronize(s));
     flags_read = true;   // every kernel that can flag a malformed graph has run
-    if (try_mirrors && (h[0] & 8)) {   // not a symmetric edge list (or very long rows): the sort after all.  Its buffers (keysA /
-      // keysB) hold the triplet keys of the optimistic pass, so it runs in the spare half of the sort scratch... which does not
-      // exist: redo the optimistic triplet pass afterwards instead (this path is the exception).
-      int rc2 = sort_in_edges();
-      if (rc2) return rc2;
+    const bool assumed_ok = !(h[1] & 3) && !(try_mirrors && (h[0] & 8));
+    if (assumed_ok) {
+      if (hinted) {
+        *host_hints = hints_word(hs);
+        // the same word stays with the buffer (flags[7]): the moment kernels run only when the word the caller hands to
+        // m3g_energy_forces is the one certified for THIS topology buffer
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, s, t.flags + 7, *host_hints);
+      }
+    } else {
+      // ---- the exception: redo what the assumption got wrong, with the radix sorts (round 3's path) ----
+      if (try_mirrors && (h[0] & 8)) {   // not a symmetric edge list (or very long rows): the stable sort after all
+        int rc2 = sort_in_edges();       // (clobbers keysA / keysB: the triplet keys are formed again below)
+        if (rc2) return rc2;
+      }
+      M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
       hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, 0, t.flags, order);
-    }
-    h[0] &= ~8;
-    uint64_t* sorted = keysA;
-    if (h[1] & 1) {      // not sorted: radix sort, then rows, partners and the mirror check again
-      M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)T, 0, 32 + bits_for(E + 1), s));
-      sorted = keysB;
+      uint64_t* sorted = keysA;
+      if (h[1] & 1) {      // not sorted: radix sort, then rows, partners and the mirror check again
+        M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)T, 0, 32 + bits_for(E + 1), s));
+        sorted = keysB;
+      }
       hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, sorted, t.t1_e2);
       hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, sorted, t.t1_ptr);
-      M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
-      hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, sorted, t.t1_ptr, order);
-      M3G_HIP_CHECK(hipMemcpyAsync(h + 1, order, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-      M3G_HIP_CHECK(hipStreamSynchronize(s));
+      bool symmetric = !(h[1] & 2);
+      if (h[1] & 1) {      // the mirror check of the optimistic pass ran on unsorted keys: its verdict means nothing
+        M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
+        hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, sorted, t.t1_ptr, order);
+        int32_t o2 = 0;
+        M3G_HIP_CHECK(hipMemcpyAsync(&o2, order, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        M3G_HIP_CHECK(hipStreamSynchronize(s));
+        symmetric = !(o2 & 2);
+      }
+      const uint64_t* t1_keys = nullptr;
+      if (symmetric) {
+        int r = mirror_lists();
+        if (r) return r;
+        t1_keys = sorted;
+      } else {
+        uint64_t* other = sorted == keysA ? keysB : keysA;   // the t1 keys are no longer needed
+        hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, other, 1, t.flags, order);
+        uint64_t* out = other == keysA ? keysB : keysA;
+        M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, other, out, (int)T, 0, 32 + bits_for(E + 1), s));
+        hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, out, t.t2_e1);
+        hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, out, t.t2_ptr);
+      }
+      int r = downstream(symmetric, t1_keys);
+      if (r) return r;
+      // the optimistic certificate described other lists: none is valid for this buffer until m3g_topology_hints forms it
+      M3G_HIP_CHECK(hipMemsetAsync(t.tb_fast, 0, sizeof(int32_t) * 2 * (E / kTbRows + 2), s));
+      M3G_HIP_CHECK(hipMemsetAsync(t.flags + 4, 0, 4 * sizeof(int32_t), s));
+      if (host_hints) {
+        M3G_HIP_CHECK(hipGetLastError());
+        int rh = m3g_topology_hints(N, E, T, S, topo_buf, host_hints, stream_);
+        if (rh) return rh;
+      }
     }
     M3G_HIP_CHECK(hipMemsetAsync(order, 0, sizeof(int32_t), s));
-    symmetric = !(h[1] & 2);
-    if (symmetric) {   // the partners of e as second edge are its partners as first edge
-      M3G_HIP_CHECK(hipMemcpyAsync(t.t2_ptr, t.t1_ptr, sizeof(int32_t) * (E + 1), hipMemcpyDeviceToDevice, s));
-      M3G_HIP_CHECK(hipMemcpyAsync(t.t2_e1, t.t1_e2, sizeof(int32_t) * T, hipMemcpyDeviceToDevice, s));
-      t1_keys = sorted;
-    } else {
-      uint64_t* other = sorted == keysA ? keysB : keysA;   // the t1 keys are no longer needed
-      hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, other, 1, t.flags, order);
-      uint64_t* out = other == keysA ? keysB : keysA;
-      M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, other, out, (int)T, 0, 32 + bits_for(E + 1), s));
-      hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, out, t.t2_e1);
-      hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, out, t.t2_ptr);
-    }
+    h[0] &= ~8;
   } else {
     M3G_HIP_CHECK(hipMemsetAsync(t.t1_ptr, 0, sizeof(int32_t) * (E + 1), s));
     M3G_HIP_CHECK(hipMemsetAsync(t.t2_ptr, 0, sizeof(int32_t) * (E + 1), s));
-  }
-  // compaction of the edges that take part in triplets (act_scan doubles as the flag array before the scan)
-  hipLaunchKernelGGL(k_active_flags, grid(E + 1), dim3(TPB), 0, s, E, t.t1_ptr, t.t2_ptr, t.act_scan);
-  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, t.act_scan, t.act_scan, (int)(E + 1), s));
-  hipLaunchKernelGGL(k_active_scatter, grid(std::max(E, N) + 1), dim3(TPB), 0, s, N, E, t.t1_ptr, t.t2_ptr, t.act_scan, t.row_ptr, t.dst, t.act_list,
-                     t.act_dst, t.act_id, t.arow_ptr, t.n_act);
-  hipLaunchKernelGGL(k_tb_windows, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t2_ptr,
-                     t.tb_win);
-  if (E > 0) hipLaunchKernelGGL(k_pair_with_lookup, grid(E), dim3(TPB), 0, s, E, t.in_edge, t.act_id, t.in_pair);
-  if (T > 0) {
-    hipLaunchKernelGGL(k_compact_partners, grid(T), dim3(TPB), 0, s, T, t.act_scan, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c);
-    if (symmetric) {   // one list serves both roles
-      hipLaunchKernelGGL(k_partner_bytes<true>, grid(T), dim3(TPB), 0, s, E, T, t.t1_ptr, t1_keys, t.act_id, t.tb_win, t.t1_e2c, t.t1_b);
-      M3G_HIP_CHECK(hipMemcpyAsync(t.t2_b, t.t1_b, (size_t)T, hipMemcpyDeviceToDevice, s));
-    } else {
-      hipLaunchKernelGGL(k_partner_bytes<false>, grid(T), dim3(TPB), 0, s, E, T, t.t1_ptr, nullptr, t.act_id, t.tb_win, t.t1_e2c, t.t1_b);
-      hipLaunchKernelGGL(k_partner_bytes<false>, grid(T), dim3(TPB), 0, s, E, T, t.t2_ptr, nullptr, t.act_id, t.tb_win, t.t2_e1c, t.t2_b);
-    }
+    int r = downstream(false, nullptr);
+    if (r) return r;
   }
   M3G_HIP_CHECK(hipGetLastError());
   if (host_flags) {
@@ -461,6 +543,12 @@ extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, co
   return M3G_OK;
 }
 
+extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
+                                  const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
+                                  size_t topo_bytes, int32_t* host_flags, void* stream_) {
+  return m3g_topology_build_hints(N, E, T, S, edge_index, triplet_edge_index, batch, topo_buf, topo_bytes, host_flags, nullptr, stream_);
+}
+
 extern "C" int m3g_topology_hints(int64_t N, int64_t E, int64_t T, int64_t S, const void* topo_buf, int32_t* host_hints, void* stream_) {
   if (!topo_buf || !host_hints) { set_error("m3g_topology_hints: null argument"); return M3G_ERR_VALUE; }
   *host_hints = 0;
@@ -468,23 +556,12 @@ extern "C" int m3g_topology_hints(int64_t N, int64_t E, int64_t T, int64_t S, co
   hipStream_t s = (hipStream_t)stream_;
   Topo t = topo_carve(N, E, T, S, const_cast<void*>(topo_buf));
   // The certificate for the three-body moment kernels, formed on demand (a topology that is used once does not pay for it): per
-  // compacted row, are its partner lists complete; per 128-row window, are all its rows, and how large do the windows get.  Row
-  // flags live in the sort scratch of the buffer, which nothing reads after the build.
-  size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
-  char* tmp = (char*)t.sort_tmp;
-  uint8_t* row_ok = (uint8_t*)(tmp + 2 * align_up(m * sizeof(uint64_t)));
-  if (t.sort_tmp_bytes < 2 * align_up(m * sizeof(uint64_t)) + (size_t)E + 1) return M3G_OK;
-  const int TPB = 256;
-  auto grid = [&](int64_t n) { return dim3((unsigned)((n + TPB - 1) / TPB)); };
-  hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok,
-                     t.flags + 4);
-  hipLaunchKernelGGL(k_tb_fast, grid((E / kTbRows + 1) * 64), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
+  // compacted row, are its partner lists complete; per 128-row window, are all its rows, and how large do the windows get.
+  if (!launch_hint_kernels(t, s)) return M3G_OK;
   int32_t h[3] = {0, 0, 0};
   M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags + 4, sizeof(h), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipStreamSynchronize(s));
-  // the window sizes travel in one byte each
-  static_assert(kTbCap <= 255 && kTbFastAtoms <= 255, "m3g_topology_hints packs the largest window (rows, atoms) in 8 bits each");
-  if (h[0] == 0 && h[1] > 0) *host_hints = M3G_TOPO_TB_COMPLETE | ((h[1] & 0xff) << 8) | ((h[2] & 0xff) << 16);
+  *host_hints = hints_word(h);
   // the same word stays with the buffer (flags[7]): the moment kernels run only when the word the caller hands to m3g_energy_forces
   // is the one certified for THIS topology buffer -- a stale word, or one copied from another buffer, flags an error instead
   hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, s, t.flags + 7, *host_hints);

@@ -51,6 +51,8 @@ SYMBOLS = {
     "m3g_topology_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_topology_build": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]),
+    "m3g_topology_build_hints": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_hints": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_status": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_active_edges": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),

@@ -87,6 +87,10 @@ def _stream() -> C.c_void_p:
 class _Topology:
     """Device-side CSR form of a graph's index tensors (m3g_topology_build), cached on the graph."""
 
+    # form the three-body certificate (m3g_topology_hints) together with the build: one wait for the device instead of two.  False:
+    # build only; `query_hints` then asks for the certificate on demand
+    WITH_HINTS = True
+
     def __init__(self, graph) -> None:
         lib = _lib.load_library()
         ei, tei, batch = graph[K.EDGE_INDEX], graph[K.TRIPLET_EDGE_INDEX], graph[K.BATCH]
@@ -101,8 +105,9 @@ class _Topology:
         _lib.check(lib.m3g_topology_bytes(self.N, self.E, self.T, self.S, C.byref(nbytes)))
         self.buf = torch.empty(nbytes.value, dtype=torch.uint8, device=self.ei.device)
         flags = (C.c_int32 * 1)(0)
-        _lib.check(lib.m3g_topology_build(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
-                                          _ptr(self.buf), nbytes.value, flags, _stream()))
+        hints = C.c_int32(0)
+        _lib.check(lib.m3g_topology_build_hints(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
+                                                _ptr(self.buf), nbytes.value, flags, C.byref(hints) if self.WITH_HINTS else None, _stream()))
         # (the build waits for the stream itself, once, and the flags are final on return: include/m3gnet_hip.h)
         if flags[0] & 1:
             raise ValueError("edge_index must be sorted by centre atom (row 0), as MaterialGraph builds it")
@@ -110,7 +115,8 @@ class _Topology:
             raise ValueError("graph index out of range (edge_index / triplet_edge_index / batch)")
         if flags[0] & 4:
             raise ValueError("triplet_edge_index pairs edges that do not share a centre atom")
-        self._hints = None   # m3g_topology_hints, asked for before the first m3g_energy_forces call (`hints_for_call`)
+        # the certificate's word: formed with the build (WITH_HINTS), else asked for before the first m3g_energy_forces call
+        self._hints = int(hints.value) if self.WITH_HINTS else None
 
     def query_hints(self) -> int:
         """The word m3g_topology_hints returns for this topology (certifies complete triplet lists for the three-body moment
