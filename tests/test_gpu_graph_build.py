@@ -246,3 +246,27 @@ def test_long_rows_with_atoms_outside_the_home_cell_are_ordered_canonically():
     host = _host(lat, pos, 5.5, 4.0)
     assert 64 < np.bincount(host[0][0], minlength=7).max() <= 512
     _assert_same(host, _gpu([lat], [pos], 5.5, 4.0))
+
+
+def test_batch_from_structures_and_pinned_staging():
+    """The two host-side ways into the engine agree with each other: structure objects -> GPU builder (`batch_from_structures`),
+    and host-built graphs staged through pinned memory with asynchronous copies (`Batch.pin_memory().to(device,
+    non_blocking=True)`)."""
+    from types import SimpleNamespace
+
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.graph_gpu import batch_from_structures
+    from torch_m3gnet.data.material_graph import Batch, MaterialGraph
+
+    cells = _cells()
+    names = ["cu_2x2x2", "triclinic_unwrapped"]
+    structs = [SimpleNamespace(lattice=SimpleNamespace(matrix=cells[n][0]), cart_coords=cells[n][1],
+                               atomic_numbers=np.full(len(cells[n][1]), 29 if n.startswith("cu") else 8)) for n in names]
+    on_gpu = batch_from_structures(structs, 5.0, 4.0)
+    host = Batch.from_data_list([MaterialGraph.from_structure(s, 5.0, 4.0) for s in structs])
+    pinned = host.pin_memory()
+    assert all(t.is_pinned() for t in pinned.values() if torch.is_tensor(t))
+    staged = pinned.to("cuda", non_blocking=True)
+    torch.cuda.synchronize()
+    for key in (K.POS, K.ATOM_TYPES, K.EDGE_INDEX, K.EDGE_CELL_SHIFT, K.TRIPLET_EDGE_INDEX, K.LATTICE, K.BATCH):
+        assert torch.equal(staged[key], on_gpu[key]), key

@@ -152,3 +152,14 @@ def batch_from_arrays(lattices: Sequence, cart_coords: Sequence, atomic_numbers:
     g[K.NUM_TRIPLETS] = int(tei.size(1))
     g["num_graphs"] = len(sizes)
     return g
+
+
+def batch_from_structures(structures: Sequence, cutoff: float, threebody_cutoff: float, device="cuda") -> Batch:
+    """`Batch.from_data_list([MaterialGraph.from_structure(s, cutoff, threebody_cutoff) for s in structures]).to(device)` -- what a
+    user of the reference writes (data/material_graph.py:132-166 per structure, then PyG collation) -- with the neighbour search,
+    the triplet enumeration and the collation of the whole batch done on the GPU in one pass.  `structures`: pymatgen `Structure`s
+    or anything with `lattice.matrix`, `cart_coords` and atomic numbers (material_graph._structure_arrays)."""
+    from .material_graph import _structure_arrays
+
+    lats, poss, zs = zip(*(_structure_arrays(s) for s in structures))
+    return batch_from_arrays(lats, poss, zs, cutoff, threebody_cutoff, device=device)

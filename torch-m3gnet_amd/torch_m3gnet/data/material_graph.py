@@ -61,6 +61,11 @@ class MaterialGraph(dict):
     def to(self, device, non_blocking: bool = False):
         return self._map(lambda t: t.to(device, non_blocking=non_blocking))
 
+    def pin_memory(self):
+        """Host tensors in page-locked memory, so that `.to(device, non_blocking=True)` is one asynchronous copy per tensor queued
+        on the current stream (pinned host -> device staging)."""
+        return self._map(lambda t: t.pin_memory() if t.device.type == "cpu" else t)
+
     def clone(self):
         return self._map(lambda t: t.clone())
 
