@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build DESIGN.md = DESIGN_part1.md (the design as it stands, numbers taken from the committed bench line) + the measurement
+"""Build DESIGN.md = docs/DESIGN_part1.md (the design as it stands, numbers taken from the committed bench line) + the measurement
 history of earlier rounds (docs/DESIGN_history_r1_r3.md, the previous DESIGN.md with its headings marked II.).
 
     python tools/assemble_design.py profiles/r04_bench_default_run.json
@@ -34,7 +34,7 @@ vals = {
     "F16_HBM": f"{f16['roofline']['hbm_traffic_view']['frac']:.2f}",
     "C4_MS": f"{d['config4_sharded']['ms_per_step']:.2f}", "SMALL_MS": f"{d['beside']['step_ms_32_atom_cu_cell']:.3f}",
 }
-part1 = (ROOT / "DESIGN_part1.md").read_text()
+part1 = (ROOT / "docs" / "DESIGN_part1.md").read_text()
 missing = set(re.findall(r"@([A-Z0-9_]+)@", part1)) - set(vals)
 assert not missing, missing
 for k, v in vals.items():
