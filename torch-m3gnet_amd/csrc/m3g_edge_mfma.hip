@@ -26,6 +26,14 @@
 
 namespace m3g {
 
+// the fp32 forward kernel evaluates its activations on value PAIRS too (packed fp32 instructions; round 4: 1,218 -> 1,038 vector
+// instructions per tile, no spills at its 128-register budget any more, forward -2 % same-box; -DM3G_F32_SCALAR_ACT for A/B)
+#ifndef M3G_F32_SCALAR_ACT
+constexpr bool kF32Pairs = true;
+#else
+constexpr bool kF32Pairs = false;
+#endif
+
 // ---------------------------------------------------------------------------------------------- forward
 // both layers of one conv GatedMLP from the edge-feature tile x: p1 = layer-1 pre-activations (dense 0..3, gate 4..7),
 // p2 = layer-2 pre-activations.  `w1c/w2d/w2g/b2` are offsets of the forward images inside `lds`.
@@ -51,11 +59,20 @@ __device__ __forceinline__ void mlp_preacts(const float* lds, int w1c, int w2d, 
     // pre-activations -- SiLU' costs three more vector instructions here, next to the sigmoid SiLU evaluates anyway
     static_for<8>([&]<int ob>() {
       f32x4 ds;
+#ifndef M3G_F32_SCALAR_ACT
+      static_for<2>([&]<int k>() {   // value pairs on packed fp32 instructions (silu_pair: SiLU and SiLU' from one sigmoid)
+        f32x2 act, der;
+        silu_pair(f32x2{p1[ob][2 * k], p1[ob][2 * k + 1]}, act, der);
+        p1[ob][2 * k] = act[0]; p1[ob][2 * k + 1] = act[1];
+        ds[2 * k] = der[0]; ds[2 * k + 1] = der[1];
+      });
+#else
       static_for<4>([&]<int r>() {
         const float p = p1[ob][r], sg = fsigmoid(p);
         p1[ob][r] = p * sg;
         ds[r] = sg * (1.f + p * (1.f - sg));
       });
+#endif
       M3G_SAVE_STORE(p1_out + ob * 256, ds);
     });
     chain_p<PREC, 4, 2, 0, 0>(lds + w2d, p1, p2, lane, w_inv);
@@ -103,7 +120,7 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* lds, const MfmaMlp
   st.template mark<S0 + 1>();  // both layers
   static_for<4>([&]<int ob>() {
     out[ob] = mfma16(lds[L.wl + ob * 64 + lane], hb, f32x4{0.f, 0.f, 0.f, 0.f});
-    if constexpr (PREC == kPrecF16x3) {
+    if constexpr (PREC == kPrecF16x3 || (kF32Pairs && PREC == kPrecF32)) {
       static_for<2>([&]<int k>() {
         const f32x2 v = gated_pair(f32x2{p2[ob][2 * k], p2[ob][2 * k + 1]}, f32x2{p2[4 + ob][2 * k], p2[4 + ob][2 * k + 1]}) *
                         f32x2{out[ob][2 * k], out[ob][2 * k + 1]};
@@ -176,7 +193,7 @@ __global__ void __launch_bounds__(64 * fwd_waves<PREC>()) k_edge_block_mfma(FwdA
     {  // three-body gated update (nn/interaction.py:220-221)
       f32x4 p[8];
       tb_preact_p<PREC, TBS>(lds + L.tb, tbin, p, lv);
-      if constexpr (PREC == kPrecF16x3) {
+      if constexpr (PREC == kPrecF16x3 || (kF32Pairs && PREC == kPrecF32)) {
         static_for<4>([&]<int blk>() {
           static_for<2>([&]<int k>() {
             const f32x2 v = gated_pair(f32x2{p[blk][2 * k], p[blk][2 * k + 1]}, f32x2{p[4 + blk][2 * k], p[4 + blk][2 * k + 1]});
