@@ -85,6 +85,28 @@ __device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpR
   const float hb_sel = qd == 0 ? hv[0] : qd == 1 ? hv[1] : qd == 2 ? hv[2] : hv[3];
   static_for<4>([&]<int ob>() {
     const f32x4 sl = mfma16(lds[L.wld + ob * 64 + lane], hb_sel, f32x4{0.f, 0.f, 0.f, 0.f});
+#ifndef M3G_F32_SCALAR_ACT   // (round 4: 1,885 -> 1,457 vector instructions per tile, 211 -> 200 VGPRs, reverse -0.9 % same-box; -DM3G_F32_SCALAR_ACT for A/B)
+    static_for<2>([&]<int k>() {   // value pairs on packed fp32 instructions (as the f16x3 fused kernel evaluates them)
+      const f32x2 p2d = {d2[ob][2 * k], d2[ob][2 * k + 1]}, p2g = {d2[4 + ob][2 * k], d2[4 + ob][2 * k + 1]};
+      const f32x2 du = {d_upd[ob][2 * k], d_upd[ob][2 * k + 1]}, s_lin = {sl[2 * k], sl[2 * k + 1]};
+      f32x2 sd, dsd;
+      silu_pair(p2d, sd, dsd);
+      const f32x2 sg = sigmoid_pair(p2g);
+      const f32x2 a_g = du * sg;            // dL/d(out) sg(p2g)
+      const f32x2 d_s = a_g * sd;           // dL/d(s_lin)
+      const f32x2 d_o = a_g * s_lin;
+      const f32x2 dd = d_o * dsd;           // dL/d(p2d)
+      const f32x2 dgt = (d_s * s_lin) * (1.f - sg);   // dL/d(p2g)
+      const f32x4 w0 = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + 2 * k) * 4);
+      const f32x4 w1 = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + 2 * k + 1) * 4);
+      f32x2 h01 = {dhv[0], dhv[1]}, h23 = {dhv[2], dhv[3]};
+      h01 += f32x2{w0[0], w0[1]} * d_s[0]; h23 += f32x2{w0[2], w0[3]} * d_s[0];
+      h01 += f32x2{w1[0], w1[1]} * d_s[1]; h23 += f32x2{w1[2], w1[3]} * d_s[1];
+      dhv[0] = h01[0]; dhv[1] = h01[1]; dhv[2] = h23[0]; dhv[3] = h23[1];
+      d2[ob][2 * k] = dd[0]; d2[ob][2 * k + 1] = dd[1];
+      d2[4 + ob][2 * k] = dgt[0]; d2[4 + ob][2 * k + 1] = dgt[1];
+    });
+#else
     static_for<4>([&]<int r>() {
       const float p2d = d2[ob][r], p2g = d2[4 + ob][r];
       const f32x4 w = *(const f32x4*)(lds + L.wl + (ob * 16 + 4 * qd + r) * 4);
@@ -96,6 +118,7 @@ __device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpR
       d2[ob][r] = d_out * sg * (sgd * (1.f + p2d * (1.f - sgd)));
       d2[4 + ob][r] = d_out * sd * sg * (1.f - sg);
     });
+#endif
     // pin the running dL/dh sums: otherwise LLVM sinks the accumulation chain to its only use at the end of the kernel and
     // keeps every w / sd / sg temporary alive
     asm volatile("" : "+v"(dhv[0]), "+v"(dhv[1]), "+v"(dhv[2]), "+v"(dhv[3]));
@@ -207,6 +230,19 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
     // three-body gated update, reverse (nn/interaction.py:220-221)
     f32x4 d8[8];
     tb_preact<TBS>(lds + L.tb, mb, d8, lv);
+#ifndef M3G_F32_SCALAR_ACT
+    static_for<4>([&]<int blk>() {
+      static_for<2>([&]<int k>() {
+        f32x2 sd, dsd;
+        silu_pair(f32x2{d8[blk][2 * k], d8[blk][2 * k + 1]}, sd, dsd);
+        const f32x2 sg = sigmoid_pair(f32x2{d8[4 + blk][2 * k], d8[4 + blk][2 * k + 1]});
+        const f32x2 a_g = f32x2{de[blk][2 * k], de[blk][2 * k + 1]} * sg;
+        const f32x2 dd = a_g * dsd, dgt = (a_g * sd) * (1.f - sg);
+        d8[blk][2 * k] = dd[0]; d8[blk][2 * k + 1] = dd[1];
+        d8[4 + blk][2 * k] = dgt[0]; d8[4 + blk][2 * k + 1] = dgt[1];
+      });
+    });
+#else
     static_for<4>([&]<int blk>() {
       static_for<4>([&]<int r>() {
         const float p = d8[blk][r], sgd = fsigmoid(p), sg = fsigmoid(d8[4 + blk][r]);
@@ -214,6 +250,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
         d8[4 + blk][r] = de[blk][r] * (p * sgd) * sg * (1.f - sg);
       });
     });
+#endif
     f32x4 dmv[1];
     zero(dmv);
     chain_f32<1, 8>(lds + L.tbT, d8, dmv, lv);
