@@ -102,6 +102,12 @@ def test_verlet_graph_is_the_fresh_build_along_a_trajectory():
         ref = model(fresh, extras=False)
         assert torch.equal(e, ref[K.TOTAL_ENERGY]) and torch.equal(f, ref[K.FORCES]) and torch.equal(s, ref[K.STRESSES]), step
     assert vg.stats["reuse"] > 0 and vg.stats["refill"] > 1 and vg.stats["search"] >= 3, vg.stats
+    # a change of cell (variable-cell relaxation): everything is rebuilt in the new cells, again equal to a fresh build
+    lats2 = [L * s_ for L, s_ in zip(lats, (1.02, 0.99, 1.01))]
+    pos2 = np.concatenate([p_ * s_ for p_, s_ in zip(np.split(pos, np.cumsum(sizes)[:-1]), (1.02, 0.99, 1.01))])
+    vg.set_lattice(lats2)
+    g = vg.update(torch.tensor(pos2, device=DEV))
+    _same_graph(g, batch_from_arrays(lats2, np.split(pos2, np.cumsum(sizes)[:-1]), zs, 5.0, 4.0, device=DEV))
 
 
 def test_verlet_graph_reuses_everything_on_the_headline_cell():

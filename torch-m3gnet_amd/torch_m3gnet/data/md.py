@@ -64,6 +64,17 @@ class VerletGraph:
         self._pending = None         # positions of a begin() whose verdict has not been read
         self._state_valid = False    # the candidates' membership bytes describe the current lists
 
+    def set_lattice(self, lattices: Sequence) -> None:
+        """New cell(s) (variable-cell relaxation, NPT): the candidates were searched in the old cell, so the next `update` /
+        `evaluate` searches again.  Positions are the caller's to rescale."""
+        lat = np.stack([np.asarray(L, dtype=np.float64).reshape(3, 3) for L in lattices])
+        if lat.shape != self._host_lattice.shape:
+            raise ValueError(f"expected {self._host_lattice.shape[0]} lattices of shape [3, 3]")
+        self._host_lattice = lat
+        self.lattice = torch.tensor(lat, device=self.device)
+        self.lattice32 = self.lattice.to(torch.float)
+        self._cand, self.graph, self._pending, self._state_valid = None, None, None, False
+
     # ------------------------------------------------------------------------------------------------ candidates
     def _search(self, pos: torch.Tensor) -> None:
         ei, shift, _ = neighbor_list_gpu(self.lattice, pos, self.batch, self.cutoff + self.skin, host_lattice=self._host_lattice)
