@@ -59,6 +59,10 @@ class Engine:
         self.plan = C.c_void_p()
         _lib.check(self.lib.m3g_plan_create(C.byref(self.cfg), C.byref(self.plan)))
         self._sig = None
+        # the per-module parameter dicts, collected once: walking `seq.parameters()` (named_modules + de-duplication) costs ~60 us per
+        # call, which a caller that waits for the device every step (MD) pays in full; a Parameter that is REPLACED later
+        # (`module.weight = Parameter(...)`) lands in the same dict and is seen
+        self._param_dicts = [m._parameters for m in self.seq.modules() if m._parameters]
         self.precision = "fp32"   # the reference's arithmetic; the split modes are explicit opt-ins (set_precision / M3G_PRECISION)
         env_prec = os.environ.get("M3G_PRECISION")   # run a whole test suite in another mode without touching it
         if env_prec:
@@ -83,7 +87,10 @@ class Engine:
     def _signature(self, dev):
         # the plan's device buffers live on the device it was committed under: a change of device is a change of plan state
         sig = [("device", dev.index if dev.index is not None else torch.cuda.current_device())]
-        sig += [(p.data_ptr(), p._version) for p in self.seq.parameters()]
+        for d in self._param_dicts:
+            for p in d.values():
+                if p is not None:
+                    sig.append((p.data_ptr(), p._version))
         for m in self.tb[:1]:
             sig.append((m.nsb.factors.data_ptr(), m.nsb.factors._version))
         e = self.atom_ref.elemental_energies
