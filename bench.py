@@ -335,7 +335,7 @@ class Job:
             self.dist.destroy_process_group()
 
 
-def series_and_clock(step, steps):
+def series_and_clock(step, steps, sample_clock=True):
     """A pass of `steps` further steps AFTER the timed region (which stays untouched): every step bracketed by HIP events on the
     launch stream -> min / median / max step time, and the shader clock sampled from the SMU on a second thread while the steps
     run (torch.cuda.clock_rate -> amdsmi: MHz of the current device).  Tells a slow box / a throttled clock from warm-up ramp."""
@@ -355,14 +355,16 @@ def series_and_clock(step, steps):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     torch.cuda.synchronize()
     th = threading.Thread(target=sampler, daemon=True)
-    th.start()
+    if sample_clock:   # (rank 0 only: one SMU client per node is enough)
+        th.start()
     ev[0].record()
     for i in range(steps):
         step()
         ev[i + 1].record()
     torch.cuda.synchronize()
     stop.set()
-    th.join(timeout=2.0)
+    if sample_clock:
+        th.join(timeout=2.0)
     ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     rec = {"ms_per_step_min": min(ms), "ms_per_step_median": statistics.median(ms), "ms_per_step_max": max(ms), "steps": steps,
            "how": "a second pass of the same steps, each bracketed by HIP events on the launch stream (the timed region itself carries no events)"}
@@ -712,7 +714,7 @@ def main():
         launches = sum(cnt * KERNELS_PER_STAGE.get(k, 1) for k, (ms, cnt) in per_launch.items() if ms * cnt > 0.006)   # (empty stages: two bare events, ~5 us)
         return views[dom], [v for k, v in views.items() if k != dom], stage_ms, step_bytes, launches
 
-    timing = series_and_clock(step, args.steps)
+    timing = series_and_clock(step, args.steps, sample_clock=rank == 0)
     roofline, others, stage_ms, step_bytes, launches = record(args.precision, ms_per_step)
     roofline["formula"] = ("achieved = algorithmic_flops (fp32) or executed_mfma_flops (split modes) / avg_launch_ms; frac = achieved / peak; "
                            "avg_launch_ms = HIP events around the kernel's launches on the launch stream, inside the library (m3g_profile_*), "
@@ -736,7 +738,7 @@ def main():
             model.engine.set_precision(other)
             step()
             el2 = job.timed(step, args.steps, args.warmup)
-            t2 = series_and_clock(step, args.steps)
+            t2 = series_and_clock(step, args.steps, sample_clock=rank == 0)
             r2, o2, st2, sb2, _ = record(other, el2 / args.steps * 1e3)
             out[other] = {"value": world * n_atoms * args.steps / el2, "unit": "atom-steps/s", "ms_per_step": el2 / args.steps * 1e3,
                           "ms_per_step_min": t2["ms_per_step_min"], "ms_per_step_median": t2["ms_per_step_median"],

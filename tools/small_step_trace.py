@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""A few steps of the 32-atom Cu cell (BASELINE configs[0]) for a kernel trace:
+rocprofv3 --kernel-trace --output-format csv -d /tmp/small -- python3 tools/small_step_trace.py ; python tools/step_sequence.py /tmp/small 2"""
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / "torch-m3gnet_amd"):
+    sys.path.insert(0, str(p))
+import bench  # noqa: E402
+from torch_m3gnet.data.synthetic import fcc_cu_graph  # noqa: E402
+
+model = bench.default_model(torch.device("cuda"))
+if len(sys.argv) > 1:
+    model.engine.set_precision(sys.argv[1])
+g = fcc_cu_graph(2, 2, 2).to("cuda")
+for _ in range(30):
+    model(g, forces=True, extras=False)
+torch.cuda.synchronize()
