@@ -131,7 +131,7 @@ __global__ void k_check_symmetric(int64_t T, const uint64_t* __restrict__ sorted
 constexpr int kInStage = 512;   // outgoing edges per atom handled here
 __global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
                                                             int32_t* in_ptr, int32_t* in_edge, int32_t* flags) {
-  __shared__ int32_t s_e[4 * kInStage];
+  __shared__ int32_t s_e[4 * kInStage], s_d[4 * kInStage];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = blockIdx.x * (int64_t)(blockDim.x >> 6) + wave;   // wave-uniform
   if (j > N) return;
@@ -144,12 +144,14 @@ __global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int
     for (int k = lane; k < n; k += 64) in_edge[r0 + k] = 0;   // defined until the sort replaces the list
     return;
   }
-  int32_t* se = s_e + wave * kInStage;
+  int32_t *se = s_e + wave * kInStage, *sd = s_d + wave * kInStage;
+  for (int k = lane; k < n; k += 64) sd[k] = dst[r0 + k];   // the row's neighbours, staged once (the duplicate count reads them k times)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   bool missing = false;
   for (int k = lane; k < n; k += 64) {
-    const int i = dst[r0 + k];
+    const int i = sd[k];
     int dup = 0;
-    for (int f = 0; f < k; ++f) dup += dst[r0 + f] == i ? 1 : 0;
+    for (int f = 0; f < k; ++f) dup += sd[f] == i ? 1 : 0;
     int found = -1;
     for (int q = row_ptr[i], q1 = row_ptr[i + 1]; q < q1; ++q)
       if (dst[q] == (int)j && dup-- == 0) { found = q; break; }
