@@ -354,3 +354,33 @@ def test_readout_depth_other_than_three_is_refused_loudly():
             nn.EdgeAdjustor(3, 8)]
     with pytest.raises(ValueError, match="num_layers = 3"):
         nn.Gradient(torch.nn.Sequential(*head, nn.AtomWiseReadout(8, 4, 1.0))).engine
+
+
+def test_host_neighbor_order_does_not_depend_on_the_wrap_state():
+    """Canonical edge order (round 4): centre, cell shift relative to the GIVEN coordinates, neighbour.  An atom drifting across a
+    cell face changes neither the shifts nor the order of any edge; moving an atom by a whole lattice vector relabels the shifts of
+    its edges (they refer to the coordinates given) and nothing else: same pair vectors, same distances, same triplet count."""
+    from torch_m3gnet.data.neighbors import neighbor_list, threebody_index
+
+    rng = np.random.default_rng(1)
+    lat = np.array([[6.1, 0.2, 0.0], [-0.4, 5.8, 0.3], [0.1, -0.2, 6.4]])
+    pos = rng.uniform(0.05, 0.95, (14, 3)) @ lat
+    a, b = pos.copy(), pos.copy()
+    a[0] = np.array([-0.001, 0.3, 0.999]) @ lat      # just outside two faces
+    b[0] = np.array([+0.001, 0.3, 1.001]) @ lat      # just inside / outside the other way
+    ea, sa, da = neighbor_list(lat, a, 5.0)
+    eb, sb, db = neighbor_list(lat, b, 5.0)
+    keep_a = np.abs(da - 5.0) > 0.05                  # (pairs within 0.05 A of the cutoff may enter / leave under the 0.02 A move)
+    keep_b = np.abs(db - 5.0) > 0.05
+    assert np.array_equal(ea[:, keep_a], eb[:, keep_b]) and np.array_equal(sa[keep_a], sb[keep_b])
+    c = pos.copy()
+    c[3] += 2 * lat[0] - lat[2]                       # a whole-lattice-vector move
+    e0, s0, d0 = neighbor_list(lat, pos, 5.0)
+    ec, sc, dc = neighbor_list(lat, c, 5.0)
+    vec = lambda p, e, s: p[e[1]] + s @ lat - p[e[0]]   # noqa: E731
+    k0 = sorted(map(tuple, np.round(np.c_[e0.T, vec(pos, e0, s0)], 9)))
+    kc = sorted(map(tuple, np.round(np.c_[ec.T, vec(c, ec, sc)], 9)))
+    assert k0 == kc
+    t0 = threebody_index(14, e0, d0.astype(np.float32), 4.0)[0].shape[1]
+    tc = threebody_index(14, ec, dc.astype(np.float32), 4.0)[0].shape[1]
+    assert t0 == tc
