@@ -153,8 +153,15 @@ __global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int
     int dup = 0;
     for (int f = 0; f < k; ++f) dup += sd[f] == i ? 1 : 0;
     int found = -1;
-    for (int q = row_ptr[i], q1 = row_ptr[i + 1]; q < q1; ++q)
-      if (dst[q] == (int)j && dup-- == 0) { found = q; break; }
+    // row i in batches of eight independent loads (one load per candidate made this a chain of ~20 dependent round trips per lane)
+    for (int q = row_ptr[i], q1 = row_ptr[i + 1]; q < q1 && found < 0; q += 8) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = q + u < q1 ? dst[q + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (found < 0 && v[u] == (int)j && dup-- == 0) found = q + u;
+    }
     missing = missing || found < 0;
     se[k] = found;
   }
@@ -278,15 +285,32 @@ __global__ void __launch_bounds__(256) k_tb_fast(int64_t blocks, const int32_t* 
     bool mine = true;
     for (int r = lo + lane; r < hi; r += 64) mine = mine && ok[r] != 0;
     const bool all = na <= kTbFastAtoms && hi - lo <= kTbCap && __all(mine);
-    if (lane == 0) {
-      if (all) { atomicMax(stats + 1, hi - lo); atomicMax(stats + 2, na); }
-      else atomicAdd(stats, 1);
-    }
     if (!all) na = 0;
   }
-  if (lane == 0) {
+  if (lane == 0) {   // (the statistics of all windows are formed by k_tb_stats: thousands of atomics on three words serialise, 33 us)
     fast[2 * b] = na;
     fast[2 * b + 1] = a0;
+  }
+}
+// one workgroup: stats[0] = windows that hold rows but may not use the moment path, [1] = largest such window (rows), [2] = most atoms
+__global__ void __launch_bounds__(1024) k_tb_stats(int64_t blocks, const int32_t* __restrict__ n_act, const int32_t* __restrict__ win,
+                                                   const int32_t* __restrict__ fast, int32_t* stats) {
+  __shared__ int s_bad[16], s_rows[16], s_atoms[16];
+  const int A = *n_act;
+  int bad = 0, rows = 0, atoms = 0;
+  for (int64_t b = threadIdx.x; b < blocks; b += blockDim.x) {
+    if (b * kTbRows >= A) continue;
+    const int na = fast[2 * b];
+    if (na > 0) { rows = max(rows, win[6 * b + 1] - win[6 * b]); atoms = max(atoms, na); }
+    else ++bad;
+  }
+  for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o); rows = max(rows, __shfl_xor(rows, o)); atoms = max(atoms, __shfl_xor(atoms, o)); }
+  if ((threadIdx.x & 63) == 0) { s_bad[threadIdx.x >> 6] = bad; s_rows[threadIdx.x >> 6] = rows; s_atoms[threadIdx.x >> 6] = atoms; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bad = 0; rows = 0; atoms = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { bad += s_bad[k]; rows = max(rows, s_rows[k]); atoms = max(atoms, s_atoms[k]); }
+    stats[0] = bad; stats[1] = rows; stats[2] = atoms;
   }
 }
 __global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
@@ -364,6 +388,7 @@ static bool launch_hint_kernels(const Topo& t, hipStream_t s) {
   hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok,
                      t.flags + 4);
   hipLaunchKernelGGL(k_tb_fast, grid((E / kTbRows + 1) * 64), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
+  hipLaunchKernelGGL(k_tb_stats, dim3(1), dim3(1024), 0, s, E / kTbRows + 1, t.n_act, t.tb_win, t.tb_fast, t.flags + 4);
   return true;
 }
 static int32_t hints_word(const int32_t (&h)[3]) {
