@@ -536,6 +536,8 @@ def measure_beside(model, device):
                certificate are reused, only the positions are new -- bit-identical to a fresh build (tests/test_gpu_md.py);
                `reuse_verdict_read_after_the_step`: the same with the evaluation queued behind the skin test before its verdict
                is read (VerletGraph.evaluate: no wait in front of the step; a changed list would re-run the step);
+      refill   the same iteration forced to re-derive the lists from the skin list (no search) and rebuild triplets, topology and
+               certificate: what a step costs when some pair has crossed a cutoff -- every step of a liquid or a hot crystal;
       rebuild  the same iteration forced through a new candidate search (cutoff + skin), list fill, triplets, topology and
                certificate: what a step costs when an atom has moved further than skin / 2.
     Both in the headline's arithmetic mode and in the opt-in f16x3 mode."""
@@ -595,7 +597,7 @@ def measure_beside(model, device):
     for mode in dict.fromkeys((current, "f16x3")):
         model.engine.set_precision(mode)
         md[mode] = {"reuse": md_loop(None), "reuse_verdict_read_after_the_step": {"total": md_loop("no_wait", reps=20)["total"]},
-                    "rebuild": md_loop("search")}
+                    "refill": md_loop("refill"), "rebuild": md_loop("search")}
     model.engine.set_precision(current)
     md["paths_taken"] = dict(vg.stats)
     md["note"] = ("positions generated and kept on the device; `total` includes the jitter kernel and two waits for the device per "

@@ -28,6 +28,7 @@ vals = {
     "CPU_MS": f"{d['cpu_baseline']['ms_per_step']:.0f}", "CPU_VALUE": f"{d['cpu_baseline']['value']:,.0f}",
     "MD_REUSE": f"{md['fp32']['reuse_verdict_read_after_the_step']['total']:.2f}", "MD_REUSE_F16": f"{md['f16x3']['reuse_verdict_read_after_the_step']['total']:.2f}",
     "MD_REBUILD": f"{md['fp32']['rebuild']['total']:.2f}", "MD_REBUILD_F16": f"{md['f16x3']['rebuild']['total']:.2f}",
+    "MD_REFILL": f"{md['fp32']['refill']['total']:.2f}", "MD_REFILL_F16": f"{md['f16x3']['refill']['total']:.2f}",
     "FP32_GB": f"{step_gb('fp32'):.2f}", "F16_GB": f"{step_gb('f16x3'):.2f}", "BF16_GB": f"{step_gb('bf16x3'):.2f}",
     "FP32_REV_US": f"{d['roofline']['avg_launch_ms'] * 1e3:.0f}", "FP32_FRAC": f"{d['roofline']['frac']:.2f}",
     "F16_REV_US": f"{f16['roofline']['avg_launch_ms'] * 1e3:.0f}", "F16_FRAC": f"{f16['roofline']['frac']:.2f}",
