@@ -17,16 +17,17 @@ import numpy as np
 import torch
 
 ROOT = Path(__file__).resolve().parent.parent
-for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
+for p in (ROOT, ROOT / "torch-m3gnet_amd"):
     sys.path.insert(0, str(p))
-from helpers import build_engine_model  # noqa: E402  (fixture weights)
 from torch_m3gnet.data import MaterialGraphKey as K  # noqa: E402
 from torch_m3gnet.data.md import VerletGraph  # noqa: E402
+from torch_m3gnet.model.build import build_model_from_npz  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dt = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 temperature = float(sys.argv[3]) if len(sys.argv) > 3 else 300.0
-model, cfg = build_engine_model("cu32fit", "ref")
+model = build_model_from_npz(ROOT / "tests" / "golden" / "model_fitted_lj.npz")   # (weights as data; nothing of the test code runs here)
+cutoff, threebody_cutoff = 5.0, 4.0
 if len(sys.argv) > 4:
     model.engine.set_precision(sys.argv[4])
 
@@ -42,7 +43,7 @@ dev = torch.device("cuda")
 pos = torch.tensor(pos0 + rng.normal(0, 0.01, pos0.shape), device=dev)
 vel = torch.tensor(rng.normal(0, np.sqrt(kB * temperature / mass * acc_unit), pos0.shape), device=dev)
 vel -= vel.mean(0, keepdim=True)
-vg = VerletGraph([lat], [np.full(n_atoms, 29)], cfg.cutoff, cfg.threebody_cutoff, skin=0.4, device=dev)
+vg = VerletGraph([lat], [np.full(n_atoms, 29)], cutoff, threebody_cutoff, skin=0.4, device=dev)
 
 
 def energy_forces(p):

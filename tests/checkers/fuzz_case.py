@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """One case of tests/checkers/fuzz_parity.py (same random stream) in the three precision modes against the fp32 and fp64 oracles:
-    python tools/fuzz_case.py 84      (GPU box)"""
+    python tests/checkers/fuzz_case.py 84      (GPU box)"""
 import sys
 from pathlib import Path
 import numpy as np, torch
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
 from helpers import random_cell_graph

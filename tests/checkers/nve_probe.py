@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Exploration: NVE energy drift of the 108-atom Cu cell on the LJ-fitted weights for several time steps / list strategies."""
+"""Checker (imports the test helpers, which import the oracle): NVE energy drift of the 108-atom Cu cell on the LJ-fitted weights for several time steps / list strategies."""
 import sys
 from pathlib import Path
 import numpy as np, torch
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
 from helpers import build_engine_model

@@ -158,7 +158,7 @@ def test_nve_trajectory_conserves_energy_across_list_updates():
     shrink with the time step; here the error is the integrator's own: it falls by ~4 when dt is halved.
 
     The REFERENCE MODEL's energy is discontinuous where a pair crosses the two-body cutoff (its radial basis does not vanish
-    there: tools/nve_probe.py, 5.5 meV per pair on these weights -- reproduced faithfully, oracle and engine alike), so the test
+    there: tests/checkers/nve_probe.py, 5.5 meV per pair on these weights -- reproduced faithfully, oracle and engine alike), so the test
     keeps the cutoff in a gap of the fcc shells (4.42 A < 4.76 A < 5.10 A) and the amplitude small: no pair crosses it, while
     pairs cross the three-body cutoff (4.38 A, next to the 4.42 A shell) on most steps -- in the `ref` mode of `factors` the
     three-body term is ~1e-9 of the energy, so those crossings rebuild the triplet lists and the topology without a jump."""

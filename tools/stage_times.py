@@ -10,7 +10,7 @@ ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
 import bench  # noqa: E402
-from helpers import fcc_cu_graph  # noqa: E402
+from torch_m3gnet.data.synthetic import fcc_cu_graph  # noqa: E402
 
 model = bench.default_model(torch.device("cuda"))
 graph = fcc_cu_graph(10, 10, 25, seed=0).to("cuda")

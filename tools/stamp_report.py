@@ -10,7 +10,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
-from helpers import fcc_cu_graph  # noqa: E402
+from torch_m3gnet.data.synthetic import fcc_cu_graph  # noqa: E402
 from torch_m3gnet import _lib  # noqa: E402
 from torch_m3gnet.model.build import build_model  # noqa: E402
 

@@ -5,7 +5,7 @@ import sys, torch
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / 'torch-m3gnet_amd'), str(ROOT / 'tests')]
-from helpers import fcc_cu_graph, random_cell_graph
+from torch_m3gnet.data.synthetic import fcc_cu_graph, random_cell_graph
 from torch_m3gnet.data import MaterialGraphKey as K
 from torch_m3gnet.data.material_graph import Batch
 from torch_m3gnet.model.build import build_model

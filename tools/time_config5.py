@@ -14,7 +14,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
-from helpers import random_cell_arrays  # noqa: E402
+from torch_m3gnet.data.synthetic import random_cell_arrays  # noqa: E402
 from torch_m3gnet.data.graph_gpu import batch_from_arrays  # noqa: E402
 from torch_m3gnet.model.build import build_model  # noqa: E402
 from torch_m3gnet.nn.modules import _Topology  # noqa: E402

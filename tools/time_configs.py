@@ -12,7 +12,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
-from helpers import random_cell_graph  # noqa: E402
+from torch_m3gnet.data.synthetic import random_cell_graph  # noqa: E402
 from torch_m3gnet.data.material_graph import Batch  # noqa: E402
 from torch_m3gnet.model.build import build_model  # noqa: E402
 

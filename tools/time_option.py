@@ -14,7 +14,7 @@ import bench  # noqa: E402
 
 model = bench.default_model(torch.device("cuda"))
 cells = tuple(int(v) for v in os.environ.get("M3G_CELLS", "10 10 25").split())
-from helpers import fcc_cu_graph  # noqa: E402
+from torch_m3gnet.data.synthetic import fcc_cu_graph  # noqa: E402
 
 graph = fcc_cu_graph(*cells, seed=0).to("cuda")
 if os.environ.get("M3G_PRECISION"):

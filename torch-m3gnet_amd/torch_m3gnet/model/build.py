@@ -37,3 +37,24 @@ def build_model(
         stages.append(nn.M3GNetConv(degree=n_max, num_node_features=embedding_dim, num_edge_features=embedding_dim, device=device))
     stages.append(nn.AtomWiseReadout(in_features=embedding_dim, num_layers=3, scale=energy_scale, device=device))
     return nn.Gradient(torch.nn.Sequential(*stages))
+
+
+def build_model_from_npz(path, cutoff: float | None = None, threebody_cutoff: float | None = None) -> nn.Gradient:
+    """A model from an `.npz` archive that holds a `state_dict` (keys `model.<index>.<attr>`, as the reference's checkpoints name
+    them), the `build_model` arguments as `__cfg_<name>` scalars and `__elemental_energies` -- the format of tests/golden/model_*.npz.
+    `cutoff` / `threebody_cutoff` override the archive's (the same weights under other cutoffs are another, equally valid
+    potential)."""
+    import numpy as np
+
+    z = np.load(path)
+    cfg = {k[6:]: z[k].item() for k in z.files if k.startswith("__cfg_")}
+    for k in ("l_max", "n_max", "num_types", "embedding_dim", "num_blocks"):
+        cfg[k] = int(cfg[k])
+    if cutoff is not None:
+        cfg["cutoff"] = float(cutoff)
+    if threebody_cutoff is not None:
+        cfg["threebody_cutoff"] = float(threebody_cutoff)
+    elemental = torch.tensor(z["__elemental_energies"], dtype=torch.float) if "__elemental_energies" in z.files else None
+    model = build_model(elemental_energies=elemental, **cfg)
+    model.load_state_dict({k: torch.tensor(z[k]) for k in z.files if not k.startswith("__")})
+    return model
