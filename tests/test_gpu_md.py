@@ -210,3 +210,46 @@ def test_nve_trajectory_conserves_energy_across_list_updates():
     assert stats["refill"] > 100 and stats["search"] >= 2
     assert swing > 0.2 and drift1 < 3e-4 and drift1 < 1e-3 * swing, (drift1, swing)
     assert 2.0 < drift2 / drift1 < 8.0, (drift1, drift2)                            # second-order integrator error, nothing else
+
+
+def test_verlet_graph_fuzz_random_lattices():
+    """30 random batches (tools/fuzz_graph_build.py's generator: cubic to sheared and left-handed lattices of 2-25 A, 1-120 atoms
+    placed up to half a cell outside the home cell, cutoffs 2.5-9 A, 1-4 structures): a four-step random walk each, the skin-list
+    graph against a fresh build, index tensors identical."""
+    import importlib.util
+    from pathlib import Path
+
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.md import VerletGraph
+
+    spec = importlib.util.spec_from_file_location("fuzz_graph_build", Path(__file__).resolve().parent.parent / "tools" / "fuzz_graph_build.py")
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(123)
+    done = 0
+    paths = {"reuse": 0, "refill": 0, "search": 0}
+    while done < 30:
+        cutoff = float(rng.uniform(2.5, 9.0))
+        tb = float(rng.uniform(0.5, 1.0) * cutoff)
+        cells = [fz.random_cell(rng) for _ in range(int(rng.integers(1, 5)))]
+        if min(abs(np.linalg.det(l)) for l, _ in cells) < 8.0:
+            continue
+        lats, poss = [l for l, _ in cells], [p for _, p in cells]
+        sizes = [len(p) for p in poss]
+        zs = [rng.integers(1, 90, n) for n in sizes]
+        vg = VerletGraph(lats, zs, cutoff, tb, skin=0.35, device=DEV)
+        pos = np.concatenate(poss)
+        try:
+            for step in range(4):
+                pos = pos + rng.normal(0.0, (0.0, 0.25, 0.02, 1e-9)[step], pos.shape)   # the first search, a second one (moves beyond skin / 2), a refill, a reuse
+                g = vg.update(torch.tensor(pos, device=DEV))
+                if g[_K().NUM_TRIPLETS] > 4_000_000:
+                    break
+                _same_graph(g, batch_from_arrays(lats, np.split(pos, np.cumsum(sizes)[:-1]), zs, cutoff, tb, device=DEV))
+        except AssertionError:
+            print(f"case {done}: cutoff {cutoff:.3f} tb {tb:.3f} sizes {sizes}")
+            raise
+        for k in paths:
+            paths[k] += vg.stats[k]
+        done += 1
+    assert paths["reuse"] >= 15 and paths["refill"] >= 60 and paths["search"] >= 50, paths
