@@ -1,12 +1,12 @@
 """Random cells through the GPU graph builder (m3g_neighbor_*, m3g_threebody_*) against the host numpy builder, element by
 element (index tensors identical, fp64 distances to 1e-12): random lattices (cubic to strongly sheared, 2-25 A), 1-120 atoms,
-cutoffs 2.5-9 A, batches of 1-6 structures.  Usage: python tools/fuzz_graph_build.py [cases] [seed]"""
+cutoffs 2.5-9 A, batches of 1-6 structures.  Usage: python tests/checkers/fuzz_graph_build.py [cases] [seed]"""
 import sys
 from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 for p in (ROOT, ROOT / "torch-m3gnet_amd", ROOT / "tests"):
     sys.path.insert(0, str(p))
 from test_gpu_graph_build import _assert_same, _gpu, _host  # noqa: E402

@@ -182,13 +182,13 @@ def test_long_segments_take_the_fallback_paths():
 
 
 def test_random_cells_match_host_builder():
-    """60 random batches (tools/fuzz_graph_build.py: cubic to sheared and left-handed lattices of 2-25 A, 1-120 atoms, cutoffs
+    """60 random batches (tests/checkers/fuzz_graph_build.py: cubic to sheared and left-handed lattices of 2-25 A, 1-120 atoms, cutoffs
     2.5-9 A, 1-6 structures per call) -- the sub-wave image groups of small cells, multi-bin cells and mixed batches."""
     import importlib.util
     import sys
     from pathlib import Path
 
-    path = Path(__file__).resolve().parent.parent / "tools" / "fuzz_graph_build.py"
+    path = Path(__file__).resolve().parent / "checkers" / "fuzz_graph_build.py"
     spec = importlib.util.spec_from_file_location("fuzz_graph_build", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -213,7 +213,7 @@ def test_nve_trajectory_conserves_energy_across_list_updates():
 
 
 def test_verlet_graph_fuzz_random_lattices():
-    """30 random batches (tools/fuzz_graph_build.py's generator: cubic to sheared and left-handed lattices of 2-25 A, 1-120 atoms
+    """30 random batches (tests/checkers/fuzz_graph_build.py's generator: cubic to sheared and left-handed lattices of 2-25 A, 1-120 atoms
     placed up to half a cell outside the home cell, cutoffs 2.5-9 A, 1-4 structures): a four-step random walk each, the skin-list
     graph against a fresh build, index tensors identical."""
     import importlib.util
@@ -222,7 +222,7 @@ def test_verlet_graph_fuzz_random_lattices():
     from torch_m3gnet.data.graph_gpu import batch_from_arrays
     from torch_m3gnet.data.md import VerletGraph
 
-    spec = importlib.util.spec_from_file_location("fuzz_graph_build", Path(__file__).resolve().parent.parent / "tools" / "fuzz_graph_build.py")
+    spec = importlib.util.spec_from_file_location("fuzz_graph_build", Path(__file__).resolve().parent / "checkers" / "fuzz_graph_build.py")
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     rng = np.random.default_rng(123)
