@@ -155,7 +155,9 @@ int m3g_topology_build_hints(int64_t n_atoms, int64_t n_edges, int64_t n_triplet
 /* Sticky error bits the hot call left on a topology buffer (0 = none).  M3G_TOPO_ERR_HINTS: m3g_energy_forces was handed a
  * non-zero m3g_io.topo_hints that is not the word m3g_topology_hints certified for THIS buffer (stale after a rebuild, or copied
  * from another topology): the three-body moment kernels then touch nothing (no out-of-bounds access) and the call's three-body
- * terms, hence its results, are INVALID.  Synchronises the stream. */
+ * terms, hence its results, are INVALID.  m3g_energy_forces itself never reads the word back (that would stall the stream):
+ * a caller that passes hints words around must poll this entry point -- once per topology is enough, the bits are sticky (the
+ * Python engine does so at the second call with a topology).  Synchronises the stream. */
 #define M3G_TOPO_ERR_HINTS 1
 int m3g_topology_status(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
                         int32_t* host_status, void* stream);

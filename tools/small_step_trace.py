@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A few steps of the 32-atom Cu cell (BASELINE configs[0]) for a kernel trace:
-rocprofv3 --kernel-trace --output-format csv -d /tmp/small -- python3 tools/small_step_trace.py ; python tools/step_sequence.py /tmp/small 2"""
+"""A few steps of a small fcc Cu cell (n x n x n conventional cells; n = 2 is BASELINE configs[0]) for a kernel trace:
+rocprofv3 --kernel-trace --output-format csv -d /tmp/small -- python3 tools/small_step_trace.py [precision [n]] ;
+python tools/step_sequence.py /tmp/small 2"""
 import sys
 from pathlib import Path
 
@@ -15,7 +16,8 @@ from torch_m3gnet.data.synthetic import fcc_cu_graph  # noqa: E402
 model = bench.default_model(torch.device("cuda"))
 if len(sys.argv) > 1:
     model.engine.set_precision(sys.argv[1])
-g = fcc_cu_graph(2, 2, 2).to("cuda")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+g = fcc_cu_graph(n, n, n).to("cuda")
 for _ in range(30):
     model(g, forces=True, extras=False)
 torch.cuda.synchronize()

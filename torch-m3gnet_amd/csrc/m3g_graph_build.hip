@@ -458,17 +458,19 @@ __global__ void k_verlet_prep(int64_t N, int64_t S, const double* __restrict__ p
                               const double* __restrict__ lattice, const int64_t* __restrict__ batch, double* pos_w, int32_t* wrap,
                               unsigned long long* acc) {
   const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (a >= N) return;
-  int64_t s = batch[a];
-  if (s < 0 || s >= S) s = 0;
-  const LatticeFrame fr = lattice_frame(lattice + s * 9);
-  const double x = pos[a * 3], y = pos[a * 3 + 1], z = pos[a * 3 + 2];
-  double f[3], w[3], pw[3];
-  wrap_point(fr.lat, fr.inv, x, y, z, f, w, pw);
-  for (int c = 0; c < 3; ++c) { pos_w[a * 3 + c] = pw[c]; wrap[a * 3 + c] = (int32_t)w[c]; }
-  const double dx = x - pos_ref[a * 3], dy = y - pos_ref[a * 3 + 1], dz = z - pos_ref[a * 3 + 2];
-  double m = dx * dx + dy * dy + dz * dz;
-  if (!(m >= 0.0)) m = 1e300;   // NaN positions: force the rebuild path (which reports them)
+  double m = 0.0;   // lanes beyond N stay in the wave reduction below with a neutral value (a shuffle from an exited lane is undefined)
+  if (a < N) {
+    int64_t s = batch[a];
+    if (s < 0 || s >= S) s = 0;
+    const LatticeFrame fr = lattice_frame(lattice + s * 9);
+    const double x = pos[a * 3], y = pos[a * 3 + 1], z = pos[a * 3 + 2];
+    double f[3], w[3], pw[3];
+    wrap_point(fr.lat, fr.inv, x, y, z, f, w, pw);
+    for (int c = 0; c < 3; ++c) { pos_w[a * 3 + c] = pw[c]; wrap[a * 3 + c] = (int32_t)w[c]; }
+    const double dx = x - pos_ref[a * 3], dy = y - pos_ref[a * 3 + 1], dz = z - pos_ref[a * 3 + 2];
+    m = dx * dx + dy * dy + dz * dz;
+    if (!(m >= 0.0)) m = 1e300;   // NaN positions: force the rebuild path (which reports them)
+  }
   // wave maximum first: one atomic per wave (non-negative doubles order like their bit patterns)
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(acc, (unsigned long long)__double_as_longlong(m));

@@ -278,8 +278,16 @@ __global__ void __launch_bounds__(256) k_tb_fast(int64_t blocks, const int32_t* 
   const int lane = threadIdx.x & 63;
   if (b >= blocks) return;
   int na = 0, a0 = 0;
-  if (b * kTbRows < *n_act) {
+  const int A = *n_act;
+  if (b * kTbRows < A) {
     const int lo = win[6 * b], hi = win[6 * b + 1];
+    // This kernel runs in the optimistic pass, BEFORE the malformed-graph flags are read back: an edge list not sorted by centre
+    // leaves row_ptr / arow_ptr non-monotonic and k_tb_windows then writes windows with hi <= lo (or beyond A).  Such a window
+    // is never used (the build raises), but it must not be dereferenced here: act_list[hi - 1] would index padding.
+    if (lo < 0 || hi <= lo || hi > A) {
+      if (lane == 0) { fast[2 * b] = 0; fast[2 * b + 1] = 0; }
+      return;
+    }
     a0 = src[act_list[lo]];
     na = src[act_list[hi - 1]] - a0 + 1;
     bool mine = true;

@@ -62,7 +62,9 @@ class Engine:
         # the per-module parameter dicts, collected once: walking `seq.parameters()` (named_modules + de-duplication) costs ~60 us per
         # call, which a caller that waits for the device every step (MD) pays in full; a Parameter that is REPLACED later
         # (`module.weight = Parameter(...)`) lands in the same dict and is seen
-        self._param_dicts = [m._parameters for m in self.seq.modules() if m._parameters]
+        # Every module's dict is kept (a Parameter registered LATER on a module that had none is then seen too), and the `_modules`
+        # dicts are walked per call for their identities: a submodule replaced after construction rebuilds both lists.
+        self._collect_param_dicts()
         self.precision = "fp32"   # the reference's arithmetic; the split modes are explicit opt-ins (set_precision / M3G_PRECISION)
         env_prec = os.environ.get("M3G_PRECISION")   # run a whole test suite in another mode without touching it
         if env_prec:
@@ -84,7 +86,18 @@ class Engine:
             pass
 
     # ---------------------------------------------------------------- parameters
+    def _collect_param_dicts(self) -> None:
+        mods = list(self.seq.modules())
+        self._param_dicts = [m._parameters for m in mods]
+        self._module_dicts = [m._modules for m in mods]
+        self._module_ids = self._tree_ids()
+
+    def _tree_ids(self):
+        return tuple(id(v) for d in self._module_dicts for v in d.values())
+
     def _signature(self, dev):
+        if self._tree_ids() != self._module_ids:   # a submodule was replaced or added: its parameters are new objects
+            self._collect_param_dicts()
         # the plan's device buffers live on the device it was committed under: a change of device is a change of plan state
         sig = [("device", dev.index if dev.index is not None else torch.cuda.current_device())]
         for d in self._param_dicts:
@@ -213,6 +226,14 @@ class Engine:
                 triplet_angles=p(out.get(K.TRIPLET_ANGLES)), mid_edge_features=p(out.get(K.MID_EDGE_FEATURES)),
                 topo_hints=topo.hints_for_call() if self.topology_hints else 0,
             )
+            # The hot call leaves sticky error bits on the topology buffer instead of failing (e.g. a hints word that was not
+            # certified for this buffer: the moment kernels then touch nothing and the results are INVALID, include/m3gnet_hip.h).
+            # Read back once per topology, at its second call (the first one has long finished then: no pipeline stall).
+            calls = getattr(topo, "_engine_calls", 0)
+            if calls == 1 and topo.status():
+                raise RuntimeError(f"m3g_energy_forces flagged topology error bits {topo.status():#x} on the previous call with this "
+                                   "graph: its results were invalid (m3g_topology_status, include/m3gnet_hip.h)")
+            topo._engine_calls = calls + 1
             _lib.check(self.lib.m3g_energy_forces(self.plan, C.byref(io), p(self._workspace), self._workspace.numel(), M._stream()))
         for key, val in out.items():
             graph[key] = val
