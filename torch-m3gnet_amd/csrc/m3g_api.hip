@@ -364,6 +364,12 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->rev_kernel = value;
     return M3G_OK;
   }
+  if (strcmp(name, "small_tiles") == 0) {   // graphs of at most this many 16-edge tiles take the split-tile edge kernels (m3g_edge_small.hip); 0: never
+    if (value < 0) { set_error("small_tiles must be >= 0"); return M3G_ERR_VALUE; }
+    plan->small_tiles = value;
+    drop_graphs(plan);
+    return M3G_OK;
+  }
   if (strcmp(name, "graph_replay") == 0) {
     plan->graph_replay = value != 0;
     if (!plan->graph_replay) drop_graphs(plan);

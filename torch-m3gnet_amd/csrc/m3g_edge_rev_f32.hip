@@ -265,6 +265,7 @@ void launch_edge_rev_f32(const m3g_plan* plan, const Consts& c, const Topo& t, c
                          bool de_is_zero, hipStream_t s) {
   const int64_t tiles = tiles_for(t.E);
   if (tiles == 0) return;
+  if (tiles <= plan->small_tiles && launch_edge_rev_split(plan, c, t, w, b, dx_new, de_is_zero, s)) return;
   const MfmaRevF32Layout L = mfma_rev_f32_layout();
   static_assert(kRevF32Floats * 4 + 16 <= 160 * 1024, "fused fp32 reverse image exceeds the LDS");
   const float* img = plan->d_mfma_revf32 + (size_t)b * L.total;

@@ -214,6 +214,8 @@ struct m3g_plan {
   float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as exact-fp32 chain images (k_readout_mfma; fp32 and bf16x3 modes)
   float* d_readout_img_h = nullptr; // the same layout as scaled two-part fp16 chain images (f16x3 mode), weights scaled by 1 / ro_w_scale_inv
   float ro_w_scale_inv = 1.f;
+  int small_tiles = 1024;        // option "small_tiles": graphs of at most this many 16-edge tiles run the split-tile edge kernels
+                                 // (m3g_edge_small.hip: a tile over the four SIMDs of a CU, operands in registers); 0 = never
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   bool readout_f16 = false; // option "readout_f16": the readout layers on scaled two-part fp16 chains in the f16x3 mode (5 us faster at 10,000
                             // atoms); default: exact-fp32 chains in every mode -- the per-atom energy can be the ill-conditioned remainder of its
@@ -455,6 +457,11 @@ void launch_edge_rev_fused(const m3g_plan* plan, const Consts& c, const Topo& t,
                            bool de_is_zero, hipStream_t s);
 void launch_edge_rev_f32(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new,
                          bool de_is_zero, hipStream_t s);
+// edge_small.hip: the exact-fp32 edge kernels with one tile split over the four waves of a workgroup (small systems); false: the
+// configuration is not one they cover (another precision / A-B option / stamps) -- the caller then launches the persistent kernel
+bool launch_edge_fwd_split(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, bool for_reverse, hipStream_t s);
+bool launch_edge_rev_split(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* dx_new, bool de_is_zero,
+                           hipStream_t s);
 void launch_embed_edges_soa(const Consts& c, const float* adj_t, const float* h, float* soa, int64_t E, hipStream_t s);
 void launch_embed_edges_reverse_soa(const float* adj, const float* h, const float* de_soa, float* dh_slice, int64_t E, hipStream_t s);
 void launch_embed_nodes_only(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,
