@@ -203,8 +203,10 @@ def cpu_baseline(cells=(10, 10, 25), steps=3):
     return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "ms_per_step": dt * 1e3,
             "threads_1": {"value": n / dt1, "unit": "atom-steps/s", "cores": 1, "ms_per_step": dt1 * 1e3},
+            "threads_note": "deliberately capped at 16 threads = the host-core share a one-GPU box of this pool gives a job (BASELINE.md asks for all "
+                            "physical cores; the port is bandwidth-bound on [3,3,T] tensors: 16 threads are 1.8x one thread)",
             "sample": f"the headline workload itself: {n}-atom fcc Cu supercell ({'x'.join(map(str, cells))} cells), fp32, {steps} timed "
-                      f"steps after 1 warm-up at {cores} threads ({dt * 1e3:.0f} ms/step), then 1 timed step at 1 thread "
+                      f"steps after 1 warm-up at {cores} threads -- a deliberate cap, the per-GPU host-core share of the box -- ({dt * 1e3:.0f} ms/step), then 1 timed step at 1 thread "
                       f"({dt1 * 1e3:.0f} ms/step), torch {torch.__version__} CPU"}
 
 
@@ -556,7 +558,35 @@ def measure_beside(model, device):
         return (time.perf_counter() - t0) / reps * 1e3
 
     small = fcc_cu_graph(2, 2, 2).to(device)
-    rec = {"step_ms_32_atom_cu_cell": per_call(lambda: model(small, forces=True, extras=False), 50, warm=5)}
+    rec = {"step_ms_32_atom_cu_cell": per_call(lambda: model(small, forces=True, extras=False), 200, warm=20)}
+    mid = fcc_cu_graph(6, 6, 6).to(device)
+    rec["step_ms_864_atom_cu_cell"] = per_call(lambda: model(mid, forces=True, extras=False), 100, warm=10)
+    # MD-style iteration on the two small cells (VerletGraph.evaluate, reuse path: what an MD user of a small cell pays per step)
+    for n_cells, key in ((2, "md_iteration_ms_32_atom_cell"), (6, "md_iteration_ms_864_atom_cell")):
+        gi_s = np.stack(np.meshgrid(np.arange(n_cells), np.arange(n_cells), np.arange(n_cells), indexing="ij"), -1)
+        base_s = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+        p0 = torch.tensor((gi_s.reshape(-1, 1, 3) + base_s[None]).reshape(-1, 3) * 3.61, device=device)
+        vgs = VerletGraph([np.eye(3) * n_cells * 3.61], [np.full(p0.size(0), 29)], 5.0, 4.0, skin=0.5, device=device)
+        gen_s = torch.Generator(device=device)
+        gen_s.manual_seed(0)
+
+        def it_small():
+            vgs.evaluate(model, p0 + (torch.rand(p0.shape, generator=gen_s, device=device, dtype=torch.float64) - 0.5) * 0.05, forces=True, extras=False)
+
+        rec[key] = per_call(it_small, 200, warm=20)
+    # BASELINE config 5 (2,000 atoms in L = 31.1 A, cutoff 6 A, three-body cutoff 4 A and 6 A): step time on a model of those cutoffs
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.synthetic import random_cell_arrays
+    from torch_m3gnet.model.build import build_model
+
+    lat5, pos5, z5 = random_cell_arrays(2000, 31.1, seed=0)
+    for tb in (4.0, 6.0):
+        torch.manual_seed(0)
+        m5 = build_model(6.0, tb, 3, 3, 95, 64, 3).to(device)
+        m5.engine.set_precision(model.engine.precision)
+        g5 = batch_from_arrays([lat5], [pos5], [z5], 6.0, tb)
+        rec[f"step_ms_config5_r3_{int(tb)}A"] = per_call(lambda: m5(g5, forces=True, extras=False), 20, warm=3)
+        del m5, g5
     a = 3.61
     base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
     gi = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(25), indexing="ij"), -1)
@@ -753,6 +783,19 @@ def main():
         if world == 1 and tuple(args.cells) == (10, 10, 25):
             out["beside"] = measure_beside(model, device)
             log(f"beside: {out['beside']}")
+        # the secondary figures as ONE flat dict of numbers under `config` (the driver's record keeps `config`; the full sub-records
+        # stay in the top-level keys above)
+        bs = out.get("beside", {})
+        md = bs.get("md_iteration_ms_10k_atom_cell", {}).get(args.precision, {})
+        out["config"]["secondary"] = {
+            **{f"{m}_ms_per_step": out[m]["ms_per_step"] for m in other_modes if m in out},
+            "config4_ms_per_step": out["config4_sharded"]["ms_per_step"],
+            **{k: bs[k] for k in ("step_ms_32_atom_cu_cell", "step_ms_864_atom_cu_cell", "md_iteration_ms_32_atom_cell",
+                                  "md_iteration_ms_864_atom_cell", "step_ms_config5_r3_4A", "step_ms_config5_r3_6A") if k in bs},
+            **({f"md_10k_{args.precision}_{k}_ms": md[k]["total"] for k in ("reuse", "refill", "rebuild") if k in md}),
+            **({f"md_10k_{args.precision}_reuse_no_wait_ms": md["reuse_verdict_read_after_the_step"]["total"]}
+               if "reuse_verdict_read_after_the_step" in md else {}),
+        }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tuple(args.cells))

@@ -19,9 +19,26 @@ def test_generator_reproduces_the_committed_fixtures(tmp_path):
     proc = subprocess.run([sys.executable, str(GOLDEN / "generate_golden.py"), "--out", str(tmp_path)], capture_output=True, text=True,
                           timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
-    committed = sorted(p.name for p in GOLDEN.glob("*.npz"))
+    committed = sorted(p.name for p in GOLDEN.glob("*.npz") if not p.name.startswith("big_"))   # (big_*: the opt-in test below)
     assert sorted(p.name for p in tmp_path.glob("*.npz")) == committed
     for name in committed:
+        new, old = np.load(tmp_path / name), np.load(GOLDEN / name)
+        assert sorted(new.files) == sorted(old.files), name
+        for key in old.files:
+            assert new[key].dtype == old[key].dtype and new[key].shape == old[key].shape, (name, key)
+            assert new[key].tobytes() == old[key].tobytes(), (name, key)
+
+
+@pytest.mark.skipif(not Path("/root/reference/src/torch_m3gnet").is_dir(), reason="the reference lives in the build container only")
+@pytest.mark.skipif(not __import__("os").environ.get("M3G_PIN_CU10K"), reason="opt-in (M3G_PIN_CU10K=1): ~10 min of one CPU thread and ~20 GB of host memory")
+def test_generator_reproduces_the_10k_atom_fixture(tmp_path):
+    """BASELINE config 3 at full size: the reference's own outputs for the 10,000-atom cell (big_cu10k_{ref,doc}.npz, outputs only)
+    regenerate bit-identically from the committed generator.  Opt-in: the reference's autograd over 3 M triplets takes ~5 min per
+    `factors` mode on one thread, beyond the budget of the default CPU suite."""
+    proc = subprocess.run([sys.executable, str(GOLDEN / "generate_golden.py"), "--out", str(tmp_path), "--cases", "cu10k"], capture_output=True,
+                          text=True, timeout=3000)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    for name in ("big_cu10k_ref.npz", "big_cu10k_doc.npz"):
         new, old = np.load(tmp_path / name), np.load(GOLDEN / name)
         assert sorted(new.files) == sorted(old.files), name
         for key in old.files:

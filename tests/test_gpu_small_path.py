@@ -98,3 +98,39 @@ def test_small_path_is_deterministic_and_selected_by_size():
     g = model(engine_graph(graph))
     assert torch.equal(g[K.TOTAL_ENERGY], ref[K.TOTAL_ENERGY])
     assert rel_err(g[K.FORCES], ref[K.FORCES]) < 1e-5
+
+
+@pytest.mark.parametrize("case,mode", [("cu32", "doc"), ("mix", "doc"), ("tri", "doc"), ("mixfit", "doc"), ("alna", "ref")])
+def test_fused_launches_are_bit_identical(case, mode):
+    """Option small_launches: the fused launches (readout + per-structure energy sums; geometry reverse + force gather + virial)
+    form every sum in the order of the kernels they replace -- energies, forces and stresses equal bit for bit."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    outs = []
+    for fused in (1, 0):
+        model, _ = build_engine_model(case, mode)
+        model.engine.set_option("small_launches", fused)
+        _, _, _, graph, _ = load_oracle_case(case, mode)
+        g = model(engine_graph(graph))
+        outs.append({k: g[k].clone() for k in (K.TOTAL_ENERGY, K.SCALED_TOTAL_ENERGY, K.FORCES, K.STRESSES)})
+    for k, v in outs[0].items():
+        assert torch.equal(v, outs[1][k]), k
+
+
+def test_fused_launches_on_a_larger_cell_and_many_structures():
+    """2,048-atom cell (force gather ends with the virial; readout with the energy sum) and a 12-structure batch (more structures
+    than the fused launches walk: the stand-alone sum kernels run) -- identical bits with and without the option."""
+    from helpers import fcc_cu_graph, random_cell_graph
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.material_graph import Batch
+
+    graphs = [fcc_cu_graph(8, 8, 8).to("cuda"), Batch.from_data_list([random_cell_graph(12, 6.0, s) for s in range(12)]).to("cuda")]
+    for g0 in graphs:
+        outs = []
+        for fused in (1, 0):
+            model, _ = build_engine_model("cu32", "doc")
+            model.engine.set_option("small_launches", fused)
+            g = model(g0.clone())
+            outs.append({k: g[k].clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES)})
+        for k, v in outs[0].items():
+            assert torch.equal(v, outs[1][k]), k

@@ -1,6 +1,6 @@
 # round 5: small-path tests, then the step sequence of the 32- and 864-atom cells and the small-cell timings
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_small_path.py -x -q > gpurun_out/r05_small_tests.log 2>&1 || { tail -30 gpurun_out/r05_small_tests.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_small_path.py tests/test_gpu_determinism.py -x -q > gpurun_out/r05_small_tests.log 2>&1 || { tail -30 gpurun_out/r05_small_tests.log; exit 1; }
 tail -3 gpurun_out/r05_small_tests.log
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

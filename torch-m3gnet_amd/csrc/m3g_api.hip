@@ -173,7 +173,9 @@ Work work_carve(const Consts& c, bool mfma, int save_acts, int64_t N, int64_t E,
     w.de = take(e * kDP);
     for (int b = 0; b < c.B; ++b) w.act[b] = take(e * 8 * kDP);
   }
-  // tail scratch for optional outputs the caller did not ask for
+  // tail scratch for optional outputs the caller did not ask for ([N] per-atom energies, [2 S] sums), then the step's sync words
+  w.sync = p ? (int32_t*)(p + off + (n + (size_t)S * 2) * sizeof(float)) : nullptr;
+  static_assert(kSyncWords <= 64, "the tail scratch reserves 64 words");
   off += align_up((n + (size_t)S * 2 + 64) * sizeof(float));
   w.total_bytes = off;
   return w;
@@ -367,6 +369,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
   if (strcmp(name, "small_tiles") == 0) {   // graphs of at most this many 16-edge tiles take the split-tile edge kernels (m3g_edge_small.hip); 0: never
     if (value < 0) { set_error("small_tiles must be >= 0"); return M3G_ERR_VALUE; }
     plan->small_tiles = value;
+    drop_graphs(plan);
+    return M3G_OK;
+  }
+  if (strcmp(name, "small_launches") == 0) {   // 0: never fuse the small-system launches (A/B tests; results are bit-identical either way)
+    plan->small_launches = value != 0;
     drop_graphs(plan);
     return M3G_OK;
   }
@@ -751,9 +758,12 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
       else launch_embed_reverse(c, W, wl, t, w, s);
     }
     M3G_STAGE(ST_GEOM_REV);
-    if (mfma) launch_geometry_reverse(c, t, w, w.dh_parts, fused_rev ? c.B : 2 * c.B + 1, io->forces, io->stresses, s);
+    // few structures: the force-gather launch ends with the reference virial (one launch less, bit-identical)
+    const bool fuse = mfma && plan->small_launches && plan->stress_mode == 0;
+    bool tail_fused = false;
+    if (mfma) tail_fused = launch_geometry_reverse(c, t, w, w.dh_parts, fused_rev ? c.B : 2 * c.B + 1, io->forces, io->stresses, s, fuse, io->pos, io->lattice);
     else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, io->stresses, s);
-    if (io->stresses) {
+    if (io->stresses && !tail_fused) {
       if (plan->stress_mode == 1) launch_stress_pair(t, w, io->lattice, io->stresses, s);
       else launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);
     }

@@ -3,6 +3,7 @@
 //            nn/interaction.py:268-350,389-400, nn/gradient.py:35-62.
 // All HBM-bound elementwise work: one thread per edge / atom, coalesced SoA-ish rows.
 #include "m3g_internal.h"
+#include "m3g_struct_sum.h"
 
 namespace m3g {
 
@@ -73,8 +74,10 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int
                                                   const int32_t* __restrict__ shift, float* __restrict__ u,
                                                   float* __restrict__ dist, float* __restrict__ h, float* __restrict__ hp,
                                                   float* __restrict__ q, float* __restrict__ qp, float* __restrict__ fc3,
-                                                  float* __restrict__ fc3p, const int32_t* __restrict__ act_id) {
+                                                  float* __restrict__ fc3p, const int32_t* __restrict__ act_id, int32_t* __restrict__ sync) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // the step's "last workgroup" counters (Work::sync): cleared by the first kernel of every step
+  if (sync && blockIdx.x == 0 && threadIdx.x < kSyncWords) sync[threadIdx.x] = 0;
   if (e >= E) return;
   int i = src[e], j = dst[e], s = batch[i];
   float ls = c.length_scale;
@@ -135,45 +138,91 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int
   }
 }
 
-__global__ void __launch_bounds__(256) k_geometry_reverse(Consts c, int64_t E, const float* __restrict__ u,
-                                                          const float* __restrict__ dist, const float* __restrict__ hp,
-                                                          const float* __restrict__ dh, int dh_parts, const float* __restrict__ dd,
-                                                          const float* __restrict__ du, float* __restrict__ dr,
-                                                          const int32_t* __restrict__ act_id) {
-  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  // dd / du (three-body share of dL/dd, dL/du) hold one row per ACTIVE edge; act_id == nullptr: no three-body reverse ran
-  const int ar = act_id ? act_id[e] : -1;
-  float g = ar >= 0 ? dd[ar] : 0.f;
-  // dL/dh arrives in `dh_parts` slices (one per reverse kernel that produced a share); summed here, in a fixed order
+// dE/dr of one edge from dL/dd (three-body share dd + the radial-basis share dh . h') and dL/du (projected off u):
+// dd / du hold one row per ACTIVE edge (act_id == nullptr: no three-body reverse ran); dL/dh arrives in `dh_parts` slices (one
+// per reverse kernel that produced a share), summed here in a fixed order
+struct GeomRev {
+  int64_t E;
+  const float *u, *dist, *hp, *dh;
+  int dh_parts;
+  const float *dd, *du;
+  const int32_t* act_id;
+};
+__device__ __forceinline__ void edge_dr(const GeomRev& a, int64_t e, float& rx, float& ry, float& rz) {
+  // Nothing here is left to the compiler's choice of which multiply-add pairs to contract: every fused operation is written out
+  // (the placement the kernel compiled to in round 4), so the bits do not depend on the context the function is inlined into.
+#pragma clang fp contract(off)
+  const int ar = a.act_id ? a.act_id[e] : -1;
+  float g = ar >= 0 ? a.dd[ar] : 0.f;
   float dhs[kRP] = {0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < dh_parts; ++p) {
-    const float4 t = *(const float4*)(dh + ((int64_t)p * E + e) * kRP);
+  for (int p = 0; p < a.dh_parts; ++p) {
+    const float4 t = *(const float4*)(a.dh + ((int64_t)p * a.E + e) * kRP);
     dhs[0] += t.x; dhs[1] += t.y; dhs[2] += t.z; dhs[3] += t.w;
   }
   {
-    const float4 t = *(const float4*)(hp + e * kRP);
-    g += dhs[0] * t.x + dhs[1] * t.y + dhs[2] * t.z + dhs[3] * t.w;
+    const float4 t = *(const float4*)(a.hp + e * kRP);
+    float dot = dhs[1] * t.y;
+    dot = __builtin_fmaf(dhs[0], t.x, dot);
+    dot = __builtin_fmaf(dhs[2], t.z, dot);
+    dot = __builtin_fmaf(dhs[3], t.w, dot);
+    g = g + dot;
   }
-  float ux = u[e * 3], uy = u[e * 3 + 1], uz = u[e * 3 + 2];
+  const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
   float ax = 0.f, ay = 0.f, az = 0.f;
-  if (ar >= 0) { ax = du[(int64_t)ar * 3]; ay = du[(int64_t)ar * 3 + 1]; az = du[(int64_t)ar * 3 + 2]; }
-  float proj = ax * ux + ay * uy + az * uz;
-  float inv = 1.f / dist[e];
-  dr[e * 3 + 0] = g * ux + (ax - proj * ux) * inv;
-  dr[e * 3 + 1] = g * uy + (ay - proj * uy) * inv;
-  dr[e * 3 + 2] = g * uz + (az - proj * uz) * inv;
+  if (ar >= 0) { ax = a.du[(int64_t)ar * 3]; ay = a.du[(int64_t)ar * 3 + 1]; az = a.du[(int64_t)ar * 3 + 2]; }
+  const float proj = __builtin_fmaf(ax, ux, ay * uy) + az * uz;
+  const float inv = 1.f / a.dist[e];
+  rx = __builtin_fmaf(g, ux, __builtin_fmaf(-proj, ux, ax) * inv);
+  ry = __builtin_fmaf(g, uy, __builtin_fmaf(-proj, uy, ay) * inv);
+  rz = __builtin_fmaf(g, uz, __builtin_fmaf(-proj, uz, az) * inv);
+}
+__global__ void __launch_bounds__(256) k_geometry_reverse(GeomRev a, float* __restrict__ dr) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= a.E) return;
+  float rx, ry, rz;
+  edge_dr(a, e, rx, ry, rz);
+  dr[e * 3 + 0] = rx;
+  dr[e * 3 + 1] = ry;
+  dr[e * 3 + 2] = rz;
 }
 
 // F_i = (sum_{e in row(i)} dr_e - sum_{e: dst(e)=i} dr_e) / length_scale   (no atomics: both CSR lists)
 // 16 lanes per atom (a DPP row): each lane takes every 16th edge of both lists, then the row is reduced -- a thread per
 // atom left 160 waves on the whole chip walking 84 dependent 12-byte gathers each.
+__device__ __forceinline__ float inv_volume(const float* __restrict__ L) {
+  const float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
+  return 1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
+}
+// sum_a pos_a (x) F_a / V of structure s (nn/gradient.py:39-62), Voigt order
+template <int REAL>
+__device__ __forceinline__ void struct_stress(int s, const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags, int64_t n_atoms,
+                                              const int32_t* __restrict__ batch, const float* __restrict__ pos, const float* __restrict__ lattice,
+                                              const float* forces, float* __restrict__ stresses, float* part) {
+  float tot[6];
+  struct_reduce<6, REAL>(s, struct_ptr, flags, n_atoms, batch, tot, part, [&](int a, int ss, float* v) {
+    const float inv = inv_volume(lattice + (int64_t)ss * 9);
+    const float px = pos[a * 3], py = pos[a * 3 + 1], pz = pos[a * 3 + 2];
+    const float fx = forces[a * 3], fy = forces[a * 3 + 1], fz = forces[a * 3 + 2];
+    v[0] = px * fx * inv; v[1] = py * fy * inv; v[2] = pz * fz * inv;
+    v[3] = py * fz * inv; v[4] = pz * fx * inv; v[5] = px * fy * inv;
+  });
+  if (threadIdx.x < 6) stresses[(int64_t)s * 6 + threadIdx.x] = tot[threadIdx.x];
+}
+// virial inputs of the launches that end with the reference stress (sum_a pos_a (x) F_a / V per structure) formed by their LAST
+// workgroup: counter == nullptr -> no stress in this launch
+struct StressTail {
+  int64_t S;
+  const int32_t *struct_ptr, *flags, *batch;
+  const float *pos, *lattice;
+  float* stresses;
+  int32_t* counter;
+};
 __global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_t N, const int32_t* __restrict__ row_ptr,
                                                       const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_edge,
-                                                      const float* __restrict__ dr, float* __restrict__ forces,
-                                                      float* __restrict__ stresses, int64_t n_stress) {
+                                                      const float* __restrict__ dr, float* forces,
+                                                      float* __restrict__ stresses, int64_t n_stress, StressTail st) {
   const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  // the stress kernel that follows accumulates with atomics: its output is cleared here instead of by memset launches
+  // (a stress kernel that accumulates with atomics would need its output cleared: kept for the generic path's callers)
   if (blockIdx.x == 0) for (int64_t k = threadIdx.x; k < n_stress; k += blockDim.x) stresses[k] = 0.f;
   const int64_t i = gid >> 4;
   const int l = (int)(gid & 15);
@@ -194,69 +243,35 @@ __global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_
     forces[i * 3 + 1] = fy / length_scale;
     forces[i * 3 + 2] = fz / length_scale;
   }
+  if (!st.counter) return;   // uniform
+  // publish this workgroup's forces, then count it: the workgroup that counts last sees all forces and forms the virial of
+  // every structure exactly as k_struct_stress does (no workgroup ever waits for another)
+  __shared__ float part[kStructThreads * 6];
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(st.counter, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int s = 0; s < (int)st.S; ++s) struct_stress<256>(s, st.struct_ptr, st.flags, N, st.batch, st.pos, st.lattice, forces, st.stresses, part);
 }
 
-// Per-structure sums without atomics: the atoms of a structure are contiguous when `batch` is sorted (as the reference's
-// batching produces it), so one workgroup per structure adds its atoms in a fixed order -- strided private sums, then a
-// fixed LDS tree: energies and stresses are then bit-reproducible like the forces.  An unsorted `batch` (flags[3] != 0, which
-// the reference's scatter_sum accepts) has no contiguous range: the structure's workgroup then walks ALL atoms and keeps its
-// own -- O(N S) index tests on a path nobody benchmarks, in exchange for the same fixed order, no float atomics anywhere and
-// no second set of kernels that is launched only to return (round 2 launched both kinds every step).
-constexpr int kStructThreads = 1024;   // one large cell is ONE workgroup: 1,024 threads keep its strided loop at ~10 trips for 10k atoms
-template <int W, class F>
-__device__ __forceinline__ void struct_reduce(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags, int64_t n_atoms,
-                                              const int32_t* __restrict__ batch, float (&total)[W], F per_atom) {
-  __shared__ float part[kStructThreads][W];
-  const int s = blockIdx.x;
-  float acc[W];
-#pragma unroll
-  for (int k = 0; k < W; ++k) acc[k] = 0.f;
-  const bool sorted = flags[3] == 0;   // uniform
-  const int a0 = sorted ? struct_ptr[s] : 0, a1 = sorted ? struct_ptr[s + 1] : (int)n_atoms;
-  for (int a = a0 + (int)threadIdx.x; a < a1; a += kStructThreads) {
-    if (!sorted && batch[a] != s) continue;
-    float v[W];
-    per_atom(a, s, v);
-#pragma unroll
-    for (int k = 0; k < W; ++k) acc[k] += v[k];
-  }
-#pragma unroll
-  for (int k = 0; k < W; ++k) part[threadIdx.x][k] = acc[k];
-  __syncthreads();
-  for (int off = kStructThreads / 2; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off)
-#pragma unroll
-      for (int k = 0; k < W; ++k) part[threadIdx.x][k] += part[threadIdx.x + off][k];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < W; ++k) total[k] = part[0][k];   // every thread holds the sums
-}
-__device__ __forceinline__ float inv_volume(const float* __restrict__ L) {
-  const float cx = L[4] * L[8] - L[5] * L[7], cy = L[5] * L[6] - L[3] * L[8], cz = L[3] * L[7] - L[4] * L[6];
-  return 1.f / fabsf(L[0] * cx + L[1] * cy + L[2] * cz);
-}
 __global__ void __launch_bounds__(kStructThreads) k_struct_stress(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
                                                        int64_t n_atoms, const int32_t* __restrict__ batch,
                                                        const float* __restrict__ pos, const float* __restrict__ lattice,
                                                        const float* __restrict__ forces, float* __restrict__ stresses) {
-  float tot[6];
-  struct_reduce<6>(struct_ptr, flags, n_atoms, batch, tot, [&](int a, int s, float* v) {
-    const float inv = inv_volume(lattice + (int64_t)s * 9);
-    const float px = pos[a * 3], py = pos[a * 3 + 1], pz = pos[a * 3 + 2];
-    const float fx = forces[a * 3], fy = forces[a * 3 + 1], fz = forces[a * 3 + 2];
-    v[0] = px * fx * inv; v[1] = py * fy * inv; v[2] = pz * fz * inv;
-    v[3] = py * fz * inv; v[4] = pz * fx * inv; v[5] = px * fy * inv;
-  });
-  if (threadIdx.x < 6) stresses[(int64_t)blockIdx.x * 6 + threadIdx.x] = tot[threadIdx.x];
+  __shared__ float part[kStructThreads * 6];
+  struct_stress<kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, pos, lattice, forces, stresses, part);
 }
 __global__ void __launch_bounds__(kStructThreads) k_struct_stress_pair(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
                                                             int64_t n_atoms, const int32_t* __restrict__ batch,
                                                             const int32_t* __restrict__ row_ptr, const float* __restrict__ lattice,
                                                             const float* __restrict__ u, const float* __restrict__ dist,
                                                             const float* __restrict__ dr, float* __restrict__ stresses) {
+  __shared__ float part[kStructThreads * 6];
   float tot[6];
-  struct_reduce<6>(struct_ptr, flags, n_atoms, batch, tot, [&](int a, int s, float* v) {
+  struct_reduce<6, kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, tot, part, [&](int a, int s, float* v) {
     const float inv = -inv_volume(lattice + (int64_t)s * 9);
 #pragma unroll
     for (int k = 0; k < 6; ++k) v[k] = 0.f;
@@ -272,16 +287,12 @@ __global__ void __launch_bounds__(kStructThreads) k_struct_stress_pair(const int
   });
   if (threadIdx.x < 6) stresses[(int64_t)blockIdx.x * 6 + threadIdx.x] = tot[threadIdx.x];
 }
-// scaled_total[s] = sum of the structure's scaled atomic energies (nn/readout.py:49-53), total[s] = energy_scale * that (:55-57)
+
 __global__ void __launch_bounds__(kStructThreads) k_struct_energy(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
                                                        int64_t n_atoms, const int32_t* __restrict__ batch, const float* __restrict__ ea,
                                                        float energy_scale, float* __restrict__ scaled_total, float* __restrict__ total) {
-  float tot[1];
-  struct_reduce<1>(struct_ptr, flags, n_atoms, batch, tot, [&](int a, int, float* v) { v[0] = ea[a]; });
-  if (threadIdx.x == 0) {
-    scaled_total[blockIdx.x] = tot[0];
-    total[blockIdx.x] = energy_scale * tot[0];
-  }
+  __shared__ float part[kStructThreads];
+  struct_energy<kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, ea, energy_scale, scaled_total, total, part);
 }
 void launch_struct_energy(const Consts& c, const Topo& t, const float* ea, float* scaled_total, float* total, hipStream_t s) {
   if (t.S > 0)
@@ -325,9 +336,12 @@ static inline dim3 grid_for(int64_t n, int tpb = 256) { return dim3((unsigned)((
 
 void launch_geometry(const Consts& c, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
                      const Work& w, hipStream_t s) {
-  if (t.E == 0) return;
+  if (t.E == 0) {   // no edge, no geometry kernel: the step's sync words are cleared by a memset instead
+    if (w.sync) (void)hipMemsetAsync(w.sync, 0, sizeof(int32_t) * kSyncWords, s);
+    return;
+  }
   M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_geometry<true, L, R>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos,
-                                               lattice, shift, w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p, t.act_id));
+                                               lattice, shift, w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p, t.act_id, w.sync));
 }
 
 void launch_distance_only(float length_scale, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
@@ -336,27 +350,32 @@ void launch_distance_only(float length_scale, const Topo& t, const float* pos, c
   Consts c{};
   c.length_scale = length_scale;
   hipLaunchKernelGGL((k_geometry<false, 1, 1>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos, lattice, shift,
-                     u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                     u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-// `stresses` (may be null): cleared by the force-gather kernel for the stress kernel that follows (launch_stress*)
-void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
-                             float* stresses, hipStream_t s) {
-  if (t.E > 0)
-    hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, c, t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, w.dr,
-                       (t.T > 0 && c.B > 0) ? t.act_id : nullptr);
-  if (t.N > 0)
+// Geometry reverse + force gather.  `fuse_stress`: the force-gather launch also forms the reference virial (its last workgroup,
+// bit-identical to k_struct_stress) when the batch has few structures; returns whether it did (else the caller launches
+// launch_stress / launch_stress_pair).
+bool launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
+                             float* stresses, hipStream_t s, bool fuse_stress, const float* pos, const float* lattice) {
+  const GeomRev g{t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, (t.T > 0 && c.B > 0) ? t.act_id : nullptr};
+  if (t.E > 0) hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, g, w.dr);
+  const bool fused = fuse_stress && stresses && w.sync && t.N > 0 && t.N <= kFusedSumsMaxAtoms && t.S > 0 && t.S <= kForceTailMaxStructs;
+  if (t.N > 0) {
+    StressTail st{t.S, t.struct_ptr, t.flags, t.batch, pos, lattice, stresses, fused ? w.sync + kSyncForceTail : nullptr};
     hipLaunchKernelGGL(k_force_gather, grid_for(t.N * 16), dim3(256), 0, s, c.length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge,
-                       w.dr, forces, stresses, stresses ? 6 * t.S : 0);
-  else if (stresses)
+                       w.dr, forces, stresses, (stresses && !fused) ? 6 * t.S : 0, st);
+  } else if (stresses) {
     (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
+  }
+  return fused;
 }
 
 // force gather on its own (generic path, m3g_generic.hip): F = -(d E / d r) summed through both CSR lists, / length_scale
 void launch_force_gather(float length_scale, const Topo& t, const float* dr, float* forces, float* stresses, hipStream_t s) {
   if (t.N > 0)
     hipLaunchKernelGGL(k_force_gather, grid_for(t.N * 16), dim3(256), 0, s, length_scale, t.N, t.row_ptr, t.in_ptr, t.in_edge, dr, forces,
-                       stresses, stresses ? 6 * t.S : 0);
+                       stresses, stresses ? 6 * t.S : 0, StressTail{});
   else if (stresses)
     (void)hipMemsetAsync(stresses, 0, sizeof(float) * 6 * t.S, s);
 }

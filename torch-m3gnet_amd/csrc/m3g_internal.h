@@ -216,6 +216,7 @@ struct m3g_plan {
   float ro_w_scale_inv = 1.f;
   int small_tiles = 1024;        // option "small_tiles": graphs of at most this many 16-edge tiles run the split-tile edge kernels
                                  // (m3g_edge_small.hip: a tile over the four SIMDs of a CU, operands in registers); 0 = never
+  int small_launches = 1;        // option "small_launches": small systems take fused launches (force tail, readout + energy sums, ...)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   bool readout_f16 = false; // option "readout_f16": the readout layers on scaled two-part fp16 chains in the f16x3 mode (5 us faster at 10,000
                             // atoms); default: exact-fp32 chains in every mode -- the per-atom energy can be the ill-conditioned remainder of its
@@ -379,16 +380,27 @@ struct Work {
   // tile's first run (the centre owning column 0), seg_first[i] = sum of the run in which centre i's row starts mid-tile
   float* seg_head;            // [tiles][4*kDP]
   float* seg_first;           // [N][4*kDP]
+  int32_t* sync;              // [kSyncWords] "last workgroup" counters of the step's fused launches: cleared by k_geometry, the first
+                              // kernel of every step (nullptr when carved without a base)
   size_t total_bytes;
 };
+constexpr int kSyncWords = 16;
+constexpr int kSyncForceTail = 0, kSyncReadout = 1, kSyncNodeRev = 2;   // (+ block index for the per-block ones)
+// fused launches: the per-structure sums (energies after the readout, virial after the force gather) are formed by the LAST
+// workgroup of the producing launch when the batch has at most this many structures (it walks them one after the other)
+constexpr int64_t kForceTailMaxStructs = 8;
+// ... and at most this many atoms: the last workgroup's 256 threads then read <= 8 atoms each (measured on the 10,000-atom cell: 40
+// dependent reads per thread of values other XCDs have just written cost 24 us after the readout and 65 us after the force gather,
+// against 6 and 10 us for the stand-alone sum kernels)
+constexpr int64_t kFusedSumsMaxAtoms = 2048;
 Work work_carve(const Consts& c, bool mfma, int save_acts /* 0 none, 1 p1, 2 p1 + p2 */, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
 
 // ---- kernel launchers (each in its own .hip) -----------------------------------------------------------
 // geometry.hip
 void launch_geometry(const Consts& c, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
                      const Work& w, hipStream_t s);
-void launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
-                             float* stresses, hipStream_t s);
+bool launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
+                             float* stresses, hipStream_t s, bool fuse_stress = false, const float* pos = nullptr, const float* lattice = nullptr);
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s);
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s);

@@ -1,6 +1,7 @@
 // Node-side stages on the matrix pipe: per-node tables TA / TB / v (k_node_pre_mfma, stage S2) and the readout with its
 // reverse (k_readout_mfma, stage S5).  Split from m3g_edge_mfma.hip (shared device code: m3g_edge_common.h).
 #include "m3g_edge_common.h"
+#include "m3g_struct_sum.h"
 
 namespace m3g {
 
@@ -103,13 +104,20 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
 // branch as exact-fp32 MFMA chains (this stage seeds the reverse pass), the final 64 -> 1 products as lane-local dots + a lane-quarter sum, then (forces wanted) the
 // transposed chains back to dE/dx.  All seven weight images (130 KB) resident in LDS; x^B = x^(B-1) + per-centre message
 // sums of the last block is formed while the tile is loaded.  Replaces the vector-ALU k_readout on the MFMA path.
+constexpr int64_t kReadoutSplitMaxTiles = 128;   // up to 2,048 atoms: k_readout_split (one tile per workgroup)
+// per-structure sums formed by the launch's last workgroup (counter == nullptr: a separate k_struct_energy launch follows)
+struct ReadoutSums {
+  const int32_t *struct_ptr, *flags, *batch;
+  float* total;
+  int32_t* counter;
+};
 template <int PREC>   // kPrecF32: exact fp32 MFMA chains; kPrecF16x3: the same layers on scaled two-part fp16 operands (w_inv = 1 / weight scale)
 __global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const float* __restrict__ img, float w_inv, const float* __restrict__ elemental,
                                                       const int64_t* __restrict__ types, const float* __restrict__ x_prev,
                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
                                                       const int32_t* __restrict__ row_ptr, float* __restrict__ x,
-                                                      float* __restrict__ scaled_atomic, float* __restrict__ dx,
-                                                      float* __restrict__ scaled_total, int64_t S) {
+                                                      float* scaled_atomic, float* __restrict__ dx,
+                                                      float* __restrict__ scaled_total, int64_t S, ReadoutSums rs) {
   __shared__ __attribute__((aligned(16))) float lds[ReadoutImg::total + 4 * 16 * kNodeXPitch];
   // the per-structure sums are accumulated with atomics by the next kernel: cleared here instead of a memset launch
   if (blockIdx.x == 0) for (int64_t i = threadIdx.x; i < S; i += blockDim.x) scaled_total[i] = 0.f;
@@ -208,26 +216,205 @@ __global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const
     chain_p<PREC, 4, 4>(lds + ReadoutImg::w1T, dp1, dxb, lv, w_inv);
     if (live) static_for<4>([&]<int blk>() { *(f32x4*)(dx + atom * kDP + blk * 16 + 4 * q) = dxb[blk]; });
   }
+  if (!rs.counter) return;   // uniform
+  // per-structure energy sums by the LAST workgroup of this launch (few structures: one launch less than k_struct_energy, same
+  // fixed summation order -> bit-identical totals; no workgroup waits for another)
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(rs.counter, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  float* part = lds + ReadoutImg::total;   // the x staging area (4 x 16 x kNodeXPitch floats >= kStructThreads)
+  static_assert(4 * 16 * kNodeXPitch >= kStructThreads, "staging area too small for the energy sums");
+  for (int sidx = 0; sidx < (int)S; ++sidx)
+    struct_energy<256>(sidx, rs.struct_ptr, rs.flags, N, rs.batch, scaled_atomic, c.energy_scale, scaled_total, rs.total, part);
+}
+
+// Small systems: one 16-atom tile per WORKGROUP, its four waves each owning a quarter of every layer's output rows (dense
+// block w, gate block 4 + w), the wave's weight operands resident in registers -- the scheme of m3g_edge_small.hip.  A tile is
+// 512 exact-fp32 MFMAs (7 us for the one wave k_readout_mfma gives it, behind a 130-KB image copy); here 128 per wave.
+// Every layer output is the same k-ordered chain, and the two 64 -> 1 sums are formed by every wave over ALL blocks in
+// k_readout_mfma's order (the layer-2 pre-activations cross through LDS): energies and dE/dx are bit-identical.
+template <bool GRAD>
+__global__ void __launch_bounds__(256) k_readout_split(Consts c, int64_t N, const float* __restrict__ img, const float* __restrict__ elemental,
+                                                       const int64_t* __restrict__ types, const float* __restrict__ x_prev,
+                                                       const float* __restrict__ seg_head, const float* __restrict__ seg_first,
+                                                       const int32_t* __restrict__ row_ptr, float* __restrict__ x, float* scaled_atomic,
+                                                       float* __restrict__ dx, float* __restrict__ scaled_total, int64_t S, ReadoutSums rs) {
+  __shared__ __attribute__((aligned(16))) float xs[4 * 16 * kNodeXPitch];   // per-wave x staging (also the energy sums' scratch)
+  __shared__ __attribute__((aligned(16))) float hs[8 * 256];                // exchanged activations / gradients, two blocks per wave
+  const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* xw = xs + w * 16 * kNodeXPitch;
+  // this wave's rows of the images, once, into registers
+  float a_w1[2][16], a_w2[2][16], a_w2t[2][16], a_w1t[32];
+  static_for<2>([&]<int hf>() {
+    static_for<16>([&]<int k>() {
+      a_w1[hf][k] = img[ReadoutImg::w1 + ((hf * 4 + w) * 16 + k) * 64 + lane];
+      a_w2[hf][k] = img[(hf == 0 ? ReadoutImg::w2d : ReadoutImg::w2g) + (w * 16 + k) * 64 + lane];
+      if (GRAD) a_w2t[hf][k] = img[(hf == 0 ? ReadoutImg::w2dT : ReadoutImg::w2gT) + (w * 16 + k) * 64 + lane];
+    });
+  });
+  if (GRAD) static_for<32>([&]<int k>() { a_w1t[k] = img[ReadoutImg::w1T + (w * 32 + k) * 64 + lane]; });
+  f32x4 b1[2], b2[2], w3[8];
+  static_for<2>([&]<int hf>() {
+    b1[hf] = *(const f32x4*)(img + ReadoutImg::b1 + (hf * 4 + w) * 16 + 4 * q);
+    b2[hf] = *(const f32x4*)(img + ReadoutImg::b2 + (hf * 4 + w) * 16 + 4 * q);
+  });
+  static_for<8>([&]<int ob>() { w3[ob] = *(const f32x4*)(img + ReadoutImg::w3 + ob * 16 + 4 * q); });
+  const float b3d = img[ReadoutImg::b3], b3g = img[ReadoutImg::b3 + 1];
+  const int64_t tiles = (N + 15) / 16;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t atom = tile * 16 + m;
+    const bool live = atom < N;
+    // x^B = x^(B-1) + per-centre message sums, formed by every wave for itself (wave 0 stores it)
+    f32x4 xr[4];
+    static_for<4>([&]<int j>() { xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+    if (live) {
+      const float* src = (x_prev ? x_prev : x) + atom * kDP + 16 * q;
+      static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
+      if (x_prev) {
+        const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
+        if (r1 > r0) {
+          if (r0 & 15) static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_first + atom * (4 * kDP) + 16 * q + 4 * j); });
+          for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
+            static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
+        }
+        if (w == 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+      }
+    }
+    static_for<4>([&]<int j>() { *(f32x4*)(xw + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
+    f32x4 xb[4];   // (only this wave reads its staging area: LDS operations of a wave complete in order)
+    static_for<4>([&]<int blk>() { xb[blk] = *(const f32x4*)(xw + m * kNodeXPitch + blk * 16 + 4 * q); });
+    // layer 1, rows w (dense) and 4 + w (gate): p1 -> hidden, p1 keeps SiLU'
+    f32x4 p1d = b1[0], p1g = b1[1];
+    static_for<4>([&]<int blk>() {
+      static_for<4>([&]<int r>() {
+        p1d = mfma16(a_w1[0][blk * 4 + r], xb[blk][r], p1d);
+        p1g = mfma16(a_w1[1][blk * 4 + r], xb[blk][r], p1g);
+      });
+    });
+    f32x4 hd, hg;
+    static_for<4>([&]<int r>() {
+      float p = p1d[r], sg = fsigmoid(p);
+      hd[r] = p * sg; p1d[r] = sg * (1.f + p * (1.f - sg));
+      p = p1g[r]; sg = fsigmoid(p);
+      hg[r] = p * sg; p1g[r] = sg * (1.f + p * (1.f - sg));
+    });
+    *(f32x4*)(hs + w * 256 + lane * 4) = hd;
+    *(f32x4*)(hs + (4 + w) * 256 + lane * 4) = hg;
+    __syncthreads();
+    f32x4 hid[8];
+    static_for<8>([&]<int ob>() { hid[ob] = *(const f32x4*)(hs + ob * 256 + lane * 4); });
+    // layer 2, rows w of both branches
+    f32x4 p2d = b2[0], p2g = b2[1];
+    static_for<4>([&]<int blk>() {
+      static_for<4>([&]<int r>() {
+        p2d = mfma16(a_w2[0][blk * 4 + r], hid[blk][r], p2d);
+        p2g = mfma16(a_w2[1][blk * 4 + r], hid[4 + blk][r], p2g);
+      });
+    });
+    __syncthreads();   // every wave has read the hidden activations: hs is free
+    *(f32x4*)(hs + w * 256 + lane * 4) = p2d;
+    *(f32x4*)(hs + (4 + w) * 256 + lane * 4) = p2g;
+    __syncthreads();
+    f32x4 p2[8];
+    static_for<8>([&]<int ob>() { p2[ob] = *(const f32x4*)(hs + ob * 256 + lane * 4); });
+    // final 64 -> 1 of both branches over ALL blocks, in k_readout_mfma's order
+    float od = 0.f, og = 0.f;
+    static_for<4>([&]<int ob>() {
+      static_for<4>([&]<int r>() {
+        od += w3[ob][r] * fsilu(p2[ob][r]);
+        og += w3[4 + ob][r] * fsilu(p2[4 + ob][r]);
+      });
+    });
+    od = sum_lane_quarters(od) + b3d;
+    og = sum_lane_quarters(og) + b3g;
+    const float sg = fsigmoid(og);
+    if (live && q == 0 && w == 0) {
+      int64_t ty = types[atom];
+      ty = ty < 0 ? 0 : (ty >= c.num_types ? c.num_types - 1 : ty);
+      scaled_atomic[atom] = elemental[ty] / c.energy_scale + od * sg;
+    }
+    if constexpr (GRAD) {
+      // reverse: dL/d eps = energy_scale
+      const float d_od = c.energy_scale * sg, d_og = c.energy_scale * od * sg * (1.f - sg);
+      f32x4 d2d, d2g;
+      static_for<4>([&]<int r>() {
+        d2d[r] = d_od * w3[w][r] * fdsilu(p2d[r]);
+        d2g[r] = d_og * w3[4 + w][r] * fdsilu(p2g[r]);
+      });
+      __syncthreads();   // every wave has read p2
+      *(f32x4*)(hs + w * 256 + lane * 4) = d2d;
+      *(f32x4*)(hs + (4 + w) * 256 + lane * 4) = d2g;
+      __syncthreads();
+      f32x4 d2[8];
+      static_for<8>([&]<int ob>() { d2[ob] = *(const f32x4*)(hs + ob * 256 + lane * 4); });
+      f32x4 dp1d = {0.f, 0.f, 0.f, 0.f}, dp1g = {0.f, 0.f, 0.f, 0.f};
+      static_for<4>([&]<int blk>() {
+        static_for<4>([&]<int r>() {
+          dp1d = mfma16(a_w2t[0][blk * 4 + r], d2[blk][r], dp1d);
+          dp1g = mfma16(a_w2t[1][blk * 4 + r], d2[4 + blk][r], dp1g);
+        });
+      });
+      dp1d *= p1d;
+      dp1g *= p1g;
+      __syncthreads();   // every wave has read d2
+      *(f32x4*)(hs + w * 256 + lane * 4) = dp1d;
+      *(f32x4*)(hs + (4 + w) * 256 + lane * 4) = dp1g;
+      __syncthreads();
+      f32x4 dp1[8];
+      static_for<8>([&]<int ob>() { dp1[ob] = *(const f32x4*)(hs + ob * 256 + lane * 4); });
+      f32x4 dxb = {0.f, 0.f, 0.f, 0.f};
+      static_for<8>([&]<int blk>() { static_for<4>([&]<int r>() { dxb = mfma16(a_w1t[blk * 4 + r], dp1[blk][r], dxb); }); });
+      if (live) *(f32x4*)(dx + atom * kDP + w * 16 + 4 * q) = dxb;
+    }
+    __syncthreads();   // hs is rewritten by the next tile
+  }
+  if (!rs.counter) return;   // uniform
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(rs.counter, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int sidx = 0; sidx < (int)S; ++sidx)
+    struct_energy<256>(sidx, rs.struct_ptr, rs.flags, N, rs.batch, scaled_atomic, c.energy_scale, scaled_total, rs.total, xs);
 }
 
 void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayout& wl, const Topo& t, const int64_t* types,
                          const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
                          bool want_grad, hipStream_t s) {
   if (t.N == 0) (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
+  bool sums_fused = false;
   if (t.N > 0) {
     const int64_t tiles = (t.N + 15) / 16;
     const int wgs = (int)std::min<int64_t>((tiles + 3) / 4, 256);
+    sums_fused = plan->small_launches && w.sync && t.N <= kFusedSumsMaxAtoms && t.S > 0 && t.S <= kForceTailMaxStructs;
+    const ReadoutSums rs{t.struct_ptr, t.flags, t.batch, total, sums_fused ? w.sync + kSyncReadout : nullptr};
+    const bool f16_readout = plan->precision == kPrecF16x3 && plan->readout_f16;
+    if (!f16_readout && plan->small_launches && tiles <= kReadoutSplitMaxTiles) {   // small systems: a tile over the four waves of a workgroup
+      if (want_grad)
+        hipLaunchKernelGGL(k_readout_split<true>, dim3((unsigned)tiles), dim3(256), 0, s, c, t.N, plan->d_readout_img, plan->d_weights + wl.elemental,
+                           types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic, w.dx, scaled_total, t.S, rs);
+      else
+        hipLaunchKernelGGL(k_readout_split<false>, dim3((unsigned)tiles), dim3(256), 0, s, c, t.N, plan->d_readout_img, plan->d_weights + wl.elemental,
+                           types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic, nullptr, scaled_total, t.S, rs);
+    } else
     if (plan->precision == kPrecF16x3 && plan->readout_f16)   // (option; default: exact-fp32 readout in every mode)
       hipLaunchKernelGGL(k_readout_mfma<kPrecF16x3>, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img_h, plan->ro_w_scale_inv,
                          plan->d_weights + wl.elemental, types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic,
-                         want_grad ? w.dx : nullptr, scaled_total, t.S);
+                         want_grad ? w.dx : nullptr, scaled_total, t.S, rs);
     else   // every mode by default: this stage forms the energies and seeds the reverse pass (bf16x3 products here moved the Cu-32 virial from
            // 4.5e-5 to 1.2e-4 of its fp64 value; f16x3 products put a six-atom structure's ill-conditioned energy 5.3e-5 off instead of 9e-6)
       hipLaunchKernelGGL(k_readout_mfma<kPrecF32>, dim3(wgs), dim3(256), 0, s, c, t.N, plan->d_readout_img, 1.f,
                          plan->d_weights + wl.elemental, types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic,
-                         want_grad ? w.dx : nullptr, scaled_total, t.S);
+                         want_grad ? w.dx : nullptr, scaled_total, t.S, rs);
   }
-  launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
+  if (!sums_fused) launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
 }
 
 // types != nullptr (block 0): x is formed from the atom embedding `emb` ([num_types][kDP]) instead of being read
