@@ -159,6 +159,7 @@ int m3g_topology_build_hints(int64_t n_atoms, int64_t n_edges, int64_t n_triplet
  * a caller that passes hints words around must poll this entry point -- once per topology is enough, the bits are sticky (the
  * Python engine does so at the second call with a topology).  Synchronises the stream. */
 #define M3G_TOPO_ERR_HINTS 1
+#define M3G_TOPO_ERR_SYNC 2    /* an in-launch wait between workgroup roles ran into its bound (never expected; results INVALID) */
 int m3g_topology_status(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
                         int32_t* host_status, void* stream);
 

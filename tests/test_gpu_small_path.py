@@ -134,3 +134,29 @@ def test_fused_launches_on_a_larger_cell_and_many_structures():
             outs.append({k: g[k].clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES)})
         for k, v in outs[0].items():
             assert torch.equal(v, outs[1][k]), k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3"])
+def test_node_and_threebody_reverse_in_one_launch_is_bit_identical(precision):
+    """Option fuse_node_tb: the three-body reverse (moment path) and the node reverse of a block run as two workgroup roles of one
+    launch (k_node_tb_reverse; the node role's v-gradient term waits for the three-body role's rows inside the launch and is then
+    gathered in the one-pass order).  Same bits as the two launches, on fixtures and on a 108-atom cell, in every mode."""
+    from helpers import fcc_cu_graph
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    # (the launch is taken for cells of at most 128 atoms -- beyond that its in-launch publishing costs more than a launch boundary;
+    #  the 108-atom cell is the largest fcc cell below the limit)
+    cases = [engine_graph(load_oracle_case(c, m)[3]) for c, m in (("cu32fit", "doc"), ("mixfit", "doc"), ("tri", "doc"))] + [fcc_cu_graph(3, 3, 3).to("cuda")]
+    names = [("cu32fit", "doc"), ("mixfit", "doc"), ("tri", "doc"), ("cu32fit", "doc")]
+    for g0, (c, m) in zip(cases, names):
+        outs = []
+        for fused in (1, 0):
+            model, _ = build_engine_model(c, m)
+            model.engine.set_precision(precision)
+            model.engine.set_option("fuse_node_tb", fused)
+            g = model(g0.clone() if hasattr(g0, "clone") else g0)
+            outs.append({k: g[k].clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES)})
+        for k, v in outs[0].items():
+            assert torch.equal(v, outs[1][k]), (c, m, k)
+    from torch_m3gnet.nn.modules import _Topology
+    assert _Topology.of(cases[-1]).status() == 0   # no in-launch wait ran into its bound

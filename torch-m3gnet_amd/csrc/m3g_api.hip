@@ -372,6 +372,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     drop_graphs(plan);
     return M3G_OK;
   }
+  if (strcmp(name, "fuse_node_tb") == 0) {   // 0: three-body reverse and node reverse as two launches (A/B tests; bit-identical either way)
+    plan->fuse_node_tb = value != 0;
+    drop_graphs(plan);
+    return M3G_OK;
+  }
   if (strcmp(name, "small_launches") == 0) {   // 0: never fuse the small-system launches (A/B tests; results are bit-identical either way)
     plan->small_launches = value != 0;
     drop_graphs(plan);
@@ -741,6 +746,10 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*dp1 format=*/dp1_format(plan), /*with_v_term=*/false, s);
         M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_join, 0));
         launch_node_reverse_v_term(c, W, wl.blk[b], t, w, w.v[b], dx_alt, s);
+        float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
+      } else if (b > 0 && fused_rev && plan->fuse_node_tb && !plan->profile &&
+                 launch_node_tb_reverse(c, W, wl.blk[b], t, w, w.v[b], /*first=*/b == c.B - 1, dx_cur, dx_alt, dp1_format(plan), b, s, tb_hints)) {
+        // (moment path) three-body reverse and node reverse of the block as two workgroup roles of ONE launch
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
       } else {
         { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s, tb_hints); }

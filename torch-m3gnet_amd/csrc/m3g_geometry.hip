@@ -248,12 +248,12 @@ __global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_
   // every structure exactly as k_struct_stress does (no workgroup ever waits for another)
   __shared__ float part[kStructThreads * 6];
   __shared__ int s_last;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(st.counter, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   for (int s = 0; s < (int)st.S; ++s) struct_stress<256>(s, st.struct_ptr, st.flags, N, st.batch, st.pos, st.lattice, forces, st.stresses, part);
 }
 

@@ -216,6 +216,8 @@ struct m3g_plan {
   float ro_w_scale_inv = 1.f;
   int small_tiles = 1024;        // option "small_tiles": graphs of at most this many 16-edge tiles run the split-tile edge kernels
                                  // (m3g_edge_small.hip: a tile over the four SIMDs of a CU, operands in registers); 0 = never
+  int fuse_node_tb = 1;          // option "fuse_node_tb": three-body reverse (moment path) + node reverse of a block as two workgroup roles of
+                                 // one launch (k_node_tb_reverse, m3g_threebody.hip)
   int small_launches = 1;        // option "small_launches": small systems take fused launches (force tail, readout + energy sums, ...)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   bool readout_f16 = false; // option "readout_f16": the readout layers on scaled two-part fp16 chains in the f16x3 mode (5 us faster at 10,000
@@ -393,6 +395,7 @@ constexpr int64_t kForceTailMaxStructs = 8;
 // dependent reads per thread of values other XCDs have just written cost 24 us after the readout and 65 us after the force gather,
 // against 6 and 10 us for the stand-alone sum kernels)
 constexpr int64_t kFusedSumsMaxAtoms = 2048;
+constexpr int64_t kNodeTbFusedMaxAtoms = 128;   // k_node_tb_reverse (two roles in one launch): see launch_node_tb_reverse
 Work work_carve(const Consts& c, bool mfma, int save_acts /* 0 none, 1 p1, 2 p1 + p2 */, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
 
 // ---- kernel launchers (each in its own .hip) -----------------------------------------------------------
@@ -445,6 +448,8 @@ void launch_copy_strided(const float* in, int in_stride, float* out, int out_str
 // threebody.hip
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s, int topo_hints = 0);
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints = 0);
+bool launch_node_tb_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v, bool first,
+                            const float* dx_new, float* dx_out, int dp1_packed, int block, hipStream_t s, int topo_hints);
 // pack_mfma.hip / edge_mfma.hip
 int pack_mfma_images(m3g_plan* plan);
 void free_mfma_images(m3g_plan* plan);

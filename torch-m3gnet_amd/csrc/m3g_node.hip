@@ -6,6 +6,7 @@
 #include "m3g_internal.h"
 #include "m3g_device.h"
 #include "m3g_mfma_common.h"
+#include "m3g_node_rev.h"
 
 namespace m3g {
 
@@ -122,204 +123,8 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
   }
 }
 
-// ---- B2: dx_in[i] = dx_new[i] + (sum_{row(i)} dp1) W1a + (sum_{in(i)} dp1) W1b + (dv v(1-v)) W1 ----
-// kNodesRev atoms per workgroup: phase 1 streams the dp1 rows (HBM-bound gather: a wave reads a whole 1-KB row per
-// instruction, 16 B per lane), phase 2 applies the transposed first-layer weights once for all atoms of the group
-// (the 128 KB of W1a/W1b would otherwise be re-read from L2 for every atom).
-#ifndef M3G_NODES_REV
-#define M3G_NODES_REV 4   // measured: 4 -> 0.259, 8 -> 0.288, 16 -> 0.293 ms per step (one atom per wave keeps more independent gathers in flight)
-#endif
-constexpr int kNodesRev = M3G_NODES_REV;
-#ifndef M3G_NR_BATCH
-#define M3G_NR_BATCH 8   // 768-byte nontemporal rows, index pairs handed out by v_readlane: 4 -> 0.172, 8 -> 0.166, 12 -> 0.171 ms per step
-#endif
-constexpr int kNrBatch = M3G_NR_BATCH;   // rows in flight per wave in the dp1 gather (multiple of 4)
-__global__ void __launch_bounds__(256) k_node_reverse(int C, int64_t N, const float* __restrict__ W, BlockW bw,
-                                                      const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ in_ptr,
-                                                      const int32_t* __restrict__ in_edge, const float* __restrict__ dp1,
-                                                      const float* __restrict__ dgq, const float* __restrict__ v,
-                                                      const float* __restrict__ dx_new, float* __restrict__ dx_out,
-                                                      const float* __restrict__ seg_head, const float* __restrict__ seg_first,
-                                                      int with_v_term, const int2* __restrict__ in_pair, int dp1_packed,
-                                                      const float* __restrict__ dp1_scale) {
-  __shared__ float4 sA[kNodesRev][64], sB[kNodesRev][64];   // row / in-edge sums of dp1, 256 columns as 64 float4
-  __shared__ float tv[kNodesRev][kCP];
-  __shared__ float part[4][kNodesRev][kDP];
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int64_t n0 = (int64_t)blockIdx.x * kNodesRev;
-  const float4* rows = reinterpret_cast<const float4*>(dp1) + ln;
-  // phase 1: wave wv gathers for atoms wv, wv+4 of the group
-  for (int nb = wv; nb < kNodesRev; nb += 4) {
-    const int64_t i = n0 + nb;
-    float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
-    float dv = 0.f, dvv = 0.f;
-    if (i < N) {
-      const int e1 = row_ptr[i + 1];
-      int e = row_ptr[i];
-      if (seg_head) {
-        // the fused reverse kernel already summed the rows of each centre inside its tiles: add the partial rows
-        // (run starting mid-tile + first runs of the tiles whose column 0 belongs to this centre)
-        if (e1 > e) {
-          if (e & 15) a0 = reinterpret_cast<const float4*>(seg_first)[i * 64 + ln];
-          for (int t = (e + 15) >> 4; t <= (e1 - 1) >> 4; ++t) {
-            const float4 u = reinterpret_cast<const float4*>(seg_head)[(int64_t)t * 64 + ln];
-            a1.x += u.x; a1.y += u.y; a1.z += u.z; a1.w += u.w;
-          }
-        }
-        e = e1;
-      }
-      for (; e + 1 < e1; e += 2) {
-        const float4 u = rows[(int64_t)e * 64], w2 = rows[(int64_t)(e + 1) * 64];
-        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
-        a1.x += w2.x; a1.y += w2.y; a1.z += w2.z; a1.w += w2.w;
-      }
-      if (e < e1) {
-        const float4 u = rows[(int64_t)e * 64];
-        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
-      }
-      // in-edge rows: 8 whole 1-KB rows in flight per wave (random rows: latency-bound unless enough bytes are in
-      // flight); lanes 0-15 also pick up the matching dL/dg row elements for the v-gradient (same edge list)
-      const int k1 = in_ptr[i + 1];
-      int k = in_ptr[i];
-      float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f), b3 = b2;
-      const int cq = ln & 15;
-      // kNrBatch whole 1-KB rows in flight per wave, the remainder in one guarded batch as well (a row-at-a-time tail
-      // is a dependent round trip per row)
-#ifndef M3G_NR_NO_CHUNK
-      // the (edge, three-body row) pairs of up to 64 in-edges arrive in ONE coalesced load, a lane each, and are handed
-      // out by v_readlane: a pair load per batch would put a dependent round trip in front of every batch of row loads
-      const int ks = __builtin_amdgcn_readfirstlane(k), k1s = __builtin_amdgcn_readfirstlane(k1);
-      for (int kc = ks; kc < k1s; kc += 64) {
-        const int cnt = k1s - kc < 64 ? k1s - kc : 64;
-        const int2 mine = ln < cnt ? in_pair[kc + ln] : make_int2(-1, -1);
-      for (int b = 0; b < cnt; b += kNrBatch) {
-        int2 f[kNrBatch];   // (edge id, compact three-body row or -1)
-        float4 u[kNrBatch];
-        float g[kNrBatch];
-#pragma unroll
-        for (int j = 0; j < kNrBatch; ++j) {
-          const int src = b + j < 64 ? b + j : 63;   // lanes >= cnt hold (-1, -1)
-          f[j].x = b + j < 64 ? __builtin_amdgcn_readlane(mine.x, src) : -1;
-          f[j].y = b + j < 64 ? __builtin_amdgcn_readlane(mine.y, src) : -1;
-        }
-#else
-      for (; k < k1; k += kNrBatch) {
-        int2 f[kNrBatch];   // (edge id, compact three-body row or -1)
-        float4 u[kNrBatch];
-        float g[kNrBatch];
-#pragma unroll
-        for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_pair[k + j] : make_int2(-1, -1);
-#endif
-#ifndef M3G_DP1_F32
-        if (dp1_packed == kDp1Fixed) {   // rows of the fused f16x3 reverse kernel: 24-bit fixed point + a scale per 64 columns (pack24_fixed)
-          u32x3 pk[kNrBatch];
-          float sc[kNrBatch];
-#pragma unroll
-          for (int j = 0; j < kNrBatch; ++j) {
-            pk[j] = f[j].x >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(reinterpret_cast<const unsigned*>(dp1) +
-                                                                   (int64_t)f[j].x * kDp1PackedDwords + 3 * ln))
-                                : u32x3{0u, 0u, 0u};   // (any bytes decode to finite numbers; the zero scale makes them 0)
-            sc[j] = f[j].x >= 0 ? dp1_scale[(int64_t)f[j].x * 4 + (ln >> 4)] : 0.f;
-          }
-#pragma unroll
-          for (int j = 0; j < kNrBatch; ++j) {
-            const f32x4 t = unpack24_fixed(pk[j], sc[j]);
-            u[j] = make_float4(t[0], t[1], t[2], t[3]);
-            g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
-          }
-        } else if (dp1_packed) {   // rows written by the fused bf16x3 reverse kernel: 24-bit values, 12 B per lane (m3g_mfma_common.h: pack24)
-          u32x3 pk[kNrBatch];
-#pragma unroll
-          for (int j = 0; j < kNrBatch; ++j)
-            // nontemporal: every row is read exactly once, and keeping it out of L2 leaves the cache to the weights and
-            // partial rows (node reverse 0.218 -> 0.187 ms per step)
-            pk[j] = f[j].x >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(reinterpret_cast<const unsigned*>(dp1) +
-                                                                   (int64_t)f[j].x * kDp1PackedDwords + 3 * ln))
-                                : u32x3{0u, 0u, 0u};
-#pragma unroll
-          for (int j = 0; j < kNrBatch; ++j) {
-            const f32x4 t = unpack24(pk[j]);
-            u[j] = make_float4(t[0], t[1], t[2], t[3]);
-            g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
-          }
-        } else
-#endif
-#pragma unroll
-        for (int j = 0; j < kNrBatch; ++j) {
-          // fp32 rows (fp32 mode, split reverse kernels): read once -> nontemporal, like the packed rows
-          if (f[j].x >= 0) {
-            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dp1) + (int64_t)f[j].x * 64 + ln);
-            u[j] = make_float4(t[0], t[1], t[2], t[3]);
-          } else {
-            u[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-          // dL/dg holds one row per ACTIVE edge; other edges contribute nothing
-          g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < kNrBatch; j += 4) {
-          b0.x += u[j].x; b0.y += u[j].y; b0.z += u[j].z; b0.w += u[j].w;
-          b1.x += u[j + 1].x; b1.y += u[j + 1].y; b1.z += u[j + 1].z; b1.w += u[j + 1].w;
-          b2.x += u[j + 2].x; b2.y += u[j + 2].y; b2.z += u[j + 2].z; b2.w += u[j + 2].w;
-          b3.x += u[j + 3].x; b3.y += u[j + 3].y; b3.z += u[j + 3].z; b3.w += u[j + 3].w;
-          dv += (g[j] + g[j + 1]) + (g[j + 2] + g[j + 3]);
-        }
-      }
-#ifndef M3G_NR_NO_CHUNK
-      }
-#endif
-      b0.x += b2.x; b0.y += b2.y; b0.z += b2.z; b0.w += b2.w;
-      b1.x += b3.x; b1.y += b3.y; b1.z += b3.z; b1.w += b3.w;
-      if (ln < kCP) {
-        const float vv = v[i * kCP + ln];
-        dvv = ln < C ? dv * vv * (1.f - vv) : 0.f;
-      }
-    }
-    sA[nb][ln] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-    sB[nb][ln] = make_float4(b0.x + b1.x, b0.y + b1.y, b0.z + b1.z, b0.w + b1.w);
-    if (ln < kCP) tv[nb][ln] = dvv;
-  }
-  __syncthreads();
-  // phase 2: quarter pq of the threads handles table columns [pq*64, pq*64+64) for output feature k
-  {
-    const int k = tid & 63, pq = tid >> 6;
-    const MlpW& mw = pq < 2 ? bw.e : bw.n;
-    const int row0 = (pq & 1) * kDP;  // row inside the MLP's [2*kDP][kDP] matrices
-    const float* wa = W + mw.w1a + (size_t)row0 * kDP + k;
-    const float* wb = W + mw.w1b + (size_t)row0 * kDP + k;
-    float acc[kNodesRev];
-#pragma unroll
-    for (int nb = 0; nb < kNodesRev; ++nb) acc[nb] = 0.f;
-    const float* fa = reinterpret_cast<const float*>(&sA[0][0]) + pq * kDP;
-    const float* fb = reinterpret_cast<const float*>(&sB[0][0]) + pq * kDP;
-#ifdef M3G_DIAG_NR_NO_PHASE2   // timing diagnostic only (wrong results): what re-reading W1a^T / W1b^T per 4-atom group costs
-    for (int o = 0; o < 4; o += 4) {
-#else
-    for (int o = 0; o < kDP; o += 4) {
-#endif
-      // four weight rows per trip: the row sums come from LDS as 16-byte broadcasts (a b32 read per term made this phase
-      // LDS-issue-bound: 512 reads per thread), the eight weight loads of a trip are independent
-      float a[4], b[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] = wa[(o + j) * kDP]; b[j] = wb[(o + j) * kDP]; }
-#pragma unroll
-      for (int nb = 0; nb < kNodesRev; ++nb) {
-        const float4 va = *reinterpret_cast<const float4*>(fa + nb * 256 + o), vb = *reinterpret_cast<const float4*>(fb + nb * 256 + o);
-        acc[nb] += (va.x * a[0] + vb.x * b[0]) + (va.y * a[1] + vb.y * b[1]) + (va.z * a[2] + vb.z * b[2]) + (va.w * a[3] + vb.w * b[3]);
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < kNodesRev; ++nb) part[pq][nb][k] = acc[nb];
-  }
-  __syncthreads();
-  for (int idx = tid; idx < kNodesRev * kDP; idx += 256) {
-    const int nb = idx >> 6, k = idx & 63;
-    const int64_t i = n0 + nb;
-    if (i >= N) continue;
-    float acc = dx_new[i * kDP + k] + ((part[0][nb][k] + part[1][nb][k]) + (part[2][nb][k] + part[3][nb][k]));
-    for (int c = 0; c < C; ++c) acc += tv[nb][c] * W[bw.tb_w1 + c * kDP + k];
-    dx_out[i * kDP + k] = acc;
-  }
+__global__ void __launch_bounds__(256) k_node_reverse(NodeRevArgs a) {
+  node_reverse_body<false>(a, blockIdx.x, [] {});
 }
 
 // the v-gradient share of the node reverse on its own (dx_out += (dv v (1-v)) W1), for when k_node_reverse ran without it
@@ -510,10 +315,10 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
                          const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, int dp1_packed, bool with_v_term,
                          hipStream_t s) {
-  if (t.N > 0)
-    hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge,
-                       w.dp1, w.dg, v, dx_new, dx_out, row_sums_in_seg ? w.seg_head : nullptr, row_sums_in_seg ? w.seg_first : nullptr,
-                       with_v_term ? 1 : 0, reinterpret_cast<const int2*>(t.in_pair), dp1_packed, dp1_scale_of(w.dp1, t.E));
+  if (t.N > 0) {
+    const NodeRevArgs a = node_rev_args(c, W, bw, t, w, v, dx_new, dx_out, row_sums_in_seg, dp1_packed, with_v_term);
+    hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, a);
+  }
 }
 
 void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,

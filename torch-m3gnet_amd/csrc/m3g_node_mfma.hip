@@ -220,12 +220,12 @@ __global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const
   // per-structure energy sums by the LAST workgroup of this launch (few structures: one launch less than k_struct_energy, same
   // fixed summation order -> bit-identical totals; no workgroup waits for another)
   __shared__ int s_last;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(rs.counter, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   float* part = lds + ReadoutImg::total;   // the x staging area (4 x 16 x kNodeXPitch floats >= kStructThreads)
   static_assert(4 * 16 * kNodeXPitch >= kStructThreads, "staging area too small for the energy sums");
   for (int sidx = 0; sidx < (int)S; ++sidx)
@@ -375,12 +375,12 @@ __global__ void __launch_bounds__(256) k_readout_split(Consts c, int64_t N, cons
   }
   if (!rs.counter) return;   // uniform
   __shared__ int s_last;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(rs.counter, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   for (int sidx = 0; sidx < (int)S; ++sidx)
     struct_energy<256>(sidx, rs.struct_ptr, rs.flags, N, rs.batch, scaled_atomic, c.energy_scale, scaled_total, rs.total, xs);
 }

@@ -14,7 +14,10 @@
 // half) in LDS once -- the per-atom triplet tile -- and the triplet loops read LDS instead of gathering from
 // L2.  Partners outside the staged window (only possible for degrees beyond the LDS budget) fall back to global
 // memory, so correctness does not depend on the window size.
+#include <algorithm>
+
 #include "m3g_internal.h"
+#include "m3g_node_rev.h"
 
 namespace m3g {
 
@@ -399,10 +402,13 @@ template <int L, int R, bool REV>
 constexpr size_t mom_lds_bytes(int rows, int atoms) {
   return sizeof(float) * ((size_t)rows * 4 + (size_t)rows * L * R * (REV ? 2 : 1) + (size_t)(REV ? 2 : 1) * atoms * R * mom_count<L>()) + sizeof(int) * (atoms + 1);
 }
-template <int L, int R, bool REV>
-__global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomArgs a, int cap_rows, int cap_atoms) {
-  constexpr int C = L * R, NM = mom_count<L>(), kThreads = kTbRows;
-  extern __shared__ __attribute__((aligned(16))) float lds_mom[];
+// THREADS >= kTbRows threads work on a block of kTbRows rows: all of them stage the window and form the moments, the first kTbRows
+// own a row each (the stand-alone kernel has THREADS = kTbRows; as a role of k_node_tb_reverse the workgroup has 256).
+// vblock / vgrid: this workgroup's index among the `vgrid` workgroups that walk the row blocks.
+template <int L, int R, bool REV, int THREADS>
+__device__ __forceinline__ void tb_moments_body(const Consts& c, const TbMomArgs& a, int cap_rows, int cap_atoms, int vblock, int vgrid, float* lds_mom) {
+  constexpr int C = L * R, NM = mom_count<L>(), kThreads = THREADS;
+  static_assert(THREADS >= kTbRows, "a thread per row");
   float* su = lds_mom;                                        // (1, ux, uy, uz) per window row
   float* sg = su + cap_rows * 4;                              // g = q v[dst]
   float* ss = sg + cap_rows * C;                              // dS = fc dm (reverse)
@@ -411,12 +417,12 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomAr
   // The launch sizes (cap_rows, cap_atoms -> the LDS carve-up above) come from the caller's hints word; they are only valid for the
   // topology buffer that word was certified for.  Anything else flags an error and touches nothing.
   if (a.flags[7] != a.hints) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.flags + 8, M3G_TOPO_ERR_HINTS);
+    if (vblock == 0 && threadIdx.x == 0) atomicOr(a.flags + 8, M3G_TOPO_ERR_HINTS);
     return;
   }
   // (the row count A lives on the device; a workgroup beyond it finds an empty window -- k_tb_windows writes one for every block
   // index the grid can reach -- so nothing here waits for A: one dependent load less in a kernel that is a chain of them)
-  for (int blk = blockIdx.x; blk < a.blocks; blk += gridDim.x) {
+  for (int blk = vblock; blk < a.blocks; blk += vgrid) {
     const int rb = blk * kTbRows;
     const int lo = a.tb_win[6 * blk], n = a.tb_win[6 * blk + 1] - lo;
     if (n <= 0) break;   // windows are in row order: the first empty one ends the list
@@ -428,7 +434,7 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomAr
       continue;
     }
     const int r = rb + (int)threadIdx.x;
-    const bool live = r < A;
+    const bool live = (int)threadIdx.x < kTbRows && r < A;
     const int rr = live ? r : A - 1;
     const int64_t e = a.act_list[rr];
     const int64_t kd = a.act_dst[rr];
@@ -535,6 +541,50 @@ __global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomAr
     __syncthreads();   // the staged window is rewritten by the next row block
   }
 }
+template <int L, int R, bool REV>
+__global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomArgs a, int cap_rows, int cap_atoms) {
+  extern __shared__ __attribute__((aligned(16))) float lds_mom[];
+  tb_moments_body<L, R, REV, kTbRows>(c, a, cap_rows, cap_atoms, (int)blockIdx.x, (int)gridDim.x, lds_mom);
+}
+
+// Three-body reverse (moment path) and node reverse of one block as the two workgroup ROLES of one launch.  Both consume what
+// k_edge_rev_* of the block wrote (dL/dm resp. the dL/dp1 rows) and neither fills the chip for long: the three-body reverse is a
+// chain of dependent loads (25 us on the 10k-atom cell at a fifth of the HBM rate), the node reverse an HBM gather (100 us).
+//   * workgroups [0, n_tb) take the three-body role, then publish: device-scope fence + one atomic increment of `done`;
+//   * workgroups [n_tb, ...) take the node role: the dp1 gather needs nothing from the three-body role; its last term (the
+//     v-gradient, from the dL/dg rows the three-body role writes) waits until `done` == n_tb.
+// No deadlock: workgroups are dispatched in index order, so when a node workgroup runs every three-body workgroup has been
+// dispatched, and those never wait for anything.  The wait is bounded all the same (a sticky error bit instead of a hang).
+struct NodeTbArgs {
+  int n_tb;          // workgroups of the three-body role
+  int32_t* done;     // Work::sync word of this block (cleared at the start of every step)
+};
+template <int L, int R>
+__global__ void __launch_bounds__(256) k_node_tb_reverse(Consts c, TbMomArgs ta, int cap_rows, int cap_atoms, NodeRevArgs na, NodeTbArgs f) {
+  extern __shared__ __attribute__((aligned(16))) float lds_mom[];
+  if ((int)blockIdx.x < f.n_tb) {
+    tb_moments_body<L, R, true, 256>(c, ta, cap_rows, cap_atoms, (int)blockIdx.x, f.n_tb, lds_mom);
+    // this workgroup's dL/dg rows are visible device-wide (release at agent scope = write-back of its XCD's L2: the L2s of different
+    // XCDs are not coherent with each other for ordinary device memory; agent-scope stores / loads alone do NOT make the rows
+    // visible -- tried, stale rows) ...
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before it counts as done
+    return;
+  }
+  node_reverse_body<true>(na, (int64_t)blockIdx.x - f.n_tb, [&] {
+    // ONE lane per wave polls (64 lanes polling one word from every waiting wave starve the increments they wait for: 73 us
+    // instead of 24 on the 864-atom cell), ~0.5 us apart
+    if ((threadIdx.x & 63) == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.n_tb) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1 << 22)) { atomicOr(ta.flags + 8, M3G_TOPO_ERR_SYNC); break; }   // (cannot happen: see above)
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows read below are the ones published before the increments
+  });
+}
 
 // at most kTbGridCap workgroups (what 256 CUs hold at once at this LDS footprint and then some): they walk the row blocks
 #ifndef M3G_TB_GRID_CAP
@@ -584,6 +634,28 @@ void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float
   TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t1_b, w.u, w.fc3, w.q, v, m};
   if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListLong, kTbCap, kTbLprLong>), grid_rows(t.E), dim3(kTbRows * kTbLprLong), 0, s, c, a)); }
   else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListShort, kTbCapShort, kTbLprShort>), grid_rows(t.E), dim3(kTbRows * kTbLprShort), 0, s, c, a)); }
+}
+
+// three-body reverse + node reverse of a block in one launch (k_node_tb_reverse); false: not applicable (list kernels, no atoms, no
+// sync words) -- the caller then launches the two kernels
+bool launch_node_tb_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v, bool first,
+                            const float* dx_new, float* dx_out, int dp1_packed, int block, hipStream_t s, int topo_hints) {
+  // Small cells only.  Measured: 32 atoms 20.7 -> 15.8 us for the pair, 108 atoms a gain, 256 atoms a small loss, 864 atoms 24 -> 47 us,
+  // 10,000 atoms 2.40 -> 2.62 ms per step: publishing costs an L2 write-back per three-body workgroup and an L2 invalidate per
+  // waiting wave (the XCDs' L2s are not coherent with each other), which a launch boundary does once for everybody.
+  if (t.N > kNodeTbFusedMaxAtoms) return false;
+  if (t.E == 0 || t.T == 0 || t.N == 0 || !w.sync || !use_moments(c, topo_hints) || kSyncNodeRev + block >= kSyncWords) return false;
+  TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, t.flags, topo_hints, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd, w.du, w.dg, first ? 1 : 0};
+  const int rows = (topo_hints >> 8) & 0xff, atoms = (topo_hints >> 16) & 0xff;
+  const NodeRevArgs na = node_rev_args(c, W, bw, t, w, v, dx_new, dx_out, /*row_sums_in_seg=*/true, dp1_packed, /*with_v_term=*/true);
+  // the three-body role walks its row blocks with at most 128 workgroups: each publishes once, and a publish is a write-back of
+  // its XCD's L2 (one per row block -- 284 on the 864-atom cell -- cost 59 us instead of the 24 us of the two separate kernels);
+  // beside the node role's gather a longer walk costs nothing
+  const int n_tb = (int)std::min<unsigned>(grid_rows(t.E).x, 128u), n_node = (int)((t.N + kNodesRev - 1) / kNodesRev);
+  const NodeTbArgs f{n_tb, w.sync + kSyncNodeRev + block};
+  M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_node_tb_reverse<L, R>), dim3((unsigned)(n_tb + n_node)), dim3(256), (mom_lds_bytes<L, R, true>(rows, atoms)), s, c, a,
+                                                 rows, atoms, na, f));
+  return true;
 }
 
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints) {
