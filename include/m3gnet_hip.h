@@ -152,6 +152,15 @@ int m3g_topology_build_hints(int64_t n_atoms, int64_t n_edges, int64_t n_triplet
                              const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
                              void* topo, size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream);
 
+/* m3g_topology_build_hints for lists THIS LIBRARY's builders have just written (m3g_neighbor_fill / m3g_verlet_fill /
+ * m3g_verlet_fill_lists + m3g_threebody_*), untouched since: their triplet lists are symmetric and complete by construction, so the
+ * mirror check of the triplet list and the per-row completeness test of the certificate are skipped; index ranges, row order and
+ * edge-list symmetry are still checked.  Handing it any other list is a caller error (the moment kernels would then sum over
+ * partners the list does not hold).  Replaces the host loops of data/material_graph.py:196-254 on the trajectory path. */
+int m3g_topology_build_canonical(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
+                                 const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
+                                 void* topo, size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream);
+
 /* Sticky error bits the hot call left on a topology buffer (0 = none).  M3G_TOPO_ERR_HINTS: m3g_energy_forces was handed a
  * non-zero m3g_io.topo_hints that is not the word m3g_topology_hints certified for THIS buffer (stale after a rebuild, or copied
  * from another topology): the three-body moment kernels then touch nothing (no out-of-bounds access) and the call's three-body
@@ -318,6 +327,18 @@ int m3g_verlet_update_async(int64_t n_atoms, int64_t n_structs, int64_t n_candid
 int m3g_verlet_fill(int64_t n_atoms, int64_t n_candidates, int64_t n_edges, void* scratch, const int64_t* cand_edge_index,
                     const int32_t* cand_shift, const int32_t* cand_row_ptr, int64_t* edge_index /* [2,E] */,
                     int32_t* edge_cell_shift /* [E,3] */, double* distances /* [E] */, uint8_t* cand_state /* [Ec] out */, void* stream);
+/* m3g_verlet_fill + m3g_threebody_build in TWO launches: edge list, shifts, membership bytes, triplet list (the reference's
+ * order, data/material_graph.py:239-248) and the per-centre / per-edge triplet counts straight from the candidates and the state the
+ * preceding m3g_verlet_update left in `scratch` (n_edges, n_triplets: its E and T).  max_cand_row = the longest candidate row (the
+ * caller knows it from cand_row_ptr); rows beyond M3G_VERLET_FILL_LISTS_MAX_ROW or more than 262,144 atoms return
+ * M3G_ERR_UNSUPPORTED -- use the two calls above, which have no limits and return identical lists.  No wait.
+ * Replaces, for a trajectory, the per-structure rebuild of data/material_graph.py:168-254. */
+#define M3G_VERLET_FILL_LISTS_MAX_ROW 1024
+int m3g_verlet_fill_lists(int64_t n_atoms, int64_t n_candidates, int64_t n_edges, int64_t n_triplets, int64_t max_cand_row, void* scratch,
+                          const int64_t* cand_edge_index, const int32_t* cand_shift, const int32_t* cand_row_ptr,
+                          int64_t* edge_index /* [2,E] */, int32_t* edge_cell_shift /* [E,3] */, uint8_t* cand_state /* [Ec] out */,
+                          int64_t* triplet_edge_index /* [2,T] */, int64_t* num_triplet_i /* [N] or NULL */,
+                          int32_t* num_triplet_ij /* [E] or NULL */, void* stream);
 
 /* ---- measurement: per-stage device time from HIP events recorded on the call's own stream ---------
  * m3g_profile_enable(plan, 1) makes every following m3g_energy_forces record an event pair around each
@@ -337,8 +358,9 @@ int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
  * event pool).  They are bound to the plan's device: a commit that moves the plan to another device releases all of them. */
 int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out);
 
-#define M3G_ABI_VERSION 3   /* 2: m3g_io.topo_hints, m3g_topology_hints; 3: m3g_verlet_*, m3g_topology_status, hints word certified on the buffer,
-                             * canonical edge order by the shift relative to the given coordinates, default precision fp32 */
+#define M3G_ABI_VERSION 4   /* 2: m3g_io.topo_hints, m3g_topology_hints; 3: m3g_verlet_*, m3g_topology_status, hints word certified on the buffer,
+                             * canonical edge order by the shift relative to the given coordinates, default precision fp32;
+                             * 4: m3g_verlet_fill_lists, m3g_topology_build_canonical, M3G_TOPO_ERR_SYNC, options small_tiles / small_launches / fuse_node_tb */
 
 #ifdef __cplusplus
 }

@@ -253,3 +253,51 @@ def test_verlet_graph_fuzz_random_lattices():
             paths[k] += vg.stats[k]
         done += 1
     assert paths["reuse"] >= 15 and paths["refill"] >= 60 and paths["search"] >= 50, paths
+
+
+def test_two_launch_refill_writes_the_lists_of_the_general_calls():
+    """m3g_verlet_fill_lists (edges + triplets + counts of a refill in two launches) against m3g_verlet_fill + m3g_threebody_build on
+    the same candidates and positions: every index tensor equal, along a random walk of a batch that includes a cell smaller than
+    the cutoff (self-images, rows of ~190 candidates) and a dense one."""
+    from torch_m3gnet.data.md import VerletGraph
+
+    cells = [random_cell_arrays(40, 8.0, 21), random_cell_arrays(6, 4.2, 22, dmin=1.8), random_cell_arrays(30, 6.0, 23, dmin=1.4)]
+    lats, pos0, zs = zip(*cells)
+    a, b = (VerletGraph(lats, zs, 5.0, 4.0, skin=0.4, device=DEV) for _ in range(2))
+    b.split_fill = True
+    rng = np.random.default_rng(9)
+    pos = np.concatenate(pos0)
+    for step in range(12):
+        pos = pos + rng.normal(0, 0.04, pos.shape)
+        p = torch.tensor(pos, device=DEV)
+        ga, gb = a.update(p, force="refill"), b.update(p, force="refill")
+        _same_graph(ga, gb)
+    assert a.stats["refill"] >= 12 and b.stats["refill"] >= 12
+
+
+def test_canonical_topology_build_equals_the_checked_build():
+    """A graph marked as written by the library's own builders takes m3g_topology_build_canonical (no mirror / completeness checks);
+    the same tensors without the mark take the checked build: same certificate word, bit-identical results.  An in-place change of
+    an index tensor voids the mark (the checked build then raises for the broken list)."""
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.nn.modules import _Topology
+
+    K = _K()
+    model = _model()
+    lat, pos, z = random_cell_arrays(48, 8.5, 31)
+    g = batch_from_arrays([lat], [pos], [z], 5.0, 4.0, device=DEV)
+    assert g.get("_m3g_canonical_lists") == _Topology.signature(g)
+    h = g.clone() if hasattr(g, "clone") else g
+    plain = type(g).__new__(type(g))
+    dict.__init__(plain)
+    for k, v in g.items():
+        if not str(k).startswith("_m3g_"):
+            plain[k] = v
+    t_can, t_chk = _Topology(g), _Topology(plain)
+    assert t_can.query_hints() == t_chk.query_hints() and (t_can.query_hints() & 1)
+    out_c, out_p = model(g), model(plain)
+    for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+        assert torch.equal(out_c[key], out_p[key]), key
+    # an in-place edit voids the mark
+    g[K.TRIPLET_EDGE_INDEX][1, 0] = g[K.TRIPLET_EDGE_INDEX][1, 1]
+    assert g.get("_m3g_canonical_lists") != _Topology.signature(g)

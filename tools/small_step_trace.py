@@ -17,6 +17,9 @@ model = bench.default_model(torch.device("cuda"))
 if len(sys.argv) > 1:
     model.engine.set_precision(sys.argv[1])
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+import os  # noqa: E402
+if os.environ.get("M3G_SMALL_TILES"):   # threshold of the split-tile edge kernels (plan option "small_tiles")
+    model.engine.set_option("small_tiles", int(os.environ["M3G_SMALL_TILES"]))
 g = fcc_cu_graph(n, n, n).to("cuda")
 for _ in range(30):
     model(g, forces=True, extras=False)

@@ -431,6 +431,8 @@ struct VerletScratch {
   void* scan_tmp;
   size_t scan_tmp_bytes;
   unsigned long long* acc;   // [4] max displacement^2 (bits of a non-negative double), changed flag, E, T
+  int32_t* off_e;      // [N+1] first edge slot of each centre (m3g_verlet_fill_lists)
+  int64_t* off_t;      // [N+1] first triplet slot of each centre
   size_t total;
 };
 static VerletScratch verlet_carve(int64_t N, int64_t Ec, void* base) {
@@ -449,6 +451,8 @@ static VerletScratch verlet_carve(int64_t N, int64_t Ec, void* base) {
   w.scan_tmp_bytes = tmp;
   w.scan_tmp = take(tmp);
   w.acc = (unsigned long long*)take(sizeof(unsigned long long) * 4);
+  w.off_e = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 2));
+  w.off_t = (int64_t*)take(sizeof(int64_t) * (size_t)(N + 2));
   w.total = off;
   return w;
 }
@@ -568,6 +572,129 @@ __global__ void __launch_bounds__(256) k_verlet_fill(int64_t N, int64_t Ec, int6
       }
     }
     out += __popcll(m);
+  }
+}
+
+// ---- refill in two launches (m3g_verlet_fill_lists) ----------------------------------------------------------------------
+// The update pass left, per centre, the number of kept candidates and of triplets.  One workgroup turns both into exclusive
+// offsets (N + 1 = 10,001 items: a library scan is two launches per array plus a clear); one wave per centre then writes the
+// centre's edges AND its triplets -- the d (d - 1) ordered pairs of its edges inside the three-body cutoff, in the reference's order
+// (data/material_graph.py:239-248) -- and the per-centre / per-edge triplet counts: what m3g_verlet_fill, a dtype cast,
+// m3g_threebody_build and their scans did in twelve launches.
+constexpr int kRefillScanThreads = 1024;
+constexpr int64_t kRefillMaxAtoms = (int64_t)kRefillScanThreads * 256;   // at most 256 chunks for the one-workgroup scan
+__global__ void __launch_bounds__(kRefillScanThreads) k_verlet_offsets(int64_t N, const int32_t* __restrict__ row_keep, const int64_t* __restrict__ row_tri,
+                                                                       int32_t* __restrict__ off_e, int64_t* __restrict__ off_t) {
+  // Chunks of 1,024 consecutive items, a thread per item (coalesced): 32-bit inclusive scan inside the wave by lane shifts (a chunk's
+  // triplets are < 2^30: rows of at most 1,024 candidates), the 16 wave totals scanned by wave 0, 64-bit carries from chunk to chunk.
+  // The loads of the first kPre chunks are all in flight before the first scan.
+  __shared__ unsigned w_e[16], w_t[16], x_e[17], x_t[17];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int kPre = 12;
+  const int64_t chunks = (N + kRefillScanThreads - 1) / kRefillScanThreads;
+  unsigned pe[kPre], pt[kPre];
+#pragma unroll
+  for (int c = 0; c < kPre; ++c) {
+    const int64_t i = (int64_t)c * kRefillScanThreads + t;
+    pe[c] = (c < chunks && i < N) ? (unsigned)row_keep[i] : 0u;
+    pt[c] = (c < chunks && i < N) ? (unsigned)row_tri[i] : 0u;
+  }
+  long long carry_e = 0, carry_t = 0;
+  auto chunk = [&](int64_t c, unsigned e, unsigned tr) {
+    const int64_t i = c * kRefillScanThreads + t;
+    unsigned ie = e, it = tr;   // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned ae = __shfl_up(ie, off), at = __shfl_up(it, off);
+      if (lane >= off) { ie += ae; it += at; }
+    }
+    if (lane == 63) { w_e[wave] = ie; w_t[wave] = it; }
+    __syncthreads();
+    if (wave == 0) {   // exclusive scan of the 16 wave totals, chunk totals in slot 16
+      unsigned ve = lane < 16 ? w_e[lane] : 0u, vt = lane < 16 ? w_t[lane] : 0u;
+      const unsigned oe = ve, ot = vt;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        const unsigned ae = __shfl_up(ve, off), at = __shfl_up(vt, off);
+        if (lane >= off) { ve += ae; vt += at; }
+      }
+      if (lane < 16) { x_e[lane] = ve - oe; x_t[lane] = vt - ot; }
+      if (lane == 15) { x_e[16] = ve; x_t[16] = vt; }
+    }
+    __syncthreads();
+    if (i < N) { off_e[i] = (int32_t)(carry_e + (long long)(x_e[wave] + ie - e)); off_t[i] = carry_t + (long long)(x_t[wave] + it - tr); }
+    carry_e += x_e[16]; carry_t += x_t[16];
+    // (w_* are rewritten before the next chunk's first barrier, x_* between its barriers: every read above precedes both)
+  };
+#pragma unroll
+  for (int c = 0; c < kPre; ++c)
+    if (c < chunks) chunk(c, pe[c], pt[c]);
+  for (int64_t c = kPre; c < chunks; ++c) {
+    const int64_t i = c * kRefillScanThreads + t;
+    chunk(c, i < N ? (unsigned)row_keep[i] : 0u, i < N ? (unsigned)row_tri[i] : 0u);
+  }
+  if (t == 0) { off_e[N] = (int32_t)carry_e; off_t[N] = carry_t; }
+}
+
+constexpr int kRefillList = 1024;   // valid edges of a centre listed in LDS (the host checks the longest candidate row against it)
+__global__ void __launch_bounds__(256) k_verlet_fill_lists(int64_t N, int64_t Ec, int64_t E, int64_t T, const int64_t* __restrict__ cand_ei,
+                                                           const int32_t* __restrict__ cand_shift, const int32_t* __restrict__ row_ptr,
+                                                           const int32_t* __restrict__ off_e, const int64_t* __restrict__ off_t,
+                                                           const uint8_t* __restrict__ state, int64_t* __restrict__ edge_index,
+                                                           int32_t* __restrict__ shift, uint8_t* cand_state, int64_t* __restrict__ tei,
+                                                           int64_t* __restrict__ num_triplet_i, int32_t* __restrict__ num_triplet_ij) {
+  __shared__ int32_t vlist_all[4 * kRefillList];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + wave;
+  if (i >= N) return;
+  int32_t* vlist = vlist_all + wave * kRefillList;
+  const int r0 = row_ptr[i], r1 = row_ptr[i + 1];
+  int64_t out = off_e[i];
+  int d = 0;   // edges of this centre inside the three-body cutoff so far
+  for (int base = r0; base < r1; base += 64) {
+    const int c = base + lane;
+    const uint8_t st = c < r1 ? state[c] : (uint8_t)0;
+    const bool keep = (st & 1) != 0, valid = (st & 2) != 0;
+    const unsigned long long m = __ballot(keep), mv = __ballot(valid);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (c < r1) cand_state[c] = st;
+    if (keep) {
+      const int64_t a = out + __popcll(m & below);
+      if (a < E) {
+        edge_index[a] = i;
+        edge_index[E + a] = cand_ei[Ec + c];
+        for (int p = 0; p < 3; ++p) shift[a * 3 + p] = cand_shift[(int64_t)c * 3 + p];
+        if (valid) {
+          const int rk = d + __popcll(mv & below);
+          if (rk < kRefillList) vlist[rk] = (int32_t)a;
+        }
+      }
+    }
+    out += __popcll(m);
+    d += __popcll(mv);
+  }
+  if (lane == 0 && num_triplet_i) num_triplet_i[i] = (int64_t)d * (d > 0 ? d - 1 : 0);
+  if (num_triplet_ij) {   // per kept edge: d - 1 partners when it lies inside the three-body cutoff
+    int64_t o2 = off_e[i];
+    for (int base = r0; base < r1; base += 64) {
+      const int c = base + lane;
+      const uint8_t st = c < r1 ? state[c] : (uint8_t)0;
+      const unsigned long long m = __ballot((st & 1) != 0);
+      if (st & 1) {
+        const int64_t a = o2 + __popcll(m & ((1ull << lane) - 1ull));
+        if (a < E) num_triplet_ij[a] = (st & 2) ? d - 1 : 0;
+      }
+      o2 += __popcll(m);
+    }
+  }
+  if (d < 2) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // vlist entries written by other lanes of this wave
+  const int64_t out0 = off_t[i];
+  const int n = d * (d - 1);
+  for (int q = lane; q < n; q += 64) {   // slot q: first edge of rank q / (d - 1), partner of rank k or k + 1, k = q % (d - 1)
+    const int a = q / (d - 1), k = q - a * (d - 1);
+    const int64_t o = out0 + q;
+    if (o < T) { tei[o] = vlist[a]; tei[T + o] = vlist[k < a ? k : k + 1]; }
   }
 }
 
@@ -838,6 +965,29 @@ extern "C" int m3g_verlet_fill(int64_t N, int64_t Ec, int64_t n_edges, void* scr
   M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, w.scan_tmp_bytes, w.row_keep, w.row_keep, (int)(N + 1), s));
   hipLaunchKernelGGL(k_verlet_fill, g_for(N * 64), dim3(256), 0, s, N, Ec, n_edges, cand_edge_index, cand_shift, cand_row_ptr, w.row_keep, w.state,
                      w.dist, edge_index, edge_cell_shift, distances, cand_state);
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+
+// Refill in two launches: edges, shifts, membership bytes, triplets and the triplet counts straight from the candidates and the
+// state the preceding m3g_verlet_update(_async) left in `scratch` (n_edges / n_triplets: its E and T).  Requires every candidate
+// row to hold at most M3G_VERLET_FILL_LISTS_MAX_ROW entries and n_atoms <= 262,144 (M3G_ERR_UNSUPPORTED otherwise: use
+// m3g_verlet_fill + m3g_threebody_build, which have no such limits).  The lists are identical to theirs.  No wait.
+extern "C" int m3g_verlet_fill_lists(int64_t N, int64_t Ec, int64_t n_edges, int64_t n_triplets, int64_t max_cand_row, void* scratch,
+                                     const int64_t* cand_edge_index, const int32_t* cand_shift, const int32_t* cand_row_ptr, int64_t* edge_index,
+                                     int32_t* edge_cell_shift, uint8_t* cand_state, int64_t* triplet_edge_index, int64_t* num_triplet_i,
+                                     int32_t* num_triplet_ij, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (N == 0) return M3G_OK;
+  if (max_cand_row > kRefillList || N > kRefillMaxAtoms) { set_error("m3g_verlet_fill_lists: candidate rows or atom count beyond its limits"); return M3G_ERR_UNSUPPORTED; }
+  if (!scratch || !cand_row_ptr || !cand_state || (n_edges > 0 && (!edge_index || !edge_cell_shift)) || (n_triplets > 0 && !triplet_edge_index)) {
+    set_error("m3g_verlet_fill_lists: null argument");
+    return M3G_ERR_VALUE;
+  }
+  VerletScratch w = verlet_carve(N, Ec, scratch);
+  hipLaunchKernelGGL(k_verlet_offsets, dim3(1), dim3(kRefillScanThreads), 0, s, N, w.row_keep, w.row_tri, w.off_e, w.off_t);
+  hipLaunchKernelGGL(k_verlet_fill_lists, g_for(N * 64), dim3(256), 0, s, N, Ec, n_edges, n_triplets, cand_edge_index, cand_shift, cand_row_ptr, w.off_e,
+                     w.off_t, w.state, edge_index, edge_cell_shift, cand_state, triplet_edge_index, num_triplet_i, num_triplet_ij);
   M3G_HIP_CHECK(hipGetLastError());
   return M3G_OK;
 }

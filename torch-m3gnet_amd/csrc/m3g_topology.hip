@@ -92,8 +92,9 @@ __global__ void k_convert_batch(int64_t N, int64_t S, const int64_t* __restrict_
 }
 
 // `order` (which == 0 only): order[0] != 0 when the (e1, e2) keys are not already in ascending order
+// low_out != nullptr: the keys' low words (the partner of each slot, for a list that is already in key order) in the same pass
 __global__ void k_convert_triplets(int64_t E, int64_t T, const int64_t* __restrict__ tei, const int32_t* __restrict__ src,
-                                   uint64_t* keys, int which, int32_t* flags, int32_t* order) {
+                                   uint64_t* keys, int which, int32_t* flags, int32_t* order, int32_t* __restrict__ low_out = nullptr) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= T) return;
   int64_t e1 = tei[t], e2 = tei[T + t];
@@ -101,6 +102,7 @@ __global__ void k_convert_triplets(int64_t E, int64_t T, const int64_t* __restri
   if (e1 < 0 || e1 >= E || e2 < 0 || e2 >= E) { bad |= 2; e1 = 0; e2 = 0; }
   else if (src[e1] != src[e2]) bad |= 4;
   keys[t] = which == 0 ? (((uint64_t)e1 << 32) | (uint64_t)e2) : (((uint64_t)e2 << 32) | (uint64_t)e1);
+  if (low_out) low_out[t] = (int32_t)(which == 0 ? e2 : e1);
   if (bad) atomicOr(flags, bad);
   if (which == 0 && t > 0) {
     const int64_t p1 = tei[t - 1], p2 = tei[T + t - 1];
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(256) k_tb_fast(int64_t blocks, const int32_t* 
     a0 = src[act_list[lo]];
     na = src[act_list[hi - 1]] - a0 + 1;
     bool mine = true;
-    for (int r = lo + lane; r < hi; r += 64) mine = mine && ok[r] != 0;
+    if (ok) for (int r = lo + lane; r < hi; r += 64) mine = mine && ok[r] != 0;   // (ok == nullptr: lists complete by construction)
     const bool all = na <= kTbFastAtoms && hi - lo <= kTbCap && __all(mine);
     if (!all) na = 0;
   }
@@ -385,7 +387,7 @@ extern "C" int m3g_topology_bytes(int64_t N, int64_t E, int64_t T, int64_t S, si
 
 // The certificate kernels of m3g_topology_hints (row flags in the sort scratch of the buffer, which nothing reads after the build);
 // false when the scratch is too small for the row flags (never for buffers sized by m3g_topology_bytes)
-static bool launch_hint_kernels(const Topo& t, hipStream_t s) {
+static bool launch_hint_kernels(const Topo& t, hipStream_t s, bool trusted = false) {
   const int64_t E = t.E, T = t.T;
   size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
   char* tmp = (char*)t.sort_tmp;
@@ -393,9 +395,13 @@ static bool launch_hint_kernels(const Topo& t, hipStream_t s) {
   if (t.sort_tmp_bytes < 2 * align_up(m * sizeof(uint64_t)) + (size_t)E + 1) return false;
   const int TPB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TPB - 1) / TPB)); };
-  hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok,
-                     t.flags + 4);
-  hipLaunchKernelGGL(k_tb_fast, grid((E / kTbRows + 1) * 64), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win, row_ok, t.tb_fast, t.flags + 4);
+  // trusted (m3g_topology_build_canonical): the lists come from this library's own builders, whose triplet lists hold every ordered
+  // pair of a centre's active edges by construction -- no per-row completeness test, the windows only have to fit
+  if (!trusted)
+    hipLaunchKernelGGL(k_tb_row_complete, grid(E), dim3(TPB), 0, s, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, row_ok,
+                       t.flags + 4);
+  hipLaunchKernelGGL(k_tb_fast, grid((E / kTbRows + 1) * 64), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.tb_win,
+                     trusted ? (const uint8_t*)nullptr : row_ok, t.tb_fast, t.flags + 4);
   hipLaunchKernelGGL(k_tb_stats, dim3(1), dim3(1024), 0, s, E / kTbRows + 1, t.n_act, t.tb_win, t.tb_fast, t.flags + 4);
   return true;
 }
@@ -409,9 +415,9 @@ static int32_t hints_word(const int32_t (&h)[3]) {
 // (triplets sorted by (e1, e2) and symmetric, edge list symmetric) the WHOLE build -- rows, partner lists, active-edge compaction,
 // windows, certificate -- is queued on that assumption and ONE read-back (malformed-graph bits, order / symmetry verdicts, the
 // certificate's statistics) confirms it; any other list redoes the affected parts with the radix sorts (the round-3 path).
-extern "C" int m3g_topology_build_hints(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
-                                        const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
-                                        size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream_) {
+static int topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
+                          const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
+                          size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream_, bool trusted) {
   hipStream_t s = (hipStream_t)stream_;
   size_t need = 0;
   int rc = m3g_topology_bytes(N, E, T, S, &need);
@@ -491,13 +497,12 @@ extern "C" int m3g_topology_build_hints(int64_t N, int64_t E, int64_t T, int64_t
   if (T > 0) {
     // optimistic pass: rows and partners as if the list were sorted and symmetric, the mirror check on it, and -- on the same
     // assumption -- everything downstream and the certificate; ONE host read-back decides
-    hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, 0, t.flags, order);
-    hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, keysA, t.t1_e2);
+    hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, 0, t.flags, order, t.t1_e2);
     hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, keysA, t.t1_ptr);
-    hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, keysA, t.t1_ptr, order);
+    if (!trusted) hipLaunchKernelGGL(k_check_symmetric, grid(T), dim3(TPB), 0, s, T, keysA, t.t1_ptr, order);
     { int r = mirror_lists(); if (r) return r; }
     { int r = downstream(true, keysA); if (r) return r; }
-    const bool hinted = host_hints && E > 0 && launch_hint_kernels(t, s);
+    const bool hinted = host_hints && E > 0 && launch_hint_kernels(t, s, trusted);
     int32_t hs[3] = {0, 0, 0};
     M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (hinted) M3G_HIP_CHECK(hipMemcpyAsync(hs, t.flags + 4, sizeof(hs), hipMemcpyDeviceToHost, s));
@@ -576,6 +581,21 @@ extern "C" int m3g_topology_build_hints(int64_t N, int64_t E, int64_t T, int64_t
     host_flags[0] = h[0];
   }
   return M3G_OK;
+}
+
+extern "C" int m3g_topology_build_hints(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
+                                        const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
+                                        size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream_) {
+  return topology_build(N, E, T, S, edge_index, triplet_edge_index, batch, topo_buf, topo_bytes, host_flags, host_hints, stream_, false);
+}
+// For lists this library's own builders have just written (m3g_neighbor_fill / m3g_verlet_fill* + m3g_threebody_*): symmetric
+// triplet lists that hold every ordered pair of a centre's edges inside the three-body cutoff BY CONSTRUCTION, so the mirror check of
+// the triplet list and the per-row completeness test of the certificate are skipped (two kernels over all triplets, 38 us of the
+// 0.25-ms build on the 10k-atom cell).  Everything else -- index ranges, row order, edge-list symmetry -- is still checked.
+extern "C" int m3g_topology_build_canonical(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
+                                            const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
+                                            size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream_) {
+  return topology_build(N, E, T, S, edge_index, triplet_edge_index, batch, topo_buf, topo_bytes, host_flags, host_hints, stream_, true);
 }
 
 extern "C" int m3g_topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,

@@ -10,7 +10,8 @@ _PKG_ROOT = Path(__file__).resolve().parent.parent  # .../torch-m3gnet_amd
 LIB_PATH = _PKG_ROOT / "lib" / "libm3gnet_hip.so"
 
 M3G_OK, M3G_ERR_VALUE, M3G_ERR_STATE, M3G_ERR_SIZE, M3G_ERR_HIP, M3G_ERR_UNSUPPORTED = range(6)
-ABI_VERSION = 3
+ABI_VERSION = 4
+VERLET_FILL_LISTS_MAX_ROW = 1024   # M3G_VERLET_FILL_LISTS_MAX_ROW (include/m3gnet_hip.h)
 
 
 class M3GConfig(C.Structure):
@@ -53,6 +54,8 @@ SYMBOLS = {
                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_build_hints": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
+    "m3g_topology_build_canonical": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_hints": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_status": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_active_edges": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
@@ -84,6 +87,8 @@ SYMBOLS = {
                                           C.c_void_p, C.c_double, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "m3g_verlet_fill": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "m3g_verlet_fill_lists": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "m3g_neighbor_scratch_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_neighbor_count": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                      C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),

@@ -151,7 +151,18 @@ def batch_from_arrays(lattices: Sequence, cart_coords: Sequence, atomic_numbers:
     g[K.NUM_EDGES] = int(ei.size(1))
     g[K.NUM_TRIPLETS] = int(tei.size(1))
     g["num_graphs"] = len(sizes)
+    mark_canonical(g)
     return g
+
+
+def mark_canonical(g) -> None:
+    """Record that the index tensors of `g` are, as they stand, lists this library's own builders wrote (symmetric, complete triplet
+    lists by construction): the engine's topology build may then skip its mirror / completeness checks
+    (m3g_topology_build_canonical).  The mark is the identity and version of the three tensors -- any later in-place change, or a
+    replaced tensor, voids it."""
+    from ..nn.modules import _Topology
+
+    dict.__setitem__(g, "_m3g_canonical_lists", _Topology.signature(g))
 
 
 def batch_from_structures(structures: Sequence, cutoff: float, threebody_cutoff: float, device="cuda") -> Batch:

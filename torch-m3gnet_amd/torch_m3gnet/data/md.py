@@ -31,7 +31,7 @@ import torch
 
 from .. import _lib
 from . import MaterialGraphKey as K
-from .graph_gpu import _ptr, _stream, neighbor_list_gpu
+from .graph_gpu import _ptr, _stream, mark_canonical, neighbor_list_gpu
 from .material_graph import Batch
 
 
@@ -63,6 +63,8 @@ class VerletGraph:
         self._verdict_ready = torch.cuda.Event()
         self._pending = None         # positions of a begin() whose verdict has not been read
         self._state_valid = False    # the candidates' membership bytes describe the current lists
+        self._max_row = 0
+        self.split_fill = False      # True: refill through m3g_verlet_fill + m3g_threebody_build (tests; identical lists)
 
     def set_lattice(self, lattices: Sequence) -> None:
         """New cell(s) (variable-cell relaxation, NPT): the candidates were searched in the old cell, so the next `update` /
@@ -87,6 +89,8 @@ class VerletGraph:
         scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
         state = torch.empty(ec + 16, dtype=torch.uint8, device=self.device)   # written by the first fill
         self._cand = (ei, shift, rows, state, pos.clone(), scratch)
+        # longest candidate row (one read-back per SEARCH): decides whether the two-launch refill applies (m3g_verlet_fill_lists)
+        self._max_row = int((rows[1:self.N + 1] - rows[:self.N]).max()) if self.N else 0
         self._state_valid = False
         self.stats["search"] += 1
 
@@ -117,20 +121,26 @@ class VerletGraph:
         dev, N = self.device, self.N
         ei = torch.empty(2, n_e, dtype=torch.int64, device=dev)
         shift = torch.empty(n_e, 3, dtype=torch.int32, device=dev)
-        dist = torch.empty(n_e, dtype=torch.float64, device=dev)
         tei = torch.empty(2, n_t, dtype=torch.int64, device=dev)
         nti = torch.empty(N, dtype=torch.int64, device=dev)
         ntij = torch.empty(n_e, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(self.lib.m3g_verlet_fill(N, int(c_ei.size(1)), n_e, _ptr(scratch), _ptr(c_ei), _ptr(c_shift), _ptr(rows), _ptr(ei),
-                                                _ptr(shift), _ptr(dist), _ptr(state), _stream()))
-            self._state_valid = True
-            d32 = dist.to(torch.float32)
-            tb_bytes = C.c_size_t()
-            _lib.check(self.lib.m3g_threebody_scratch_bytes(N, n_e, C.byref(tb_bytes)))
-            tb_scratch = torch.empty(tb_bytes.value, dtype=torch.uint8, device=dev)
-            _lib.check(self.lib.m3g_threebody_build(N, n_e, _ptr(ei), _ptr(d32), float(self.threebody_cutoff), _ptr(tb_scratch),
-                                                    tb_bytes.value, n_t, _ptr(tei), _ptr(nti), _ptr(ntij), _stream()))
+            if self._max_row <= _lib.VERLET_FILL_LISTS_MAX_ROW and N <= 262144 and not self.split_fill:
+                # edges, shifts, membership bytes, triplets and triplet counts in two launches
+                _lib.check(self.lib.m3g_verlet_fill_lists(N, int(c_ei.size(1)), n_e, n_t, self._max_row, _ptr(scratch), _ptr(c_ei), _ptr(c_shift),
+                                                          _ptr(rows), _ptr(ei), _ptr(shift), _ptr(state), _ptr(tei), _ptr(nti), _ptr(ntij), _stream()))
+                self._state_valid = True
+            else:   # very long candidate rows / very many atoms: the general calls (identical lists)
+                dist = torch.empty(n_e, dtype=torch.float64, device=dev)
+                _lib.check(self.lib.m3g_verlet_fill(N, int(c_ei.size(1)), n_e, _ptr(scratch), _ptr(c_ei), _ptr(c_shift), _ptr(rows), _ptr(ei),
+                                                    _ptr(shift), _ptr(dist), _ptr(state), _stream()))
+                self._state_valid = True
+                d32 = dist.to(torch.float32)
+                tb_bytes = C.c_size_t()
+                _lib.check(self.lib.m3g_threebody_scratch_bytes(N, n_e, C.byref(tb_bytes)))
+                tb_scratch = torch.empty(tb_bytes.value, dtype=torch.uint8, device=dev)
+                _lib.check(self.lib.m3g_threebody_build(N, n_e, _ptr(ei), _ptr(d32), float(self.threebody_cutoff), _ptr(tb_scratch),
+                                                        tb_bytes.value, n_t, _ptr(tei), _ptr(nti), _ptr(ntij), _stream()))
         g = Batch.__new__(Batch)
         dict.__init__(g)
         g[K.POS] = pos.to(torch.float)
@@ -149,6 +159,7 @@ class VerletGraph:
         # the species check of the engine is a property of `atom_types`, which every graph of this trajectory shares
         if self.graph is not None and "_m3g_species_ok" in self.graph:
             dict.__setitem__(g, "_m3g_species_ok", self.graph["_m3g_species_ok"])
+        mark_canonical(g)   # lists of this library's own builder: the topology build skips the checks they pass by construction
         self.graph = g
 
     # ------------------------------------------------------------------------------------------------ the per-step call

@@ -106,8 +106,12 @@ class _Topology:
         self.buf = torch.empty(nbytes.value, dtype=torch.uint8, device=self.ei.device)
         flags = (C.c_int32 * 1)(0)
         hints = C.c_int32(0)
-        _lib.check(lib.m3g_topology_build_hints(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
-                                                _ptr(self.buf), nbytes.value, flags, C.byref(hints) if self.WITH_HINTS else None, _stream()))
+        # lists written by this library's own builders and untouched since (graph_gpu.mark_canonical): the build skips the checks
+        # those lists pass by construction
+        canonical = isinstance(graph, dict) and graph.get("_m3g_canonical_lists") == self.signature(graph)
+        build = lib.m3g_topology_build_canonical if canonical else lib.m3g_topology_build_hints
+        _lib.check(build(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
+                         _ptr(self.buf), nbytes.value, flags, C.byref(hints) if self.WITH_HINTS else None, _stream()))
         # (the build waits for the stream itself, once, and the flags are final on return: include/m3gnet_hip.h)
         if flags[0] & 1:
             raise ValueError("edge_index must be sorted by centre atom (row 0), as MaterialGraph builds it")
