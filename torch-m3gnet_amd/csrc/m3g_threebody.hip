@@ -541,10 +541,14 @@ __device__ __forceinline__ void tb_moments_body(const Consts& c, const TbMomArgs
     __syncthreads();   // the staged window is rewritten by the next row block
   }
 }
+#ifndef M3G_TB_MOM_THREADS
+#define M3G_TB_MOM_THREADS 128   // (256 measured: forward -3.6 us, reverse +2 us per step on the 10k-atom cell -- no gain) threads per workgroup of the stand-alone moment kernels (kTbRows of them own a row; all stage and sum)
+#endif
+constexpr int kTbMomThreads = M3G_TB_MOM_THREADS;
 template <int L, int R, bool REV>
-__global__ void __launch_bounds__(kTbRows) k_threebody_moments(Consts c, TbMomArgs a, int cap_rows, int cap_atoms) {
+__global__ void __launch_bounds__(kTbMomThreads) k_threebody_moments(Consts c, TbMomArgs a, int cap_rows, int cap_atoms) {
   extern __shared__ __attribute__((aligned(16))) float lds_mom[];
-  tb_moments_body<L, R, REV, kTbRows>(c, a, cap_rows, cap_atoms, (int)blockIdx.x, (int)gridDim.x, lds_mom);
+  tb_moments_body<L, R, REV, kTbMomThreads>(c, a, cap_rows, cap_atoms, (int)blockIdx.x, (int)gridDim.x, lds_mom);
 }
 
 // Three-body reverse (moment path) and node reverse of one block as the two workgroup ROLES of one launch.  Both consume what
@@ -628,7 +632,7 @@ void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float
   if (use_moments(c, topo_hints)) {
     TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, t.flags, topo_hints, w.u, w.fc3, nullptr, w.q, nullptr, v, nullptr, m, nullptr, nullptr, nullptr, 0};
     const int rows = (topo_hints >> 8) & 0xff, atoms = (topo_hints >> 16) & 0xff;
-    M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments<L, R, false>), grid_rows(t.E), dim3(kTbRows), (mom_lds_bytes<L, R, false>(rows, atoms)), s, c, a, rows, atoms));
+    M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments<L, R, false>), grid_rows(t.E), dim3(kTbMomThreads), (mom_lds_bytes<L, R, false>(rows, atoms)), s, c, a, rows, atoms));
     return;
   }
   TbArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t1_b, w.u, w.fc3, w.q, v, m};
@@ -664,7 +668,7 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
   if (use_moments(c, topo_hints)) {
     TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, t.flags, topo_hints, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd, w.du, w.dg, first ? 1 : 0};
     const int rows = (topo_hints >> 8) & 0xff, atoms = (topo_hints >> 16) & 0xff;
-    M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments<L, R, true>), grid_rows(t.E), dim3(kTbRows), (mom_lds_bytes<L, R, true>(rows, atoms)), s, c, a, rows, atoms));
+    M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments<L, R, true>), grid_rows(t.E), dim3(kTbMomThreads), (mom_lds_bytes<L, R, true>(rows, atoms)), s, c, a, rows, atoms));
     return;
   }
   TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, t.t1_b, t.t2_b, w.u, w.fc3, w.fc3p, w.q,
