@@ -5,6 +5,8 @@
 
 namespace m3g {
 
+constexpr int64_t kReadoutSplitMaxTiles = 128;   // up to 2,048 atoms: k_readout_split / k_node_pre_split (one tile per workgroup)
+
 // ---------------------------------------------------------------------------------------------- node tables
 // S2 on the matrix pipe: [TA | TB | v]^T (528 rows) = W (528 x 64) . x^T (64 x 16 atoms) per 16-atom tile, bf16x3 chains
 // (fp32 accumulate) like the edge kernels', the whole weight image (135 KB) resident in LDS.  Replaces the vector-ALU k_node_pre, which
@@ -99,12 +101,82 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
   }
 }
 
+// Small systems: the node tables of one 16-atom tile and one of the three 11-row-block passes per WORKGROUP, the pass's row blocks
+// dealt to its four waves (w, w + 4, w + 8), each wave's weight rows resident in registers (48): 176 exact-fp32 MFMAs per tile and
+// pass take one wave 2.4 us behind a 45-KB image copy, here 48 per wave and no copy.  Rows are independent: no exchange, no barrier.
+// Same chains, same bits (fp32 mode only: the split modes' images have another layout).
+__global__ void __launch_bounds__(256) k_node_pre_split(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
+                                                        const float* __restrict__ seg_head, const float* __restrict__ seg_first,
+                                                        const int32_t* __restrict__ row_ptr, float* __restrict__ x, float* __restrict__ v,
+                                                        float* __restrict__ TA, float* __restrict__ TB, const int64_t* __restrict__ types,
+                                                        const float* __restrict__ emb, int num_types) {
+  __shared__ __attribute__((aligned(16))) float xs_all[4 * 16 * kNodeXPitch];
+  const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = blockIdx.x % 3;   // this workgroup's pass (uniform)
+  const int64_t tile = blockIdx.x / 3;
+  float* xs = xs_all + w * 16 * kNodeXPitch;
+  // this wave's row blocks of the pass: j = w, w + 4, w + 8 (< 11); image [33 row blocks][16 k-steps][64] + [528] biases
+  float a[3][16];
+  f32x4 acc[3];
+  static_for<3>([&]<int jj>() {
+    const int j = w + 4 * jj;
+    const int ob = 11 * g + (j < 11 ? j : 0);
+    static_for<16>([&]<int k>() { a[jj][k] = img[(ob * 16 + k) * 64 + lane]; });
+    acc[jj] = *(const f32x4*)(img + kNodeRowBlocks * 16 * 64 + ob * 16 + 4 * q);
+  });
+  const int64_t atom = tile * 16 + m;
+  const bool live = atom < N;
+  f32x4 xr[4];
+  static_for<4>([&]<int j>() { xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+  if (live) {
+    const float* src = (x_prev ? x_prev : x) + atom * kDP + 16 * q;
+    if (types) {   // block 0: x^0 = atom embedding row (nn/featurizer.py:99-103), formed and stored here
+      int64_t ty = types[atom];
+      ty = ty < 0 ? 0 : (ty >= num_types ? num_types - 1 : ty);
+      src = emb + ty * kDP + 16 * q;
+    }
+    static_for<4>([&]<int j>() { xr[j] = *(const f32x4*)(src + 4 * j); });
+    if (types && g == 0 && w == 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });
+    if (x_prev) {
+      const int r0 = row_ptr[atom], r1 = row_ptr[atom + 1];
+      if (r1 > r0) {
+        if (r0 & 15) static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_first + atom * (4 * kDP) + 16 * q + 4 * j); });
+        for (int t = (r0 + 15) >> 4; t <= (r1 - 1) >> 4; ++t)
+          static_for<4>([&]<int j>() { xr[j] += *(const f32x4*)(seg_head + (int64_t)t * (4 * kDP) + 16 * q + 4 * j); });
+      }
+      if (g == 0 && w == 0) static_for<4>([&]<int j>() { *(f32x4*)(x + atom * kDP + 16 * q + 4 * j) = xr[j]; });   // (one wave writes x^b back)
+    }
+  }
+  static_for<4>([&]<int j>() { *(f32x4*)(xs + m * kNodeXPitch + 16 * q + 4 * j) = xr[j]; });
+  f32x4 xb[4];   // (only this wave reads its staging area)
+  static_for<4>([&]<int blk>() { xb[blk] = *(const f32x4*)(xs + m * kNodeXPitch + blk * 16 + 4 * q); });
+  static_for<4>([&]<int blk>() {
+    static_for<4>([&]<int r>() {
+      const float b = xb[blk][r];
+      static_for<3>([&]<int jj>() { acc[jj] = mfma16(a[jj][blk * 4 + r], b, acc[jj]); });
+    });
+  });
+  if (!live) return;
+  static_for<3>([&]<int jj>() {
+    const int j = w + 4 * jj;
+    if (j >= 11) return;
+    const int ob = 11 * g + j;
+    if (ob < 16) *(f32x4*)(TA + atom * (4 * kDP) + ob * 16 + 4 * q) = acc[jj];
+    else if (ob < 32) *(f32x4*)(TB + atom * (4 * kDP) + (ob - 16) * 16 + 4 * q) = acc[jj];
+    else {
+      f32x4 o;
+      static_for<4>([&]<int r>() { o[r] = 4 * q + r < C ? fsigmoid(acc[jj][r]) : 0.f; });
+      *(f32x4*)(v + atom * kCP + 4 * q) = o;
+    }
+  });
+}
+
 // ---------------------------------------------------------------------------------------------- readout
 // S5 (nn/readout.py:39-58) and its reverse on the matrix pipe, per 16-atom tile: both layers of the dense and the gate
 // branch as exact-fp32 MFMA chains (this stage seeds the reverse pass), the final 64 -> 1 products as lane-local dots + a lane-quarter sum, then (forces wanted) the
 // transposed chains back to dE/dx.  All seven weight images (130 KB) resident in LDS; x^B = x^(B-1) + per-centre message
 // sums of the last block is formed while the tile is loaded.  Replaces the vector-ALU k_readout on the MFMA path.
-constexpr int64_t kReadoutSplitMaxTiles = 128;   // up to 2,048 atoms: k_readout_split (one tile per workgroup)
 // per-structure sums formed by the launch's last workgroup (counter == nullptr: a separate k_struct_energy launch follows)
 struct ReadoutSums {
   const int32_t *struct_ptr, *flags, *batch;
@@ -422,6 +494,11 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
                           float* v, float* TA, float* TB, const int64_t* types, const float* emb, hipStream_t s) {
   if (t.N == 0) return;
   const int64_t tiles = (t.N + 15) / 16;
+  if (plan->precision == kPrecF32 && plan->small_launches && tiles <= kReadoutSplitMaxTiles) {   // small systems: a tile and pass per workgroup
+    hipLaunchKernelGGL(k_node_pre_split, dim3((unsigned)(3 * tiles)), dim3(256), 0, s, c.C, t.N, plan->d_node_img[kPrecF32] + (size_t)b * kNodeImgFloats,
+                       x_prev, w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB, types, emb, c.num_types);
+    return;
+  }
   const int wgs = 3 * (int)std::min<int64_t>((tiles + 3) / 4, 256);   // (pass, group of four tiles); groups beyond 256 loop
   M3G_PREC_SWITCH(plan->precision,
                   hipLaunchKernelGGL((k_node_pre_mfma<PREC>), dim3(wgs), dim3(256), 0, s, c.C, t.N,
