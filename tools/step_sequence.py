@@ -19,8 +19,9 @@ def main():
     for p in paths:
         rows += list(csv.DictReader(open(p)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marker = sys.argv[3] if len(sys.argv) > 3 else "k_geometry<"   # a kernel that runs once per iteration, first
-    geo = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+    # a kernel that runs once per iteration, first: the geometry stage (small systems: fused with block 0's node tables)
+    markers = [sys.argv[3]] if len(sys.argv) > 3 else ["k_geometry<", "k_geometry_node_pre<"]
+    geo = [i for i, r in enumerate(rows) if any(m in r["Kernel_Name"] for m in markers)]
     if len(geo) < 2:
         print("fewer than two steps in the trace")
         return

@@ -662,7 +662,13 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   float* st = io->scaled_total_energy ? io->scaled_total_energy : tail + N;
 
   // ---------------- forward ----------------
-  { M3G_STAGE(ST_GEOM); launch_geometry(c, t, io->pos, io->lattice, io->edge_cell_shift, w, s); }
+  // small systems: the geometry stage and block 0's node tables (independent of each other) as two roles of one launch
+  bool np0_done = false;
+  {
+    M3G_STAGE(ST_GEOM);
+    np0_done = mfma && !plan->profile && launch_geometry_node_pre(plan, c, t, w, io->pos, io->lattice, io->edge_cell_shift, io->atom_types, W + wl.emb, s);
+    if (!np0_done) launch_geometry(c, t, io->pos, io->lattice, io->edge_cell_shift, w, s);
+  }
   {
     M3G_STAGE(ST_EMBED);
     if (mfma) {
@@ -676,8 +682,9 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     {
       M3G_STAGE(ST_NODE_PRE);
       // MFMA path: block b > 0 forms x^b = x^(b-1) + per-centre message sums of block b-1 while loading it
-      if (mfma) launch_node_pre_mfma(plan, c, t, w, b, b > 0 ? w.x[b - 1] : nullptr, w.x[b], w.v[b], w.TAb[b], w.TBb[b],
-                                     b == 0 ? io->atom_types : nullptr, W + wl.emb, s);
+      if (mfma && b == 0 && np0_done) { /* formed beside the geometry stage */ }
+      else if (mfma) launch_node_pre_mfma(plan, c, t, w, b, b > 0 ? w.x[b - 1] : nullptr, w.x[b], w.v[b], w.TAb[b], w.TBb[b],
+                                          b == 0 ? io->atom_types : nullptr, W + wl.emb, s);
       else launch_node_pre(c, W, wl.blk[b], t, w, nullptr, w.x[b], w.v[b], w.TA, w.TB, s);
     }
     { M3G_STAGE(ST_THREEBODY); launch_threebody(c, t, w, w.v[b], w.m[b], s, tb_hints); }

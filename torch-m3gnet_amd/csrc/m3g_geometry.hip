@@ -4,138 +4,13 @@
 // All HBM-bound elementwise work: one thread per edge / atom, coalesced SoA-ish rows.
 #include "m3g_internal.h"
 #include "m3g_struct_sum.h"
+#include "m3g_geometry_body.h"
 
 namespace m3g {
 
-// torch.sinc: sin(pi x)/(pi x), and cos(pi x) from the same argument reduction
-__device__ __forceinline__ float sinc_cos_pi(float x, float& cos_px) {
-  const float kPi = 3.14159265358979323846f;
-  float px = kPi * x, sn;
-  sincosf(px, &sn, &cos_px);
-  return x == 0.f ? 1.f : sn / px;
-}
-
-// radial basis h_m(d) and dh_m/dd (nn/featurizer.py:84-96)
-__device__ __forceinline__ void radial_basis(const Consts& c, float d, float* h, float* hp) {
-#pragma unroll
-  for (int m = 0; m < kRCap; ++m) {
-    if (m < c.R) {
-      float x1 = c.a1[m] * d, x2 = c.a2[m] * d;
-      float c1, c2;
-      float s1 = sinc_cos_pi(x1, c1), s2 = sinc_cos_pi(x2, c2);
-      float f = c.coeff[m] * (s1 + s2);
-      float df = c.coeff[m] * ((c1 - s1) + (c2 - s2)) / d;
-      if (m == 0) {
-        h[0] = f;
-        hp[0] = df;
-      } else {
-        h[m] = (f + c.rec_mul[m] * h[m - 1]) / c.rec_div[m];
-        hp[m] = (df + c.rec_mul[m] * hp[m - 1]) / c.rec_div[m];
-      }
-    } else {
-      h[m] = 0.f;
-      hp[m] = 0.f;
-    }
-  }
-}
-
-// j_l(x), j_l'(x) for l = 0..L-1, upward recurrence with the reference's x <= 1e-8 branch
-__device__ __forceinline__ void sph_bessel(int L, float x, float* j, float* dj) {
-  float seq[kLCap + 1];
-  if (x > 1e-8f) {
-    float sn, cx;
-    sincosf(x, &sn, &cx);
-    float sx = sn / x;
-    seq[0] = sx;
-    seq[1] = (sx - cx) / x;
-#pragma unroll
-    for (int n = 1; n < kLCap; ++n) seq[n + 1] = (float)(2 * n + 1) / x * seq[n] - seq[n - 1];
-#pragma unroll
-    for (int l = 0; l < kLCap; ++l) {
-      j[l] = seq[l];
-      dj[l] = l == 0 ? -seq[1] : seq[l - 1] - (float)(l + 1) / x * seq[l];
-    }
-  } else {
-    float dfact = 1.f;
-#pragma unroll
-    for (int l = 0; l < kLCap; ++l) {
-      if (l > 0) dfact *= (float)(2 * l + 1);
-      j[l] = l == 0 ? 1.f : x / dfact;
-      dj[l] = l == 1 ? 1.f / 3.f : 0.f;
-    }
-  }
-  (void)L;
-}
-
 template <bool FULL, int L, int R>
-__global__ void __launch_bounds__(256) k_geometry(Consts c, int64_t E, const int32_t* __restrict__ src,
-                                                  const int32_t* __restrict__ dst, const int32_t* __restrict__ batch,
-                                                  const float* __restrict__ pos, const float* __restrict__ lattice,
-                                                  const int32_t* __restrict__ shift, float* __restrict__ u,
-                                                  float* __restrict__ dist, float* __restrict__ h, float* __restrict__ hp,
-                                                  float* __restrict__ q, float* __restrict__ qp, float* __restrict__ fc3,
-                                                  float* __restrict__ fc3p, const int32_t* __restrict__ act_id, int32_t* __restrict__ sync) {
-  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  // the step's "last workgroup" counters (Work::sync): cleared by the first kernel of every step
-  if (sync && blockIdx.x == 0 && threadIdx.x < kSyncWords) sync[threadIdx.x] = 0;
-  if (e >= E) return;
-  int i = src[e], j = dst[e], s = batch[i];
-  float ls = c.length_scale;
-  float r[3];
-  float sh0 = (float)shift[e * 3 + 0], sh1 = (float)shift[e * 3 + 1], sh2 = (float)shift[e * 3 + 2];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float l0 = lattice[s * 9 + 0 + a] / ls, l1 = lattice[s * 9 + 3 + a] / ls, l2 = lattice[s * 9 + 6 + a] / ls;
-    float sv = (sh0 * l0 + sh1 * l1) + sh2 * l2;
-    r[a] = (pos[(int64_t)j * 3 + a] / ls + sv) - pos[(int64_t)i * 3 + a] / ls;
-  }
-  float d = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-  dist[e] = d;
-  u[e * 3 + 0] = r[0] / d;
-  u[e * 3 + 1] = r[1] / d;
-  u[e * 3 + 2] = r[2] / d;
-  if (!FULL) return;
-  float hh[kRCap], hd[kRCap];
-  radial_basis(c, d, hh, hd);
-  // every per-edge row leaves as 16-byte stores (a scalar store per element touched 64 cache lines per instruction)
-  *(float4*)(h + e * kRP) = float4{hh[0], hh[1], hh[2], hh[3]};
-  *(float4*)(hp + e * kRP) = float4{hd[0], hd[1], hd[2], hd[3]};
-  // three-body cutoff envelope (nn/interaction.py:389-400) and its derivative
-  float rho = d / c.rc3;
-  float f = 0.f, fp = 0.f;
-  if (rho <= 1.f) {
-    float r2 = rho * rho, r3 = r2 * rho;
-    f = 1.f - 6.f * r3 * r2 + 15.f * r2 * r2 - 10.f * r3;
-    fp = (-30.f * r2 * r2 + 60.f * r3 - 30.f * r2) / c.rc3;
-  }
-  fc3[e] = f;
-  fc3p[e] = fp;
-  // q[ar,c] = chi_ln(d) fc(d),  c = l*R + n  (nn/interaction.py:268-281), one row per ACTIVE edge (ar = act_id[e]): an edge
-  // without triplets -- beyond the three-body cutoff or without a partner -- needs no row and no Bessel evaluation
-  const int ar = act_id[e];
-  if (ar < 0) return;
-  float qr[kCP], qpr[kCP];
-#pragma unroll
-  for (int cc = 0; cc < kCP; ++cc) { qr[cc] = 0.f; qpr[cc] = 0.f; }
-#pragma unroll
-  for (int n = 0; n < R; ++n) {
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      float jl[kLCap], djl[kLCap];
-      // the argument differs per (l,n): z_ln * d / rc
-      float x = c.zeros[l][n] * d / c.rc;
-      sph_bessel(L, x, jl, djl);
-      float chi = jl[l] / c.factors[l][n];
-      float dchi = djl[l] * (c.zeros[l][n] / c.rc) / c.factors[l][n];
-      qr[l * R + n] = chi * f;
-      qpr[l * R + n] = dchi * f + chi * fp;
-    }
-  }
-#pragma unroll
-  for (int cc = 0; cc < kCP; cc += 4) {
-    *(float4*)(q + (int64_t)ar * kCP + cc) = float4{qr[cc], qr[cc + 1], qr[cc + 2], qr[cc + 3]};
-    *(float4*)(qp + (int64_t)ar * kCP + cc) = float4{qpr[cc], qpr[cc + 1], qpr[cc + 2], qpr[cc + 3]};
-  }
+__global__ void __launch_bounds__(256) k_geometry(Consts c, GeomArgs a) {
+  geometry_body<FULL, L, R>(c, a, blockIdx.x);
 }
 
 // dE/dr of one edge from dL/dd (three-body share dd + the radial-basis share dh . h') and dL/du (projected off u):
@@ -340,8 +215,8 @@ void launch_geometry(const Consts& c, const Topo& t, const float* pos, const flo
     if (w.sync) (void)hipMemsetAsync(w.sync, 0, sizeof(int32_t) * kSyncWords, s);
     return;
   }
-  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_geometry<true, L, R>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos,
-                                               lattice, shift, w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p, t.act_id, w.sync));
+  const GeomArgs a = geometry_args(t, pos, lattice, shift, w);
+  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_geometry<true, L, R>), grid_for(t.E), dim3(256), 0, s, c, a));
 }
 
 void launch_distance_only(float length_scale, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
@@ -349,8 +224,8 @@ void launch_distance_only(float length_scale, const Topo& t, const float* pos, c
   if (t.E == 0) return;
   Consts c{};
   c.length_scale = length_scale;
-  hipLaunchKernelGGL((k_geometry<false, 1, 1>), grid_for(t.E), dim3(256), 0, s, c, t.E, t.src, t.dst, t.batch, pos, lattice, shift,
-                     u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  const GeomArgs a{t.E, t.src, t.dst, t.batch, pos, lattice, shift, u, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL((k_geometry<false, 1, 1>), grid_for(t.E), dim3(256), 0, s, c, a);
 }
 
 // Geometry reverse + force gather.  `fuse_stress`: the force-gather launch also forms the reference virial (its last workgroup,

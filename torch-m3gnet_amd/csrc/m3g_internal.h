@@ -427,6 +427,8 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
                      float* v, float* TA, float* TB, hipStream_t s);
 void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, const float* x_prev, float* x,
                           float* v, float* TA, float* TB, const int64_t* types, const float* emb, hipStream_t s);
+bool launch_geometry_node_pre(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, const float* pos, const float* lattice,
+                              const int32_t* shift, const int64_t* types, const float* emb, hipStream_t s);
 void launch_energy_sums(const Consts& c, const Topo& t, const float* scaled_atomic, float* scaled_total, float* total, hipStream_t s);
 void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayout& wl, const Topo& t, const int64_t* types,
                          const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,

@@ -2,6 +2,7 @@
 // reverse (k_readout_mfma, stage S5).  Split from m3g_edge_mfma.hip (shared device code: m3g_edge_common.h).
 #include "m3g_edge_common.h"
 #include "m3g_struct_sum.h"
+#include "m3g_geometry_body.h"
 
 namespace m3g {
 
@@ -105,16 +106,36 @@ __global__ void __launch_bounds__(256) k_node_pre_mfma(int C, int64_t N, const f
 // dealt to its four waves (w, w + 4, w + 8), each wave's weight rows resident in registers (48): 176 exact-fp32 MFMAs per tile and
 // pass take one wave 2.4 us behind a 45-KB image copy, here 48 per wave and no copy.  Rows are independent: no exchange, no barrier.
 // Same chains, same bits (fp32 mode only: the split modes' images have another layout).
-__global__ void __launch_bounds__(256) k_node_pre_split(int C, int64_t N, const float* __restrict__ img, const float* __restrict__ x_prev,
-                                                        const float* __restrict__ seg_head, const float* __restrict__ seg_first,
-                                                        const int32_t* __restrict__ row_ptr, float* __restrict__ x, float* __restrict__ v,
-                                                        float* __restrict__ TA, float* __restrict__ TB, const int64_t* __restrict__ types,
-                                                        const float* __restrict__ emb, int num_types) {
+struct NodePreArgs {
+  int C;
+  int64_t N;
+  const float *img, *x_prev, *seg_head, *seg_first;
+  const int32_t* row_ptr;
+  float *x, *v, *TA, *TB;
+  const int64_t* types;
+  const float* emb;
+  int num_types;
+};
+__device__ __forceinline__ void node_pre_split_body(const NodePreArgs& args, int64_t vblock) {
+  const int C = args.C;
+  const int64_t N = args.N;
+  const float* __restrict__ img = args.img;
+  const float* __restrict__ x_prev = args.x_prev;
+  const float* __restrict__ seg_head = args.seg_head;
+  const float* __restrict__ seg_first = args.seg_first;
+  const int32_t* __restrict__ row_ptr = args.row_ptr;
+  float* __restrict__ x = args.x;
+  float* __restrict__ v = args.v;
+  float* __restrict__ TA = args.TA;
+  float* __restrict__ TB = args.TB;
+  const int64_t* __restrict__ types = args.types;
+  const float* __restrict__ emb = args.emb;
+  const int num_types = args.num_types;
   __shared__ __attribute__((aligned(16))) float xs_all[4 * 16 * kNodeXPitch];
   const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int g = blockIdx.x % 3;   // this workgroup's pass (uniform)
-  const int64_t tile = blockIdx.x / 3;
+  const int g = (int)(vblock % 3);   // this workgroup's pass (uniform)
+  const int64_t tile = vblock / 3;
   float* xs = xs_all + w * 16 * kNodeXPitch;
   // this wave's row blocks of the pass: j = w, w + 4, w + 8 (< 11); image [33 row blocks][16 k-steps][64] + [528] biases
   float a[3][16];
@@ -170,6 +191,16 @@ __global__ void __launch_bounds__(256) k_node_pre_split(int C, int64_t N, const 
       *(f32x4*)(v + atom * kCP + 4 * q) = o;
     }
   });
+}
+
+__global__ void __launch_bounds__(256) k_node_pre_split(NodePreArgs a) { node_pre_split_body(a, blockIdx.x); }
+// Block 0's node tables need nothing from the geometry stage (x^0 is the species embedding) and the geometry stage nothing from
+// them: for small systems the two run as the two workgroup ROLES of one launch (no dependency, no fence -- one launch boundary
+// less).  Same device functions as the two kernels: same bits.
+template <int L, int R>
+__global__ void __launch_bounds__(256) k_geometry_node_pre(Consts c, GeomArgs ga, int n_geo, NodePreArgs na) {
+  if ((int)blockIdx.x < n_geo) geometry_body<true, L, R>(c, ga, blockIdx.x);
+  else node_pre_split_body(na, (int64_t)blockIdx.x - n_geo);
 }
 
 // ---------------------------------------------------------------------------------------------- readout
@@ -495,8 +526,9 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
   if (t.N == 0) return;
   const int64_t tiles = (t.N + 15) / 16;
   if (plan->precision == kPrecF32 && plan->small_launches && tiles <= kReadoutSplitMaxTiles) {   // small systems: a tile and pass per workgroup
-    hipLaunchKernelGGL(k_node_pre_split, dim3((unsigned)(3 * tiles)), dim3(256), 0, s, c.C, t.N, plan->d_node_img[kPrecF32] + (size_t)b * kNodeImgFloats,
-                       x_prev, w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB, types, emb, c.num_types);
+    const NodePreArgs a{c.C, t.N, plan->d_node_img[kPrecF32] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB,
+                        types, emb, c.num_types};
+    hipLaunchKernelGGL(k_node_pre_split, dim3((unsigned)(3 * tiles)), dim3(256), 0, s, a);
     return;
   }
   const int wgs = 3 * (int)std::min<int64_t>((tiles + 3) / 4, 256);   // (pass, group of four tiles); groups beyond 256 loop
@@ -505,6 +537,19 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
                                      plan->d_node_img[plan->precision] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first,
                                      t.row_ptr, x, v, TA, TB, types, emb, c.num_types,
                                      plan->precision == kPrecF16x3 ? plan->w_scale_inv : 1.f));
+}
+
+// geometry stage + block 0's node tables in one launch (small systems, exact-fp32 mode); false: not a case it covers
+bool launch_geometry_node_pre(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, const float* pos, const float* lattice,
+                              const int32_t* shift, const int64_t* types, const float* emb, hipStream_t s) {
+  const int64_t tiles = (t.N + 15) / 16;
+  if (plan->precision != kPrecF32 || !plan->small_launches || c.B == 0 || t.E == 0 || t.N == 0 || tiles > kReadoutSplitMaxTiles) return false;
+  const int n_geo = (int)((t.E + 255) / 256);
+  const GeomArgs ga = geometry_args(t, pos, lattice, shift, w);
+  const NodePreArgs na{c.C, t.N, plan->d_node_img[kPrecF32], nullptr, w.seg_head, w.seg_first, t.row_ptr, w.x[0], w.v[0], w.TAb[0], w.TBb[0], types, emb,
+                       c.num_types};
+  M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_geometry_node_pre<L, R>), dim3((unsigned)(n_geo + 3 * tiles)), dim3(256), 0, s, c, ga, n_geo, na));
+  return true;
 }
 
 }  // namespace m3g
