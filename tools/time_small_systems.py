@@ -18,6 +18,8 @@ model.engine.set_precision(sys.argv[1] if len(sys.argv) > 1 else "fp32")
 import os  # noqa: E402
 if os.environ.get("M3G_SMALL_TILES"):   # threshold of the split-tile edge kernels (plan option "small_tiles"; 0 = persistent kernels only)
     model.engine.set_option("small_tiles", int(os.environ["M3G_SMALL_TILES"]))
+if os.environ.get("M3G_SMALL_TILES_FWD"):   # ... of the forward kernel alone
+    model.engine.set_option("small_tiles_fwd", int(os.environ["M3G_SMALL_TILES_FWD"]))
 for n in ([int(v) for v in sys.argv[2:]] or (2, 3, 4, 6, 8, 10)):
     g = fcc_cu_graph(n, n, n).to("cuda")
     for _ in range(5):

@@ -369,6 +369,13 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
   if (strcmp(name, "small_tiles") == 0) {   // graphs of at most this many 16-edge tiles take the split-tile edge kernels (m3g_edge_small.hip); 0: never
     if (value < 0) { set_error("small_tiles must be >= 0"); return M3G_ERR_VALUE; }
     plan->small_tiles = value;
+    plan->small_tiles_fwd = value;   // (small_tiles_fwd, set afterwards, moves the forward kernel's threshold alone)
+    drop_graphs(plan);
+    return M3G_OK;
+  }
+  if (strcmp(name, "small_tiles_fwd") == 0) {   // the forward kernel's threshold alone (set after small_tiles)
+    if (value < 0) { set_error("small_tiles_fwd must be >= 0"); return M3G_ERR_VALUE; }
+    plan->small_tiles_fwd = value;
     drop_graphs(plan);
     return M3G_OK;
   }
@@ -762,7 +769,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s, tb_hints); }
         if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
           M3G_STAGE(ST_NODE_REV);
-          launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*dp1 format=*/dp1_format(plan), /*with_v_term=*/true, s);
+          launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*dp1 format=*/dp1_format(plan), /*with_v_term=*/true, s,
+                              /*small=*/plan->small_launches && N <= kFusedSumsMaxAtoms);
           float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
         }
       }

@@ -852,7 +852,7 @@ void launch_embed_edges_reverse_soa(const float* adj, const float* h, const floa
 void launch_edge_block_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, int b, bool for_reverse, hipStream_t s) {
   const int64_t tiles = tiles_for(t.E);
   const MfmaFwdLayout L = mfma_fwd_layout();
-  if (tiles > 0 && tiles <= plan->small_tiles && launch_edge_fwd_split(plan, c, t, w, b, for_reverse, s)) return;
+  if (tiles > 0 && tiles <= plan->small_tiles_fwd && launch_edge_fwd_split(plan, c, t, w, b, for_reverse, s)) return;
   if (tiles > 0) {
     FwdArgs a{t.E, tiles, plan->d_mfma_fwd[plan->precision] + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], w.TAb[b], w.TBb[b], t.act_id,
               w.e_blk[b], w.e_blk[b + 1], w.seg_head, w.seg_first, plan->d_stamps, saves_p1(plan) ? w.p1_blk[b] : nullptr,

@@ -10,8 +10,9 @@
 //     what the next layer needs of the other waves' rows (its B operand is the whole activation vector) crosses through 4-8 KB
 //     of LDS and a workgroup barrier, four (forward) / five (reverse) times per tile;
 //   * the A operands a wave needs -- its quarter of the weight images -- are loaded ONCE from the L2-resident packed images
-//     straight into registers (136-145 per lane; one wave per SIMD has 512) and stay there across the tiles of the workgroup:
-//     no LDS image, no LDS operand reads;
+//     straight into registers (136-145 per lane) and stay there across the tiles of the workgroup: no LDS image, no LDS operand
+//     reads; both kernels stay within 256 registers (two workgroups per CU: each hides the other's tile-start loads -- the
+//     reverse kernel by reading its B operands block by block from the exchange buffers and its small plain tables from LDS);
 //   * tile loads, stores and table gathers split four ways as well (each wave touches only its own blocks).
 // Arithmetic: every output element is the same k-ordered fp32 fmaf chain the persistent kernels form, so edge features,
 // saved activations, messages, dp1 rows and dL/de are BIT-IDENTICAL to theirs.  Two sums are associated differently (stated
@@ -217,9 +218,10 @@ struct RevMlpA {
   float wld;          // direct image row block w of W_l (A operand of W_l h)
   float w2t[2][16];   // W2d^T / W2g^T: this wave's 16 input-feature rows, k over the 64 outputs of the branch
   float w1ct[32];     // W1c^T: this wave's 16 edge-feature rows, k over the 128 layer-1 outputs
-  f32x4 wl[4];        // plain W_l rows w*16 + 4 qd + {0..3} (dL/dh accumulation)
+  const float* wl;    // LDS copy of the plain W_l [64][4] (dL/dh accumulation: rows w*16 + 4 qd + {0..3}); in registers these 16
+                      // values per MLP (+ 16 of W_adj in block 0) put the kernel at 292 registers = one workgroup per CU
 };
-__device__ __forceinline__ void load_rev_mlp(const float* __restrict__ img, const MfmaMlpRevF32& L, int w, int lane, RevMlpA& A) {
+__device__ __forceinline__ void load_rev_mlp(const float* __restrict__ img, const MfmaMlpRevF32& L, int w, int lane, RevMlpA& A, const float* wl_lds) {
   const int m = lane & 15, q = lane >> 4;
   const int base = q * 256 + (m ^ (((q & 1) << 4) | ((q >> 1) << 3)));   // chain_dual32_t's lane offset (m3g_dual_f32.h)
   A.wld = img[L.wld + w * 64 + lane];
@@ -229,7 +231,7 @@ __device__ __forceinline__ void load_rev_mlp(const float* __restrict__ img, cons
     });
   });
   static_for<32>([&]<int k>() { A.w1ct[k] = img[L.w1cT + (w * 32 + k) * 64 + lane]; });   // f32 chain image [4 ob][32 k-steps]
-  static_for<4>([&]<int r>() { A.wl[r] = *(const f32x4*)(img + L.wl + (w * 16 + 4 * q + r) * 4); });
+  A.wl = wl_lds + (w * 16 + 4 * q) * 4;
 }
 
 // reverse of one conv GatedMLP from its saved activations, split over the four waves: d_upd = this wave's block of
@@ -241,8 +243,6 @@ __device__ __forceinline__ f32x4 mlp_reverse_split(const RevMlpA& A, const RevAr
   const float* p2_src = a.p2 + tile * (2 * kP1TileFloats) + MLP * kP1TileFloats + lane * 4;
   const float* p1_src = a.p1 + tile * (2 * kP1TileFloats) + MLP * kP1TileFloats + lane * 4;
   f32x4 d2d = load_tile4(p2_src + w * 256), d2g = load_tile4(p2_src + (4 + w) * 256);   // saved layer-2 pre-activations
-  f32x4 ds1[2];                                                                          // saved SiLU'(p1), this wave's blocks
-  static_for<2>([&]<int hf>() { ds1[hf] = load_tile4(p1_src + (4 * hf + w) * 256); });
   // gating derivatives; W_l h on the matrix pipe, dL/dh on the vector ALU (as mlp_reverse_f32, for row block w)
   const f32x4 sl = mfma16(A.wld, hb_sel, zero4());
   static_for<2>([&]<int k>() {
@@ -256,7 +256,7 @@ __device__ __forceinline__ f32x4 mlp_reverse_split(const RevMlpA& A, const RevAr
     const f32x2 d_o = a_g * s_lin;
     const f32x2 dd = d_o * dsd;           // dL/d(p2d)
     const f32x2 dgt = (d_s * s_lin) * (1.f - sg);   // dL/d(p2g)
-    const f32x4 w0 = A.wl[2 * k], w1 = A.wl[2 * k + 1];
+    const f32x4 w0 = *(const f32x4*)(A.wl + (2 * k) * 4), w1 = *(const f32x4*)(A.wl + (2 * k + 1) * 4);
     f32x2 h01 = {dhv[0], dhv[1]}, h23 = {dhv[2], dhv[3]};
     h01 += f32x2{w0[0], w0[1]} * d_s[0]; h23 += f32x2{w0[2], w0[3]} * d_s[0];
     h01 += f32x2{w1[0], w1[1]} * d_s[1]; h23 += f32x2{w1[2], w1[3]} * d_s[1];
@@ -268,15 +268,17 @@ __device__ __forceinline__ f32x4 mlp_reverse_split(const RevMlpA& A, const RevAr
   *(f32x4*)(hs1 + w * 256 + lane * 4) = d2d;
   *(f32x4*)(hs1 + (4 + w) * 256 + lane * 4) = d2g;
   __syncthreads();
-  f32x4 d2[8];
-  static_for<8>([&]<int ob>() { d2[ob] = *(const f32x4*)(hs1 + ob * 256 + lane * 4); });
   f32x4 dp1h[2];
   static_for<2>([&]<int hf>() {
     f32x4 dp1 = zero4();
+    const f32x4 ds1 = load_tile4(p1_src + (4 * hf + w) * 256);   // saved SiLU'(p1), this wave's block of this half (requested ahead of its chain)
     M3G_F32_CHAIN_PRIO(1);
-    static_for<4>([&]<int blk>() { static_for<4>([&]<int r>() { dp1 = mfma16(A.w2t[hf][blk * 4 + r], d2[4 * hf + blk][r], dp1); }); });
+    static_for<4>([&]<int blk>() {   // (B operands block by block from LDS: all eight blocks at once are 32 live registers)
+      const f32x4 d2b = *(const f32x4*)(hs1 + (4 * hf + blk) * 256 + lane * 4);
+      static_for<4>([&]<int r>() { dp1 = mfma16(A.w2t[hf][blk * 4 + r], d2b[r], dp1); });
+    });
     M3G_F32_CHAIN_PRIO(0);
-    dp1 *= ds1[hf];
+    dp1 *= ds1;
     if (NEED_DP1 && edge < a.E) *(f32x4*)(a.dp1 + edge * (4 * kDP) + MLP * (2 * kDP) + hf * kDP + 4 * qd + w * 16) = dp1;
     dp1h[hf] = dp1;
     if (NEED_DP1) {   // per-centre sums of the dp1 rows (x_i half of the node reverse)
@@ -289,17 +291,18 @@ __device__ __forceinline__ f32x4 mlp_reverse_split(const RevMlpA& A, const RevAr
   *(f32x4*)(hs2 + w * 256 + lane * 4) = dp1h[0];
   *(f32x4*)(hs2 + (4 + w) * 256 + lane * 4) = dp1h[1];
   __syncthreads();
-  f32x4 dp1a[8];
-  static_for<8>([&]<int ob>() { dp1a[ob] = *(const f32x4*)(hs2 + ob * 256 + lane * 4); });
   f32x4 contrib = zero4();
   M3G_F32_CHAIN_PRIO(1);
-  static_for<8>([&]<int blk>() { static_for<4>([&]<int r>() { contrib = mfma16(A.w1ct[blk * 4 + r], dp1a[blk][r], contrib); }); });
+  static_for<8>([&]<int blk>() {
+    const f32x4 db = *(const f32x4*)(hs2 + blk * 256 + lane * 4);
+    static_for<4>([&]<int r>() { contrib = mfma16(A.w1ct[blk * 4 + r], db[r], contrib); });
+  });
   M3G_F32_CHAIN_PRIO(0);
   return contrib;
 }
 
 template <int TBS, bool NEED_DP1>
-__global__ void __launch_bounds__(64 * kSplitWaves) k_edge_rev_split(RevArgs a, MfmaRevF32Layout L) {
+__global__ void __launch_bounds__(64 * kSplitWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) k_edge_rev_split(RevArgs a, MfmaRevF32Layout L) {
   __shared__ __attribute__((aligned(16))) float hs1[8 * 256];    // dL/dp2 of one MLP, two blocks per wave
   __shared__ __attribute__((aligned(16))) float hs2[8 * 256];    // dL/dp1 of one MLP
   __shared__ __attribute__((aligned(16))) float part[8 * 256];   // per-wave partial dL/dm rows, then partial dL/dh rows
@@ -312,15 +315,17 @@ __global__ void __launch_bounds__(64 * kSplitWaves) k_edge_rev_split(RevArgs a, 
     static_for<TBS>([&]<int s>() { a_tb[hf][s] = a.img[L.tb + ((hf * 4 + w) * kTbSteps + s) * 64 + lane]; });
     static_for<4>([&]<int r>() { a_tbt[hf][r] = a.img[L.tbT + ((hf * 4 + w) * 4 + r) * 64 + lane]; });   // f32 chain image [1][32 k-steps]
   });
+  __shared__ __attribute__((aligned(16))) float small_tabs[3 * 256];   // plain W_l of both MLPs, plain W_adj (block 0)
+  small_tabs[threadIdx.x] = a.img[L.mlp[0].wl + threadIdx.x];
+  small_tabs[256 + threadIdx.x] = a.img[L.mlp[1].wl + threadIdx.x];
+  small_tabs[512 + threadIdx.x] = FIRST ? a.img[L.adjp + threadIdx.x] : 0.f;
+  __syncthreads();
   RevMlpA A0, A1;
-  load_rev_mlp(a.img, L.mlp[0], w, lane, A0);
-  load_rev_mlp(a.img, L.mlp[1], w, lane, A1);
+  load_rev_mlp(a.img, L.mlp[0], w, lane, A0, small_tabs);
+  load_rev_mlp(a.img, L.mlp[1], w, lane, A1, small_tabs + 256);
   float a_adj = 0.f;
-  f32x4 adjp[4] = {zero4(), zero4(), zero4(), zero4()};
-  if (FIRST) {
-    a_adj = a.img[L.adj + w * 64 + lane];
-    static_for<4>([&]<int r>() { adjp[r] = *(const f32x4*)(a.img + L.adjp + (w * 16 + 4 * qd + r) * 4); });
-  }
+  const float* adjp = small_tabs + 512 + (w * 16 + 4 * qd) * 4;
+  if (FIRST) a_adj = a.img[L.adj + w * 64 + lane];
   for (int64_t tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
@@ -348,7 +353,7 @@ __global__ void __launch_bounds__(64 * kSplitWaves) k_edge_rev_split(RevArgs a, 
       // edge embedding, reverse: dL/dh += W_adj^T (dL/de0 * SiLU'(W_adj h)), rows of block w
       const f32x4 pe = mfma16(a_adj, hb_sel, zero4());
       static_for<4>([&]<int r>() {
-        const f32x4 wr = adjp[r];
+        const f32x4 wr = *(const f32x4*)(adjp + r * 4);
         const float t = de[r] * fdsilu(pe[r]);
         dhv[0] += t * wr[0]; dhv[1] += t * wr[1]; dhv[2] += t * wr[2]; dhv[3] += t * wr[3];
       });

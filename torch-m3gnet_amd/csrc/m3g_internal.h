@@ -214,7 +214,8 @@ struct m3g_plan {
   float* d_readout_img = nullptr;   // [ReadoutImg::total]: readout MLP weights as exact-fp32 chain images (k_readout_mfma; fp32 and bf16x3 modes)
   float* d_readout_img_h = nullptr; // the same layout as scaled two-part fp16 chain images (f16x3 mode), weights scaled by 1 / ro_w_scale_inv
   float ro_w_scale_inv = 1.f;
-  int small_tiles = 1024;        // option "small_tiles": graphs of at most this many 16-edge tiles run the split-tile edge kernels
+  int small_tiles_fwd = 3072;    // option "small_tiles_fwd": the same threshold for the forward kernel alone (measured: a gain up to ~900 atoms, equal at 1,372)
+  int small_tiles = 1536;        // option "small_tiles": graphs of at most this many 16-edge tiles run the split-tile edge kernels
                                  // (m3g_edge_small.hip: a tile over the four SIMDs of a CU, operands in registers); 0 = never
   int fuse_node_tb = 1;          // option "fuse_node_tb": three-body reverse (moment path) + node reverse of a block as two workgroup roles of
                                  // one launch (k_node_tb_reverse, m3g_threebody.hip)
@@ -435,7 +436,7 @@ void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayo
                          bool want_grad, hipStream_t s);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
                          const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, int dp1_packed, bool with_v_term,
-                         hipStream_t s);
+                         hipStream_t s, bool small = false);
 void launch_node_reverse_v_term(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v,
                                 float* dx_out, hipStream_t s);
 void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, const Topo& t, const int64_t* types,

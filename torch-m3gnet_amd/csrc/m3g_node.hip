@@ -126,6 +126,9 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
 __global__ void __launch_bounds__(256) k_node_reverse(NodeRevArgs a) {
   node_reverse_body<false>(a, blockIdx.x, [] {});
 }
+__global__ void __launch_bounds__(256) k_node_reverse_small(NodeRevArgs a) {   // weights of phase 2 requested at entry (small systems)
+  node_reverse_body<false, true>(a, blockIdx.x, [] {});
+}
 
 // the v-gradient share of the node reverse on its own (dx_out += (dv v (1-v)) W1), for when k_node_reverse ran without it
 // beside the three-body reverse that produces dL/dg: 16 lanes per atom gather the dL/dg rows of the incoming edges
@@ -314,10 +317,11 @@ void launch_node_pre(const Consts& c, const float* W, const BlockW& bw, const To
 
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
                          const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, int dp1_packed, bool with_v_term,
-                         hipStream_t s) {
+                         hipStream_t s, bool small) {
   if (t.N > 0) {
     const NodeRevArgs a = node_rev_args(c, W, bw, t, w, v, dx_new, dx_out, row_sums_in_seg, dp1_packed, with_v_term);
-    hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, a);
+    if (small) hipLaunchKernelGGL(k_node_reverse_small, grid_for(t.N, kNodesRev), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_node_reverse, grid_for(t.N, kNodesRev), dim3(256), 0, s, a);
   }
 }
 

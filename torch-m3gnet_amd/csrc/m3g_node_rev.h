@@ -37,7 +37,11 @@ struct NodeRevArgs {
 // k_node_tb_reverse, m3g_threebody.hip): the dp1 gather runs first, `wait_for_dgq()` then blocks until those rows are visible, and
 // the v-gradient terms are gathered in a second pass over the same in-edge list -- in the order the one-pass form adds them
 // (batches of kNrBatch, pairwise inside a batch), so dx_out is bit-identical either way.
-template <bool DEFER_V, class WAIT>
+// PRELOAD (small systems): the 128 weight values a thread needs in phase 2 (its column of the W1a^T / W1b^T quarter) are requested
+// at kernel entry and arrive during the gather of phase 1 -- phase 2 is otherwise a chain of 16 dependent L2 round trips per
+// thread (0.3 us each), most of what a 32-atom launch costs.  128 more registers per lane: not for the large-system gather, which
+// lives on the waves it can keep resident.
+template <bool DEFER_V, bool PRELOAD = false, class WAIT>
 __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64_t vblock, WAIT wait_for_dgq) {
   const int C = args.C;
   const int64_t N = args.N;
@@ -61,6 +65,16 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
   __shared__ float part[4][kNodesRev][kDP];
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int64_t n0 = vblock * kNodesRev;
+  float pre_a[PRELOAD ? kDP : 1], pre_b[PRELOAD ? kDP : 1];
+  if constexpr (PRELOAD) {
+    const int k = tid & 63, pq = tid >> 6;
+    const MlpW& mw = pq < 2 ? bw.e : bw.n;
+    const int row0 = (pq & 1) * kDP;
+    const float* wa = W + mw.w1a + (size_t)row0 * kDP + k;
+    const float* wb = W + mw.w1b + (size_t)row0 * kDP + k;
+#pragma unroll
+    for (int o = 0; o < kDP; ++o) { pre_a[o] = wa[o * kDP]; pre_b[o] = wb[o * kDP]; }
+  }
   const float4* rows = reinterpret_cast<const float4*>(dp1) + ln;
   // phase 1: wave wv gathers for atoms wv, wv+4 of the group
   for (int nb = wv; nb < kNodesRev; nb += 4) {
@@ -229,6 +243,17 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
     for (int nb = 0; nb < kNodesRev; ++nb) acc[nb] = 0.f;
     const float* fa = reinterpret_cast<const float*>(&sA[0][0]) + pq * kDP;
     const float* fb = reinterpret_cast<const float*>(&sB[0][0]) + pq * kDP;
+    if constexpr (PRELOAD) {
+#pragma unroll
+      for (int o = 0; o < kDP; o += 4) {
+#pragma unroll
+        for (int nb = 0; nb < kNodesRev; ++nb) {
+          const float4 va = *reinterpret_cast<const float4*>(fa + nb * 256 + o), vb = *reinterpret_cast<const float4*>(fb + nb * 256 + o);
+          acc[nb] += (va.x * pre_a[o] + vb.x * pre_b[o]) + (va.y * pre_a[o + 1] + vb.y * pre_b[o + 1]) + (va.z * pre_a[o + 2] + vb.z * pre_b[o + 2]) +
+                     (va.w * pre_a[o + 3] + vb.w * pre_b[o + 3]);
+        }
+      }
+    } else
 #ifdef M3G_DIAG_NR_NO_PHASE2   // timing diagnostic only (wrong results): what re-reading W1a^T / W1b^T per 4-atom group costs
     for (int o = 0; o < 4; o += 4) {
 #else

@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(256) k_node_tb_reverse(Consts c, TbMomArgs ta,
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before it counts as done
     return;
   }
-  node_reverse_body<true>(na, (int64_t)blockIdx.x - f.n_tb, [&] {
+  node_reverse_body<true, true>(na, (int64_t)blockIdx.x - f.n_tb, [&] {
     // ONE lane per wave polls (64 lanes polling one word from every waiting wave starve the increments they wait for: 73 us
     // instead of 24 on the 864-atom cell), ~0.5 us apart
     if ((threadIdx.x & 63) == 0) {
