@@ -379,6 +379,12 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     drop_graphs(plan);
     return M3G_OK;
   }
+  if (strcmp(name, "split_node_tiles") == 0) {
+    if (value < 0) { set_error("split_node_tiles must be >= 0"); return M3G_ERR_VALUE; }
+    plan->split_node_tiles = value;
+    drop_graphs(plan);
+    return M3G_OK;
+  }
   if (strcmp(name, "fuse_node_tb") == 0) {   // 0: three-body reverse and node reverse as two launches (A/B tests; bit-identical either way)
     plan->fuse_node_tb = value != 0;
     drop_graphs(plan);
@@ -705,9 +711,13 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     }
   }
   const bool want_f = io->forces != nullptr;
+  bool energy_deferred = false;
   {
     M3G_STAGE(ST_READOUT);
-    if (mfma) launch_readout_mfma(plan, c, wl, t, io->atom_types, c.B > 0 ? w.x[c.B - 1] : nullptr, w.x[c.B], w, ea, st, io->total_energy, want_f, s);
+    // a step that ends with the reference virial forms the per-structure energy sums in that launch (nothing in between reads them)
+    energy_deferred = mfma && plan->small_launches && want_f && io->stresses && plan->stress_mode == 0 && !plan->profile;
+    if (mfma) launch_readout_mfma(plan, c, wl, t, io->atom_types, c.B > 0 ? w.x[c.B - 1] : nullptr, w.x[c.B], w, ea, st, io->total_energy, want_f, s,
+                                  &energy_deferred);
     else launch_readout(c, W, wl, t, io->atom_types, nullptr, w.x[c.B], w, ea, st, io->total_energy, want_f, s);
   }
   StageTimer* st_out = new StageTimer(plan, ST_OUTPUTS, s);
@@ -789,7 +799,9 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, io->stresses, s);
     if (io->stresses && !tail_fused) {
       if (plan->stress_mode == 1) launch_stress_pair(t, w, io->lattice, io->stresses, s);
-      else launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s);
+      else launch_stress(c, t, io->pos, io->lattice, io->forces, io->stresses, s, energy_deferred ? ea : nullptr, st, io->total_energy);
+    } else if (energy_deferred) {
+      launch_energy_sums(c, t, ea, st, io->total_energy, s);   // (the virial was formed by the force gather's last workgroup after all)
     }
   } else if (io->stresses) {
     set_error("stresses require forces");

@@ -132,11 +132,16 @@ __global__ void __launch_bounds__(256) k_force_gather(float length_scale, int64_
   for (int s = 0; s < (int)st.S; ++s) struct_stress<256>(s, st.struct_ptr, st.flags, N, st.batch, st.pos, st.lattice, forces, st.stresses, part);
 }
 
+// ea != nullptr: the structure's energy sums as well (k_struct_energy's work, deferred to this launch: nothing in the reverse pass
+// reads the totals, so a step that ends with the virial needs no launch of its own for them)
 __global__ void __launch_bounds__(kStructThreads) k_struct_stress(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
                                                        int64_t n_atoms, const int32_t* __restrict__ batch,
                                                        const float* __restrict__ pos, const float* __restrict__ lattice,
-                                                       const float* __restrict__ forces, float* __restrict__ stresses) {
+                                                       const float* __restrict__ forces, float* __restrict__ stresses,
+                                                       const float* __restrict__ ea, float energy_scale, float* __restrict__ scaled_total,
+                                                       float* __restrict__ total) {
   __shared__ float part[kStructThreads * 6];
+  if (ea) struct_energy<kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, ea, energy_scale, scaled_total, total, part);
   struct_stress<kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, pos, lattice, forces, stresses, part);
 }
 __global__ void __launch_bounds__(kStructThreads) k_struct_stress_pair(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
@@ -256,11 +261,10 @@ void launch_force_gather(float length_scale, const Topo& t, const float* dr, flo
 }
 
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
-                   float* stresses, hipStream_t s) {
-  (void)c;
+                   float* stresses, hipStream_t s, const float* ea, float* scaled_total, float* total) {
   if (t.S > 0)
     hipLaunchKernelGGL(k_struct_stress, dim3((unsigned)t.S), dim3(kStructThreads), 0, s, t.struct_ptr, t.flags, t.N, t.batch, pos, lattice, forces,
-                       stresses);
+                       stresses, ea, c.energy_scale, scaled_total, total);
 }
 
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s) {

@@ -217,6 +217,8 @@ struct m3g_plan {
   int small_tiles_fwd = 3072;    // option "small_tiles_fwd": the same threshold for the forward kernel alone (measured: a gain up to ~900 atoms, equal at 1,372)
   int small_tiles = 1536;        // option "small_tiles": graphs of at most this many 16-edge tiles run the split-tile edge kernels
                                  // (m3g_edge_small.hip: a tile over the four SIMDs of a CU, operands in registers); 0 = never
+  int split_node_tiles = 128;    // option "split_node_tiles": 16-atom tiles (2,048 atoms) up to which the node tables and the readout take their split forms
+                                 // (m3g_node_mfma.hip; measured at 625 tiles: node tables 58 -> 85 us, readout 28 -> 36 us per step -- not beyond)
   int fuse_node_tb = 1;          // option "fuse_node_tb": three-body reverse (moment path) + node reverse of a block as two workgroup roles of
                                  // one launch (k_node_tb_reverse, m3g_threebody.hip)
   int small_launches = 1;        // option "small_launches": small systems take fused launches (force tail, readout + energy sums, ...)
@@ -406,7 +408,7 @@ void launch_geometry(const Consts& c, const Topo& t, const float* pos, const flo
 bool launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
                              float* stresses, hipStream_t s, bool fuse_stress = false, const float* pos = nullptr, const float* lattice = nullptr);
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
-                   float* stresses, hipStream_t s);
+                   float* stresses, hipStream_t s, const float* ea = nullptr, float* scaled_total = nullptr, float* total = nullptr);
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s);
 void launch_struct_energy(const Consts& c, const Topo& t, const float* ea, float* scaled_total, float* total, hipStream_t s);
 void launch_force_gather(float length_scale, const Topo& t, const float* dr, float* forces, float* stresses, hipStream_t s);
@@ -431,9 +433,11 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
 bool launch_geometry_node_pre(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, const float* pos, const float* lattice,
                               const int32_t* shift, const int64_t* types, const float* emb, hipStream_t s);
 void launch_energy_sums(const Consts& c, const Topo& t, const float* scaled_atomic, float* scaled_total, float* total, hipStream_t s);
+// energy_sums_deferred (in/out): in true = the caller can form the per-structure energy sums later (k_struct_stress); out true =
+// they are still to be formed (neither this launch's last workgroup nor k_struct_energy did)
 void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayout& wl, const Topo& t, const int64_t* types,
                          const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
-                         bool want_grad, hipStream_t s);
+                         bool want_grad, hipStream_t s, bool* energy_sums_deferred = nullptr);
 void launch_node_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w,
                          const float* v, const float* dx_new, float* dx_out, bool row_sums_in_seg, int dp1_packed, bool with_v_term,
                          hipStream_t s, bool small = false);

@@ -6,7 +6,6 @@
 
 namespace m3g {
 
-constexpr int64_t kReadoutSplitMaxTiles = 128;   // up to 2,048 atoms: k_readout_split / k_node_pre_split (one tile per workgroup)
 
 // ---------------------------------------------------------------------------------------------- node tables
 // S2 on the matrix pipe: [TA | TB | v]^T (528 rows) = W (528 x 64) . x^T (64 x 16 atoms) per 16-atom tile, bf16x3 chains
@@ -490,7 +489,9 @@ __global__ void __launch_bounds__(256) k_readout_split(Consts c, int64_t N, cons
 
 void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayout& wl, const Topo& t, const int64_t* types,
                          const float* x_prev, float* x, const Work& w, float* scaled_atomic, float* scaled_total, float* total,
-                         bool want_grad, hipStream_t s) {
+                         bool want_grad, hipStream_t s, bool* energy_sums_deferred) {
+  const bool may_defer = energy_sums_deferred && *energy_sums_deferred;
+  if (energy_sums_deferred) *energy_sums_deferred = false;
   if (t.N == 0) (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
   bool sums_fused = false;
   if (t.N > 0) {
@@ -499,7 +500,7 @@ void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayo
     sums_fused = plan->small_launches && w.sync && t.N <= kFusedSumsMaxAtoms && t.S > 0 && t.S <= kForceTailMaxStructs;
     const ReadoutSums rs{t.struct_ptr, t.flags, t.batch, total, sums_fused ? w.sync + kSyncReadout : nullptr};
     const bool f16_readout = plan->precision == kPrecF16x3 && plan->readout_f16;
-    if (!f16_readout && plan->small_launches && tiles <= kReadoutSplitMaxTiles) {   // small systems: a tile over the four waves of a workgroup
+    if (!f16_readout && plan->small_launches && tiles <= plan->split_node_tiles) {   // small systems: a tile over the four waves of a workgroup
       if (want_grad)
         hipLaunchKernelGGL(k_readout_split<true>, dim3((unsigned)tiles), dim3(256), 0, s, c, t.N, plan->d_readout_img, plan->d_weights + wl.elemental,
                            types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic, w.dx, scaled_total, t.S, rs);
@@ -517,7 +518,8 @@ void launch_readout_mfma(const m3g_plan* plan, const Consts& c, const WeightLayo
                          plan->d_weights + wl.elemental, types, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, scaled_atomic,
                          want_grad ? w.dx : nullptr, scaled_total, t.S, rs);
   }
-  if (!sums_fused) launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
+  if (!sums_fused && may_defer && t.N > 0) *energy_sums_deferred = true;   // formed by the step's last launch (k_struct_stress)
+  else if (!sums_fused) launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
 }
 
 // types != nullptr (block 0): x is formed from the atom embedding `emb` ([num_types][kDP]) instead of being read
@@ -525,7 +527,7 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
                           float* v, float* TA, float* TB, const int64_t* types, const float* emb, hipStream_t s) {
   if (t.N == 0) return;
   const int64_t tiles = (t.N + 15) / 16;
-  if (plan->precision == kPrecF32 && plan->small_launches && tiles <= kReadoutSplitMaxTiles) {   // small systems: a tile and pass per workgroup
+  if (plan->precision == kPrecF32 && plan->small_launches && tiles <= plan->split_node_tiles) {   // small systems: a tile and pass per workgroup
     const NodePreArgs a{c.C, t.N, plan->d_node_img[kPrecF32] + (size_t)b * kNodeImgFloats, x_prev, w.seg_head, w.seg_first, t.row_ptr, x, v, TA, TB,
                         types, emb, c.num_types};
     hipLaunchKernelGGL(k_node_pre_split, dim3((unsigned)(3 * tiles)), dim3(256), 0, s, a);
@@ -543,7 +545,7 @@ void launch_node_pre_mfma(const m3g_plan* plan, const Consts& c, const Topo& t, 
 bool launch_geometry_node_pre(const m3g_plan* plan, const Consts& c, const Topo& t, const Work& w, const float* pos, const float* lattice,
                               const int32_t* shift, const int64_t* types, const float* emb, hipStream_t s) {
   const int64_t tiles = (t.N + 15) / 16;
-  if (plan->precision != kPrecF32 || !plan->small_launches || c.B == 0 || t.E == 0 || t.N == 0 || tiles > kReadoutSplitMaxTiles) return false;
+  if (plan->precision != kPrecF32 || !plan->small_launches || c.B == 0 || t.E == 0 || t.N == 0 || tiles > plan->split_node_tiles) return false;
   const int n_geo = (int)((t.E + 255) / 256);
   const GeomArgs ga = geometry_args(t, pos, lattice, shift, w);
   const NodePreArgs na{c.C, t.N, plan->d_node_img[kPrecF32], nullptr, w.seg_head, w.seg_first, t.row_ptr, w.x[0], w.v[0], w.TAb[0], w.TBb[0], types, emb,
