@@ -379,6 +379,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     drop_graphs(plan);
     return M3G_OK;
   }
+  if (strcmp(name, "dp1_by_dst") == 0) {   // 0: dp1 rows of the exact-fp32 fused path in edge order (A/B tests; bit-identical either way)
+    plan->dp1_by_dst = value != 0;
+    drop_graphs(plan);
+    return M3G_OK;
+  }
   if (strcmp(name, "split_node_tiles") == 0) {
     if (value < 0) { set_error("split_node_tiles must be >= 0"); return M3G_ERR_VALUE; }
     plan->split_node_tiles = value;
@@ -632,6 +637,7 @@ static int energy_forces_graph(const m3g_plan* plan, const m3g_io* io, void* wor
 // fixed point + scales in the f16x3 mode), everything else fp32 rows
 static int dp1_format(const m3g_plan* plan) {
   if (!fused_reverse(plan)) return kDp1F32;
+  if (dp1_rows_by_dst(plan)) return kDp1F32ByDst;
   return plan->precision == kPrecBf16x3 ? kDp1Packed : plan->precision == kPrecF16x3 ? kDp1Fixed : kDp1F32;
 }
 

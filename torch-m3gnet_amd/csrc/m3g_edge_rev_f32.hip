@@ -56,7 +56,7 @@ constexpr int kWavesRevF32 = M3G_WAVES_REV_F32;
 // SAVED_P2: the forward kernel also stored the layer-2 pre-activations (RevArgs::p2) and SiLU'(p1) in place of p1: no recompute
 // at all, and SiLU'(p1) is loaded half by half where it is used
 template <bool NEED_DP1, int MLP, bool SAVED_P2>
-__device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpRevF32& L, const RevArgs& a, int64_t edge, int64_t tile,
+__device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpRevF32& L, const RevArgs& a, int64_t edge, int64_t drow, int64_t tile,
                                                 int64_t ci, const SegMasks& sk, const f32x4& hv, const f32x4 (&d_upd)[4],
                                                 f32x4 (&contrib)[4], f32x4& dhv, int lane, f32x4 (&d2)[8]) {
   const int qd = lane >> 4;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void mlp_reverse_f32(const float* lds, const MfmaMlpR
     if constexpr (SAVED_P2) static_for<4>([&]<int ob>() { dp1[ob] *= ds1[ob]; });
     else static_for<4>([&]<int ob>() { dp1[ob] *= p1[4 * half + ob]; });
     if (NEED_DP1 && edge < a.E) {
-      float* row = a.dp1 + edge * (4 * kDP) + MLP * (2 * kDP) + half * kDP + 4 * qd;
+      float* row = a.dp1 + drow * (4 * kDP) + MLP * (2 * kDP) + half * kDP + 4 * qd;
       static_for<4>([&]<int ob>() { *(f32x4*)(row + ob * 16) = dp1[ob]; });
     }
     chain_f32<4, 4, 0, 0, 8, 4 * half>(lds + L.w1cT, dp1, contrib, lane);   // k-blocks half*4 .. +4 of the 128 layer-1 outputs
@@ -176,6 +176,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
     const int64_t ci = ci_i;
+    // row of this lane's edge in the dp1 array: by position in the by-neighbour list when the node reverse streams them
+    const int64_t drow = (NEED_DP1 && a.in_pos) ? (int64_t)a.in_pos[ec] : edge;
     const SegMasks sk = seg_masks((int)ci, lane);
     float* de_tile = a.de_soa + tile * kTileFloats + lane * 4;
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
       // the edge MLP's saved rows are requested now, a whole MLP reverse ahead of their use (32 registers; the kernel has them)
       if constexpr (SAVED_P2) load_p2(a, tile, 0, d2e);
 #endif
-      mlp_reverse_f32<NEED_DP1, 1, SAVED_P2>(lds, L.mlp[1], a, edge, tile, ci, sk, hv, dmsg, contrib, dhv, lv, d2n);
+      mlp_reverse_f32<NEED_DP1, 1, SAVED_P2>(lds, L.mlp[1], a, edge, drow, tile, ci, sk, hv, dmsg, contrib, dhv, lv, d2n);
     }
     // dL/d e2 = what flows in from later blocks + the node MLP's contribution
     if (a.de_is_zero) {
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
 #ifndef M3G_P2_PREFETCH
     if constexpr (SAVED_P2) load_p2(a, tile, 0, d2e);
 #endif
-    mlp_reverse_f32<NEED_DP1, 0, SAVED_P2>(lds, L.mlp[0], a, edge, tile, ci, sk, hv, de, contrib, dhv, lv, d2e);
+    mlp_reverse_f32<NEED_DP1, 0, SAVED_P2>(lds, L.mlp[0], a, edge, drow, tile, ci, sk, hv, de, contrib, dhv, lv, d2e);
     static_for<4>([&]<int blk>() {  // dL/d e1 = dL/d e2 + contribution
       de[blk] += contrib[blk];
       if (!FIRST) *(f32x4*)(de_tile + blk * 256) = de[blk];
@@ -271,7 +273,7 @@ void launch_edge_rev_f32(const m3g_plan* plan, const Consts& c, const Topo& t, c
   const float* img = plan->d_mfma_revf32 + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, nullptr, nullptr, nullptr, nullptr, w.de_soa, nullptr,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, w.p1_blk[b],
-             saves_p2(plan) ? w.p2_blk[b] : nullptr, 1.f};
+             saves_p2(plan) ? w.p2_blk[b] : nullptr, 1.f, nullptr, dp1_rows_by_dst(plan) ? t.in_pos : nullptr};
   constexpr int WV = kWavesRevF32;
   dim3 grid(grid_for_tiles(tiles, WV)), block(64 * WV);
   const bool p2 = saves_p2(plan);

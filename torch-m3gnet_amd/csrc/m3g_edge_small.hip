@@ -237,7 +237,7 @@ __device__ __forceinline__ void load_rev_mlp(const float* __restrict__ img, cons
 // reverse of one conv GatedMLP from its saved activations, split over the four waves: d_upd = this wave's block of
 // dL/d(output); returns this wave's block of contrib = W1c^T dL/dp1; accumulates the wave's share of dL/dh into dhv.
 template <bool NEED_DP1, int MLP>
-__device__ __forceinline__ f32x4 mlp_reverse_split(const RevMlpA& A, const RevArgs& a, int64_t edge, int64_t tile, int64_t ci, const SegMasks& sk,
+__device__ __forceinline__ f32x4 mlp_reverse_split(const RevMlpA& A, const RevArgs& a, int64_t edge, int64_t drow, int64_t tile, int64_t ci, const SegMasks& sk,
                                                    float hb_sel, const f32x4& d_upd, f32x4& dhv, float* hs1, float* hs2, int w, int lane) {
   const int qd = lane >> 4;
   const float* p2_src = a.p2 + tile * (2 * kP1TileFloats) + MLP * kP1TileFloats + lane * 4;
@@ -279,7 +279,7 @@ __device__ __forceinline__ f32x4 mlp_reverse_split(const RevMlpA& A, const RevAr
     });
     M3G_F32_CHAIN_PRIO(0);
     dp1 *= ds1;
-    if (NEED_DP1 && edge < a.E) *(f32x4*)(a.dp1 + edge * (4 * kDP) + MLP * (2 * kDP) + hf * kDP + 4 * qd + w * 16) = dp1;
+    if (NEED_DP1 && edge < a.E) *(f32x4*)(a.dp1 + drow * (4 * kDP) + MLP * (2 * kDP) + hf * kDP + 4 * qd + w * 16) = dp1;
     dp1h[hf] = dp1;
     if (NEED_DP1) {   // per-centre sums of the dp1 rows (x_i half of the node reverse)
       f32x4 t = edge < a.E ? dp1 : zero4();
@@ -330,6 +330,7 @@ __global__ void __launch_bounds__(64 * kSplitWaves) __attribute__((amdgpu_waves_
     const int64_t edge = tile * kTileEdges + (lane & 15);
     const int64_t ec = edge < a.E ? edge : a.E - 1;
     const int64_t ci = a.src[ec];
+    const int64_t drow = (NEED_DP1 && a.in_pos) ? (int64_t)a.in_pos[ec] : edge;   // row of this edge in the dp1 array (see RevArgs::in_pos)
     const SegMasks sk = seg_masks((int)ci, lane);
     const f32x4 hv = *(const f32x4*)(a.h + ec * kRP);
     const float hb_sel = qd == 0 ? hv[0] : qd == 1 ? hv[1] : qd == 2 ? hv[2] : hv[3];
@@ -341,12 +342,12 @@ __global__ void __launch_bounds__(64 * kSplitWaves) __attribute__((amdgpu_waves_
     const f32x4 dmsg = *(const f32x4*)(a.dx_new + ci * kDP + 4 * qd + w * 16);
     f32x4 de;
     if (!a.de_is_zero) de = load_tile4(a.de_soa + tile * kTileFloats + w * 256 + lane * 4);
-    f32x4 contrib = mlp_reverse_split<NEED_DP1, 1>(A1, a, edge, tile, ci, sk, hb_sel, dmsg, dhv, hs1, hs2, w, lane);
+    f32x4 contrib = mlp_reverse_split<NEED_DP1, 1>(A1, a, edge, drow, tile, ci, sk, hb_sel, dmsg, dhv, hs1, hs2, w, lane);
     // dL/d e2 = what flows in from later blocks + the node MLP's contribution
     if (a.de_is_zero) de = contrib;
     else de = de + contrib;
     // edge-update MLP (nn/conv.py:68-75)
-    contrib = mlp_reverse_split<NEED_DP1, 0>(A0, a, edge, tile, ci, sk, hb_sel, de, dhv, hs1, hs2, w, lane);
+    contrib = mlp_reverse_split<NEED_DP1, 0>(A0, a, edge, drow, tile, ci, sk, hb_sel, de, dhv, hs1, hs2, w, lane);
     de += contrib;   // dL/d e1
     if (!FIRST) *(f32x4*)(a.de_soa + tile * kTileFloats + w * 256 + lane * 4) = de;
     if (FIRST) {
@@ -423,7 +424,7 @@ bool launch_edge_rev_split(const m3g_plan* plan, const Consts& c, const Topo& t,
   const MfmaRevF32Layout L = mfma_rev_f32_layout();
   RevArgs ar{t.E, tiles, plan->d_mfma_revf32 + (size_t)b * L.total, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, nullptr, nullptr, nullptr, nullptr,
              w.de_soa, nullptr, de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, w.p1_blk[b],
-             w.p2_blk[b], 1.f};
+             w.p2_blk[b], 1.f, nullptr, dp1_rows_by_dst(plan) ? t.in_pos : nullptr};
   const dim3 grid(grid_for_split(tiles)), block(64 * kSplitWaves);
   if (b > 0) { M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_split<TBS, true>), grid, block, 0, s, ar, L)); }
   else { M3G_TBS_SWITCH(c.C, hipLaunchKernelGGL((k_edge_rev_split<TBS, false>), grid, block, 0, s, ar, L)); }

@@ -217,6 +217,8 @@ struct m3g_plan {
   int small_tiles_fwd = 3072;    // option "small_tiles_fwd": the same threshold for the forward kernel alone (measured: a gain up to ~900 atoms, equal at 1,372)
   int small_tiles = 1536;        // option "small_tiles": graphs of at most this many 16-edge tiles run the split-tile edge kernels
                                  // (m3g_edge_small.hip: a tile over the four SIMDs of a CU, operands in registers); 0 = never
+  int dp1_by_dst = 0;            // option "dp1_by_dst": see dp1_rows_by_dst().  Measured on the 10k-atom cell: node reverse 205 -> 207 us, reverse edge kernels
+                                 // 1.012 -> 1.017 ms per step -- the gather of whole 1-KB rows is not what bounds the node reverse; off by default
   int split_node_tiles = 128;    // option "split_node_tiles": 16-atom tiles (2,048 atoms) up to which the node tables and the readout take their split forms
                                  // (m3g_node_mfma.hip; measured at 625 tiles: node tables 58 -> 85 us, readout 28 -> 36 us per step -- not beyond)
   int fuse_node_tb = 1;          // option "fuse_node_tb": three-body reverse (moment path) + node reverse of a block as two workgroup roles of
@@ -304,6 +306,8 @@ struct Topo {
   int32_t* row_ptr;  // [N+1] edges of centre i: row_ptr[i] .. row_ptr[i+1]
   int32_t* in_ptr;   // [N+1] incoming edges of atom j (dst == j)
   int32_t* in_edge;  // [E]
+  int32_t* in_pos;   // [E] position of edge e in the by-neighbour list: in_edge[in_pos[e]] == e (dp1 rows are stored by that position in the
+                     // exact-fp32 fused path, so the node reverse STREAMS the rows of an atom instead of gathering them)
   int32_t* in_pair;  // [E][2] (in_edge[k], act_id[in_edge[k]]): the k-th incoming edge and its compact three-body row (-1: none),
                      // one 8-byte load in the node reverse gather
   int32_t* t1_ptr;   // [E+1] triplets grouped by first edge e1
@@ -348,7 +352,7 @@ size_t topo_sort_tmp_bytes(int64_t E, int64_t T);
 inline float* dp1_scale_of(float* dp1, int64_t E) { return dp1 ? dp1 + (size_t)E * 192 : nullptr; }
 // dp1 hand-over formats of k_node_reverse: fp32 rows, 24-bit floating rows (bf16x3 fused kernel), 24-bit fixed-point rows + scales
 // (f16x3 fused kernel)
-enum { kDp1F32 = 0, kDp1Packed = 1, kDp1Fixed = 2 };
+enum { kDp1F32 = 0, kDp1Packed = 1, kDp1Fixed = 2, kDp1F32ByDst = 3 /* fp32 rows stored by position in the by-neighbour list */ };
 
 struct Work {
   // per-edge geometry / bases
@@ -469,6 +473,10 @@ inline bool saves_p1(const m3g_plan* plan) { return plan->edge_kernel == 1 && pl
 // reverse kernel then issues no recompute MFMA at all (576 instead of 832 per tile)
 inline bool saves_p2(const m3g_plan* plan) { return saves_p1(plan) && plan->rev_kernel == 1 && plan->save_p2 != 0; }
 inline int saved_activations(const m3g_plan* plan) { return saves_p2(plan) ? 2 : saves_p1(plan) ? 1 : 0; }
+// exact-fp32 fused reverse kernels: dp1 rows stored by the edge's position in the by-neighbour list (option "dp1_by_dst")
+inline bool dp1_rows_by_dst(const m3g_plan* plan) {
+  return plan->dp1_by_dst && plan->edge_kernel == 1 && plan->rev_kernel == 1 && plan->precision == kPrecF32 && saves_p1(plan);
+}
 inline bool fused_reverse(const m3g_plan* plan) {
   return plan->edge_kernel == 1 && plan->rev_kernel == 1 && (plan->precision != kPrecF32 || saves_p1(plan));
 }

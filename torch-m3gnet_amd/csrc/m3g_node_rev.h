@@ -32,6 +32,7 @@ struct NodeRevArgs {
   const int2* in_pair;
   int dp1_packed;
   const float* dp1_scale;
+  int dp1_by_dst;   // fp32 rows stored by position in the by-neighbour list (RevArgs::in_pos): the rows of an atom are consecutive
 };
 // DEFER_V: the dL/dg rows (dgq) are produced by OTHER workgroups of the same launch (the three-body reverse role of
 // k_node_tb_reverse, m3g_threebody.hip): the dp1 gather runs first, `wait_for_dgq()` then blocks until those rows are visible, and
@@ -129,6 +130,7 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
           const int src = b + j < 64 ? b + j : 63;   // lanes >= cnt hold (-1, -1)
           f[j].x = b + j < 64 ? __builtin_amdgcn_readlane(mine.x, src) : -1;
           f[j].y = b + j < 64 ? __builtin_amdgcn_readlane(mine.y, src) : -1;
+          if (args.dp1_by_dst && f[j].x >= 0) f[j].x = kc + b + j;   // rows stored in list order: a stream, not a gather
         }
 #else
       for (; k < k1; k += kNrBatch) {
@@ -287,9 +289,11 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
 
 inline NodeRevArgs node_rev_args(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v, const float* dx_new,
                                  float* dx_out, bool row_sums_in_seg, int dp1_packed, bool with_v_term) {
+  const bool by_dst = dp1_packed == kDp1F32ByDst;   // fp32 rows either way; only their order in the array differs
+  if (by_dst) dp1_packed = kDp1F32;
   return NodeRevArgs{c.C, t.N, W, bw, t.row_ptr, t.in_ptr, t.in_edge, w.dp1, w.dg, v, dx_new, dx_out, row_sums_in_seg ? w.seg_head : nullptr,
                      row_sums_in_seg ? w.seg_first : nullptr, with_v_term ? 1 : 0, reinterpret_cast<const int2*>(t.in_pair), dp1_packed,
-                     dp1_scale_of(w.dp1, t.E)};
+                     dp1_scale_of(w.dp1, t.E), by_dst ? 1 : 0};
 }
 
 }  // namespace m3g

@@ -39,6 +39,7 @@ Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
   t.in_ptr = (int32_t*)take(sizeof(int32_t) * (N + 1));
   t.in_edge = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.in_pair = (int32_t*)take(sizeof(int32_t) * 2 * (E + 1));
+  t.in_pos = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.t1_ptr = (int32_t*)take(sizeof(int32_t) * (E + 1));
   t.t1_e2 = (int32_t*)take(sizeof(int32_t) * (T + 1));
   t.t2_ptr = (int32_t*)take(sizeof(int32_t) * (E + 1));
@@ -326,13 +327,14 @@ __global__ void __launch_bounds__(1024) k_tb_stats(int64_t blocks, const int32_t
 __global__ void k_set_word(int32_t* dst, int32_t v) { *dst = v; }
 // (idx may hold anything while a build runs ahead of its own verdict -- an edge list that turns out not to be symmetric leaves
 // rows of in_edge unwritten until the sort replaces them --, so the lookup is bounded: never an out-of-range read)
-__global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ table, int32_t* out) {
+__global__ void k_pair_with_lookup(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ table, int32_t* out, int32_t* pos) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t e = idx[i];
   const bool ok = e >= 0 && (int64_t)e < n;
   out[2 * i] = ok ? e : 0;
   out[2 * i + 1] = ok ? table[e] : -1;
+  if (ok) pos[e] = (int32_t)i;   // inverse of the by-neighbour list (a permutation of the edges once the build has passed its checks)
 }
 // byte-sized partner ids: for triplet slot t of list (t_ptr, t_other_c), the row it belongs to fixes the workgroup and so the
 // staged window [lo, lo + n); the partner is stored relative to lo, 255 when it falls outside.  The row is the high word of the
@@ -469,7 +471,7 @@ static int topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int6
                        t.act_dst, t.act_id, t.arow_ptr, t.n_act);
     hipLaunchKernelGGL(k_tb_windows, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t2_ptr,
                        t.tb_win);
-    if (E > 0) hipLaunchKernelGGL(k_pair_with_lookup, grid(E), dim3(TPB), 0, s, E, t.in_edge, t.act_id, t.in_pair);
+    if (E > 0) hipLaunchKernelGGL(k_pair_with_lookup, grid(E), dim3(TPB), 0, s, E, t.in_edge, t.act_id, t.in_pair, t.in_pos);
     if (T > 0) {
       hipLaunchKernelGGL(k_compact_partners, grid(T), dim3(TPB), 0, s, T, t.act_scan, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c);
       if (symmetric) {   // one list serves both roles
