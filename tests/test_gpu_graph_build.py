@@ -230,7 +230,7 @@ def test_graphs_without_edges_or_triplets_run_end_to_end():
 def test_long_rows_with_atoms_outside_the_home_cell_are_ordered_canonically():
     """The canonical order sorts a centre's edges by the shift relative to the GIVEN coordinates.  The search emits them by image
     of the wrapped cell, so rows that hold a neighbour outside the home cell are re-ranked (k_rows_canonical): from an LDS stage
-    for rows of up to 512 edges, in place by one lane beyond -- a 7-atom cell of 3.3 A under a 9 A cutoff has ~590 edges per
+    for rows of up to 512 edges, by a block-wise odd-even merge through the same stage beyond -- a 7-atom cell of 3.3 A under a 9 A cutoff has ~590 edges per
     centre, and half of the atoms are moved out of the home cell by lattice vectors.  Against the host builder, element by
     element."""
     rng = np.random.default_rng(17)
@@ -242,6 +242,10 @@ def test_long_rows_with_atoms_outside_the_home_cell_are_ordered_canonically():
     deg = np.bincount(host[0][0], minlength=7)
     assert deg.max() > 512 and (np.abs(np.floor(frac)).sum() > 0)
     _assert_same(host, _gpu([lat], [pos], 9.0, 3.0))
+    # rows of ~1,700 edges: seven blocks of 256 through the block-wise odd-even merge of k_rows_canonical
+    host = _host(lat, pos, 12.8, 3.0)
+    assert np.bincount(host[0][0], minlength=7).max() > 1536
+    _assert_same(host, _gpu([lat], [pos], 12.8, 3.0))
     # and a moderate case through the LDS stage (rows of ~150 edges)
     host = _host(lat, pos, 5.5, 4.0)
     assert 64 < np.bincount(host[0][0], minlength=7).max() <= 512

@@ -395,21 +395,37 @@ __global__ void __launch_bounds__(256) k_rows_canonical(int64_t N, int64_t M, co
       shift[a * 3] = x; shift[a * 3 + 1] = y; shift[a * 3 + 2] = z;
       dist[a] = sd[k];
     }
-  } else if (lane == 0) {   // very long rows (a tiny cell under a large cutoff): in place
-    for (int64_t a = b + 1; a < e; ++a) {
-      const int64_t j = edge_index[E + a];
-      const int x = shift[a * 3], y = shift[a * 3 + 1], z = shift[a * 3 + 2];
-      const double d = dist[a];
-      int64_t c = a;
-      while (c > b && canon_less(x, y, z, (int)j, shift[(c - 1) * 3], shift[(c - 1) * 3 + 1], shift[(c - 1) * 3 + 2], (int)edge_index[E + c - 1])) {
-        edge_index[E + c] = edge_index[E + c - 1];
-        shift[c * 3] = shift[(c - 1) * 3]; shift[c * 3 + 1] = shift[(c - 1) * 3 + 1]; shift[c * 3 + 2] = shift[(c - 1) * 3 + 2];
-        dist[c] = dist[c - 1];
-        --c;
+  } else {
+    // very long rows (a tiny cell under a large cutoff): odd-even transposition over BLOCKS of kCanonStage / 2 edges -- in pass p the
+    // wave stages the block pairs (p & 1, p & 1 + 1), (p & 1 + 2, ...) in its LDS share, ranks the pair's <= 512 edges as above
+    // and writes them back in order (a merge-split step); after as many passes as there are blocks the row is sorted.  The keys
+    // (shift, neighbour) are distinct, so the result is the one canonical order whatever the method.  (Until round 5: an
+    // insertion sort by one lane on global memory, O(n^2) dependent round trips.)
+    constexpr int H = kCanonStage / 2;
+    int32_t *sj = s_j + wave * kCanonStage, *sx = s_x + wave * kCanonStage, *sy = s_y + wave * kCanonStage, *sz = s_z + wave * kCanonStage;
+    double* sd = s_d + wave * kCanonStage;
+    const int nc = (n + H - 1) / H;
+    for (int pass = 0; pass < nc; ++pass) {
+      for (int blk = pass & 1; blk + 1 < nc; blk += 2) {
+        const int64_t b0 = b + (int64_t)blk * H;
+        const int m = (int)((e - b0) < 2 * H ? (e - b0) : 2 * H);   // edges of the two blocks (the last block may be short)
+        for (int k = lane; k < m; k += 64) {
+          sj[k] = (int32_t)edge_index[E + b0 + k];
+          sx[k] = shift[(b0 + k) * 3]; sy[k] = shift[(b0 + k) * 3 + 1]; sz[k] = shift[(b0 + k) * 3 + 2];
+          sd[k] = dist[b0 + k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int k = lane; k < m; k += 64) {
+          const int x = sx[k], y = sy[k], z = sz[k], j = sj[k];
+          int rank = 0;
+          for (int f = 0; f < m; ++f) rank += canon_less(sx[f], sy[f], sz[f], sj[f], x, y, z, j) ? 1 : 0;
+          const int64_t a = b0 + rank;
+          edge_index[E + a] = j;
+          shift[a * 3] = x; shift[a * 3 + 1] = y; shift[a * 3 + 2] = z;
+          dist[a] = sd[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the stage is rewritten by the next pair; its global writes precede the next pass's reads
       }
-      edge_index[E + c] = j;
-      shift[c * 3] = x; shift[c * 3 + 1] = y; shift[c * 3 + 2] = z;
-      dist[c] = d;
     }
   }
 }
