@@ -118,13 +118,15 @@ def test_fused_launches_are_bit_identical(case, mode):
 
 
 def test_fused_launches_on_a_larger_cell_and_many_structures():
-    """2,048-atom cell (force gather ends with the virial; readout with the energy sum) and a 12-structure batch (more structures
-    than the fused launches walk: the stand-alone sum kernels run) -- identical bits with and without the option."""
+    """864-atom cell (force gather ends with the virial; readout with the energy sum), a 2,048-atom cell (beyond the fused sums' range:
+    the energy sums are deferred into the final stress launch) and a 12-structure batch (more structures than the fused launches
+    walk: the stand-alone sum kernels run) -- identical bits with and without the option."""
     from helpers import fcc_cu_graph, random_cell_graph
     from torch_m3gnet.data import MaterialGraphKey as K
     from torch_m3gnet.data.material_graph import Batch
 
-    graphs = [fcc_cu_graph(8, 8, 8).to("cuda"), Batch.from_data_list([random_cell_graph(12, 6.0, s) for s in range(12)]).to("cuda")]
+    graphs = [fcc_cu_graph(6, 6, 6).to("cuda"), fcc_cu_graph(8, 8, 8).to("cuda"),
+              Batch.from_data_list([random_cell_graph(12, 6.0, s) for s in range(12)]).to("cuda")]
     for g0 in graphs:
         outs = []
         for fused in (1, 0):

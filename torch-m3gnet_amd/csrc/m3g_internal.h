@@ -398,10 +398,10 @@ constexpr int kSyncForceTail = 0, kSyncReadout = 1, kSyncNodeRev = 2;   // (+ bl
 // fused launches: the per-structure sums (energies after the readout, virial after the force gather) are formed by the LAST
 // workgroup of the producing launch when the batch has at most this many structures (it walks them one after the other)
 constexpr int64_t kForceTailMaxStructs = 8;
-// ... and at most this many atoms: the last workgroup's 256 threads then read <= 8 atoms each (measured on the 10,000-atom cell: 40
+// ... and at most this many atoms: the last workgroup's 256 threads then read <= 4 atoms each (measured on the 10,000-atom cell: 40
 // dependent reads per thread of values other XCDs have just written cost 24 us after the readout and 65 us after the force gather,
 // against 6 and 10 us for the stand-alone sum kernels)
-constexpr int64_t kFusedSumsMaxAtoms = 2048;
+constexpr int64_t kFusedSumsMaxAtoms = 1024;   // (2,000 atoms: readout + sums 23 us against ~20 separately, gather + virial 19 against 17: no gain any more)
 constexpr int64_t kNodeTbFusedMaxAtoms = 128;   // k_node_tb_reverse (two roles in one launch): see launch_node_tb_reverse
 Work work_carve(const Consts& c, bool mfma, int save_acts /* 0 none, 1 p1, 2 p1 + p2 */, int64_t N, int64_t E, int64_t T, int64_t S, void* base);
 
