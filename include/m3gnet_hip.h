@@ -317,13 +317,14 @@ int m3g_verlet_update(int64_t n_atoms, int64_t n_structs, int64_t n_candidates, 
                       const int32_t* cand_row_ptr, double cutoff, float threebody_cutoff, const uint8_t* cand_state, void* scratch,
                       size_t scratch_bytes, double* host_max_disp, int32_t* host_changed, int64_t* host_n_edges,
                       int64_t* host_n_triplets, void* stream);
-/* m3g_verlet_update without the wait: the pass and its 32-byte result copy are queued on the stream; host_out (PINNED host memory)
- * receives {bits of max_disp^2 as a double, changed, E, T} when the stream reaches the copy.  A caller may queue the evaluation
+/* m3g_verlet_update without the wait: the pass and its 48-byte result copy are queued on the stream; host_out (PINNED host memory,
+ * SIX words) receives {bits of max_disp^2 as a double, changed, E, T, (internal), the longest candidate row -- what
+ * m3g_verlet_fill_lists wants as max_cand_row} when the stream reaches the copy.  A caller may queue the evaluation
  * behind it on the assumption that nothing changed and read the verdict afterwards. */
 int m3g_verlet_update_async(int64_t n_atoms, int64_t n_structs, int64_t n_candidates, const double* pos, const double* pos_ref,
                             const double* lattice, const int64_t* batch, const int64_t* cand_edge_index, const int32_t* cand_shift,
                             const int32_t* cand_row_ptr, double cutoff, float threebody_cutoff, const uint8_t* cand_state, void* scratch,
-                            size_t scratch_bytes, uint64_t* host_out /* [4] */, void* stream);
+                            size_t scratch_bytes, uint64_t* host_out /* [6] */, void* stream);
 int m3g_verlet_fill(int64_t n_atoms, int64_t n_candidates, int64_t n_edges, void* scratch, const int64_t* cand_edge_index,
                     const int32_t* cand_shift, const int32_t* cand_row_ptr, int64_t* edge_index /* [2,E] */,
                     int32_t* edge_cell_shift /* [E,3] */, double* distances /* [E] */, uint8_t* cand_state /* [Ec] out */, void* stream);

@@ -546,18 +546,27 @@ __global__ void __launch_bounds__(256) k_verlet_rows(int64_t N, int64_t S, int64
   }
 }
 // one workgroup: E = sum of the rows' kept candidates, T = sum of their triplets (fixed order: integers anyway)
+// (acc[5] = the longest candidate row: the caller chooses the refill entry point by it without a read-back of its own)
 __global__ void __launch_bounds__(1024) k_verlet_totals(int64_t N, const int32_t* __restrict__ row_keep, const int64_t* __restrict__ row_tri,
-                                                        unsigned long long* acc) {
-  __shared__ unsigned long long se[16], st[16];
-  unsigned long long e = 0, t = 0;
-  for (int64_t i = threadIdx.x; i < N; i += blockDim.x) { e += (unsigned long long)row_keep[i]; t += (unsigned long long)row_tri[i]; }
-  for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); t += __shfl_xor(t, o); }
-  if ((threadIdx.x & 63) == 0) { se[threadIdx.x >> 6] = e; st[threadIdx.x >> 6] = t; }
+                                                        const int32_t* __restrict__ row_ptr, unsigned long long* acc) {
+  __shared__ unsigned long long se[16], st[16], sm[16];
+  unsigned long long e = 0, t = 0, m = 0;
+  for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
+    e += (unsigned long long)row_keep[i]; t += (unsigned long long)row_tri[i];
+    const unsigned long long len = (unsigned long long)(row_ptr[i + 1] - row_ptr[i]);
+    m = len > m ? len : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    e += __shfl_xor(e, o); t += __shfl_xor(t, o);
+    const unsigned long long mo = __shfl_xor(m, o);
+    m = mo > m ? mo : m;
+  }
+  if ((threadIdx.x & 63) == 0) { se[threadIdx.x >> 6] = e; st[threadIdx.x >> 6] = t; sm[threadIdx.x >> 6] = m; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    e = 0; t = 0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { e += se[k]; t += st[k]; }
-    acc[2] = e; acc[3] = t;
+    e = 0; t = 0; m = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { e += se[k]; t += st[k]; m = sm[k] > m ? sm[k] : m; }
+    acc[2] = e; acc[3] = t; acc[5] = m;
   }
 }
 
@@ -665,12 +674,26 @@ __global__ void __launch_bounds__(256) k_verlet_update_small(int64_t N, int64_t 
   __syncthreads();
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  unsigned long long e = 0, t = 0;
-  for (int64_t k = threadIdx.x; k < N; k += blockDim.x) { e += (unsigned long long)row_keep[k]; t += (unsigned long long)row_tri[k]; }
-  for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); t += __shfl_xor(t, o); }
-  if (lane == 0) { se[threadIdx.x >> 6] = e; st4[threadIdx.x >> 6] = t; }
+  __shared__ unsigned long long sm4[4];
+  unsigned long long e = 0, t = 0, m = 0;
+  for (int64_t k = threadIdx.x; k < N; k += blockDim.x) {
+    e += (unsigned long long)row_keep[k]; t += (unsigned long long)row_tri[k];
+    const unsigned long long len = (unsigned long long)(row_ptr[k + 1] - row_ptr[k]);
+    m = len > m ? len : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    e += __shfl_xor(e, o); t += __shfl_xor(t, o);
+    const unsigned long long mo = __shfl_xor(m, o);
+    m = mo > m ? mo : m;
+  }
+  if (lane == 0) { se[threadIdx.x >> 6] = e; st4[threadIdx.x >> 6] = t; sm4[threadIdx.x >> 6] = m; }
   __syncthreads();
-  if (threadIdx.x == 0) { acc[2] = (se[0] + se[1]) + (se[2] + se[3]); acc[3] = (st4[0] + st4[1]) + (st4[2] + st4[3]); }
+  if (threadIdx.x == 0) {
+    acc[2] = (se[0] + se[1]) + (se[2] + se[3]); acc[3] = (st4[0] + st4[1]) + (st4[2] + st4[3]);
+    m = sm4[0];
+    for (int k = 1; k < 4; ++k) m = sm4[k] > m ? sm4[k] : m;
+    acc[5] = m;
+  }
 }
 
 // ---- refill in two launches (m3g_verlet_fill_lists) ----------------------------------------------------------------------
@@ -1001,7 +1024,7 @@ extern "C" int m3g_verlet_rows(int64_t N, int64_t n_candidates, const int64_t* c
   return M3G_OK;
 }
 
-// The pass itself, queued on the stream with its 32-byte result copy: host_out[0] = bits of the largest squared displacement
+// The pass itself, queued on the stream with its 48-byte result copy ([4] internal, [5] = the longest candidate row): host_out[0] = bits of the largest squared displacement
 // (a non-negative double), [1] = changed flag, [2] = E, [3] = T.  No wait: a caller with PINNED host memory can queue the
 // evaluation behind it and look at the verdict afterwards (torch_m3gnet.data.md.VerletGraph.begin / confirm).
 extern "C" int m3g_verlet_update_async(int64_t N, int64_t S, int64_t Ec, const double* pos, const double* pos_ref, const double* lattice,
@@ -1013,7 +1036,7 @@ extern "C" int m3g_verlet_update_async(int64_t N, int64_t S, int64_t Ec, const d
   int rc = m3g_verlet_scratch_bytes(N, Ec, &need);
   if (rc) return rc;
   if (!scratch || scratch_bytes < need || !host_out) { set_error("m3g_verlet_update: scratch too small or null argument"); return M3G_ERR_SIZE; }
-  if (N == 0) { host_out[0] = host_out[1] = host_out[2] = host_out[3] = 0; return M3G_OK; }
+  if (N == 0) { for (int k = 0; k < 6; ++k) host_out[k] = 0; return M3G_OK; }
   if (!pos || !pos_ref || !lattice || !batch || !cand_row_ptr || (Ec > 0 && (!cand_edge_index || !cand_shift))) {
     set_error("m3g_verlet_update: null argument");
     return M3G_ERR_VALUE;
@@ -1025,14 +1048,14 @@ extern "C" int m3g_verlet_update_async(int64_t N, int64_t S, int64_t Ec, const d
   if (N <= kVerletFusedMaxAtoms) {   // small cells: the whole pass in one launch
     hipLaunchKernelGGL(k_verlet_update_small, g_for(N * 64), dim3(256), 0, s, N, S, Ec, pos, pos_ref, batch, lattice, cand_edge_index, cand_shift,
                        cand_row_ptr, cutoff, threebody_cutoff, cand_state, w.state, w.dist, w.row_keep, w.row_tri, w.acc);
-    M3G_HIP_CHECK(hipMemcpyAsync(host_out, w.acc, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, s));
+    M3G_HIP_CHECK(hipMemcpyAsync(host_out, w.acc, sizeof(uint64_t) * 6, hipMemcpyDeviceToHost, s));
     return M3G_OK;
   }
   hipLaunchKernelGGL(k_verlet_prep, g_for(N), dim3(256), 0, s, N, S, pos, pos_ref, lattice, batch, w.pos_w, w.wrap, w.acc);
   hipLaunchKernelGGL(k_verlet_rows, g_for(N * 64), dim3(256), 0, s, N, S, Ec, batch, lattice, cand_edge_index, cand_shift, cand_row_ptr, w.pos_w,
                      w.wrap, cutoff, threebody_cutoff, cand_state, w.state, w.dist, w.row_keep, w.row_tri, w.acc);
-  hipLaunchKernelGGL(k_verlet_totals, dim3(1), dim3(1024), 0, s, N, w.row_keep, w.row_tri, w.acc);
-  M3G_HIP_CHECK(hipMemcpyAsync(host_out, w.acc, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_verlet_totals, dim3(1), dim3(1024), 0, s, N, w.row_keep, w.row_tri, cand_row_ptr, w.acc);
+  M3G_HIP_CHECK(hipMemcpyAsync(host_out, w.acc, sizeof(uint64_t) * 6, hipMemcpyDeviceToHost, s));
   return M3G_OK;
 }
 
@@ -1041,7 +1064,7 @@ extern "C" int m3g_verlet_update(int64_t N, int64_t S, int64_t Ec, const double*
                                  double cutoff, float threebody_cutoff, const uint8_t* cand_state, void* scratch, size_t scratch_bytes,
                                  double* host_max_disp, int32_t* host_changed, int64_t* host_n_edges, int64_t* host_n_triplets, void* stream_) {
   if (!host_max_disp || !host_changed || !host_n_edges || !host_n_triplets) { set_error("m3g_verlet_update: null argument"); return M3G_ERR_VALUE; }
-  uint64_t h[4] = {0, 0, 0, 0};
+  uint64_t h[6] = {0, 0, 0, 0, 0, 0};
   int rc = m3g_verlet_update_async(N, S, Ec, pos, pos_ref, lattice, batch, cand_edge_index, cand_shift, cand_row_ptr, cutoff, threebody_cutoff,
                                    cand_state, scratch, scratch_bytes, h, stream_);
   if (rc) return rc;

@@ -59,7 +59,7 @@ class VerletGraph:
         self.graph = None
         self._cand = None            # (edge_index [2,Ec], shift [Ec,3], row_ptr [N+2], state [Ec] u8, pos_ref [N,3] f64, scratch)
         self.stats = {"reuse": 0, "refill": 0, "search": 0}
-        self._verdict = torch.zeros(4, dtype=torch.int64).pin_memory()   # m3g_verlet_update_async: max disp^2 (bits), changed, E, T
+        self._verdict = torch.zeros(8, dtype=torch.int64).pin_memory()   # m3g_verlet_update_async: max disp^2 (bits), changed, E, T, -, longest candidate row
         self._verdict_ready = torch.cuda.Event()
         self._pending = None         # positions of a begin() whose verdict has not been read
         self._state_valid = False    # the candidates' membership bytes describe the current lists
@@ -89,8 +89,7 @@ class VerletGraph:
         scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
         state = torch.empty(ec + 16, dtype=torch.uint8, device=self.device)   # written by the first fill
         self._cand = (ei, shift, rows, state, pos.clone(), scratch)
-        # longest candidate row (one read-back per SEARCH): decides whether the two-launch refill applies (m3g_verlet_fill_lists)
-        self._max_row = int((rows[1:self.N + 1] - rows[:self.N]).max()) if self.N else 0
+        self._max_row = 1 << 30   # the longest candidate row arrives with the next verdict (m3g_verlet_update_async, word 5)
         self._state_valid = False
         self.stats["search"] += 1
 
@@ -108,6 +107,7 @@ class VerletGraph:
         self._verdict_ready.synchronize()
         v = self._verdict
         disp = float(np.sqrt(np.frombuffer(np.int64(int(v[0])).tobytes(), dtype=np.float64)[0]))
+        self._max_row = int(v[5])   # decides whether the two-launch refill applies (m3g_verlet_fill_lists)
         return disp, bool(int(v[1])), int(v[2]), int(v[3])
 
     def _update(self, pos: torch.Tensor):
