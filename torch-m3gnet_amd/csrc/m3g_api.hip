@@ -745,6 +745,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   if (want_f) {
     float* dx_cur = w.dx;
     float* dx_alt = w.dx2;
+    bool dr_done = false;
     for (int b = c.B - 1; b >= 0; --b) {
       if (b == c.B - 1 && E > 0) {
           if (!mfma) {
@@ -781,6 +782,9 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
                  launch_node_tb_reverse(c, W, wl.blk[b], t, w, w.v[b], /*first=*/b == c.B - 1, dx_cur, dx_alt, dp1_format(plan), b, s, tb_hints)) {
         // (moment path) three-body reverse and node reverse of the block as two workgroup roles of ONE launch
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
+      } else if (b == 0 && mfma && fused_rev && plan->small_launches && !plan->profile &&
+                 launch_threebody_reverse_final(c, t, w, w.v[b], /*first=*/b == c.B - 1, w.dh_parts, c.B, s, tb_hints)) {
+        dr_done = true;   // (moment path) the step's last three-body reverse formed dE/dr of every edge as well
       } else {
         { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s, tb_hints); }
         if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
@@ -801,7 +805,8 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
     // few structures: the force-gather launch ends with the reference virial (one launch less, bit-identical)
     const bool fuse = mfma && plan->small_launches && plan->stress_mode == 0;
     bool tail_fused = false;
-    if (mfma) tail_fused = launch_geometry_reverse(c, t, w, w.dh_parts, fused_rev ? c.B : 2 * c.B + 1, io->forces, io->stresses, s, fuse, io->pos, io->lattice);
+    if (mfma) tail_fused = launch_geometry_reverse(c, t, w, w.dh_parts, fused_rev ? c.B : 2 * c.B + 1, io->forces, io->stresses, s, fuse, io->pos, io->lattice,
+                                                   dr_done);
     else launch_geometry_reverse(c, t, w, w.dh, 1, io->forces, io->stresses, s);
     if (io->stresses && !tail_fused) {
       if (plan->stress_mode == 1) launch_stress_pair(t, w, io->lattice, io->stresses, s);

@@ -13,44 +13,6 @@ __global__ void __launch_bounds__(256) k_geometry(Consts c, GeomArgs a) {
   geometry_body<FULL, L, R>(c, a, blockIdx.x);
 }
 
-// dE/dr of one edge from dL/dd (three-body share dd + the radial-basis share dh . h') and dL/du (projected off u):
-// dd / du hold one row per ACTIVE edge (act_id == nullptr: no three-body reverse ran); dL/dh arrives in `dh_parts` slices (one
-// per reverse kernel that produced a share), summed here in a fixed order
-struct GeomRev {
-  int64_t E;
-  const float *u, *dist, *hp, *dh;
-  int dh_parts;
-  const float *dd, *du;
-  const int32_t* act_id;
-};
-__device__ __forceinline__ void edge_dr(const GeomRev& a, int64_t e, float& rx, float& ry, float& rz) {
-  // Nothing here is left to the compiler's choice of which multiply-add pairs to contract: every fused operation is written out
-  // (the placement the kernel compiled to in round 4), so the bits do not depend on the context the function is inlined into.
-#pragma clang fp contract(off)
-  const int ar = a.act_id ? a.act_id[e] : -1;
-  float g = ar >= 0 ? a.dd[ar] : 0.f;
-  float dhs[kRP] = {0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < a.dh_parts; ++p) {
-    const float4 t = *(const float4*)(a.dh + ((int64_t)p * a.E + e) * kRP);
-    dhs[0] += t.x; dhs[1] += t.y; dhs[2] += t.z; dhs[3] += t.w;
-  }
-  {
-    const float4 t = *(const float4*)(a.hp + e * kRP);
-    float dot = dhs[1] * t.y;
-    dot = __builtin_fmaf(dhs[0], t.x, dot);
-    dot = __builtin_fmaf(dhs[2], t.z, dot);
-    dot = __builtin_fmaf(dhs[3], t.w, dot);
-    g = g + dot;
-  }
-  const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
-  float ax = 0.f, ay = 0.f, az = 0.f;
-  if (ar >= 0) { ax = a.du[(int64_t)ar * 3]; ay = a.du[(int64_t)ar * 3 + 1]; az = a.du[(int64_t)ar * 3 + 2]; }
-  const float proj = __builtin_fmaf(ax, ux, ay * uy) + az * uz;
-  const float inv = 1.f / a.dist[e];
-  rx = __builtin_fmaf(g, ux, __builtin_fmaf(-proj, ux, ax) * inv);
-  ry = __builtin_fmaf(g, uy, __builtin_fmaf(-proj, uy, ay) * inv);
-  rz = __builtin_fmaf(g, uz, __builtin_fmaf(-proj, uz, az) * inv);
-}
 __global__ void __launch_bounds__(256) k_geometry_reverse(GeomRev a, float* __restrict__ dr) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= a.E) return;
@@ -237,9 +199,9 @@ void launch_distance_only(float length_scale, const Topo& t, const float* pos, c
 // bit-identical to k_struct_stress) when the batch has few structures; returns whether it did (else the caller launches
 // launch_stress / launch_stress_pair).
 bool launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
-                             float* stresses, hipStream_t s, bool fuse_stress, const float* pos, const float* lattice) {
+                             float* stresses, hipStream_t s, bool fuse_stress, const float* pos, const float* lattice, bool dr_done) {
   const GeomRev g{t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, (t.T > 0 && c.B > 0) ? t.act_id : nullptr};
-  if (t.E > 0) hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, g, w.dr);
+  if (t.E > 0 && !dr_done) hipLaunchKernelGGL(k_geometry_reverse, grid_for(t.E), dim3(256), 0, s, g, w.dr);   // (dr_done: formed by the last three-body reverse)
   const bool fused = fuse_stress && stresses && w.sync && t.N > 0 && t.N <= kFusedSumsMaxAtoms && t.S > 0 && t.S <= kForceTailMaxStructs;
   if (t.N > 0) {
     StressTail st{t.S, t.struct_ptr, t.flags, t.batch, pos, lattice, stresses, fused ? w.sync + kSyncForceTail : nullptr};

@@ -159,6 +159,45 @@ __device__ __forceinline__ void geometry_body(const Consts& c, const GeomArgs& a
 }
 
 
+// dE/dr of one edge from dL/dd (three-body share dd + the radial-basis share dh . h') and dL/du (projected off u):
+// dd / du hold one row per ACTIVE edge (act_id == nullptr: no three-body reverse ran); dL/dh arrives in `dh_parts` slices (one
+// per reverse kernel that produced a share), summed here in a fixed order
+struct GeomRev {
+  int64_t E;
+  const float *u, *dist, *hp, *dh;
+  int dh_parts;
+  const float *dd, *du;
+  const int32_t* act_id;
+};
+__device__ __forceinline__ void edge_dr(const GeomRev& a, int64_t e, float& rx, float& ry, float& rz) {
+  // Nothing here is left to the compiler's choice of which multiply-add pairs to contract: every fused operation is written out
+  // (the placement the kernel compiled to in round 4), so the bits do not depend on the context the function is inlined into.
+#pragma clang fp contract(off)
+  const int ar = a.act_id ? a.act_id[e] : -1;
+  float g = ar >= 0 ? a.dd[ar] : 0.f;
+  float dhs[kRP] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < a.dh_parts; ++p) {
+    const float4 t = *(const float4*)(a.dh + ((int64_t)p * a.E + e) * kRP);
+    dhs[0] += t.x; dhs[1] += t.y; dhs[2] += t.z; dhs[3] += t.w;
+  }
+  {
+    const float4 t = *(const float4*)(a.hp + e * kRP);
+    float dot = dhs[1] * t.y;
+    dot = __builtin_fmaf(dhs[0], t.x, dot);
+    dot = __builtin_fmaf(dhs[2], t.z, dot);
+    dot = __builtin_fmaf(dhs[3], t.w, dot);
+    g = g + dot;
+  }
+  const float ux = a.u[e * 3], uy = a.u[e * 3 + 1], uz = a.u[e * 3 + 2];
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  if (ar >= 0) { ax = a.du[(int64_t)ar * 3]; ay = a.du[(int64_t)ar * 3 + 1]; az = a.du[(int64_t)ar * 3 + 2]; }
+  const float proj = __builtin_fmaf(ax, ux, ay * uy) + az * uz;
+  const float inv = 1.f / a.dist[e];
+  rx = __builtin_fmaf(g, ux, __builtin_fmaf(-proj, ux, ax) * inv);
+  ry = __builtin_fmaf(g, uy, __builtin_fmaf(-proj, uy, ay) * inv);
+  rz = __builtin_fmaf(g, uz, __builtin_fmaf(-proj, uz, az) * inv);
+}
+
 inline GeomArgs geometry_args(const Topo& t, const float* pos, const float* lattice, const int32_t* shift, const Work& w) {
   return GeomArgs{t.E, t.src, t.dst, t.batch, pos, lattice, shift, w.u, w.d, w.h, w.hp, w.q, w.qp, w.fc3, w.fc3p, t.act_id, w.sync};
 }

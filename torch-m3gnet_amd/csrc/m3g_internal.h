@@ -410,7 +410,8 @@ Work work_carve(const Consts& c, bool mfma, int save_acts /* 0 none, 1 p1, 2 p1 
 void launch_geometry(const Consts& c, const Topo& t, const float* pos, const float* lattice, const int32_t* shift,
                      const Work& w, hipStream_t s);
 bool launch_geometry_reverse(const Consts& c, const Topo& t, const Work& w, const float* dh, int dh_parts, float* forces,
-                             float* stresses, hipStream_t s, bool fuse_stress = false, const float* pos = nullptr, const float* lattice = nullptr);
+                             float* stresses, hipStream_t s, bool fuse_stress = false, const float* pos = nullptr, const float* lattice = nullptr,
+                             bool dr_done = false);
 void launch_stress(const Consts& c, const Topo& t, const float* pos, const float* lattice, const float* forces,
                    float* stresses, hipStream_t s, const float* ea = nullptr, float* scaled_total = nullptr, float* total = nullptr);
 void launch_stress_pair(const Topo& t, const Work& w, const float* lattice, float* stresses, hipStream_t s);
@@ -459,6 +460,8 @@ void launch_copy_strided(const float* in, int in_stride, float* out, int out_str
 // threebody.hip
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s, int topo_hints = 0);
 void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints = 0);
+bool launch_threebody_reverse_final(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, const float* dh, int dh_parts,
+                                    hipStream_t s, int topo_hints);
 bool launch_node_tb_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v, bool first,
                             const float* dx_new, float* dx_out, int dp1_packed, int block, hipStream_t s, int topo_hints);
 // pack_mfma.hip / edge_mfma.hip

@@ -18,6 +18,7 @@
 
 #include "m3g_internal.h"
 #include "m3g_node_rev.h"
+#include "m3g_geometry_body.h"
 
 namespace m3g {
 
@@ -395,6 +396,9 @@ struct TbMomArgs {
   float* m;                                        // forward out
   float *dd, *du, *dgq;                            // reverse out
   int first;
+  // FINAL (the step's last three-body reverse, block 0): dE/dr of every edge is formed here as well (k_geometry_reverse's work)
+  GeomRev geom;
+  float* dr;
 };
 
 // LDS of one workgroup for windows of at most `rows` rows over at most `atoms` centre atoms (both from the topology hints)
@@ -405,7 +409,7 @@ constexpr size_t mom_lds_bytes(int rows, int atoms) {
 // THREADS >= kTbRows threads work on a block of kTbRows rows: all of them stage the window and form the moments, the first kTbRows
 // own a row each (the stand-alone kernel has THREADS = kTbRows; as a role of k_node_tb_reverse the workgroup has 256).
 // vblock / vgrid: this workgroup's index among the `vgrid` workgroups that walk the row blocks.
-template <int L, int R, bool REV, int THREADS>
+template <int L, int R, bool REV, int THREADS, bool FINAL = false>
 __device__ __forceinline__ void tb_moments_body(const Consts& c, const TbMomArgs& a, int cap_rows, int cap_atoms, int vblock, int vgrid, float* lds_mom) {
   constexpr int C = L * R, NM = mom_count<L>(), kThreads = THREADS;
   static_assert(THREADS >= kTbRows, "a thread per row");
@@ -536,9 +540,25 @@ __device__ __forceinline__ void tb_moments_body(const Consts& c, const TbMomArgs
         a.du[(int64_t)r * 3] = du0 + ax;
         a.du[(int64_t)r * 3 + 1] = du1 + ay;
         a.du[(int64_t)r * 3 + 2] = du2 + az;
+        if constexpr (FINAL) {
+          // dd / du of this edge are final (nothing adds to them after block 0's three-body reverse): its dE/dr right away -- the
+          // same edge_dr k_geometry_reverse runs, reading back this thread's own stores
+          float rx, ry, rz;
+          edge_dr(a.geom, e, rx, ry, rz);
+          a.dr[e * 3] = rx; a.dr[e * 3 + 1] = ry; a.dr[e * 3 + 2] = rz;
+        }
       }
     }
     __syncthreads();   // the staged window is rewritten by the next row block
+  }
+  if constexpr (FINAL) {
+    // edges without a three-body row (beyond the three-body cutoff, or without a partner): dE/dr from the radial-basis share alone
+    for (int64_t e = (int64_t)vblock * THREADS + threadIdx.x; e < a.geom.E; e += (int64_t)vgrid * THREADS) {
+      if (a.geom.act_id[e] >= 0) continue;
+      float rx, ry, rz;
+      edge_dr(a.geom, e, rx, ry, rz);
+      a.dr[e * 3] = rx; a.dr[e * 3 + 1] = ry; a.dr[e * 3 + 2] = rz;
+    }
   }
 }
 #ifndef M3G_TB_MOM_THREADS
@@ -549,6 +569,12 @@ template <int L, int R, bool REV>
 __global__ void __launch_bounds__(kTbMomThreads) k_threebody_moments(Consts c, TbMomArgs a, int cap_rows, int cap_atoms) {
   extern __shared__ __attribute__((aligned(16))) float lds_mom[];
   tb_moments_body<L, R, REV, kTbMomThreads>(c, a, cap_rows, cap_atoms, (int)blockIdx.x, (int)gridDim.x, lds_mom);
+}
+// the step's LAST three-body reverse (block 0) also forms dE/dr of every edge: one launch less (k_geometry_reverse)
+template <int L, int R>
+__global__ void __launch_bounds__(kTbMomThreads) k_threebody_moments_final(Consts c, TbMomArgs a, int cap_rows, int cap_atoms) {
+  extern __shared__ __attribute__((aligned(16))) float lds_mom[];
+  tb_moments_body<L, R, true, kTbMomThreads, true>(c, a, cap_rows, cap_atoms, (int)blockIdx.x, (int)gridDim.x, lds_mom);
 }
 
 // Three-body reverse (moment path) and node reverse of one block as the two workgroup ROLES of one launch.  Both consume what
@@ -659,6 +685,18 @@ bool launch_node_tb_reverse(const Consts& c, const float* W, const BlockW& bw, c
   const NodeTbArgs f{n_tb, w.sync + kSyncNodeRev + block};
   M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_node_tb_reverse<L, R>), dim3((unsigned)(n_tb + n_node)), dim3(256), (mom_lds_bytes<L, R, true>(rows, atoms)), s, c, a,
                                                  rows, atoms, na, f));
+  return true;
+}
+
+// the step's last three-body reverse + the geometry reverse (dE/dr of every edge) in one launch; false: not the moment path / no
+// triplets -- the caller then launches launch_threebody_reverse and k_geometry_reverse
+bool launch_threebody_reverse_final(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, const float* dh, int dh_parts,
+                                    hipStream_t s, int topo_hints) {
+  if (t.E == 0 || t.T == 0 || c.B == 0 || !use_moments(c, topo_hints)) return false;
+  TbMomArgs a{(int)(t.E / kTbRows + 1), t.src, t.arow_ptr, t.tb_fast, t.act_list, t.act_dst, t.tb_win, t.n_act, t.flags, topo_hints, w.u, w.fc3, w.fc3p, w.q, w.qp, v, w.dm, nullptr, w.dd, w.du, w.dg, first ? 1 : 0,
+              GeomRev{t.E, w.u, w.d, w.hp, dh, dh_parts, w.dd, w.du, t.act_id}, w.dr};
+  const int rows = (topo_hints >> 8) & 0xff, atoms = (topo_hints >> 16) & 0xff;
+  M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_threebody_moments_final<L, R>), grid_rows(t.E), dim3(kTbMomThreads), (mom_lds_bytes<L, R, true>(rows, atoms)), s, c, a, rows, atoms));
   return true;
 }
 
