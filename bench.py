@@ -721,7 +721,8 @@ def main():
         """Roofline objects of one precision mode from live stage timers (the mode must be the engine's current one)."""
         per_launch = stage_times(model, lambda: model(graph, forces=True, extras=False), args.steps)
         views = rooflines(per_launch, n_atoms, n_edges, n_trip, n_active, precision, pmc_all.get(precision, {}),
-                          moments=bool(topo_hints & 1) and "threebody_moments=0" not in args.engine_option)
+                          moments=bool(topo_hints & 1) and "threebody_moments=0" not in args.engine_option
+                          and "legendre_backward=1" not in args.engine_option)
         edge = {k: v for k, v in views.items() if k in EDGE_KERNELS}
         dom = max(edge, key=lambda k: edge[k]["avg_launch_ms"] * per_launch[k][1])   # dominant kernel = largest share of the step
         stage_ms = {k: round(ms * cnt, 4) for k, (ms, cnt) in per_launch.items()}

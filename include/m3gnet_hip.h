@@ -109,6 +109,11 @@ int m3g_plan_set_const(m3g_plan* plan, const char* name, const float* host_data,
  *                   fp32's 24 bits per product);
  *   "threebody_moments" = 1 (default) the three-body sums run over per-atom moments when m3g_io.topo_hints says every centre's
  *                   triplet list is complete (m3g_topology_hints), 0 = always walk the lists (A/B tests);
+ *   "legendre_backward" = 0 (default) d P_l / d cos(theta) is the true derivative; 1 = what the reference's
+ *                   LegendreCosPolynomial.backward returns (nn/interaction.py:373-382 multiplies grad_output in at every level of
+ *                   its recurrence: inexact for l >= 2), so forces and stresses reproduce the reference's own numbers rather than
+ *                   the gradient of its energy.  Not linear in a triplet's incoming gradient: the list kernels run (as with
+ *                   "threebody_moments" = 0).  Energies are unaffected;
  *   "overlap"     = 1 the three-body reverse of a block runs on an internal side stream beside the node reverse's gather
  *                   (fork/join with events on the caller's stream), 0 = everything on the caller's stream (default: the
  *                   cross-stream waits measured slower than the overlap gains on the benchmark workload);

@@ -555,6 +555,15 @@ def test_config3_10k_atom_cu_supercell_vs_the_reference_itself(mode, request):
         assert defect < 5e-3
     f_err = rel_err(out[K.FORCES], f_ref)
     assert f_err < 1e-4 + defect
+    # the reference's own backward of P_l (engine option "legendre_backward"): its forces without the defect allowance
+    f_exact = out[K.FORCES].clone()
+    model.engine.set_option("legendre_backward", 1)
+    f_ref_mode = model(g, extras=False)[K.FORCES].clone()
+    model.engine.set_option("legendre_backward", 0)
+    f_err_ref_mode = rel_err(f_ref_mode, f_ref)
+    assert f_err_ref_mode < 2e-5
+    assert mode == "ref" or f_err_ref_mode < 0.5 * f_err
+    assert torch.equal(model(g, extras=False)[K.FORCES], f_exact)
     e_sum64, e_ref32 = float(z["sum64_scaled_atomic_energies"]), float(z["out_total_energy"][0])
     e_eng = float(out[K.TOTAL_ENERGY][0])
     assert abs(e_eng - e_sum64) < 1e-5 * abs(e_sum64)
@@ -563,7 +572,7 @@ def test_config3_10k_atom_cu_supercell_vs_the_reference_itself(mode, request):
     if os.path.isdir("gpurun_out"):
         with open("gpurun_out/config3_vs_reference.txt", "a") as fh:
             fh.write(f"cu10k_{mode}: per-atom E {rel_err(out[K.SCALED_ATOMIC_ENERGIES], ea_ref):.2e}  F {f_err:.2e} of max|F| = {float(f_ref.abs().max()):.3e} "
-                     f"(reference's own defect vs the exact derivative: {defect:.2e})  total: engine {e_eng:.6f}, fp64 sum of the reference's "
+                     f"(reference's own defect vs the exact derivative: {defect:.2e}; with legendre_backward=1: F {f_err_ref_mode:.2e})  total: engine {e_eng:.6f}, fp64 sum of the reference's "
                      f"per-atom energies {e_sum64:.6f}, reference's fp32 scatter_sum {e_ref32:.6f} ({abs(e_ref32 - e_sum64) / abs(e_sum64):.2e} off its own exact sum)\n")
 
 

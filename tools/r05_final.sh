@@ -8,6 +8,10 @@ tail -3 gpurun_out/r05_gputest_final.log
 python bench.py > gpurun_out/r05_bench_default_run.json 2> gpurun_out/r05_bench_default_run.err || exit 1
 python -c "
 import json; d=json.load(open('gpurun_out/r05_bench_default_run.json')); print(d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('traffic'), d['cpu_baseline']['value']); print(d['config']['secondary'])"
+# the reference's own Legendre backward (three-body list kernels): what the option costs at the headline size
+python bench.py --engine-option legendre_backward=1 --no-secondary --no-cpu-baseline > gpurun_out/r05_bench_legendre_backward_reference.json 2>/dev/null
+python -c "
+import json; d=json.load(open('gpurun_out/r05_bench_legendre_backward_reference.json')); print('legendre_backward=1:', d['ms_per_step'], 'ms/step')"
 cd /tmp && export TMPDIR=/tmp
 for n in 2 6; do
   rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$n -- python3 $R/tools/small_step_trace.py fp32 $n > /dev/null 2>&1

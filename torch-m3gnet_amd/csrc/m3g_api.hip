@@ -413,6 +413,12 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     plan->tb_moments = value != 0;
     return M3G_OK;
   }
+  if (strcmp(name, "legendre_backward") == 0) {
+    if (value != 0 && value != 1) { set_error("legendre_backward: 0 (exact derivative) or 1 (the reference's backward)"); return M3G_ERR_VALUE; }
+    plan->legendre_ref = value != 0;
+    drop_graphs(plan);
+    return M3G_OK;
+  }
   if (strcmp(name, "readout_f16") == 0) {
     plan->readout_f16 = value != 0;
     return M3G_OK;
@@ -669,7 +675,9 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
   const WeightLayout& wl = plan->wl;
   const float* W = plan->d_weights;
   Topo t = topo_carve(N, E, T, S, const_cast<void*>(io->topo));
-  const int tb_hints = plan->tb_moments ? io->topo_hints : 0;   // (0: the list kernels, always valid)
+  // (0: the list kernels, always valid; the reference's Legendre backward is not linear in the incoming gradient of a triplet,
+  // so the moment sums cannot carry it)
+  const int tb_hints = plan->tb_moments && !plan->legendre_ref ? io->topo_hints : 0;
   const bool mfma = plan->edge_kernel == 1;
   const bool fused_rev = fused_reverse(plan);
   Work w = work_carve(c, mfma, saved_activations(plan), N, E, T, S, nullptr);
@@ -772,7 +780,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         // side stream beside it, then add the v-gradient share (which needs its dL/dg) once both are done
         M3G_HIP_CHECK(hipEventRecord(plan->ev_fork, s));
         M3G_HIP_CHECK(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
-        launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, plan->side_stream, tb_hints);
+        launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, plan->side_stream, tb_hints, plan->legendre_ref);
         M3G_HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
         launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, true, /*dp1 format=*/dp1_format(plan), /*with_v_term=*/false, s);
         M3G_HIP_CHECK(hipStreamWaitEvent(s, plan->ev_join, 0));
@@ -786,7 +794,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
                  launch_threebody_reverse_final(c, t, w, w.v[b], /*first=*/b == c.B - 1, w.dh_parts, c.B, s, tb_hints)) {
         dr_done = true;   // (moment path) the step's last three-body reverse formed dE/dr of every edge as well
       } else {
-        { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s, tb_hints); }
+        { M3G_STAGE(ST_THREEBODY_REV); launch_threebody_reverse(c, t, w, w.v[b], /*first=*/b == c.B - 1, s, tb_hints, plan->legendre_ref); }
         if (b > 0) {  // x^0 is the species embedding: no position dependence, its gradient is never needed
           M3G_STAGE(ST_NODE_REV);
           launch_node_reverse(c, W, wl.blk[b], t, w, w.v[b], dx_cur, dx_alt, fused_rev, /*dp1 format=*/dp1_format(plan), /*with_v_term=*/true, s,

@@ -24,6 +24,7 @@ struct GenConsts {
   float length_scale, energy_scale, rc, rc3;
   float a1[kGR], a2[kGR], coeff[kGR], rec_mul[kGR], rec_div[kGR];
   float zeros[kGL][kGR], factors[kGL][kGR], ynorm[kGL];
+  int ref_legendre;   // option "legendre_backward" (m3g_threebody.hip: legendre_ref_k)
 };
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -225,6 +226,14 @@ __global__ void __launch_bounds__(256) g_embed_x(int64_t N, int D, int num_types
   x[gid] = W[(int64_t)o * num_types + types[a]];   // one_hot(types) @ W^T, W [D, num_types] (nn/featurizer.py:33-38)
 }
 
+// what the reference's LegendreCosPolynomial.backward returns per unit of its grad_output `go` (nn/interaction.py:373-382):
+// k_1 = 1, k_n = n P_{n-1} + x go k_{n-1}
+__device__ __forceinline__ float g_legendre_ref_k(int l, float x, const float* P, float go) {
+  if (l == 0) return 0.f;
+  float k = 1.f;
+  for (int n = 2; n <= l; ++n) k = (float)n * P[n - 1] + x * go * k;
+  return k;
+}
 __device__ __forceinline__ void g_legendre(int L, float x, float* P, float* dP) {
   P[0] = 1.f; dP[0] = 0.f;
   if (L > 1) { P[1] = x; dP[1] = 1.f; }
@@ -316,6 +325,15 @@ __global__ void __launch_bounds__(256) g_threebody_rev(GenConsts c, int64_t E, c
         const int cc = l * c.R + n;
         dcos += dm[e * C + cc] * c.ynorm[l] * dP[l] * q[e2 * C + cc] * v[k * C + cc];
       }
+    if (c.ref_legendre) {
+      dcos = 0.f;
+      for (int l = 1; l < c.L; ++l) {
+        float G = 0.f;
+        for (int n = 0; n < c.R; ++n) G += dm[e * C + l * c.R + n] * (q[e2 * C + l * c.R + n] * v[k * C + l * c.R + n]);
+        const float g1 = c.ynorm[l] * G;
+        dcos += g1 * g_legendre_ref_k(l, fminf(1.f, fmaxf(-1.f, raw)), P, fce * g1);
+      }
+    }
     dcos = (raw >= -1.f && raw <= 1.f) ? fce * dcos : 0.f;
     ax += dcos * vx; ay += dcos * vy; az += dcos * vz;
   }
@@ -339,6 +357,15 @@ __global__ void __launch_bounds__(256) g_threebody_rev(GenConsts c, int64_t E, c
         dg[cc] += ds * c.ynorm[l] * P[l];
         dcos += ds * c.ynorm[l] * dP[l] * q[e * C + cc] * v[kd * C + cc];
       }
+    if (c.ref_legendre) {
+      dcos = 0.f;
+      for (int l = 1; l < c.L; ++l) {
+        float G = 0.f;
+        for (int n = 0; n < c.R; ++n) G += (f1 * dm[e1 * C + l * c.R + n]) * (q[e * C + l * c.R + n] * v[kd * C + l * c.R + n]);
+        const float go = c.ynorm[l] * G;
+        dcos += go * g_legendre_ref_k(l, fminf(1.f, fmaxf(-1.f, raw)), P, go);
+      }
+    }
     dcos = (raw >= -1.f && raw <= 1.f) ? dcos : 0.f;
     ax += dcos * vx; ay += dcos * vy; az += dcos * vz;
   }
@@ -470,6 +497,7 @@ static GenConsts gen_consts(const m3g_plan* plan) {
   c.length_scale = (float)cfg.length_scale; c.energy_scale = (float)cfg.energy_scale;
   const double rc = cfg.cutoff / cfg.length_scale, rc3 = cfg.threebody_cutoff / cfg.length_scale;   // model/build.py:34-35
   c.rc = (float)rc; c.rc3 = (float)rc3;
+  c.ref_legendre = plan->legendre_ref ? 1 : 0;
   const float pi_f = (float)M_PI;
   const auto& em = plan->cvals.at("em");
   const auto& dm = plan->cvals.at("dm");

@@ -228,6 +228,7 @@ struct m3g_plan {
   bool readout_f16 = false; // option "readout_f16": the readout layers on scaled two-part fp16 chains in the f16x3 mode (5 us faster at 10,000
                             // atoms); default: exact-fp32 chains in every mode -- the per-atom energy can be the ill-conditioned remainder of its
                             // last layer's terms, where 22 against 24 bits per product show (fuzz case 84)
+  bool legendre_ref = false;   // option "legendre_backward" = 1: the reference's own (inexact) backward of P_l, list kernels only
   bool tb_moments = true;   // option "threebody_moments": per-atom moment sums where the partner lists are complete (m3g_threebody.hip)
   int stress_mode = 0;   // 0: reference formula sum pos (x) F / V; 1: pair virial (PBC consistent)
   int edge_kernel = 1;           // 0 = VALU baseline (m3g_edge_simple.hip), 1 = MFMA (m3g_edge_mfma.hip)
@@ -459,7 +460,8 @@ void launch_copy_strided(const float* in, int in_stride, float* out, int out_str
                          hipStream_t s);
 // threebody.hip
 void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float* v, float* m, hipStream_t s, int topo_hints = 0);
-void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints = 0);
+void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints = 0,
+                              bool ref_legendre = false);
 bool launch_threebody_reverse_final(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, const float* dh, int dh_parts,
                                     hipStream_t s, int topo_hints);
 bool launch_node_tb_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v, bool first,

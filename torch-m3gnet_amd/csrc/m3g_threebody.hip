@@ -173,7 +173,23 @@ struct TbRevArgs {
   const float *u, *fc3, *fc3p, *q, *qp, *v, *dm;
   float *dd, *du, *dgq;   // dd [A], du [A,3]: geometry gradients of the three-body term, one row per active edge
   int first;              // first reverse launch of the step (last block): dd/du are written, later launches accumulate
+  int ref_legendre;       // option "legendre_backward" = 1: the reference's own backward of P_l (below)
 };
+
+// LegendreCosPolynomial.backward (nn/interaction.py:373-382) multiplies grad_output in at EVERY level of its recurrence,
+//   grad_n = (n P_{n-1} + x grad_{n-1}) go   =>   grad_n = go k_n,  k_1 = 1,  k_n = n P_{n-1} + x go k_{n-1},
+// which is the derivative P_n' go only for n <= 1 (SURVEY finding 2).  The engine computes the true derivative; with the option
+// set, the list kernels return this k_n instead of P_n' so that forces and stresses reproduce the reference's own numbers.
+// `go` is the gradient arriving at legendre_cos(cos, l)'s output for ONE triplet and ONE l (the reference calls it once per l).
+template <int L>
+__device__ __forceinline__ float legendre_ref_k(int l, float x, const float* P, float go) {
+  if (l == 0) return 0.f;
+  float k = 1.f;
+#pragma unroll
+  for (int n = 2; n < L; ++n)
+    if (n <= l) k = (float)n * P[n - 1] + x * go * k;
+  return k;
+}
 
 template <int L, int R, int LIST, int CAP, int LPR>
 __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRevArgs a) {
@@ -269,6 +285,17 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRev
         dcos += dmv[k] * dy * pr[k];
       }
     }
+    if (a.ref_legendre) {   // go = fc ynorm_l sum_n dm g[e2]; this row's fc multiplies the sum at the end
+      dcos = 0.f;
+#pragma unroll
+      for (int l = 1; l < L; ++l) {
+        float G = 0.f;
+#pragma unroll
+        for (int nn = 0; nn < R; ++nn) G += dmv[l * R + nn] * pr[l * R + nn];
+        const float g1 = c.ynorm[l] * G;
+        dcos += g1 * legendre_ref_k<L>(l, cs, P, fc * g1);
+      }
+    }
     dcos = (raw >= -1.f && raw <= 1.f) ? dcos : 0.f;   // torch.clamp passes the gradient only inside [-1, 1]
     a1x += dcos * vx; a1y += dcos * vy; a1z += dcos * vz;
   }
@@ -289,6 +316,17 @@ __global__ void __launch_bounds__(kTbRows * LPR) k_threebody_rev(Consts c, TbRev
         const int k = l * R + nn;
         dg[k] += pr[k] * y;
         dcos += pr[k] * dy * gv[k];
+      }
+    }
+    if (a.ref_legendre) {   // pr = fc[e1] dm[e1]: go is complete
+      dcos = 0.f;
+#pragma unroll
+      for (int l = 1; l < L; ++l) {
+        float G = 0.f;
+#pragma unroll
+        for (int nn = 0; nn < R; ++nn) G += pr[l * R + nn] * gv[l * R + nn];
+        const float go = c.ynorm[l] * G;
+        dcos += go * legendre_ref_k<L>(l, cs, P, go);
       }
     }
     dcos = (raw >= -1.f && raw <= 1.f) ? dcos : 0.f;
@@ -700,7 +738,8 @@ bool launch_threebody_reverse_final(const Consts& c, const Topo& t, const Work& 
   return true;
 }
 
-void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints) {
+void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, hipStream_t s, int topo_hints,
+                              bool ref_legendre) {
   if (t.E == 0) return;
   if (t.T == 0) return;
   if (use_moments(c, topo_hints)) {
@@ -711,7 +750,7 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
   }
   TbRevArgs a{t.E, t.act_list, t.act_dst, t.tb_win, t.n_act, t.t1_ptr, t.t1_e2c, t.t2_ptr, t.t2_e1c, t.t1_b, t.t2_b, w.u, w.fc3, w.fc3p, w.q,
               w.qp, v,
-              w.dm, w.dd, w.du, w.dg, first ? 1 : 0};
+              w.dm, w.dd, w.du, w.dg, first ? 1 : 0, ref_legendre ? 1 : 0};
   if (long_lists(t)) { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R, kTbListLong, kTbCap, kTbLprLong>), grid_rows(t.E), dim3(kTbRows * kTbLprLong), 0, s, c, a)); }
   else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_rev<L, R, kTbListShort, kTbCapShort, kTbLprShort>), grid_rows(t.E), dim3(kTbRows * kTbLprShort), 0, s, c, a)); }
 }

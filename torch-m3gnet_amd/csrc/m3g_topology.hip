@@ -505,10 +505,11 @@ static int topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int6
     { int r = mirror_lists(); if (r) return r; }
     { int r = downstream(true, keysA); if (r) return r; }
     const bool hinted = host_hints && E > 0 && launch_hint_kernels(t, s, trusted);
-    int32_t hs[3] = {0, 0, 0};
-    M3G_HIP_CHECK(hipMemcpyAsync(h, t.flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (hinted) M3G_HIP_CHECK(hipMemcpyAsync(hs, t.flags + 4, sizeof(hs), hipMemcpyDeviceToHost, s));
+    int32_t hs[3] = {0, 0, 0}, h7[7] = {0, 0, 0, 0, 0, 0, 0};
+    // flags[0..1] and the hint words flags[4..6] in ONE copy (a second small copy to pageable memory costs ~30 us of host time)
+    M3G_HIP_CHECK(hipMemcpyAsync(h7, t.flags, (hinted ? 7 : 2) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     M3G_HIP_CHECK(hipStreamSynchronize(s));
+    h[0] = h7[0]; h[1] = h7[1]; hs[0] = h7[4]; hs[1] = h7[5]; hs[2] = h7[6];
     flags_read = true;   // every kernel that can flag a malformed graph has run
     const bool assumed_ok = !(h[1] & 3) && !(try_mirrors && (h[0] & 8));
     if (assumed_ok) {

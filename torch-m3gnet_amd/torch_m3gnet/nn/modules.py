@@ -526,12 +526,19 @@ class Gradient(torch.nn.Module):
     The wrapped `model` must be the Sequential laid out by `build_model` (model/build.py:37-76);
     forces come from the engine's analytic reverse pass, not from autograd."""
 
-    def __init__(self, model: torch.nn.Module, pair_virial: bool = False):
+    def __init__(self, model: torch.nn.Module, pair_virial: bool = False, legendre_backward: str = "exact"):
         """`pair_virial=False` reproduces the reference's stress formula sum_a pos_a (x) F_a / V (nn/gradient.py:39-62,
         absolute positions -- not invariant under a lattice translation of an atom); `pair_virial=True` returns the
-        strain derivative -(1/V) sum_e r_e (x) dE/dr_e over the pair vectors (docs/gradient.md:47-84)."""
+        strain derivative -(1/V) sum_e r_e (x) dE/dr_e over the pair vectors (docs/gradient.md:47-84).
+
+        `legendre_backward="exact"`: forces are the gradient of the energy.  `"reference"`: d P_l / d cos(theta) is what the
+        reference's LegendreCosPolynomial.backward returns (nn/interaction.py:373-382, inexact for l >= 2), so forces and
+        stresses reproduce the reference's own numbers (engine option "legendre_backward"; the three-body list kernels run)."""
         super().__init__()
+        if legendre_backward not in ("exact", "reference"):
+            raise ValueError('legendre_backward: "exact" or "reference"')
         self.model = model
+        self.legendre_backward = legendre_backward
         self.pair_virial = bool(pair_virial)
         self._engine = None
 
@@ -542,6 +549,7 @@ class Gradient(torch.nn.Module):
 
             self._engine = Engine(self.model)
             self._engine.set_option("stress_mode", 1 if self.pair_virial else 0)
+            self._engine.set_option("legendre_backward", 1 if self.legendre_backward == "reference" else 0)
         return self._engine
 
     def forward(self, graph, forces: bool = True, extras: bool = True):
