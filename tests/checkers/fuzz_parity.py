@@ -2,7 +2,10 @@
 """Randomised parity sweep (run on the GPU box): random small batches x random model shapes (l_max, n_max, blocks,
 cutoffs, scales) against the CPU oracle, with the tolerances of the test-suite (1e-5 energies, 1e-4 forces / stress).
 
-    python tests/checkers/fuzz_parity.py [n_cases] [precision = fp32 | f16x3 | bf16x3]
+    python tests/checkers/fuzz_parity.py [n_cases] [precision = fp32 | f16x3 | bf16x3] [legendre = exact | reference]
+
+`reference`: engine option "legendre_backward" = 1 against the oracle running the reference's own Legendre backward
+(nn/interaction.py:373-382); each line then also shows how far that backward is from the exact derivative on the case.
 
 Energies are gated at the strict 1e-5 against the fp64 oracle.  ONE documented exception, by index: case 84 (a six-atom
 structure whose energy, 3.1e-5, is the remainder of readout terms of 1e-3) -- there the reference's own fp32 arithmetic (the
@@ -26,6 +29,8 @@ from torch_m3gnet.model.build import build_model  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+legendre = sys.argv[3] if len(sys.argv) > 3 else "exact"
+assert legendre in ("exact", "reference")
 ILL_CONDITIONED = {84}   # documented exceptions to the strict energy gate (see the header)
 rng = np.random.default_rng(2024)
 worst = {"E": 0.0, "F": 0.0, "S": 0.0}
@@ -49,9 +54,14 @@ for case in range(n_cases):
         n = int(rng.integers(1, max(2, min(40, int(box**3 / 14.0)))))   # keeps the random packing with dmin feasible
         graphs.append(random_cell_graph(n, box, seed=1000 * case + s, cutoff=cutoff, tb_cutoff=tb, dmin=1.4))
     model.engine.set_precision(precision)
+    model.engine.set_option("legendre_backward", 1 if legendre == "reference" else 0)
     g = model(Batch.from_data_list(graphs).to("cuda"))
     p, cfg, c, og = _oracle_inputs(model, g)
-    o = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+    o = orc.energy_forces(p, cfg, c, og, legendre_backward=legendre)
+    defect = ""
+    if legendre == "reference":
+        ox = orc.energy_forces(p, cfg, c, og, legendre_backward="exact")
+        defect = f" [reference's backward vs exact: {float((ox['forces'] - o['forces']).abs().max()) / max(float(o['forces'].abs().max()), 1e-9):.1e}]"
     dbl = lambda t: t.double() if torch.is_tensor(t) and torch.is_floating_point(t) else t   # noqa: E731
     o64 = orc.energy_forces({k: dbl(v) for k, v in p.items()}, cfg, c, {k: dbl(v) for k, v in og.items()}, legendre_backward="exact")
     e64 = o64["total_energy"]
@@ -68,5 +78,5 @@ for case in range(n_cases):
     fails += 0 if ok else 1
     worst = {"E": max(worst["E"], e_err), "F": max(worst["F"], f_err), "S": max(worst["S"], s_err)}
     print(f"case {case:3d} L={l_max} R={n_max} B={blocks} rc={cutoff:.2f} r3={tb:.2f} atoms={g[K.NUM_NODES]} E={g[K.NUM_EDGES]} "
-          f"T={g[K.NUM_TRIPLETS]}: E {e_err:.1e} (fp32 oracle's own {own_rel:.1e}) F {f_err:.1e} S {s_err:.1e} {'ok' if ok else 'FAIL'}", flush=True)
-print("precision", precision, "worst", worst, "failures", fails)
+          f"T={g[K.NUM_TRIPLETS]}: E {e_err:.1e} (fp32 oracle's own {own_rel:.1e}) F {f_err:.1e} S {s_err:.1e}{defect} {'ok' if ok else 'FAIL'}", flush=True)
+print("precision", precision, "legendre", legendre, "worst", worst, "failures", fails)
