@@ -166,6 +166,25 @@ int m3g_topology_build_canonical(int64_t n_atoms, int64_t n_edges, int64_t n_tri
                                  const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
                                  void* topo, size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream);
 
+/* m3g_topology_build_canonical in two calls, so that the host prepares its next call (workspace, outputs, the m3g_io block) while
+ * the device builds: _begin queues the launches and the copy of the verdict words to `pinned_verdict` -- at least 8 int32 of PINNED
+ * host memory (hipHostMalloc / torch pin_memory) the caller leaves untouched until _end; _end (same stream, same arguments) waits for
+ * the stream and certifies the buffer, or -- when a check failed or _begin did not apply (no triplets, more atoms than its
+ * one-workgroup scan takes) -- runs the general build there and then.  Results and errors are those of m3g_topology_build_canonical. */
+int m3g_topology_build_canonical_begin(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
+                                       const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
+                                       void* topo, size_t topo_bytes, int32_t* pinned_verdict, void* stream);
+int m3g_topology_build_canonical_end(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs,
+                                     const int64_t* edge_index, const int64_t* triplet_edge_index, const int64_t* batch,
+                                     void* topo, size_t topo_bytes, const int32_t* pinned_verdict, int32_t* host_flags,
+                                     int32_t* host_hints, void* stream);
+
+/* Diagnostic / tests: the leading part of a topology buffer that holds the lists the kernels read (the rest is scratch of the build),
+ * and which build m3g_topology_build_canonical took on this thread the last time: 1 = the seven-launch build for canonical lists,
+ * 0 = the general one (a failed check, no hints asked for, no triplets, or more atoms than its one-workgroup scan takes). */
+int m3g_topology_data_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, size_t* bytes);
+int m3g_topology_debug_last_path(int32_t* path);
+
 /* Sticky error bits the hot call left on a topology buffer (0 = none).  M3G_TOPO_ERR_HINTS: m3g_energy_forces was handed a
  * non-zero m3g_io.topo_hints that is not the word m3g_topology_hints certified for THIS buffer (stale after a rebuild, or copied
  * from another topology): the three-body moment kernels then touch nothing (no out-of-bounds access) and the call's three-body
@@ -364,9 +383,10 @@ int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
  * event pool).  They are bound to the plan's device: a commit that moves the plan to another device releases all of them. */
 int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out);
 
-#define M3G_ABI_VERSION 4   /* 2: m3g_io.topo_hints, m3g_topology_hints; 3: m3g_verlet_*, m3g_topology_status, hints word certified on the buffer,
+#define M3G_ABI_VERSION 5   /* 2: m3g_io.topo_hints, m3g_topology_hints; 3: m3g_verlet_*, m3g_topology_status, hints word certified on the buffer,
                              * canonical edge order by the shift relative to the given coordinates, default precision fp32;
-                             * 4: m3g_verlet_fill_lists, m3g_topology_build_canonical, M3G_TOPO_ERR_SYNC, options small_tiles / small_launches / fuse_node_tb */
+                             * 4: m3g_verlet_fill_lists, m3g_topology_build_canonical, M3G_TOPO_ERR_SYNC, options small_tiles / small_launches / fuse_node_tb;
+                             * 5: m3g_topology_build_canonical_begin / _end, m3g_topology_data_bytes, option legendre_backward */
 
 #ifdef __cplusplus
 }

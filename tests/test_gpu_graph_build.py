@@ -274,3 +274,102 @@ def test_batch_from_structures_and_pinned_staging():
     torch.cuda.synchronize()
     for key in (K.POS, K.ATOM_TYPES, K.EDGE_INDEX, K.EDGE_CELL_SHIFT, K.TRIPLET_EDGE_INDEX, K.LATTICE, K.BATCH):
         assert torch.equal(staged[key], on_gpu[key]), key
+
+
+# ---- the seven-launch topology build for canonical lists ---------------------------------------------------------------------------------
+def _topology_buffers(g):
+    """The same graph through the general build (m3g_topology_build_hints) and the canonical one, into zero-filled buffers:
+    (data bytes of both, hints of both, path the canonical call took)."""
+    import ctypes as C
+
+    from torch_m3gnet import _lib
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    lib = _lib.load_library()
+    ei, tei, batch = g[K.EDGE_INDEX].contiguous().long(), g[K.TRIPLET_EDGE_INDEX].contiguous().long(), g[K.BATCH].contiguous().long()
+    N, E, T, S = int(batch.numel()), int(ei.size(1)), int(tei.size(1)), int(g[K.LATTICE].size(0))
+    nbytes, dbytes = C.c_size_t(), C.c_size_t()
+    _lib.check(lib.m3g_topology_bytes(N, E, T, S, C.byref(nbytes)))
+    _lib.check(lib.m3g_topology_data_bytes(N, E, T, S, C.byref(dbytes)))
+    assert 0 < dbytes.value <= nbytes.value
+    out = []
+    for build in (lib.m3g_topology_build_hints, lib.m3g_topology_build_canonical):
+        buf = torch.zeros(nbytes.value, dtype=torch.uint8, device=ei.device)
+        flags, hints = (C.c_int32 * 1)(0), C.c_int32(0)
+        _lib.check(build(N, E, T, S, C.c_void_p(ei.data_ptr()), C.c_void_p(tei.data_ptr()), C.c_void_p(batch.data_ptr()),
+                         C.c_void_p(buf.data_ptr()), nbytes.value, flags, C.byref(hints), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        out.append((buf[: dbytes.value].cpu(), int(hints.value), int(flags[0])))
+    path = C.c_int32(-1)
+    _lib.check(lib.m3g_topology_debug_last_path(C.byref(path)))
+    return out[0], out[1], int(path.value)
+
+
+def _canonical_graphs():
+    from helpers import random_cell_arrays
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    from torch_m3gnet.data.synthetic import fcc_cu_graph
+
+    yield "cu 2x2x2", fcc_cu_graph(2, 2, 2).to("cuda")
+    yield "cu 6x6x6", fcc_cu_graph(6, 6, 6).to("cuda")
+    yield "cu 10x10x25", fcc_cu_graph(10, 10, 25).to("cuda")
+    yield "one atom", batch_from_arrays(*zip(random_cell_arrays(1, 3.0, 5)), 5.0, 4.0, device="cuda")
+    cells = [random_cell_arrays(8 + 7 * s, 6.0 + 0.5 * s, 40 + s) for s in range(9)]
+    yield "9 random cells", batch_from_arrays(*zip(*cells), 5.0, 4.0, device="cuda")
+    # three-body cutoff == cutoff at ~60 neighbours: windows of more than kTbCap rows / the certificate says "not every window"
+    yield "dense, r3 = rc = 6", batch_from_arrays(*zip(random_cell_arrays(300, 16.5, 3)), 6.0, 6.0, device="cuda")
+    # rows of ~150 edges (several 64-lane passes per row), atoms outside the home cell
+    rng = np.random.default_rng(17)
+    lat = np.array([[3.3, 0.2, 0.0], [-0.3, 3.4, 0.1], [0.2, -0.1, 3.2]])
+    frac = rng.uniform(0, 1, (7, 3))
+    frac[::2] += rng.integers(-2, 3, (4, 3))
+    yield "7-atom cell, rows of ~150 edges", batch_from_arrays([lat], [frac @ lat], [np.full(7, 28)], 5.5, 4.0, device="cuda")
+    # atoms without any active edge, and structures without triplets beside structures with them
+    sparse = [random_cell_arrays(3, 9.0, 70 + s) for s in range(4)] + [random_cell_arrays(30, 7.5, 80)]
+    yield "sparse + dense structures", batch_from_arrays(*zip(*sparse), 5.0, 3.0, device="cuda")
+
+
+def test_canonical_topology_build_writes_the_general_builds_buffer():
+    """m3g_topology_build_canonical (seven launches; csrc/m3g_topology.hip, k_canon_*) against m3g_topology_build_hints on the lists
+    the library's builders write: every array of the topology buffer bit for bit, the certificate's word, and the fast path taken."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    for name, g in _canonical_graphs():
+        if int(g[K.NUM_TRIPLETS]) == 0:
+            continue
+        (a, ha, fa), (b, hb, fb), path = _topology_buffers(g)
+        assert path == 1, name
+        assert fa == 0 and fb == 0, name
+        assert ha == hb, (name, hex(ha), hex(hb))
+        if not torch.equal(a, b):
+            bad = torch.nonzero(a != b).flatten()
+            raise AssertionError(f"{name}: {bad.numel()} bytes differ, first at {int(bad[0])} of {a.numel()}")
+
+
+def test_canonical_topology_build_falls_back_on_lists_that_are_not_canonical():
+    """A shuffled triplet list / an unsorted edge list handed to the canonical entry point: its checks fail, the general build runs
+    (path 0) and returns what it returns for that list."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.synthetic import fcc_cu_graph
+
+    g = fcc_cu_graph(3, 3, 3).to("cuda")
+    tei = g[K.TRIPLET_EDGE_INDEX]
+    perm = torch.randperm(tei.size(1), device=tei.device, generator=torch.Generator(device=tei.device).manual_seed(0))
+    g[K.TRIPLET_EDGE_INDEX] = tei[:, perm].contiguous()
+    (a, ha, fa), (b, hb, fb), path = _topology_buffers(g)
+    assert path == 0 and fa == 0 and fb == 0 and ha == hb
+    # (the general build under the canonical flag skips the triplet mirror check only: same lists)
+    g = fcc_cu_graph(3, 3, 3).to("cuda")
+    ei = g[K.EDGE_INDEX].clone()
+    ei[:, [0, -1]] = ei[:, [-1, 0]]   # first and last edge swapped: row 0 no longer sorted
+    g[K.EDGE_INDEX] = ei
+    (a, ha, fa), (b, hb, fb), path = _topology_buffers(g)
+    assert path == 0 and (fa & 1) and (fb & 1)
+    # rows of ~590 edges: beyond the in-edge kernel's LDS stage, the general build sorts instead (same buffer either way)
+    from torch_m3gnet.data.graph_gpu import batch_from_arrays
+    rng = np.random.default_rng(17)
+    lat = np.array([[3.3, 0.2, 0.0], [-0.3, 3.4, 0.1], [0.2, -0.1, 3.2]])
+    frac = rng.uniform(0, 1, (7, 3))
+    g = batch_from_arrays([lat], [frac @ lat], [np.full(7, 28)], 9.0, 3.0, device="cuda")
+    (a, ha, fa), (b, hb, fb), path = _topology_buffers(g)
+    assert path == 0 and fa == 0 and fb == 0 and ha == hb and torch.equal(a, b)

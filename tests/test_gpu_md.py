@@ -301,3 +301,38 @@ def test_canonical_topology_build_equals_the_checked_build():
     # an in-place edit voids the mark
     g[K.TRIPLET_EDGE_INDEX][1, 0] = g[K.TRIPLET_EDGE_INDEX][1, 1]
     assert g.get("_m3g_canonical_lists") != _Topology.signature(g)
+
+
+def test_queued_topology_build_gives_the_same_results_and_survives_unevaluated_graphs():
+    """The trajectory graph queues its topology build behind the fill (m3g_topology_build_canonical_begin) and the engine waits for
+    it when it needs the buffer.  Same energies / forces, bit for bit, as with the build at the engine's call; and graphs that
+    are refilled again before anyone evaluated them (their builds share one pinned verdict block) do not disturb later ones."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.md import VerletGraph
+    from torch_m3gnet.nn.modules import _Topology
+
+    model = _model()
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    gi = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(3), indexing="ij"), -1)
+    pos = torch.tensor((gi.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a, device="cuda")
+    lat, z = np.eye(3) * 3 * a, np.full(108, 29)
+    outs = {}
+    for eager in (True, False):
+        vg = VerletGraph([lat], [z], 5.0, 4.0, skin=0.4, device="cuda")
+        vg.eager_topology = eager
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        res = []
+        for it in range(6):
+            p = pos + (torch.rand(pos.shape, generator=gen, device="cuda", dtype=torch.float64) - 0.5) * 0.08
+            g = vg.update(p, force="refill")
+            topo = g["_m3g_topology"][1] if eager else None
+            assert (topo is not None and topo._pending is not None) == eager
+            if it % 2 == 1:
+                continue   # never evaluated: the next refill finishes its build before queueing its own
+            out = model(g, forces=True, extras=False)
+            res.append((out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone()))
+            assert _Topology.of(g)._pending is None
+        outs[eager] = res
+    for (e1, f1), (e0, f0) in zip(outs[True], outs[False]):
+        assert torch.equal(e1, e0) and torch.equal(f1, f0)

@@ -8,6 +8,7 @@
 //     tests/test_model.py:21-38).
 // Index-only integer work: HBM-bound radix sorts (hipCUB) + binary searches; not on the per-step path
 // while the neighbour list is unchanged.
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 #include "m3g_internal.h"
@@ -367,6 +368,272 @@ __global__ void k_compact_partners(int64_t T, const int32_t* __restrict__ scan, 
   bc[t] = scan[b[t]];
 }
 
+// ---- the canonical build in seven launches (m3g_topology_build_canonical) ---------------------------------------------------------
+// For the lists this library's own builders write -- edges sorted by centre and symmetric, triplets = every ordered pair of a
+// centre's edges inside the three-body cutoff, sorted by (e1, e2) -- every array of Topo follows from per-atom rows: the rows of the
+// triplet list are found by binary search in triplet_edge_index[0] itself, the active edges of a centre are consecutive in the
+// compacted numbering (one 1-workgroup scan over the ATOMS replaces the device scan over the edges), partners as second edge are
+// the partners as first edge (every mirrored array is written by the kernel that forms the original).  The arrays are the ones
+// the general build writes, bit for bit (tests/test_gpu_graph_build.py compares the buffers); what the general build checks --
+// index ranges, row order, edge-list symmetry, triplet order and centres -- is checked here too, and any failed check sends the
+// whole build down the general path.  Every kernel after the first leaves at once when an earlier one has flagged the lists, so
+// none walks rows that are not rows.
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// the same by a whole wave: 64 probes per round, so ~log64(n) dependent loads instead of log2(n) (4 against 22 on the 10k-atom
+// cell's triplet list; the per-lane search made k_canon_triplets a 47-us chain of round trips).  Wave-uniform result.
+__device__ __forceinline__ int64_t wave_lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t key, int lane) {
+  int64_t lo = 0, hi = n;   // the answer lies in [lo, hi]
+  while (hi > lo) {
+    const int64_t step = (hi - lo + 63) / 64;
+    const int64_t p = lo + (int64_t)(lane + 1) * step - 1;
+    const bool ge = p < hi ? a[p] >= key : true;
+    const unsigned long long m = __ballot(ge);
+    if (m == 0) { lo = hi; break; }
+    const int f = __ffsll((long long)m) - 1;
+    const int64_t new_hi = lo + (int64_t)(f + 1) * step - 1;
+    lo = lo + (int64_t)f * step;
+    hi = new_hi < hi ? new_hi : hi;
+  }
+  return lo;
+}
+constexpr int kCanonStage = 512;   // edges per atom whose triplet rows are resolved in LDS (longer rows: one binary search per edge)
+// roles by thread index: edges (k_convert_edges), atoms (k_convert_batch), rows (lower bounds in the int64 lists themselves), zero
+// fill of the window tables
+__global__ void __launch_bounds__(256) k_canon_edges(int64_t N, int64_t E, int64_t S, const int64_t* __restrict__ ei, const int64_t* __restrict__ batch,
+                                                     int32_t* src, int32_t* dst, int32_t* out_batch, int32_t* row_ptr, int32_t* struct_ptr, int32_t* tb_win,
+                                                     int64_t n_win, int32_t* tb_fast, int64_t n_fast, int32_t* flags) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < E) {
+    int64_t a = ei[i], b = ei[E + i];
+    int bad = 0;
+    if (a < 0 || a >= N || b < 0 || b >= N) { bad |= 2; a = 0; b = 0; }
+    if (i > 0 && ei[i - 1] > a) bad |= 1;
+    src[i] = (int32_t)a;
+    dst[i] = (int32_t)b;
+    if (bad) atomicOr(flags, bad);
+  }
+  if (i < N) {
+    int64_t b = batch[i];
+    if (b < 0 || b >= S) { atomicOr(flags, 2); b = 0; }
+    if (i > 0 && batch[i - 1] > batch[i]) atomicOr(flags + 3, 1);
+    out_batch[i] = (int32_t)b;
+  }
+  if (i <= N) row_ptr[i] = (int32_t)lower_bound_i64(ei, E, i);
+  if (i <= S) struct_ptr[i] = (int32_t)lower_bound_i64(batch, N, i);
+  if (i < n_win) tb_win[i] = 0;
+  if (i < n_fast) tb_fast[i] = 0;
+}
+// role A (the first t_blocks workgroups, one thread per triplet): range / centre / order checks, partner lists in both roles.
+// role B (one wave per atom): rows of the triplet list for the atom's edges, and the number of its active edges (cnt[atom], scanned by
+// k_canon_scan into arow_ptr)
+__global__ void __launch_bounds__(256) k_canon_triplets(int64_t N, int64_t E, int64_t T, int64_t t_blocks, const int64_t* __restrict__ tei,
+                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ row_ptr, int32_t* flags,
+                                                        int32_t* t1_e2, int32_t* t2_e1, int32_t* t1_ptr, int32_t* t2_ptr, int32_t* cnt) {
+  __shared__ int s_start[4 * kCanonStage];
+  if (flags[0] & 7) return;   // (bits raised by k_canon_edges, complete at this launch boundary)
+  if ((int64_t)blockIdx.x < t_blocks) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    int64_t e1 = tei[t], e2 = tei[T + t];
+    int bad = 0;
+    if (e1 < 0 || e1 >= E || e2 < 0 || e2 >= E) { bad |= 2; e1 = 0; e2 = 0; }
+    else if (src[e1] != src[e2]) bad |= 4;
+    t1_e2[t] = (int32_t)e2;
+    t2_e1[t] = (int32_t)e2;
+    if (bad) atomicOr(flags, bad);
+    if (t > 0) {
+      const int64_t p1 = tei[t - 1], p2 = tei[T + t - 1];
+      if (p1 > e1 || (p1 == e1 && p2 > e2)) atomicOr(flags + 1, 1);
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t j = ((int64_t)blockIdx.x - t_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);   // wave-uniform
+  if (j > N) return;
+  if (j == N) {
+    if (lane == 0) { t1_ptr[E] = (int32_t)T; t2_ptr[E] = (int32_t)T; cnt[N] = 0; }
+    return;
+  }
+  const int r0 = row_ptr[j], r1 = row_ptr[j + 1], n = r1 - r0;
+  int n_active = 0;
+  if (n > kCanonStage) {
+    for (int base = r0; base < r1; base += 64) {
+      const int e = base + lane;
+      const bool valid = e < r1;
+      int p = valid ? (int)lower_bound_i64(tei, T, e) : 0;
+      int pn = __shfl_down(p, 1);
+      if (valid && (lane == 63 || e + 1 >= r1)) pn = (int)lower_bound_i64(tei, T, (int64_t)e + 1);
+      if (valid) { t1_ptr[e] = p; t2_ptr[e] = p; }
+      n_active += __popcll(__ballot(valid && pn > p));
+    }
+    if (lane == 0) cnt[j] = n_active;
+    return;
+  }
+  if (n <= 0) {
+    if (lane == 0) cnt[j] = 0;
+    return;
+  }
+  // the atom's triplets are one contiguous block [tlo, thi) of the sorted list: two searches by the whole wave, then the block is
+  // streamed once and every edge that heads a run of equal e1 learns where its row starts; an edge without triplets takes the start
+  // of the next edge that has some (the end of the block when there is none), which is what a lower bound per edge returns
+  const int64_t tlo = wave_lower_bound_i64(tei, T, r0, lane), thi = wave_lower_bound_i64(tei, T, r1, lane);
+  int* st = s_start + (threadIdx.x >> 6) * kCanonStage;
+  for (int k = lane; k < n; k += 64) st[k] = -1;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int64_t t = tlo + lane; t < thi; t += 64) {
+    const int64_t e1 = tei[t], prev = t > tlo ? tei[t - 1] : -1;
+    if (e1 != prev && e1 >= r0 && e1 < r1) st[e1 - r0] = (int)t;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  int carry = (int)thi;
+  for (int base = r0 + ((n - 1) / 64) * 64; base >= r0; base -= 64) {
+    const int e = base + lane;
+    const bool valid = e < r1;
+    const int v = valid ? st[e - r0] : -1;
+    const unsigned long long m = __ballot(v >= 0);
+    const unsigned long long after = m >> lane;
+    const int got = __shfl(v, after ? lane + (__ffsll((long long)after) - 1) : lane);
+    const int val = after ? got : carry;
+    if (valid) { t1_ptr[e] = val; t2_ptr[e] = val; }
+    n_active += __popcll(m);
+    carry = __shfl(val, 0);
+  }
+  if (lane == 0) cnt[j] = n_active;
+}
+// one workgroup: exclusive scan of the n counts in place (a contiguous chunk per thread), total -> *total
+__global__ void __launch_bounds__(1024) k_canon_scan(int64_t n, int32_t* data, int32_t* total, const int32_t* __restrict__ flags) {
+  __shared__ int s_wave[16];
+  if (flags[0] & 7) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t chunk = (n + 1023) / 1024;
+  const int64_t b = threadIdx.x * chunk, e = b + chunk < n ? b + chunk : n;
+  int sum = 0;
+  for (int64_t i = b; i < e; ++i) sum += data[i];
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += s_wave[w];
+  int run = before + inc - sum;
+  for (int64_t i = b; i < e; ++i) { const int v = data[i]; data[i] = run; run += v; }
+  if (threadIdx.x == 1023) *total = before + inc;
+}
+// one wave per atom: compacted ids of its edges (k_active_scatter's arrays) and the window bounds its rows own (k_tb_windows)
+__global__ void __launch_bounds__(256) k_canon_active(int64_t N, int64_t E, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
+                                                      const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ arow_ptr,
+                                                      const int32_t* __restrict__ flags, int32_t* act_scan, int32_t* act_id, int32_t* act_list,
+                                                      int32_t* act_dst, int32_t* win) {
+  if ((flags[0] & 7) || flags[1]) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t j = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j > N) return;
+  const int A = arow_ptr[N];
+  if (j == N) {
+    if (lane == 0) act_scan[E] = A;
+    return;
+  }
+  const int r0 = row_ptr[j], r1 = row_ptr[j + 1], c0 = arow_ptr[j], c1 = arow_ptr[j + 1];
+  int run = 0;
+  for (int base = r0; base < r1; base += 64) {
+    const int e = base + lane;
+    const bool valid = e < r1;
+    int ta = 0, tb = 0;
+    if (valid) { ta = t1_ptr[e]; tb = t1_ptr[e + 1]; }
+    const bool act = valid && tb > ta;
+    const unsigned long long mask = __ballot(act);
+    const int cid = c0 + run + __popcll(mask & ((1ull << lane) - 1ull));
+    if (valid) {
+      act_scan[e] = cid;
+      act_id[e] = act ? cid : -1;
+      if (act) {
+        act_list[cid] = e;
+        act_dst[cid] = dst[e];
+        const int b = cid / kTbRows;
+        if (cid % kTbRows == 0) { win[6 * b] = c0; win[6 * b + 2] = ta; win[6 * b + 4] = ta; }
+        if (cid % kTbRows == kTbRows - 1 || cid == A - 1) { win[6 * b + 1] = c1; win[6 * b + 3] = tb; win[6 * b + 5] = tb; }
+      }
+    }
+    run += __popcll(mask);
+  }
+}
+// roles by workgroup: [0, e_blocks) in-edge pairs (k_pair_with_lookup); [e_blocks, e_blocks + t_blocks) compacted partners and their
+// window bytes in both roles (k_compact_partners, k_partner_bytes); the last workgroup: which windows may use the moment path, and the
+// statistics of the certificate (k_tb_fast for lists complete by construction, k_tb_stats)
+__global__ void __launch_bounds__(256) k_canon_finish(int64_t E, int64_t T, int64_t e_blocks, int64_t t_blocks, int64_t windows,
+                                                      const int64_t* __restrict__ tei, const int32_t* __restrict__ in_edge,
+                                                      const int32_t* __restrict__ act_id, const int32_t* __restrict__ act_scan,
+                                                      const int32_t* __restrict__ act_list, const int32_t* __restrict__ src,
+                                                      const int32_t* __restrict__ win, const int32_t* __restrict__ flags, int32_t* in_pair,
+                                                      int32_t* in_pos, int32_t* t1_e2c, int32_t* t2_e1c, uint8_t* t1_b, uint8_t* t2_b, int32_t* fast,
+                                                      int32_t* stats) {
+  if ((flags[0] & 7) || flags[1]) return;
+  const int64_t blk = blockIdx.x;
+  if (blk < e_blocks) {
+    const int64_t i = blk * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const int32_t e = in_edge[i];
+    const bool ok = e >= 0 && (int64_t)e < E;
+    in_pair[2 * i] = ok ? e : 0;
+    in_pair[2 * i + 1] = ok ? act_id[e] : -1;
+    if (ok) in_pos[e] = (int32_t)i;
+    return;
+  }
+  if (blk < e_blocks + t_blocks) {
+    const int64_t t = (blk - e_blocks) * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int64_t e1 = tei[t], e2 = tei[T + t];   // (in range: k_canon_triplets has checked them)
+    const int c2 = act_scan[e2];
+    t1_e2c[t] = c2;
+    t2_e1c[t] = c2;
+    const int r = act_id[e1];
+    const int b = (r < 0 ? 0 : r) / kTbRows;
+    const int wlo = win[6 * b], whi = win[6 * b + 1];
+    const int n = (whi - wlo) < kTbCap ? (whi - wlo) : kTbCap;
+    const int d = c2 - wlo;
+    const uint8_t byte = (uint8_t)((r >= 0 && d >= 0 && d < n && d < 255) ? d : 255);
+    t1_b[t] = byte;
+    t2_b[t] = byte;
+    return;
+  }
+  __shared__ int s_bad[4], s_rows[4], s_atoms[4];
+  const int A = flags[2];
+  int bad = 0, rows = 0, atoms = 0;
+  for (int64_t b = threadIdx.x; b < windows; b += blockDim.x) {
+    int na = 0, a0 = 0;
+    if (b * kTbRows < A) {
+      const int lo = win[6 * b], hi = win[6 * b + 1];
+      if (lo >= 0 && hi > lo && hi <= A) {
+        a0 = src[act_list[lo]];
+        na = src[act_list[hi - 1]] - a0 + 1;
+        if (!(na <= kTbFastAtoms && hi - lo <= kTbCap)) na = 0;
+        if (na > 0) { rows = max(rows, hi - lo); atoms = max(atoms, na); }
+        else ++bad;
+      } else {
+        a0 = 0; ++bad;
+      }
+    }
+    fast[2 * b] = na;
+    fast[2 * b + 1] = a0;
+  }
+  for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o); rows = max(rows, __shfl_xor(rows, o)); atoms = max(atoms, __shfl_xor(atoms, o)); }
+  if ((threadIdx.x & 63) == 0) { s_bad[threadIdx.x >> 6] = bad; s_rows[threadIdx.x >> 6] = rows; s_atoms[threadIdx.x >> 6] = atoms; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bad = 0; rows = 0; atoms = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { bad += s_bad[k]; rows = max(rows, s_rows[k]); atoms = max(atoms, s_atoms[k]); }
+    stats[0] = bad; stats[1] = rows; stats[2] = atoms;
+  }
+}
+
 static inline int bits_for(int64_t n) {
   int b = 1;
   while ((int64_t(1) << b) < n) ++b;
@@ -595,9 +862,113 @@ extern "C" int m3g_topology_build_hints(int64_t N, int64_t E, int64_t T, int64_t
 // triplet lists that hold every ordered pair of a centre's edges inside the three-body cutoff BY CONSTRUCTION, so the mirror check of
 // the triplet list and the per-row completeness test of the certificate are skipped (two kernels over all triplets, 38 us of the
 // 0.25-ms build on the 10k-atom cell).  Everything else -- index ranges, row order, edge-list symmetry -- is still checked.
+// Seven launches and the copy of the verdict words (flags[0..6]) to `verdict`, PINNED host memory: queued, not waited for
+constexpr int64_t kCanonMaxAtoms = 131072;   // k_canon_scan is one workgroup
+static thread_local int32_t g_last_canonical_path = 0;
+static bool canonical_fast_applies(int64_t N, int64_t E, int64_t T, int64_t S, const void* ei, const void* tei, const void* batch) {
+  static const bool fast_off = [] { const char* v = getenv("M3G_CANON_FAST"); return v && v[0] == '0'; }();   // A/B measurements
+  return !fast_off && N > 0 && N <= kCanonMaxAtoms && E > 0 && T > 0 && S > 0 && ei && tei && batch;
+}
+static int canonical_fast_launch(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index, const int64_t* triplet_edge_index,
+                                 const int64_t* batch, const Topo& t, int32_t* verdict, hipStream_t s) {
+  const int TPB = 256;
+  auto blocks = [&](int64_t n) { return (n + TPB - 1) / TPB; };
+  const int64_t windows = E / kTbRows + 1, n_win = 6 * windows, n_fast = 2 * (E / kTbRows + 2);
+  M3G_HIP_CHECK(hipMemsetAsync(t.flags, 0, kTopoFlags * sizeof(int32_t), s));
+  const int64_t n1 = std::max(std::max(E, N + 1), std::max(S + 1, n_win));
+  hipLaunchKernelGGL(k_canon_edges, dim3((unsigned)blocks(n1)), dim3(TPB), 0, s, N, E, S, edge_index, batch, t.src, t.dst, t.batch, t.row_ptr,
+                     t.struct_ptr, t.tb_win, n_win, t.tb_fast, n_fast, t.flags);
+  hipLaunchKernelGGL(k_in_edges_symmetric, dim3((unsigned)blocks((N + 1) * 64)), dim3(TPB), 0, s, N, t.row_ptr, t.dst, t.in_ptr, t.in_edge, t.flags);
+  const int64_t t_blocks = blocks(T), a_blocks = blocks((N + 1) * 64), e_blocks = blocks(E);
+  hipLaunchKernelGGL(k_canon_triplets, dim3((unsigned)(t_blocks + a_blocks)), dim3(TPB), 0, s, N, E, T, t_blocks, triplet_edge_index, t.src, t.row_ptr,
+                     t.flags, t.t1_e2, t.t2_e1, t.t1_ptr, t.t2_ptr, t.arow_ptr);
+  hipLaunchKernelGGL(k_canon_scan, dim3(1), dim3(1024), 0, s, N + 1, t.arow_ptr, t.n_act, t.flags);
+  hipLaunchKernelGGL(k_canon_active, dim3((unsigned)a_blocks), dim3(TPB), 0, s, N, E, t.row_ptr, t.dst, t.t1_ptr, t.arow_ptr, t.flags, t.act_scan, t.act_id,
+                     t.act_list, t.act_dst, t.tb_win);
+  hipLaunchKernelGGL(k_canon_finish, dim3((unsigned)(e_blocks + t_blocks + 1)), dim3(TPB), 0, s, E, T, e_blocks, t_blocks, windows, triplet_edge_index,
+                     t.in_edge, t.act_id, t.act_scan, t.act_list, t.src, t.tb_win, t.flags, t.in_pair, t.in_pos, t.t1_e2c, t.t2_e1c, t.t1_b, t.t2_b,
+                     t.tb_fast, t.flags + 4);
+  M3G_HIP_CHECK(hipMemcpyAsync(verdict, t.flags, 7 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+// after the stream has been waited for: true = every check passed, the certificate's word is on the buffer and in *host_hints
+static int canonical_fast_settle(const Topo& t, const int32_t* verdict, int32_t* host_flags, int32_t* host_hints, hipStream_t s, bool* done) {
+  *done = false;
+  if ((verdict[0] & 15) || (verdict[1] & 1)) return M3G_OK;   // malformed, not symmetric or not sorted: the general path decides what it is
+  const int32_t hs[3] = {verdict[4], verdict[5], verdict[6]};
+  *host_hints = hints_word(hs);
+  hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, s, t.flags + 7, *host_hints);
+  M3G_HIP_CHECK(hipGetLastError());
+  if (host_flags) host_flags[0] = verdict[0];
+  *done = true;
+  return M3G_OK;
+}
+static int canonical_check_buffer(int64_t N, int64_t E, int64_t T, int64_t S, void* topo_buf, size_t topo_bytes) {
+  size_t need = 0;
+  int rc = m3g_topology_bytes(N, E, T, S, &need);
+  if (rc) return rc;
+  if (!topo_buf || topo_bytes < need) { set_error("topology buffer too small: %zu < %zu", topo_bytes, need); return M3G_ERR_SIZE; }
+  return M3G_OK;
+}
+
 extern "C" int m3g_topology_build_canonical(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
                                             const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
                                             size_t topo_bytes, int32_t* host_flags, int32_t* host_hints, void* stream_) {
+  g_last_canonical_path = 0;
+  if (host_hints && canonical_fast_applies(N, E, T, S, edge_index, triplet_edge_index, batch)) {
+    int rc = canonical_check_buffer(N, E, T, S, topo_buf, topo_bytes);
+    if (rc) return rc;
+    *host_hints = 0;
+    // the verdict lands in pinned host memory (one 64-byte block per host thread, kept for the life of the process): a copy to
+    // pageable memory goes through the runtime's staging path and cost ~45 us of host time between the copy and the return
+    static thread_local int32_t* pinned = nullptr;
+    if (!pinned) M3G_HIP_CHECK(hipHostMalloc((void**)&pinned, 16 * sizeof(int32_t), hipHostMallocDefault));
+    hipStream_t s = (hipStream_t)stream_;
+    const Topo t = topo_carve(N, E, T, S, topo_buf);
+    rc = canonical_fast_launch(N, E, T, S, edge_index, triplet_edge_index, batch, t, pinned, s);
+    if (rc) return rc;
+    M3G_HIP_CHECK(hipStreamSynchronize(s));
+    bool done = false;
+    rc = canonical_fast_settle(t, pinned, host_flags, host_hints, s, &done);
+    g_last_canonical_path = done ? 1 : 0;
+    if (rc || done) return rc;
+  }
+  return topology_build(N, E, T, S, edge_index, triplet_edge_index, batch, topo_buf, topo_bytes, host_flags, host_hints, stream_, true);
+}
+
+// The same build in two calls, so that the host prepares its next call (m3g_energy_forces: workspace, outputs) while the device builds:
+// _begin queues the launches and the copy of the verdict to `pinned_verdict` (>= 8 int32 of PINNED host memory the caller keeps
+// untouched until _end; word 7 says whether anything was queued), _end waits for the stream and certifies the buffer -- or, when a
+// check failed or _begin did not apply (no triplets, very many atoms), runs m3g_topology_build_canonical's general path there and then.
+extern "C" int m3g_topology_build_canonical_begin(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
+                                                  const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
+                                                  size_t topo_bytes, int32_t* pinned_verdict, void* stream_) {
+  if (!pinned_verdict) { set_error("m3g_topology_build_canonical_begin: null verdict buffer"); return M3G_ERR_VALUE; }
+  pinned_verdict[7] = 0;
+  int rc = canonical_check_buffer(N, E, T, S, topo_buf, topo_bytes);
+  if (rc) return rc;
+  if (!canonical_fast_applies(N, E, T, S, edge_index, triplet_edge_index, batch)) return M3G_OK;
+  rc = canonical_fast_launch(N, E, T, S, edge_index, triplet_edge_index, batch, topo_carve(N, E, T, S, topo_buf), pinned_verdict, (hipStream_t)stream_);
+  if (rc) return rc;
+  pinned_verdict[7] = 1;
+  return M3G_OK;
+}
+extern "C" int m3g_topology_build_canonical_end(int64_t N, int64_t E, int64_t T, int64_t S, const int64_t* edge_index,
+                                                const int64_t* triplet_edge_index, const int64_t* batch, void* topo_buf,
+                                                size_t topo_bytes, const int32_t* pinned_verdict, int32_t* host_flags, int32_t* host_hints,
+                                                void* stream_) {
+  if (!pinned_verdict || !host_hints) { set_error("m3g_topology_build_canonical_end: null argument"); return M3G_ERR_VALUE; }
+  g_last_canonical_path = 0;
+  *host_hints = 0;
+  if (pinned_verdict[7] == 1) {
+    hipStream_t s = (hipStream_t)stream_;
+    M3G_HIP_CHECK(hipStreamSynchronize(s));
+    bool done = false;
+    int rc = canonical_fast_settle(topo_carve(N, E, T, S, topo_buf), pinned_verdict, host_flags, host_hints, s, &done);
+    g_last_canonical_path = done ? 1 : 0;
+    if (rc || done) return rc;
+  }
   return topology_build(N, E, T, S, edge_index, triplet_edge_index, batch, topo_buf, topo_bytes, host_flags, host_hints, stream_, true);
 }
 
@@ -623,6 +994,20 @@ extern "C" int m3g_topology_hints(int64_t N, int64_t E, int64_t T, int64_t S, co
   // the same word stays with the buffer (flags[7]): the moment kernels run only when the word the caller hands to m3g_energy_forces
   // is the one certified for THIS topology buffer -- a stale word, or one copied from another buffer, flags an error instead
   hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, s, t.flags + 7, *host_hints);
+  return M3G_OK;
+}
+
+extern "C" int m3g_topology_data_bytes(int64_t N, int64_t E, int64_t T, int64_t S, size_t* bytes) {
+  size_t total = 0;
+  int rc = m3g_topology_bytes(N, E, T, S, &total);
+  if (rc) return rc;
+  const Topo t = topo_carve(N, E, T, S, nullptr);
+  *bytes = t.total_bytes - align_up(t.sort_tmp_bytes);
+  return M3G_OK;
+}
+extern "C" int m3g_topology_debug_last_path(int32_t* path) {
+  if (!path) { set_error("m3g_topology_debug_last_path: null argument"); return M3G_ERR_VALUE; }
+  *path = g_last_canonical_path;
   return M3G_OK;
 }
 

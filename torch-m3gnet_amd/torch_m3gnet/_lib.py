@@ -10,7 +10,7 @@ _PKG_ROOT = Path(__file__).resolve().parent.parent  # .../torch-m3gnet_amd
 LIB_PATH = _PKG_ROOT / "lib" / "libm3gnet_hip.so"
 
 M3G_OK, M3G_ERR_VALUE, M3G_ERR_STATE, M3G_ERR_SIZE, M3G_ERR_HIP, M3G_ERR_UNSUPPORTED = range(6)
-ABI_VERSION = 4
+ABI_VERSION = 5
 VERLET_FILL_LISTS_MAX_ROW = 1024   # M3G_VERLET_FILL_LISTS_MAX_ROW (include/m3gnet_hip.h)
 
 
@@ -56,6 +56,10 @@ SYMBOLS = {
                                            C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_build_canonical": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
+    "m3g_topology_build_canonical_begin": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "m3g_topology_build_canonical_end": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_hints": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_status": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "m3g_topology_active_edges": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
@@ -105,6 +109,8 @@ SYMBOLS = {
                                      C.c_void_p]),
     "m3g_debug_read_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "m3g_debug_live_handles": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "m3g_topology_data_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
+    "m3g_topology_debug_last_path": (C.c_int, [C.POINTER(C.c_int32)]),
     "m3g_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "m3g_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                    C.POINTER(C.c_int32)]),

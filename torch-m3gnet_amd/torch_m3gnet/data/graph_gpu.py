@@ -9,7 +9,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _cuda, _lib
 from . import MaterialGraphKey as K
 from .material_graph import Batch
 
@@ -18,8 +18,7 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _cuda.stream_ptr
 
 
 def max_images(lattices: np.ndarray, cutoff: float) -> int:
@@ -48,7 +47,7 @@ def neighbor_list_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Ten
     _lib.check(lib.m3g_neighbor_scratch_bytes(N, S, M, C.byref(nbytes)))
     scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     n_edges = C.c_int64()
-    with torch.cuda.device(dev):
+    with _cuda.on_device(dev):
         _lib.check(lib.m3g_neighbor_count(N, S, M, _ptr(pos), _ptr(lattice), _ptr(batch), float(cutoff), _ptr(scratch), nbytes.value,
                                           C.byref(n_edges), _stream()))
         E = int(n_edges.value)
@@ -73,7 +72,7 @@ def threebody_index_gpu(num_nodes: int, edge_index: torch.Tensor, distances: tor
     _lib.check(lib.m3g_threebody_scratch_bytes(N, E, C.byref(nbytes)))
     scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     n_t = C.c_int64()
-    with torch.cuda.device(dev):
+    with _cuda.on_device(dev):
         _lib.check(lib.m3g_threebody_count(N, E, _ptr(ei), _ptr(d32), float(threebody_cutoff), _ptr(scratch), nbytes.value,
                                            C.byref(n_t), _stream()))
         T = int(n_t.value)
@@ -100,7 +99,7 @@ def graph_indices_gpu(lattice: torch.Tensor, pos: torch.Tensor, batch: torch.Ten
     _lib.check(lib.m3g_neighbor_scratch_bytes(N, S, M, C.byref(nb_bytes)))
     scratch = torch.empty(nb_bytes.value, dtype=torch.uint8, device=dev)
     n_edges, n_trip = C.c_int64(), C.c_int64()
-    with torch.cuda.device(dev):
+    with _cuda.on_device(dev):
         _lib.check(lib.m3g_neighbor_count_triplets(N, S, M, _ptr(pos), _ptr(lattice), _ptr(batch), float(cutoff), float(threebody_cutoff),
                                                    _ptr(scratch), nb_bytes.value, C.byref(n_edges), C.byref(n_trip), _stream()))
         E, T = int(n_edges.value), int(n_trip.value)

@@ -29,7 +29,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _cuda, _lib
 from . import MaterialGraphKey as K
 from .graph_gpu import _ptr, _stream, mark_canonical, neighbor_list_gpu
 from .material_graph import Batch
@@ -61,9 +61,11 @@ class VerletGraph:
         self.stats = {"reuse": 0, "refill": 0, "search": 0}
         self._verdict = torch.zeros(8, dtype=torch.int64).pin_memory()   # m3g_verlet_update_async: max disp^2 (bits), changed, E, T, -, longest candidate row
         self._verdict_ready = torch.cuda.Event()
+        self._topo_verdict = torch.zeros(16, dtype=torch.int32).pin_memory()   # m3g_topology_build_canonical_begin / _end
         self._pending = None         # positions of a begin() whose verdict has not been read
         self._state_valid = False    # the candidates' membership bytes describe the current lists
         self._max_row = 0
+        self.eager_topology = True   # queue the topology build with the fill (False: the engine builds it at its call)
         self.split_fill = False      # True: refill through m3g_verlet_fill + m3g_threebody_build (tests; identical lists)
 
     def set_lattice(self, lattices: Sequence) -> None:
@@ -82,7 +84,7 @@ class VerletGraph:
         ei, shift, _ = neighbor_list_gpu(self.lattice, pos, self.batch, self.cutoff + self.skin, host_lattice=self._host_lattice)
         ec = int(ei.size(1))
         rows = torch.empty(self.N + 2, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _cuda.on_device(self.device):
             _lib.check(self.lib.m3g_verlet_rows(self.N, ec, _ptr(ei), _ptr(rows), _stream()))
         nbytes = C.c_size_t()
         _lib.check(self.lib.m3g_verlet_scratch_bytes(self.N, ec, C.byref(nbytes)))
@@ -96,7 +98,7 @@ class VerletGraph:
     def _queue_test(self, pos: torch.Tensor) -> None:
         """The skin test at `pos`, queued on the current stream together with the copy of its verdict to pinned host memory."""
         ei, shift, rows, state, pos_ref, scratch = self._cand
-        with torch.cuda.device(self.device):
+        with _cuda.on_device(self.device):
             _lib.check(self.lib.m3g_verlet_update_async(self.N, self.S, int(ei.size(1)), _ptr(pos), _ptr(pos_ref), _ptr(self.lattice),
                                                         _ptr(self.batch), _ptr(ei), _ptr(shift), _ptr(rows), self.cutoff, self.threebody_cutoff,
                                                         _ptr(state) if self._state_valid else None, _ptr(scratch), scratch.numel(),
@@ -124,7 +126,7 @@ class VerletGraph:
         tei = torch.empty(2, n_t, dtype=torch.int64, device=dev)
         nti = torch.empty(N, dtype=torch.int64, device=dev)
         ntij = torch.empty(n_e, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _cuda.on_device(dev):
             if self._max_row <= _lib.VERLET_FILL_LISTS_MAX_ROW and N <= 262144 and not self.split_fill:
                 # edges, shifts, membership bytes, triplets and triplet counts in two launches
                 _lib.check(self.lib.m3g_verlet_fill_lists(N, int(c_ei.size(1)), n_e, n_t, self._max_row, _ptr(scratch), _ptr(c_ei), _ptr(c_shift),
@@ -160,6 +162,15 @@ class VerletGraph:
         if self.graph is not None and "_m3g_species_ok" in self.graph:
             dict.__setitem__(g, "_m3g_species_ok", self.graph["_m3g_species_ok"])
         mark_canonical(g)   # lists of this library's own builder: the topology build skips the checks they pass by construction
+        # the topology build is queued right behind the fill (and waited for by the engine when it needs the buffer): the device
+        # builds while the host walks from here to its m3g_energy_forces call
+        from ..nn.modules import _Topology
+
+        if self.graph is not None and self.graph.get("_m3g_topology") is not None:
+            self.graph["_m3g_topology"][1].finish()   # one verdict buffer: a build still in flight (a graph that was never evaluated) ends first
+        dict.__setitem__(g, "_m3g_pinned_verdict", self._topo_verdict)
+        if self.eager_topology:
+            _Topology.of(g, finish=False)
         self.graph = g
 
     # ------------------------------------------------------------------------------------------------ the per-step call

@@ -5,13 +5,18 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from itertools import chain
+from operator import attrgetter
 
 import numpy as np
 import torch
 
-from . import _lib
+from . import _cuda, _lib
 from .data import MaterialGraphKey as K
 from .nn import modules as M
+
+_DATA_PTR = torch.Tensor.data_ptr
+_VERSION = attrgetter("_version")
 
 
 def _host_f32(t: torch.Tensor) -> np.ndarray:
@@ -88,27 +93,28 @@ class Engine:
     # ---------------------------------------------------------------- parameters
     def _collect_param_dicts(self) -> None:
         mods = list(self.seq.modules())
-        self._param_dicts = [m._parameters for m in mods]
-        self._module_dicts = [m._modules for m in mods]
-        self._module_ids = self._tree_ids()
+        self._dicts = [m._modules for m in mods] + [m._parameters for m in mods]
+        self._n_module_dicts = len(mods)
+        self._object_ids = self._ids()
+        self._params = [p for d in self._dicts[self._n_module_dicts:] for p in d.values() if p is not None]
 
-    def _tree_ids(self):
-        return tuple(id(v) for d in self._module_dicts for v in d.values())
+    def _ids(self):
+        """Identities of every submodule and Parameter object (None included) the tree holds now, in one pass."""
+        return tuple(map(id, chain.from_iterable(map(dict.values, self._dicts))))
 
     def _signature(self, dev):
-        if self._tree_ids() != self._module_ids:   # a submodule was replaced or added: its parameters are new objects
+        """(device, storage addresses, version counters) of everything `commit` uploads: a change of any of them -- an optimiser
+        step, load_state_dict, a replaced Parameter or submodule, .to(device) -- commits again.  Runs on every call, on the host's
+        critical path for callers that wait for the device each step: C-level maps over the cached dicts (a Python loop building
+        (ptr, version) pairs cost 87 us per call, profiles/r05_md_host_profile.txt)."""
+        ids = self._ids()
+        if ids != self._object_ids:   # a submodule or Parameter was replaced / added / removed: collect again
             self._collect_param_dicts()
+        params = self._params + [m.nsb.factors for m in self.tb[:1]]
+        params.append(self.atom_ref.elemental_energies)
         # the plan's device buffers live on the device it was committed under: a change of device is a change of plan state
-        sig = [("device", dev.index if dev.index is not None else torch.cuda.current_device())]
-        for d in self._param_dicts:
-            for p in d.values():
-                if p is not None:
-                    sig.append((p.data_ptr(), p._version))
-        for m in self.tb[:1]:
-            sig.append((m.nsb.factors.data_ptr(), m.nsb.factors._version))
-        e = self.atom_ref.elemental_energies
-        sig.append((e.data_ptr(), e._version))
-        return tuple(sig)
+        return (dev.index if dev.index is not None else torch.cuda.current_device(), tuple(map(_DATA_PTR, params)),
+                tuple(map(_VERSION, params)))
 
     def commit(self) -> None:
         lib, plan = self.lib, self.plan
@@ -177,18 +183,17 @@ class Engine:
         dev = pos.device
         sig = self._signature(dev)
         if sig != self._sig:
-            with torch.cuda.device(dev):
+            with _cuda.on_device(dev):
                 self.commit()
             self._sig = sig
-        with torch.cuda.device(dev):
+        with _cuda.on_device(dev):
             types_in = graph[K.ATOM_TYPES]
             types = types_in.contiguous().long()
             probe = self._species_probe(graph, types_in, types)   # queued before the topology build, read after it (no extra wait)
-            topo = M._Topology.of(graph)
+            topo = M._Topology.of(graph, finish=False)   # (a trajectory graph's build may still be running: finished below)
             N, E, T, S = topo.N, topo.E, topo.T, topo.S
             D, R, Cc, B = self.cfg.embedding_dim, self.cfg.n_max, self.cfg.l_max * self.cfg.n_max, self.num_blocks
             pos_c = pos.detach().contiguous().float()
-            self._check_species(graph, probe)
             shift = graph[K.EDGE_CELL_SHIFT].contiguous().to(torch.int32)
             lat = graph[K.LATTICE].contiguous().float()
             nbytes = C.c_size_t()
@@ -215,6 +220,8 @@ class Engine:
                     out[K.MID_EDGE_FEATURES] = torch.empty(B, E, Cc, **f32)
                 if self._graph_replay:
                     self._out_cache[cache_key] = out
+            topo.finish()   # waits for a queued build (everything above was host work beside it)
+            self._check_species(graph, probe)
             p = M._ptr
             io = _lib.M3GIO(
                 n_atoms=N, n_edges=E, n_triplets=T, n_structs=S, pos=p(pos_c), atom_types=p(types), edge_cell_shift=p(shift),

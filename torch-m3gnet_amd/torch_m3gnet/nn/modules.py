@@ -24,7 +24,7 @@ import math
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _cuda, _lib
 from ..data import MaterialGraphKey as K
 from ._bessel_zeros import SPHERICAL_BESSEL_ZEROS
 
@@ -80,8 +80,7 @@ def _ptr(t: torch.Tensor | None):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _cuda.stream_ptr
 
 
 class _Topology:
@@ -104,30 +103,62 @@ class _Topology:
         nbytes = C.c_size_t()
         _lib.check(lib.m3g_topology_bytes(self.N, self.E, self.T, self.S, C.byref(nbytes)))
         self.buf = torch.empty(nbytes.value, dtype=torch.uint8, device=self.ei.device)
-        flags = (C.c_int32 * 1)(0)
-        hints = C.c_int32(0)
+        self._pending = None
         # lists written by this library's own builders and untouched since (graph_gpu.mark_canonical): the build skips the checks
         # those lists pass by construction
-        canonical = isinstance(graph, dict) and graph.get("_m3g_canonical_lists") == self.signature(graph)
-        build = lib.m3g_topology_build_canonical if canonical else lib.m3g_topology_build_hints
-        _lib.check(build(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
-                         _ptr(self.buf), nbytes.value, flags, C.byref(hints) if self.WITH_HINTS else None, _stream()))
+        is_dict = isinstance(graph, dict)
+        canonical = is_dict and graph.get("_m3g_canonical_lists") == self.signature(graph)
+        # a trajectory graph (data/md.py) brings pinned host memory for the build's verdict: the build is then only QUEUED here and
+        # `finish` -- called by whoever needs the buffer -- waits for it, so the host prepares the engine call meanwhile
+        verdict = graph.get("_m3g_pinned_verdict") if is_dict else None
+        with _cuda.on_device(self.buf.device):
+            if canonical and verdict is not None and self.WITH_HINTS:
+                stream = _stream()
+                _lib.check(lib.m3g_topology_build_canonical_begin(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
+                                                                  _ptr(self.buf), nbytes.value, C.c_void_p(verdict.data_ptr()), stream))
+                self._pending = (verdict, stream, nbytes.value)
+                self._hints = None
+                return
+            flags = (C.c_int32 * 1)(0)
+            hints = C.c_int32(0)
+            build = lib.m3g_topology_build_canonical if canonical else lib.m3g_topology_build_hints
+            _lib.check(build(self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch),
+                             _ptr(self.buf), nbytes.value, flags, C.byref(hints) if self.WITH_HINTS else None, _stream()))
         # (the build waits for the stream itself, once, and the flags are final on return: include/m3gnet_hip.h)
-        if flags[0] & 1:
-            raise ValueError("edge_index must be sorted by centre atom (row 0), as MaterialGraph builds it")
-        if flags[0] & 2:
-            raise ValueError("graph index out of range (edge_index / triplet_edge_index / batch)")
-        if flags[0] & 4:
-            raise ValueError("triplet_edge_index pairs edges that do not share a centre atom")
+        self._raise_on(flags[0])
         # the certificate's word: formed with the build (WITH_HINTS), else asked for before the first m3g_energy_forces call
         self._hints = int(hints.value) if self.WITH_HINTS else None
+
+    @staticmethod
+    def _raise_on(flags: int) -> None:
+        if flags & 1:
+            raise ValueError("edge_index must be sorted by centre atom (row 0), as MaterialGraph builds it")
+        if flags & 2:
+            raise ValueError("graph index out of range (edge_index / triplet_edge_index / batch)")
+        if flags & 4:
+            raise ValueError("triplet_edge_index pairs edges that do not share a centre atom")
+
+    def finish(self) -> "_Topology":
+        """Complete a build that was only queued (m3g_topology_build_canonical_begin): wait for its stream, take the verdict."""
+        if self._pending is not None:
+            (verdict, stream, nbytes), self._pending = self._pending, None
+            flags = (C.c_int32 * 1)(0)
+            hints = C.c_int32(0)
+            with _cuda.on_device(self.buf.device):
+                _lib.check(_lib.load_library().m3g_topology_build_canonical_end(
+                    self.N, self.E, self.T, self.S, _ptr(self.ei), _ptr(self.tei), _ptr(self.batch), _ptr(self.buf), nbytes,
+                    C.c_void_p(verdict.data_ptr()), flags, C.byref(hints), stream))
+            self._raise_on(flags[0])
+            self._hints = int(hints.value)
+        return self
 
     def query_hints(self) -> int:
         """The word m3g_topology_hints returns for this topology (certifies complete triplet lists for the three-body moment
         kernels; a few small kernels and one wait for the stream).  Cached."""
+        self.finish()
         if self._hints is None:
             hints = C.c_int32(0)
-            with torch.cuda.device(self.buf.device):
+            with _cuda.on_device(self.buf.device):
                 _lib.check(_lib.load_library().m3g_topology_hints(self.N, self.E, self.T, self.S, _ptr(self.buf), C.byref(hints), _stream()))
             self._hints = int(hints.value)
         return self._hints
@@ -141,15 +172,17 @@ class _Topology:
 
     def status(self) -> int:
         """Sticky error bits the hot call left on this topology buffer (m3g_topology_status; 0 = none)."""
+        self.finish()
         st = C.c_int32(0)
-        with torch.cuda.device(self.buf.device):
+        with _cuda.on_device(self.buf.device):
             _lib.check(_lib.load_library().m3g_topology_status(self.N, self.E, self.T, self.S, _ptr(self.buf), C.byref(st), _stream()))
         return int(st.value)
 
     def n_active(self) -> int:
         """Edges that take part in a triplet (rows of the three-body arrays)."""
+        self.finish()
         n = C.c_int64()
-        with torch.cuda.device(self.buf.device):
+        with _cuda.on_device(self.buf.device):
             _lib.check(_lib.load_library().m3g_topology_active_edges(self.N, self.E, self.T, self.S, _ptr(self.buf), C.byref(n), _stream()))
         return int(n.value)
 
@@ -163,15 +196,18 @@ class _Topology:
         return tuple(sig)
 
     @classmethod
-    def of(cls, graph) -> "_Topology":
+    def of(cls, graph, finish: bool = True) -> "_Topology":
+        """The topology of `graph`, built on first use and cached on the graph.  `finish=False`: a build that was only queued (see
+        `__init__`) is returned as it is; the caller calls `finish()` before it hands the buffer to a kernel."""
         sig = cls.signature(graph)
         cached = graph.get("_m3g_topology") if isinstance(graph, dict) else None
         if cached is not None and cached[0] == sig:
-            return cached[1]
-        topo = cls(graph)
-        if isinstance(graph, dict):
-            dict.__setitem__(graph, "_m3g_topology", (sig, topo))
-        return topo
+            topo = cached[1]
+        else:
+            topo = cls(graph)
+            if isinstance(graph, dict):
+                dict.__setitem__(graph, "_m3g_topology", (sig, topo))
+        return topo.finish() if finish else topo
 
 
 # ----------------------------------------------------------------------------------------------
@@ -308,7 +344,7 @@ def _linear(x: torch.Tensor, lin: torch.nn.Linear, act: int) -> torch.Tensor:
     w = _f32(lin.weight).to(x2.device)
     b = _f32(lin.bias).to(x2.device) if lin.bias is not None else None
     y = torch.empty(x2.size(0), lin.out_features, dtype=torch.float, device=x2.device)
-    with torch.cuda.device(x2.device):
+    with _cuda.on_device(x2.device):
         _lib.check(_lib.load_library().m3g_linear(x2.size(0), lin.in_features, lin.out_features, _ptr(x2), _ptr(w), _ptr(b), act, _ptr(y), _stream()))
     return y.reshape(*x.shape[:-1], lin.out_features)
 
@@ -361,7 +397,7 @@ class GatedMLP(torch.nn.Module):
         """dense(x) * gate(x) for any layer widths (m3g_linear per layer, m3g_multiply for the product)."""
         d, g = self._branch(self.dense, x), self._branch(self.gate, x)
         out = torch.empty_like(d)
-        with torch.cuda.device(d.device):
+        with _cuda.on_device(d.device):
             _lib.check(_lib.load_library().m3g_multiply(d.numel(), _ptr(d), _ptr(g), _ptr(out), _stream()))
         return out
 
@@ -404,7 +440,7 @@ class NormalizedSphericalBessel(torch.nn.Module):
         r = _f32(rs).reshape(-1)
         z, f = self._host_tables()
         out = torch.empty(self.l_max, self.n_max, r.numel(), dtype=torch.float, device=r.device)
-        with torch.cuda.device(r.device):
+        with _cuda.on_device(r.device):
             _lib.check(_lib.load_library().m3g_bessel_basis(self.l_max, self.n_max, float(self.cutoff), z.ctypes.data, f.ctypes.data, r.numel(),
                                                              _ptr(r), _ptr(out), _stream()))
         return out
@@ -437,7 +473,7 @@ class ThreeBodyInteration(torch.nn.Module):
         mid = torch.empty(E, Cc, dtype=torch.float, device=dev)
         ws, bs = _f32(self.linear_sigmoid1.weight).to(dev), _f32(self.linear_sigmoid1.bias).to(dev)
         wd, wg = _f32(self.gated_mlp.dense[0].weight).to(dev), _f32(self.gated_mlp.gate[0].weight).to(dev)
-        with torch.cuda.device(dev):
+        with _cuda.on_device(dev):
             _lib.check(_lib.load_library().m3g_three_body(
                 self.l_max, self.n_max, D, float(self.cutoff), float(self.threebody_cutoff), z.ctypes.data, f.ctypes.data, N, E, T, _ptr(ei),
                 _ptr(tei), _ptr(d), _ptr(ang), _ptr(x), _ptr(ws), _ptr(bs), _ptr(wd), _ptr(wg), _ptr(scratch), _ptr(e_new), _ptr(mid), _stream()))
@@ -475,7 +511,7 @@ class M3GNetConv(torch.nn.Module):
         nbytes = C.c_size_t()
         _lib.check(lib.m3g_conv_block_scratch_bytes(D, topo.E, C.byref(nbytes)))
         scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _cuda.on_device(dev):
             _lib.check(lib.m3g_conv_block(D, self.degree, topo.N, topo.E, topo.T, topo.S, _ptr(topo.buf), params, _ptr(h), _ptr(x_new), _ptr(e_new),
                                           _ptr(scratch), nbytes.value, _stream()))
             torch.cuda.current_stream().synchronize()   # `keep` and `scratch` are released when this returns
@@ -512,7 +548,7 @@ class AtomWiseReadout(torch.nn.Module):
         ea = torch.empty(N, dtype=torch.float, device=dev)
         st, tot = torch.empty(S, dtype=torch.float, device=dev), torch.empty(S, dtype=torch.float, device=dev)
         scratch = torch.empty(6 * N * D + 2 * N + 16, dtype=torch.float, device=dev)
-        with torch.cuda.device(dev):
+        with _cuda.on_device(dev):
             _lib.check(_lib.load_library().m3g_readout(D, N, S, params, float(self.scale), _ptr(x), _ptr(elem), _ptr(batch), _ptr(ea), _ptr(st),
                                                        _ptr(tot), _ptr(scratch), _stream()))
             torch.cuda.current_stream().synchronize()
