@@ -25,7 +25,9 @@ size_t topo_sort_tmp_bytes(int64_t E, int64_t T) {
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, pairs, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                                            (int)std::max<int64_t>(E, 1), 0, 32, 0);
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(E + 1));
-  return align_up(std::max(std::max(cub, pairs), scan)) + 2 * align_up(m * sizeof(uint64_t));
+  // (+ E + 1: the certificate's per-row flags live behind the two key arrays, launch_hint_kernels; the library's own temporary
+  // sizes fall below that on graphs of a few hundred edges, which then never got their certificate)
+  return align_up(std::max(std::max(std::max(cub, pairs), scan), (size_t)E + 1)) + 2 * align_up(m * sizeof(uint64_t));
 }
 
 Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
