@@ -384,3 +384,49 @@ def test_host_neighbor_order_does_not_depend_on_the_wrap_state():
     t0 = threebody_index(14, e0, d0.astype(np.float32), 4.0)[0].shape[1]
     tc = threebody_index(14, ec, dc.astype(np.float32), 4.0)[0].shape[1]
     assert t0 == tc
+
+
+def test_engine_parameter_signature_sees_every_kind_of_change():
+    """Engine._signature decides on every call whether the plan's weights must be committed again (engine.py).  It is built from
+    cached dicts with C-level maps (the host's critical path of a caller that waits for the device each step); it must still see:
+    an in-place update (optimiser step, load_state_dict), a replaced Parameter, a replaced submodule, a Parameter registered later
+    on a module that had none, new captured constants -- and nothing when nothing changed."""
+    import torch
+
+    from torch_m3gnet.model.build import build_model
+
+    torch.manual_seed(0)
+    model = build_model(5.0, 4.0, 3, 3, 95, 64, 3)
+    eng = model.engine
+
+    class Dev:
+        index = 0
+
+    s0 = eng._signature(Dev)
+    assert eng._signature(Dev) == s0
+    with torch.no_grad():
+        next(model.parameters()).add_(1.0)
+    s1 = eng._signature(Dev)
+    assert s1 != s0
+    model.load_state_dict(model.state_dict())            # copy_ into every parameter: versions move
+    s2 = eng._signature(Dev)
+    assert s2 != s1
+    lin = model.model[3].linear
+    lin.weight = torch.nn.Parameter(torch.zeros_like(lin.weight))
+    s3 = eng._signature(Dev)
+    assert s3 != s2
+    model.model[3].linear = torch.nn.Linear(95, 64, bias=False)
+    s4 = eng._signature(Dev)
+    assert s4 != s3
+    model.model[3].linear.register_parameter("bias", torch.nn.Parameter(torch.zeros(64)))
+    s5 = eng._signature(Dev)
+    assert s5 != s4 and len(s5[1]) == len(s4[1]) + 1
+    tb = [m for m in model.model if type(m).__name__ == "ThreeBodyInteration"][0]
+    tb.nsb.factors = tb.nsb.factors.clone()
+    s6 = eng._signature(Dev)
+    assert s6 != s5
+
+    class Dev1:
+        index = 1
+
+    assert eng._signature(Dev1) != s6 and eng._signature(Dev) == s6
