@@ -180,7 +180,7 @@ int m3g_topology_build_canonical_end(int64_t n_atoms, int64_t n_edges, int64_t n
                                      int32_t* host_hints, void* stream);
 
 /* Diagnostic / tests: the leading part of a topology buffer that holds the lists the kernels read (the rest is scratch of the build),
- * and which build m3g_topology_build_canonical took on this thread the last time: 1 = the seven-launch build for canonical lists,
+ * and which build m3g_topology_build_canonical took on this thread the last time: 1 = the six-launch build for canonical lists,
  * 0 = the general one (a failed check, no hints asked for, no triplets, or more atoms than its one-workgroup scan takes). */
 int m3g_topology_data_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, size_t* bytes);
 int m3g_topology_debug_last_path(int32_t* path);

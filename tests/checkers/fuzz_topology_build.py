@@ -1,5 +1,5 @@
 """Random batches through BOTH topology builds (run on the GPU box): m3g_topology_build_hints (general) and
-m3g_topology_build_canonical (seven launches, csrc/m3g_topology.hip k_canon_*) on the lists of the GPU graph builder -- random
+m3g_topology_build_canonical (six launches, csrc/m3g_topology.hip k_canon_*) on the lists of the GPU graph builder -- random
 lattices (cubic to strongly sheared, 2-25 A), 1-120 atoms per cell, cutoffs 2.5-9 A, 1-6 structures, three-body cutoff from half
 the cutoff up to the cutoff itself.  The data part of the two topology buffers must agree byte for byte and carry the same
 certificate; the canonical call must have taken its own path unless a row exceeds the in-edge kernel's 512-edge stage.
@@ -44,7 +44,7 @@ def main():
         edges += int(g[K.NUM_EDGES])
         trips += int(g[K.NUM_TRIPLETS])
     print(f"{done} batches with triplets of {cases} cases: buffers identical ({edges} edges, {trips} triplets in total); "
-          f"the canonical build took its seven-launch path on {fast} of them (the rest: rows of more than 512 edges)")
+          f"the canonical build took its six-launch path on {fast} of them (the rest: rows of more than 512 edges)")
 
 
 if __name__ == "__main__":

@@ -276,7 +276,7 @@ def test_batch_from_structures_and_pinned_staging():
         assert torch.equal(staged[key], on_gpu[key]), key
 
 
-# ---- the seven-launch topology build for canonical lists ---------------------------------------------------------------------------------
+# ---- the six-launch topology build for canonical lists ---------------------------------------------------------------------------------
 def _topology_buffers(g):
     """The same graph through the general build (m3g_topology_build_hints) and the canonical one, into zero-filled buffers:
     (data bytes of both, hints of both, path the canonical call took)."""
@@ -330,7 +330,7 @@ def _canonical_graphs():
 
 
 def test_canonical_topology_build_writes_the_general_builds_buffer():
-    """m3g_topology_build_canonical (seven launches; csrc/m3g_topology.hip, k_canon_*) against m3g_topology_build_hints on the lists
+    """m3g_topology_build_canonical (six launches; csrc/m3g_topology.hip, k_canon_*) against m3g_topology_build_hints on the lists
     the library's builders write: every array of the topology buffer bit for bit, the certificate's word, and the fast path taken."""
     from torch_m3gnet.data import MaterialGraphKey as K
 

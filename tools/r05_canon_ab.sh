@@ -1,4 +1,4 @@
-# same-box A/B of the seven-launch canonical topology build (M3G_CANON_FAST=0: the general build under the canonical flag)
+# same-box A/B of the six-launch canonical topology build (M3G_CANON_FAST=0: the general build under the canonical flag)
 cd $GRAFT_REPO_ROOT
 for rep in 1 2 3; do
   for f in 1 0; do

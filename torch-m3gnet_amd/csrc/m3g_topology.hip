@@ -135,11 +135,9 @@ __global__ void k_check_symmetric(int64_t T, const uint64_t* __restrict__ sorted
 // edge to the same i), then writes the found edge ids in ascending order -- exactly what the stable sort on the neighbour index
 // produces.  A mirror that does not exist, or a row longer than the stage, raises flags[0] bit 3 and the caller sorts instead.
 constexpr int kInStage = 512;   // outgoing edges per atom handled here
-__global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
-                                                            int32_t* in_ptr, int32_t* in_edge, int32_t* flags) {
-  __shared__ int32_t s_e[4 * kInStage], s_d[4 * kInStage];
+__device__ __forceinline__ void in_edges_symmetric_body(int64_t N, int64_t j, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
+                                                        int32_t* in_ptr, int32_t* in_edge, int32_t* flags, int32_t* s_e, int32_t* s_d) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t j = blockIdx.x * (int64_t)(blockDim.x >> 6) + wave;   // wave-uniform
   if (j > N) return;
   if (lane == 0) in_ptr[j] = row_ptr[j];
   if (j == N) return;
@@ -183,6 +181,12 @@ __global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int
     for (int f = 0; f < n; ++f) rank += se[f] < e ? 1 : 0;
     in_edge[r0 + rank] = e;
   }
+}
+__global__ void __launch_bounds__(256) k_in_edges_symmetric(int64_t N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
+                                                            int32_t* in_ptr, int32_t* in_edge, int32_t* flags) {
+  __shared__ int32_t s_e[4 * kInStage], s_d[4 * kInStage];
+  const int64_t j = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);   // wave-uniform
+  in_edges_symmetric_body(N, j, row_ptr, dst, in_ptr, in_edge, flags, s_e, s_d);
 }
 
 // ptr[r] = first position whose key (high word of keys64, or keys32[pos]) >= r, for r = 0..rows
@@ -370,7 +374,7 @@ __global__ void k_compact_partners(int64_t T, const int32_t* __restrict__ scan, 
   bc[t] = scan[b[t]];
 }
 
-// ---- the canonical build in seven launches (m3g_topology_build_canonical) ---------------------------------------------------------
+// ---- the canonical build in six launches (m3g_topology_build_canonical) ---------------------------------------------------------
 // For the lists this library's own builders write -- edges sorted by centre and symmetric, triplets = every ordered pair of a
 // centre's edges inside the three-body cutoff, sorted by (e1, e2) -- every array of Topo follows from per-atom rows: the rows of the
 // triplet list are found by binary search in triplet_edge_index[0] itself, the active edges of a centre are consecutive in the
@@ -378,8 +382,9 @@ __global__ void k_compact_partners(int64_t T, const int32_t* __restrict__ scan, 
 // the partners as first edge (every mirrored array is written by the kernel that forms the original).  The arrays are the ones
 // the general build writes, bit for bit (tests/test_gpu_graph_build.py compares the buffers); what the general build checks --
 // index ranges, row order, edge-list symmetry, triplet order and centres -- is checked here too, and any failed check sends the
-// whole build down the general path.  Every kernel after the first leaves at once when an earlier one has flagged the lists, so
-// none walks rows that are not rows.
+// whole build down the general path.  Every kernel after the first leaves at once when the first has flagged the edge list, so
+// none walks rows that are not rows; the triplet list is checked in the last kernel (its one pass over the triplets), and the kernels
+// before it only read it through bounded searches and a streamed pass that ignores what does not belong to the atom's row.
 __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t key) {
   int64_t lo = 0, hi = n;
   while (lo < hi) {
@@ -404,6 +409,39 @@ __device__ __forceinline__ int64_t wave_lower_bound_i64(const int64_t* __restric
     hi = new_hi < hi ? new_hi : hi;
   }
   return lo;
+}
+// two keys (key0 <= key1) in the same rounds: the loads of both searches are in flight together
+__device__ __forceinline__ void wave_lower_bound2_i64(const int64_t* __restrict__ a, int64_t n, int64_t key0, int64_t key1, int lane,
+                                                      int64_t* out0, int64_t* out1) {
+  int64_t lo0 = 0, hi0 = n, lo1 = 0, hi1 = n;
+  while (hi0 > lo0 || hi1 > lo1) {
+    const int64_t step0 = (hi0 - lo0 + 63) / 64, step1 = (hi1 - lo1 + 63) / 64;
+    const int64_t p0 = lo0 + (int64_t)(lane + 1) * step0 - 1, p1 = lo1 + (int64_t)(lane + 1) * step1 - 1;
+    const bool in0 = hi0 > lo0 && p0 < hi0, in1 = hi1 > lo1 && p1 < hi1;
+    const int64_t v0 = in0 ? a[p0] : 0, v1 = in1 ? a[p1] : 0;   // (both loads issued before either is used)
+    if (hi0 > lo0) {
+      const unsigned long long m = __ballot(in0 ? v0 >= key0 : true);
+      if (m == 0) lo0 = hi0;
+      else {
+        const int f = __ffsll((long long)m) - 1;
+        const int64_t nh = lo0 + (int64_t)(f + 1) * step0 - 1;
+        lo0 = lo0 + (int64_t)f * step0;
+        hi0 = nh < hi0 ? nh : hi0;
+      }
+    }
+    if (hi1 > lo1) {
+      const unsigned long long m = __ballot(in1 ? v1 >= key1 : true);
+      if (m == 0) lo1 = hi1;
+      else {
+        const int f = __ffsll((long long)m) - 1;
+        const int64_t nh = lo1 + (int64_t)(f + 1) * step1 - 1;
+        lo1 = lo1 + (int64_t)f * step1;
+        hi1 = nh < hi1 ? nh : hi1;
+      }
+    }
+  }
+  *out0 = lo0;
+  *out1 = lo1;
 }
 constexpr int kCanonStage = 512;   // edges per atom whose triplet rows are resolved in LDS (longer rows: one binary search per edge)
 // roles by thread index: edges (k_convert_edges), atoms (k_convert_batch), rows (lower bounds in the int64 lists themselves), zero
@@ -432,32 +470,23 @@ __global__ void __launch_bounds__(256) k_canon_edges(int64_t N, int64_t E, int64
   if (i < n_win) tb_win[i] = 0;
   if (i < n_fast) tb_fast[i] = 0;
 }
-// role A (the first t_blocks workgroups, one thread per triplet): range / centre / order checks, partner lists in both roles.
-// role B (one wave per atom): rows of the triplet list for the atom's edges, and the number of its active edges (cnt[atom], scanned by
-// k_canon_scan into arow_ptr)
-__global__ void __launch_bounds__(256) k_canon_triplets(int64_t N, int64_t E, int64_t T, int64_t t_blocks, const int64_t* __restrict__ tei,
-                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ row_ptr, int32_t* flags,
-                                                        int32_t* t1_e2, int32_t* t2_e1, int32_t* t1_ptr, int32_t* t2_ptr, int32_t* cnt) {
-  __shared__ int s_start[4 * kCanonStage];
+// one wave per atom, two roles by workgroup range.  [0, a_blocks): the rows of the triplet list for the atom's edges, and the
+// number of its active edges (cnt[atom], scanned by k_canon_scan into arow_ptr).  [a_blocks, 2 a_blocks): its incoming-edge list from
+// the mirrors of its own row (k_in_edges_symmetric's body; the two roles share nothing but row_ptr).
+__global__ void __launch_bounds__(256) k_canon_rows(int64_t N, int64_t E, int64_t T, int64_t a_blocks, const int64_t* __restrict__ tei,
+                                                    const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst, int32_t* flags,
+                                                    int32_t* t1_ptr, int32_t* t2_ptr, int32_t* cnt, int32_t* in_ptr, int32_t* in_edge) {
+  __shared__ int32_t s_lds[8 * kInStage];   // in-edge role: two stages of kInStage per wave; row role: one of kCanonStage per wave
+  static_assert(kCanonStage <= 2 * kInStage, "k_canon_rows: the row role's stage must fit the in-edge role's");
   if (flags[0] & 7) return;   // (bits raised by k_canon_edges, complete at this launch boundary)
-  if ((int64_t)blockIdx.x < t_blocks) {
-    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    int64_t e1 = tei[t], e2 = tei[T + t];
-    int bad = 0;
-    if (e1 < 0 || e1 >= E || e2 < 0 || e2 >= E) { bad |= 2; e1 = 0; e2 = 0; }
-    else if (src[e1] != src[e2]) bad |= 4;
-    t1_e2[t] = (int32_t)e2;
-    t2_e1[t] = (int32_t)e2;
-    if (bad) atomicOr(flags, bad);
-    if (t > 0) {
-      const int64_t p1 = tei[t - 1], p2 = tei[T + t - 1];
-      if (p1 > e1 || (p1 == e1 && p2 > e2)) atomicOr(flags + 1, 1);
-    }
+  if ((int64_t)blockIdx.x >= a_blocks) {
+    const int64_t ja = ((int64_t)blockIdx.x - a_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    in_edges_symmetric_body(N, ja, row_ptr, dst, in_ptr, in_edge, flags, s_lds, s_lds + 4 * kInStage);
     return;
   }
+  int* s_start = s_lds;
   const int lane = threadIdx.x & 63;
-  const int64_t j = ((int64_t)blockIdx.x - t_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);   // wave-uniform
+  const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // wave-uniform
   if (j > N) return;
   if (j == N) {
     if (lane == 0) { t1_ptr[E] = (int32_t)T; t2_ptr[E] = (int32_t)T; cnt[N] = 0; }
@@ -485,7 +514,8 @@ __global__ void __launch_bounds__(256) k_canon_triplets(int64_t N, int64_t E, in
   // the atom's triplets are one contiguous block [tlo, thi) of the sorted list: two searches by the whole wave, then the block is
   // streamed once and every edge that heads a run of equal e1 learns where its row starts; an edge without triplets takes the start
   // of the next edge that has some (the end of the block when there is none), which is what a lower bound per edge returns
-  const int64_t tlo = wave_lower_bound_i64(tei, T, r0, lane), thi = wave_lower_bound_i64(tei, T, r1, lane);
+  int64_t tlo, thi;
+  wave_lower_bound2_i64(tei, T, r0, r1, lane, &tlo, &thi);
   int* st = s_start + (threadIdx.x >> 6) * kCanonStage;
   for (int k = lane; k < n; k += 64) st[k] = -1;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -534,7 +564,7 @@ __global__ void __launch_bounds__(256) k_canon_active(int64_t N, int64_t E, cons
                                                       const int32_t* __restrict__ t1_ptr, const int32_t* __restrict__ arow_ptr,
                                                       const int32_t* __restrict__ flags, int32_t* act_scan, int32_t* act_id, int32_t* act_list,
                                                       int32_t* act_dst, int32_t* win) {
-  if ((flags[0] & 7) || flags[1]) return;
+  if (flags[0] & 7) return;
   const int lane = threadIdx.x & 63;
   const int64_t j = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (j > N) return;
@@ -574,10 +604,12 @@ __global__ void __launch_bounds__(256) k_canon_finish(int64_t E, int64_t T, int6
                                                       const int64_t* __restrict__ tei, const int32_t* __restrict__ in_edge,
                                                       const int32_t* __restrict__ act_id, const int32_t* __restrict__ act_scan,
                                                       const int32_t* __restrict__ act_list, const int32_t* __restrict__ src,
-                                                      const int32_t* __restrict__ win, const int32_t* __restrict__ flags, int32_t* in_pair,
-                                                      int32_t* in_pos, int32_t* t1_e2c, int32_t* t2_e1c, uint8_t* t1_b, uint8_t* t2_b, int32_t* fast,
-                                                      int32_t* stats) {
-  if ((flags[0] & 15) || flags[1]) return;   // (bit 3: k_in_edges_symmetric found the edge list one-sided -- the general build sorts)
+                                                      const int32_t* __restrict__ win, int32_t* flags, int32_t* in_pair,
+                                                      int32_t* in_pos, int32_t* t1_e2, int32_t* t2_e1, int32_t* t1_e2c, int32_t* t2_e1c, uint8_t* t1_b,
+                                                      uint8_t* t2_b, int32_t* fast, int32_t* stats) {
+  // (bit 3: the in-edge role found the edge list one-sided -- the general build sorts.  The triplet checks below raise their bits
+  // while other workgroups of this launch run: whatever those write is discarded with the rest when the host reads the verdict)
+  if (__builtin_nontemporal_load(flags) & 15) return;
   const int64_t blk = blockIdx.x;
   if (blk < e_blocks) {
     const int64_t i = blk * blockDim.x + threadIdx.x;
@@ -592,7 +624,19 @@ __global__ void __launch_bounds__(256) k_canon_finish(int64_t E, int64_t T, int6
   if (blk < e_blocks + t_blocks) {
     const int64_t t = (blk - e_blocks) * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const int64_t e1 = tei[t], e2 = tei[T + t];   // (in range: k_canon_triplets has checked them)
+    // the one pass over the triplet list: range / centre / order checks (k_convert_triplets), partner lists in both roles, then the
+    // compacted partners and their window bytes
+    int64_t e1 = tei[t], e2 = tei[T + t];
+    int bad = 0;
+    if (e1 < 0 || e1 >= E || e2 < 0 || e2 >= E) { bad |= 2; e1 = 0; e2 = 0; }
+    else if (src[e1] != src[e2]) bad |= 4;
+    if (bad) atomicOr(flags, bad);
+    if (t > 0) {
+      const int64_t p1 = tei[t - 1], p2 = tei[T + t - 1];
+      if (p1 > tei[t] || (p1 == tei[t] && p2 > tei[T + t])) atomicOr(flags + 1, 1);
+    }
+    t1_e2[t] = (int32_t)e2;
+    t2_e1[t] = (int32_t)e2;
     const int c2 = act_scan[e2];
     t1_e2c[t] = c2;
     t2_e1c[t] = c2;
@@ -867,7 +911,7 @@ extern "C" int m3g_topology_build_hints(int64_t N, int64_t E, int64_t T, int64_t
 // triplet lists that hold every ordered pair of a centre's edges inside the three-body cutoff BY CONSTRUCTION, so the mirror check of
 // the triplet list and the per-row completeness test of the certificate are skipped (two kernels over all triplets, 38 us of the
 // 0.25-ms build on the 10k-atom cell).  Everything else -- index ranges, row order, edge-list symmetry -- is still checked.
-// Seven launches and the copy of the verdict words (flags[0..6]) to `verdict`, PINNED host memory: queued, not waited for
+// Six launches (a memset and five kernels) and the copy of the verdict words (flags[0..6]) to `verdict`, PINNED host memory: queued, not waited for
 constexpr int64_t kCanonMaxAtoms = 131072;   // k_canon_scan is one workgroup
 static thread_local int32_t g_last_canonical_path = 0;
 static bool canonical_fast_applies(int64_t N, int64_t E, int64_t T, int64_t S, const void* ei, const void* tei, const void* batch) {
@@ -883,16 +927,15 @@ static int canonical_fast_launch(int64_t N, int64_t E, int64_t T, int64_t S, con
   const int64_t n1 = std::max(std::max(E, N + 1), std::max(S + 1, n_win));
   hipLaunchKernelGGL(k_canon_edges, dim3((unsigned)blocks(n1)), dim3(TPB), 0, s, N, E, S, edge_index, batch, t.src, t.dst, t.batch, t.row_ptr,
                      t.struct_ptr, t.tb_win, n_win, t.tb_fast, n_fast, t.flags);
-  hipLaunchKernelGGL(k_in_edges_symmetric, dim3((unsigned)blocks((N + 1) * 64)), dim3(TPB), 0, s, N, t.row_ptr, t.dst, t.in_ptr, t.in_edge, t.flags);
   const int64_t t_blocks = blocks(T), a_blocks = blocks((N + 1) * 64), e_blocks = blocks(E);
-  hipLaunchKernelGGL(k_canon_triplets, dim3((unsigned)(t_blocks + a_blocks)), dim3(TPB), 0, s, N, E, T, t_blocks, triplet_edge_index, t.src, t.row_ptr,
-                     t.flags, t.t1_e2, t.t2_e1, t.t1_ptr, t.t2_ptr, t.arow_ptr);
+  hipLaunchKernelGGL(k_canon_rows, dim3((unsigned)(2 * a_blocks)), dim3(TPB), 0, s, N, E, T, a_blocks, triplet_edge_index, t.row_ptr, t.dst, t.flags,
+                     t.t1_ptr, t.t2_ptr, t.arow_ptr, t.in_ptr, t.in_edge);
   hipLaunchKernelGGL(k_canon_scan, dim3(1), dim3(1024), 0, s, N + 1, t.arow_ptr, t.n_act, t.flags);
   hipLaunchKernelGGL(k_canon_active, dim3((unsigned)a_blocks), dim3(TPB), 0, s, N, E, t.row_ptr, t.dst, t.t1_ptr, t.arow_ptr, t.flags, t.act_scan, t.act_id,
                      t.act_list, t.act_dst, t.tb_win);
   hipLaunchKernelGGL(k_canon_finish, dim3((unsigned)(e_blocks + t_blocks + 1)), dim3(TPB), 0, s, E, T, e_blocks, t_blocks, windows, triplet_edge_index,
-                     t.in_edge, t.act_id, t.act_scan, t.act_list, t.src, t.tb_win, t.flags, t.in_pair, t.in_pos, t.t1_e2c, t.t2_e1c, t.t1_b, t.t2_b,
-                     t.tb_fast, t.flags + 4);
+                     t.in_edge, t.act_id, t.act_scan, t.act_list, t.src, t.tb_win, t.flags, t.in_pair, t.in_pos, t.t1_e2, t.t2_e1, t.t1_e2c, t.t2_e1c,
+                     t.t1_b, t.t2_b, t.tb_fast, t.flags + 4);
   M3G_HIP_CHECK(hipMemcpyAsync(verdict, t.flags, 7 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipGetLastError());
   return M3G_OK;
