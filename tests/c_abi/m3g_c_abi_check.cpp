@@ -102,6 +102,7 @@ int main(int argc, char** argv) {
   CK(m3g_topology_bytes(N, E, T, S, &topo_bytes));
   void *topo = nullptr, *work = nullptr;
   HK(hipMalloc(&topo, topo_bytes));
+  HK(hipMemset(topo, 0, topo_bytes));   // (the two-phase build below is compared with this buffer byte by byte)
   int32_t flags = 0;
   CK(m3g_topology_build(N, E, T, S, d_ei, d_tei, d_batch, topo, topo_bytes, &flags, stream));
   HK(hipStreamSynchronize(stream));
@@ -124,6 +125,32 @@ int main(int argc, char** argv) {
   HK(hipMemcpy(e.data(), d_e, sizeof(float) * S, hipMemcpyDeviceToHost));
   HK(hipMemcpy(fo.data(), d_f, sizeof(float) * 3 * N, hipMemcpyDeviceToHost));
   HK(hipMemcpy(st.data(), d_s, sizeof(float) * 6 * S, hipMemcpyDeviceToHost));
+  // the same topology through the two-phase canonical build (the fixture's lists are in the library's canonical order): queued with
+  // its verdict in pinned host memory, the host free until _end -- the list part of the buffer must equal the one built above
+  {
+    size_t data_bytes = 0;
+    CK(m3g_topology_data_bytes(N, E, T, S, &data_bytes));
+    void* topo2 = nullptr;
+    int32_t* verdict = nullptr;
+    HK(hipMalloc(&topo2, topo_bytes));
+    HK(hipMemset(topo2, 0, topo_bytes));
+    HK(hipHostMalloc((void**)&verdict, 16 * sizeof(int32_t), hipHostMallocDefault));
+    int32_t flags2 = 0, hints2 = 0, path = -1;
+    CK(m3g_topology_build_canonical_begin(N, E, T, S, d_ei, d_tei, d_batch, topo2, topo_bytes, verdict, stream));
+    CK(m3g_topology_build_canonical_end(N, E, T, S, d_ei, d_tei, d_batch, topo2, topo_bytes, verdict, &flags2, &hints2, stream));
+    HK(hipStreamSynchronize(stream));
+    CK(m3g_topology_debug_last_path(&path));
+    std::vector<unsigned char> a(data_bytes), b(data_bytes);
+    HK(hipMemcpy(a.data(), topo, data_bytes, hipMemcpyDeviceToHost));
+    HK(hipMemcpy(b.data(), topo2, data_bytes, hipMemcpyDeviceToHost));
+    if (flags2 || hints2 != io.topo_hints || memcmp(a.data(), b.data(), data_bytes) != 0) {
+      fprintf(stderr, "two-phase canonical build differs: flags %d hints %#x vs %#x path %d\n", flags2, hints2, io.topo_hints, path);
+      return 4;
+    }
+    printf("two-phase canonical topology build: %zu list bytes identical, hints %#x, path %d\n", data_bytes, hints2, path);
+    HK(hipFree(topo2));
+    HK(hipHostFree(verdict));
+  }
   FILE* o = fopen(argv[2], "wb");
   if (!o) { perror(argv[2]); return 1; }
   fwrite(e.data(), sizeof(float), e.size(), o);

@@ -61,6 +61,9 @@ def test_c_abi_host_without_torch(tmp_path, case, mode):
     params, cfg, consts, graph, expect, (N, S) = _write_case(tmp_path / "case.bin", case, mode)
     proc = subprocess.run([str(BIN), str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
     assert proc.returncode == 0, proc.stdout + proc.stderr
+    # the host program also builds the topology a second time through m3g_topology_build_canonical_begin / _end (pinned verdict) and
+    # compares the list part of the two buffers byte by byte (exit code 4 otherwise); the fixtures' lists are canonical: path 1
+    assert "two-phase canonical topology build" in proc.stdout and "path 1" in proc.stdout, proc.stdout
     out = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     e, f = torch.tensor(out[:S]), torch.tensor(out[S : S + 3 * N]).reshape(N, 3)
     o = orc.energy_forces(params, cfg, consts, graph, legendre_backward="exact")
