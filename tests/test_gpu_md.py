@@ -77,6 +77,7 @@ def test_verlet_graph_is_the_fresh_build_along_a_trajectory():
     lats, pos0, zs = zip(*cells)
     sizes = [len(p) for p in pos0]
     vg = VerletGraph(lats, zs, 5.0, 4.0, skin=0.4, device=DEV)
+    vg.speculate_after = 0   # evaluate() always queues the step ahead of the verdict here: this test is about that path
     rng = np.random.default_rng(5)
     pos = np.concatenate(pos0)
     for step in range(24):
@@ -127,6 +128,7 @@ def test_verlet_graph_reuses_everything_on_the_headline_cell():
     lat = np.diag([10 * a, 10 * a, 25 * a]).astype(float)
     z = np.full(len(pos0), 29)
     vg = VerletGraph([lat], [z], 5.0, 4.0, skin=0.5, device=DEV)
+    vg.speculate_after = 0   # (the step queued ahead of the verdict on the last iteration, whatever the history)
     rng = np.random.default_rng(0)
     first, topo = None, None
     for step in range(4):
@@ -336,3 +338,49 @@ def test_queued_topology_build_gives_the_same_results_and_survives_unevaluated_g
         outs[eager] = res
     for (e1, f1), (e0, f0) in zip(outs[True], outs[False]):
         assert torch.equal(e1, e0) and torch.equal(f1, f0)
+
+
+def test_evaluate_guesses_only_after_a_streak_of_unchanged_lists():
+    """VerletGraph.evaluate queues the step ahead of the skin test's verdict only after `speculate_after` consecutive "unchanged"
+    verdicts: a trajectory whose lists change on every step pays for exactly one evaluation per step (a wrong guess would cost
+    two), a frozen one runs without the wait from the fifth step on.  Same results either way (bit-identical to update + model)."""
+    from torch_m3gnet.data.md import VerletGraph
+
+    K = _K()
+    model = _model()
+    calls = [0]
+
+    def counted(g, **kw):
+        calls[0] += 1
+        return model(g, **kw)
+
+    a = 3.61
+    base = np.array([[0, 0, 0], [0, 0.5, 0.5], [0.5, 0, 0.5], [0.5, 0.5, 0]])
+    gi = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(3), indexing="ij"), -1)
+    pos0 = torch.tensor((gi.reshape(-1, 1, 3) + base[None]).reshape(-1, 3) * a, device=DEV)
+    lat, z = np.eye(3) * 3 * a, np.full(108, 29)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    # hot: +-0.15 A jitter of a perfect crystal whose 5.1 A shell sits 0.1 A outside the cutoff -- pairs cross it on every step
+    vg = VerletGraph([lat], [z], 5.0, 4.0, skin=1.0, device=DEV)
+    ref = VerletGraph([lat], [z], 5.0, 4.0, skin=1.0, device=DEV)
+    for step in range(10):
+        p = pos0 + (torch.rand(pos0.shape, generator=gen, device=DEV, dtype=torch.float64) - 0.5) * 0.3
+        out = vg.evaluate(counted, p, extras=False)
+        e, f = out[K.TOTAL_ENERGY].clone(), out[K.FORCES].clone()
+        want = model(ref.update(p), extras=False)
+        assert torch.equal(e, want[K.TOTAL_ENERGY]) and torch.equal(f, want[K.FORCES])
+    assert vg.stats["reuse"] == 0 and calls[0] == 10, (vg.stats, calls)
+    # frozen: moves of 1e-9 A change nothing; the guess starts after four confirmations and is right every time
+    calls[0] = 0
+    for step in range(10):
+        p = pos0 + (torch.rand(pos0.shape, generator=gen, device=DEV, dtype=torch.float64) - 0.5) * 1e-9
+        vg.evaluate(counted, p, extras=False)
+        assert (vg._reuse_streak >= vg.speculate_after) == (step >= 4), (step, vg._reuse_streak)
+    assert calls[0] == 10
+    # a change after a long streak: one wasted evaluation, then back to waiting first
+    p = pos0 + (torch.rand(pos0.shape, generator=gen, device=DEV, dtype=torch.float64) - 0.5) * 0.3
+    calls[0] = 0
+    out = vg.evaluate(counted, p, extras=False)
+    want = model(ref.update(p), extras=False)
+    assert calls[0] == 2 and vg._reuse_streak == 0
+    assert torch.equal(out[K.TOTAL_ENERGY], want[K.TOTAL_ENERGY]) and torch.equal(out[K.FORCES], want[K.FORCES])
