@@ -574,6 +574,12 @@ def measure_beside(model, device):
             vgs.evaluate(model, p0 + (torch.rand(p0.shape, generator=gen_s, device=device, dtype=torch.float64) - 0.5) * 0.05, forces=True, extras=False)
 
         rec[key] = per_call(it_small, 200, warm=20)
+
+        def it_small_refill():   # the lists re-derived on every step (what a cell at finite temperature does): host-bound
+            model(vgs.update(p0 + (torch.rand(p0.shape, generator=gen_s, device=device, dtype=torch.float64) - 0.5) * 0.05, force="refill"),
+                  forces=True, extras=False)
+
+        rec[key.replace("md_iteration_ms", "md_refill_iteration_ms")] = per_call(it_small_refill, 100, warm=10)
     # BASELINE config 5 (2,000 atoms in L = 31.1 A, cutoff 6 A, three-body cutoff 4 A and 6 A): step time on a model of those cutoffs
     from torch_m3gnet.data.graph_gpu import batch_from_arrays
     from torch_m3gnet.data.synthetic import random_cell_arrays
@@ -802,7 +808,8 @@ def main():
             **{f"{m}_ms_per_step": out[m]["ms_per_step"] for m in other_modes if m in out},
             "config4_ms_per_step": out["config4_sharded"]["ms_per_step"],
             **{k: bs[k] for k in ("step_ms_32_atom_cu_cell", "step_ms_864_atom_cu_cell", "md_iteration_ms_32_atom_cell",
-                                  "md_iteration_ms_864_atom_cell", "step_ms_config5_r3_4A", "step_ms_config5_r3_6A") if k in bs},
+                                  "md_iteration_ms_864_atom_cell", "md_refill_iteration_ms_32_atom_cell", "md_refill_iteration_ms_864_atom_cell",
+                                  "step_ms_config5_r3_4A", "step_ms_config5_r3_6A") if k in bs},
             **({f"md_10k_{args.precision}_{k}_ms": md[k]["total"] for k in ("reuse", "refill", "rebuild") if k in md}),
             **({f"md_10k_{args.precision}_reuse_no_wait_ms": md["reuse_verdict_read_after_the_step"]["total"]}
                if "reuse_verdict_read_after_the_step" in md else {}),

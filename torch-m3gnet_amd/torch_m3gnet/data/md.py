@@ -33,7 +33,7 @@ import torch
 
 from .. import _cuda, _lib
 from . import MaterialGraphKey as K
-from .graph_gpu import _ptr, _stream, mark_canonical, neighbor_list_gpu
+from .graph_gpu import _ptr, _stream, neighbor_list_gpu
 from .material_graph import Batch
 
 
@@ -62,11 +62,17 @@ class VerletGraph:
         self._cand = None            # (edge_index [2,Ec], shift [Ec,3], row_ptr [N+2], state [Ec] u8, pos_ref [N,3] f64, scratch)
         self.stats = {"reuse": 0, "refill": 0, "search": 0}
         self._verdict = torch.zeros(8, dtype=torch.int64).pin_memory()   # m3g_verlet_update_async: max disp^2 (bits), changed, E, T, -, longest candidate row
+        self._verdict_i64 = self._verdict.numpy()                # the same pinned words as numpy views: reading six of them through
+        self._verdict_f64 = self._verdict_i64.view(np.float64)   # tensor indexing cost ~15 us of host time per step
+        self._verdict_ptr = C.c_void_p(self._verdict.data_ptr())
         self._verdict_ready = torch.cuda.Event()
         self._topo_verdict = torch.zeros(16, dtype=torch.int32).pin_memory()   # m3g_topology_build_canonical_begin / _end
         self._pending = None         # positions of a begin() whose verdict has not been read
         self._state_valid = False    # the candidates' membership bytes describe the current lists
         self._max_row = 0
+        self._test_args = None
+        self._graph_constants = {K.ATOM_TYPES: self.atom_types, K.LATTICE: self.lattice32, K.BATCH: self.batch, K.NUM_NODES: self.N,
+                                 "num_graphs": self.S}
         self._reuse_streak = 0       # consecutive verdicts "lists unchanged" (evaluate's policy)
         self.speculate_after = 4     # evaluate() queues the step ahead of the verdict after this many of them (0: always)
         self.eager_topology = True   # queue the topology build with the fill (False: the engine builds it at its call)
@@ -81,6 +87,7 @@ class VerletGraph:
         self._host_lattice = lat
         self.lattice = torch.tensor(lat, device=self.device)
         self.lattice32 = self.lattice.to(torch.float)
+        self._graph_constants[K.LATTICE] = self.lattice32
         self._cand, self.graph, self._pending, self._state_valid = None, None, None, False
 
     # ------------------------------------------------------------------------------------------------ candidates
@@ -101,20 +108,23 @@ class VerletGraph:
 
     def _queue_test(self, pos: torch.Tensor) -> None:
         """The skin test at `pos`, queued on the current stream together with the copy of its verdict to pinned host memory."""
-        ei, shift, rows, state, pos_ref, scratch = self._cand
+        a = self._test_args
+        if a is None or a[0] is not self._cand:   # the arguments that change only with a new search, converted once
+            ei, shift, rows, state, pos_ref, scratch = self._cand
+            a = self._test_args = (self._cand, int(ei.size(1)), _ptr(pos_ref), _ptr(self.lattice), _ptr(self.batch), _ptr(ei), _ptr(shift),
+                                   _ptr(rows), _ptr(state), _ptr(scratch), scratch.numel())
         with _cuda.on_device(self.device):
-            _lib.check(self.lib.m3g_verlet_update_async(self.N, self.S, int(ei.size(1)), _ptr(pos), _ptr(pos_ref), _ptr(self.lattice),
-                                                        _ptr(self.batch), _ptr(ei), _ptr(shift), _ptr(rows), self.cutoff, self.threebody_cutoff,
-                                                        _ptr(state) if self._state_valid else None, _ptr(scratch), scratch.numel(),
-                                                        C.c_void_p(self._verdict.data_ptr()), _stream()))
+            _lib.check(self.lib.m3g_verlet_update_async(self.N, self.S, a[1], _ptr(pos), a[2], a[3], a[4], a[5], a[6], a[7], self.cutoff,
+                                                        self.threebody_cutoff, a[8] if self._state_valid else None, a[9], a[10],
+                                                        self._verdict_ptr, _stream()))
             self._verdict_ready.record()
 
     def _read_verdict(self):
         self._verdict_ready.synchronize()
-        v = self._verdict
-        disp = float(np.sqrt(np.frombuffer(np.int64(int(v[0])).tobytes(), dtype=np.float64)[0]))
+        v = self._verdict_i64
+        disp = float(np.sqrt(self._verdict_f64[0]))
         self._max_row = int(v[5])   # decides whether the two-launch refill applies (m3g_verlet_fill_lists)
-        return disp, bool(int(v[1])), int(v[2]), int(v[3])
+        return disp, bool(v[1]), int(v[2]), int(v[3])
 
     def _update(self, pos: torch.Tensor):
         self._queue_test(pos)
@@ -148,33 +158,25 @@ class VerletGraph:
                 _lib.check(self.lib.m3g_threebody_build(N, n_e, _ptr(ei), _ptr(d32), float(self.threebody_cutoff), _ptr(tb_scratch),
                                                         tb_bytes.value, n_t, _ptr(tei), _ptr(nti), _ptr(ntij), _stream()))
         g = Batch.__new__(Batch)
-        dict.__init__(g)
-        g[K.POS] = pos.to(torch.float)
-        g[K.ATOM_TYPES] = self.atom_types
-        g[K.NUM_TRIPLET_I] = nti
-        g[K.EDGE_INDEX] = ei
-        g[K.EDGE_CELL_SHIFT] = shift
-        g[K.NUM_TRIPLET_IJ] = ntij
-        g[K.TRIPLET_EDGE_INDEX] = tei
-        g[K.LATTICE] = self.lattice32
-        g[K.BATCH] = self.batch
-        g[K.NUM_NODES] = N
-        g[K.NUM_EDGES] = n_e
-        g[K.NUM_TRIPLETS] = n_t
-        g["num_graphs"] = self.S
+        dict.__init__(g, self._graph_constants)   # atom_types, lattice, batch, counts of atoms / structures: the trajectory's own
+        dict.update(g, {K.POS: pos.to(torch.float), K.NUM_TRIPLET_I: nti, K.EDGE_INDEX: ei, K.EDGE_CELL_SHIFT: shift, K.NUM_TRIPLET_IJ: ntij,
+                        K.TRIPLET_EDGE_INDEX: tei, K.NUM_EDGES: n_e, K.NUM_TRIPLETS: n_t})
         # the species check of the engine is a property of `atom_types`, which every graph of this trajectory shares
         if self.graph is not None and "_m3g_species_ok" in self.graph:
             dict.__setitem__(g, "_m3g_species_ok", self.graph["_m3g_species_ok"])
-        mark_canonical(g)   # lists of this library's own builder: the topology build skips the checks they pass by construction
-        # the topology build is queued right behind the fill (and waited for by the engine when it needs the buffer): the device
-        # builds while the host walks from here to its m3g_energy_forces call
         from ..nn.modules import _Topology
 
+        # lists of this library's own builder: the topology build skips the checks they pass by construction (graph_gpu.mark_canonical;
+        # the signature is formed once here for the mark, the cache key and the build)
+        sig = _Topology.signature(g)
+        dict.__setitem__(g, "_m3g_canonical_lists", sig)
+        # the topology build is queued right behind the fill (and waited for by the engine when it needs the buffer): the device
+        # builds while the host walks from here to its m3g_energy_forces call
         if self.graph is not None and self.graph.get("_m3g_topology") is not None:
             self.graph["_m3g_topology"][1].finish()   # one verdict buffer: a build still in flight (a graph that was never evaluated) ends first
         dict.__setitem__(g, "_m3g_pinned_verdict", self._topo_verdict)
         if self.eager_topology:
-            _Topology.of(g, finish=False)
+            dict.__setitem__(g, "_m3g_topology", (sig, _Topology(g, sig)))
         self.graph = g
 
     # ------------------------------------------------------------------------------------------------ the per-step call

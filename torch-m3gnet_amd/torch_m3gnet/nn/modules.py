@@ -90,7 +90,8 @@ class _Topology:
     # build only; `query_hints` then asks for the certificate on demand
     WITH_HINTS = True
 
-    def __init__(self, graph) -> None:
+    def __init__(self, graph, sig=None) -> None:
+        """`sig`: `signature(graph)` when the caller has just formed it."""
         lib = _lib.load_library()
         ei, tei, batch = graph[K.EDGE_INDEX], graph[K.TRIPLET_EDGE_INDEX], graph[K.BATCH]
         for t, name in ((ei, K.EDGE_INDEX), (tei, K.TRIPLET_EDGE_INDEX), (batch, K.BATCH)):
@@ -107,7 +108,7 @@ class _Topology:
         # lists written by this library's own builders and untouched since (graph_gpu.mark_canonical): the build skips the checks
         # those lists pass by construction
         is_dict = isinstance(graph, dict)
-        canonical = is_dict and graph.get("_m3g_canonical_lists") == self.signature(graph)
+        canonical = is_dict and graph.get("_m3g_canonical_lists") == (sig if sig is not None else self.signature(graph))
         # a trajectory graph (data/md.py) brings pinned host memory for the build's verdict: the build is then only QUEUED here and
         # `finish` -- called by whoever needs the buffer -- waits for it, so the host prepares the engine call meanwhile
         verdict = graph.get("_m3g_pinned_verdict") if is_dict else None
@@ -204,7 +205,7 @@ class _Topology:
         if cached is not None and cached[0] == sig:
             topo = cached[1]
         else:
-            topo = cls(graph)
+            topo = cls(graph, sig)
             if isinstance(graph, dict):
                 dict.__setitem__(graph, "_m3g_topology", (sig, topo))
         return topo.finish() if finish else topo
