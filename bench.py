@@ -580,6 +580,11 @@ def measure_beside(model, device):
                   forces=True, extras=False)
 
         rec[key.replace("md_iteration_ms", "md_refill_iteration_ms")] = per_call(it_small_refill, 100, warm=10)
+
+        def it_small_step_refill():   # the same through one library call per step (VerletGraph.step -> m3g_md_step)
+            vgs.step(model, p0 + (torch.rand(p0.shape, generator=gen_s, device=device, dtype=torch.float64) - 0.5) * 0.05, force="refill")
+
+        rec[key.replace("md_iteration_ms", "md_step_refill_iteration_ms")] = per_call(it_small_step_refill, 100, warm=10)
     # BASELINE config 5 (2,000 atoms in L = 31.1 A, cutoff 6 A, three-body cutoff 4 A and 6 A): step time on a model of those cutoffs
     from torch_m3gnet.data.graph_gpu import batch_from_arrays
     from torch_m3gnet.data.synthetic import random_cell_arrays
@@ -609,6 +614,9 @@ def measure_beside(model, device):
         if force == "no_wait":   # the skin test queued in front of the evaluation, its verdict read afterwards (VerletGraph.evaluate)
             vg.evaluate(model, pos, forces=True, extras=False)
             return
+        if force in ("step", "step_refill"):
+            vg.step(model, pos, force="refill" if force == "step_refill" else None)
+            return
         if not split:            # what a trajectory loop does: graph at the new positions, then the step on it
             model(vg.update(pos, force=force), forces=True, extras=False)
             return
@@ -628,7 +636,7 @@ def measure_beside(model, device):
             iteration(force)
         torch.cuda.synchronize()
         total = (time.perf_counter() - t0) / reps * 1e3
-        if force == "no_wait":
+        if force in ("no_wait", "step", "step_refill"):
             return {"total": total}
         # the graph update on its own, from a second pass with a wait for the device on either side of it (the waits cost the
         # overlap of the queued topology build with the host's way to the engine call: that pass is slower than `total`)
@@ -643,7 +651,9 @@ def measure_beside(model, device):
     for mode in dict.fromkeys((current, "f16x3")):
         model.engine.set_precision(mode)
         md[mode] = {"reuse": md_loop(None), "reuse_verdict_read_after_the_step": {"total": md_loop("no_wait", reps=20)["total"]},
-                    "refill": md_loop("refill"), "rebuild": md_loop("search")}
+                    "refill": md_loop("refill"), "rebuild": md_loop("search"),
+                    # one library call per step (VerletGraph.step -> m3g_md_step)
+                    "step_reuse": {"total": md_loop("step")["total"]}, "step_refill": {"total": md_loop("step_refill")["total"]}}
     model.engine.set_precision(current)
     md["paths_taken"] = dict(vg.stats)
     md["note"] = ("positions generated and kept on the device; `total`: model(vg.update(pos)) per iteration, jitter kernel and the wait "
@@ -809,8 +819,9 @@ def main():
             "config4_ms_per_step": out["config4_sharded"]["ms_per_step"],
             **{k: bs[k] for k in ("step_ms_32_atom_cu_cell", "step_ms_864_atom_cu_cell", "md_iteration_ms_32_atom_cell",
                                   "md_iteration_ms_864_atom_cell", "md_refill_iteration_ms_32_atom_cell", "md_refill_iteration_ms_864_atom_cell",
+                                  "md_step_refill_iteration_ms_32_atom_cell", "md_step_refill_iteration_ms_864_atom_cell",
                                   "step_ms_config5_r3_4A", "step_ms_config5_r3_6A") if k in bs},
-            **({f"md_10k_{args.precision}_{k}_ms": md[k]["total"] for k in ("reuse", "refill", "rebuild") if k in md}),
+            **({f"md_10k_{args.precision}_{k}_ms": md[k]["total"] for k in ("reuse", "refill", "rebuild", "step_reuse", "step_refill") if k in md}),
             **({f"md_10k_{args.precision}_reuse_no_wait_ms": md["reuse_verdict_read_after_the_step"]["total"]}
                if "reuse_verdict_read_after_the_step" in md else {}),
         }

@@ -365,6 +365,59 @@ int m3g_verlet_fill_lists(int64_t n_atoms, int64_t n_candidates, int64_t n_edges
                           int64_t* triplet_edge_index /* [2,T] */, int64_t* num_triplet_i /* [N] or NULL */,
                           int32_t* num_triplet_ij /* [E] or NULL */, void* stream);
 
+/* ---- one trajectory step per call: skin test, lists + topology when they changed, energies / forces / stresses ------------------
+ * Replaces, for a structure followed along a trajectory, the reference's per-frame MaterialGraph.from_structure
+ * (data/material_graph.py:132-254) + Gradient.forward (nn/gradient.py:25-64).  The caller searches the candidates (cutoff + skin;
+ * m3g_neighbor_*, m3g_verlet_rows) and hands them over with list buffers of the candidates' capacity -- every pointer device memory
+ * it owns and keeps alive until the next m3g_md_set_lists / m3g_md_destroy; the library then sequences m3g_verlet_update_async, (when
+ * a pair crossed a cutoff) m3g_verlet_fill_lists + m3g_topology_build_canonical, and m3g_energy_forces itself.  Per step the host
+ * waits twice at most (the verdict's sizes; the topology's certificate) and allocates nothing.  Same kernels on the same inputs as
+ * the separate calls: identical lists, bit-identical results. */
+typedef struct m3g_md m3g_md;
+typedef struct {
+  int64_t n_atoms, n_structs, n_cand;     /* N, S, number of candidate pairs Ec */
+  int64_t cap_edges, cap_triplets;        /* capacity of the list buffers below (cap_edges >= n_cand; cap_triplets: an upper bound of
+                                           * T for every configuration within skin / 2 of pos_ref, e.g. sum_i c_i (c_i - 1) over the
+                                           * candidates within threebody_cutoff + skin) */
+  double cutoff, threebody_cutoff, skin;
+  const double* pos_ref;                  /* [N,3] positions the candidates were searched at */
+  const double* lattice;                  /* [S,3,3] */
+  const float* lattice32;                 /* [S,3,3] the same in fp32 (m3g_io.lattice) */
+  const int64_t* batch;                   /* [N] */
+  const int64_t* atom_types;              /* [N] */
+  const int64_t* cand_edge_index;         /* [2,Ec] */
+  const int32_t* cand_shift;              /* [Ec,3] */
+  const int32_t* cand_row_ptr;            /* [N+2] (m3g_verlet_rows) */
+  uint8_t* cand_state;                    /* [Ec+16] membership bytes (written by the library) */
+  void* verlet_scratch; size_t verlet_scratch_bytes;   /* m3g_verlet_scratch_bytes(N, Ec) */
+  int64_t* edge_index;                    /* [2 * cap_edges]      the lists the library re-derives: read as [2,E] / [E,3] / [2,T] / */
+  int32_t* edge_cell_shift;               /* [3 * cap_edges]      [N] / [E] with the E, T of m3g_md_result */
+  int64_t* triplet_edge_index;            /* [2 * cap_triplets] */
+  int64_t* num_triplet_i;                 /* [N] */
+  int32_t* num_triplet_ij;                /* [cap_edges] */
+  float* pos32;                           /* [N,3] */
+  void* topo; size_t topo_bytes;          /* m3g_topology_bytes(N, cap_edges, cap_triplets, S) */
+  void* workspace; size_t workspace_bytes;/* m3g_workspace_bytes(plan, N, cap_edges, cap_triplets, S) */
+} m3g_md_lists;
+#define M3G_MD_REUSE 0        /* lists unchanged: the step ran on the standing lists */
+#define M3G_MD_REFILL 1       /* a pair crossed a cutoff (or first step / asked for): lists and topology re-derived, then the step */
+#define M3G_MD_NEED_SEARCH 2  /* an atom moved further than skin / 2: NOTHING was evaluated; search again, m3g_md_set_lists, call again */
+#define M3G_MD_UNSUPPORTED 3  /* candidate rows beyond M3G_VERLET_FILL_LISTS_MAX_ROW, or lists beyond the buffers' capacity: NOTHING was
+                               * evaluated; use the separate calls for this step */
+typedef struct {
+  int32_t path, topo_hints;
+  int64_t n_edges, n_triplets;            /* of the lists the step ran on (path 0 / 1), of the verdict otherwise */
+  double max_displacement;                /* largest |pos - pos_ref| */
+} m3g_md_result;
+int m3g_md_create(m3g_md** md);
+void m3g_md_destroy(m3g_md* md);
+int m3g_md_set_lists(m3g_md* md, const m3g_md_lists* lists);
+int m3g_md_invalidate(m3g_md* md);   /* the caller has rewritten cand_state / the list buffers through other calls: re-derive at the next step */
+/* pos: [N,3] fp64 device positions (unwrapped).  forces / stresses may be NULL (energies only).  force_refill != 0: re-derive the
+ * lists whatever the verdict says (tests, timing).  Waits for `stream` (verdict) -- the outputs are queued, not waited for. */
+int m3g_md_step(m3g_md* md, const m3g_plan* plan, const double* pos, float* total_energy, float* forces, float* stresses,
+                int32_t force_refill, m3g_md_result* host_result, void* stream);
+
 /* ---- measurement: per-stage device time from HIP events recorded on the call's own stream ---------
  * m3g_profile_enable(plan, 1) makes every following m3g_energy_forces record an event pair around each
  * stage launch; m3g_profile_read synchronises those events, returns per-stage totals since the last
@@ -386,7 +439,7 @@ int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out);
 #define M3G_ABI_VERSION 5   /* 2: m3g_io.topo_hints, m3g_topology_hints; 3: m3g_verlet_*, m3g_topology_status, hints word certified on the buffer,
                              * canonical edge order by the shift relative to the given coordinates, default precision fp32;
                              * 4: m3g_verlet_fill_lists, m3g_topology_build_canonical, M3G_TOPO_ERR_SYNC, options small_tiles / small_launches / fuse_node_tb;
-                             * 5: m3g_topology_build_canonical_begin / _end, m3g_topology_data_bytes, option legendre_backward */
+                             * 5: m3g_topology_build_canonical_begin / _end, m3g_topology_data_bytes, option legendre_backward, m3g_md_* */
 
 #ifdef __cplusplus
 }

@@ -384,3 +384,51 @@ def test_evaluate_guesses_only_after_a_streak_of_unchanged_lists():
     want = model(ref.update(p), extras=False)
     assert calls[0] == 2 and vg._reuse_streak == 0
     assert torch.equal(out[K.TOTAL_ENERGY], want[K.TOTAL_ENERGY]) and torch.equal(out[K.FORCES], want[K.FORCES])
+
+
+def test_step_through_the_c_side_trajectory_object_is_the_update_path_bit_for_bit():
+    """VerletGraph.step (m3g_md_step: skin test, refill, topology and engine sequenced by the library on capacity buffers) against
+    model(update(pos)) of a second VerletGraph along the same random walk of three batched cells: energies, forces, stresses and the
+    lists bit-identical on every step, all three paths taken, a lattice-vector jump (search) included; then the two ways mixed on
+    ONE object."""
+    from torch_m3gnet.data.md import VerletGraph
+
+    K = _K()
+    model = _model()
+    lats, pos0, zs = [], [], []
+    for s, (n, box) in enumerate(((20, 6.5), (9, 4.4), (31, 7.3))):   # the second cell is smaller than the cutoff: self-images
+        lat, p, z = random_cell_arrays(n, box, seed=50 + s)
+        lats.append(lat); pos0.append(p); zs.append(z)
+    a, b = (VerletGraph(lats, zs, 5.0, 4.0, skin=0.4, device=DEV) for _ in range(2))
+    rng = np.random.default_rng(8)
+    pos = np.concatenate(pos0)
+    for step in range(20):
+        pos = pos + rng.normal(0.0, 1e-9 if step % 4 == 2 else 0.02, pos.shape)
+        if step % 8 == 7:
+            pos[3] += lats[0][1]
+        p = torch.tensor(pos, device=DEV)
+        got = a.step(model, p)
+        g = b.update(p)
+        want = model(g, extras=False)
+        for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+            assert torch.equal(got[key], want[key]), (step, key)
+        lists = a.step_lists()
+        for key in (K.EDGE_INDEX, K.EDGE_CELL_SHIFT, K.TRIPLET_EDGE_INDEX, K.NUM_TRIPLET_I, K.NUM_TRIPLET_IJ):
+            assert torch.equal(lists[key], g[key]), (step, key)
+    assert a.stats == b.stats and all(v > 0 for v in a.stats.values()), (a.stats, b.stats)
+    # energies only
+    p = torch.tensor(pos + rng.normal(0.0, 0.02, pos.shape), device=DEV)
+    e_only = a.step(model, p, forces=False)
+    assert K.FORCES not in e_only and torch.equal(e_only[K.TOTAL_ENERGY], model(b.update(p), extras=False)[K.TOTAL_ENERGY])
+    # the two ways on ONE object, alternating: each re-derives the lists the other wrote last
+    for step in range(8):
+        pos = pos + rng.normal(0.0, 0.02, pos.shape)
+        p = torch.tensor(pos, device=DEV)
+        want = model(b.update(p), extras=False)
+        got = a.step(model, p) if step % 2 else model(a.update(p), extras=False)
+        for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+            assert torch.equal(got[key], want[key]), (step, key)
+    # a species outside the model's table fails as in the reference
+    bad = VerletGraph([lats[0]], [np.full(3, 120)], 5.0, 4.0, skin=0.4, device=DEV)
+    with pytest.raises(IndexError):
+        bad.step(model, torch.tensor(pos0[0][:3], device=DEV))

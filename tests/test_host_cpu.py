@@ -34,6 +34,8 @@ def test_struct_layouts_match_header_sizes():
 
     assert C.sizeof(_lib.M3GConfig) == 4 * 8 + 6 * 4
     assert C.sizeof(_lib.M3GIO) == 4 * 8 + 17 * 8 + 8   # + topo_hints, reserved (int32 each)
+    assert C.sizeof(_lib.M3GMdLists) == 5 * 8 + 3 * 8 + 21 * 8   # m3g_md_lists: 5 counts, 3 doubles, 17 pointers + 4 sizes
+    assert C.sizeof(_lib.M3GMdResult) == 2 * 4 + 2 * 8 + 8
 
 
 def test_seeded_build_model_reproduces_reference_weights_and_keys():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """MD-style iterations on the 10,000-atom Cu cell with device-resident positions (torch_m3gnet.data.md.VerletGraph), for a kernel
-trace:   rocprofv3 --kernel-trace --stats -d gpurun_out/md -- python3 tools/profile_md_iteration.py [reuse|no_wait|refill|rebuild] [iterations] [precision]
+trace:   rocprofv3 --kernel-trace --stats -d gpurun_out/md -- python3 tools/profile_md_iteration.py [reuse|no_wait|refill|rebuild|step_reuse|step_refill|step_rebuild] [iterations] [precision]
 Prints the wall time per iteration as well."""
 import sys
 import time
@@ -35,6 +35,8 @@ def iteration():
     pos = pos0 + (torch.rand(pos0.shape, generator=gen, device=dev, dtype=torch.float64) - 0.5) * 0.05
     if mode == "no_wait":
         vg.evaluate(model, pos, forces=True, extras=False)
+    elif mode.startswith("step_"):   # one library call per step (VerletGraph.step -> m3g_md_step): step_reuse / step_refill / step_rebuild
+        vg.step(model, pos, force={"step_rebuild": "search", "step_refill": "refill"}.get(mode))
     else:
         model(vg.update(pos, force={"rebuild": "search", "refill": "refill"}.get(mode)), forces=True, extras=False)
 

@@ -42,5 +42,9 @@ for n in [int(a) for a in sys.argv[1:]] or [2, 3, 6]:
            "reuse, no wait (evaluate)": run(lambda: vg.evaluate(model, jitter(), forces=True, extras=False)),
            "reuse (update)": run(lambda: model(vg.update(jitter()), forces=True, extras=False)),
            "refill": run(lambda: model(vg.update(jitter(), force="refill"), forces=True, extras=False)),
-           "search": run(lambda: model(vg.update(jitter(), force="search"), forces=True, extras=False), reps=60, warm=10)}
+           "search": run(lambda: model(vg.update(jitter(), force="search"), forces=True, extras=False), reps=60, warm=10),
+           # the same through ONE library call per step (VerletGraph.step -> m3g_md_step)
+           "step(): reuse": run(lambda: vg.step(model, jitter())),
+           "step(): refill": run(lambda: vg.step(model, jitter(), force="refill")),
+           "step(): search": run(lambda: vg.step(model, jitter(), force="search"), reps=60, warm=10)}
     print(f"{p0.size(0):5d} atoms: " + "  ".join(f"{k} {v:.3f} ms" for k, v in res.items()), flush=True)

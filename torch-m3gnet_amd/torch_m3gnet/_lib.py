@@ -39,6 +39,26 @@ class M3GIO(C.Structure):
     ]
 
 
+class M3GMdLists(C.Structure):   # m3g_md_lists
+    _fields_ = [
+        ("n_atoms", C.c_int64), ("n_structs", C.c_int64), ("n_cand", C.c_int64), ("cap_edges", C.c_int64), ("cap_triplets", C.c_int64),
+        ("cutoff", C.c_double), ("threebody_cutoff", C.c_double), ("skin", C.c_double),
+        ("pos_ref", C.c_void_p), ("lattice", C.c_void_p), ("lattice32", C.c_void_p), ("batch", C.c_void_p), ("atom_types", C.c_void_p),
+        ("cand_edge_index", C.c_void_p), ("cand_shift", C.c_void_p), ("cand_row_ptr", C.c_void_p), ("cand_state", C.c_void_p),
+        ("verlet_scratch", C.c_void_p), ("verlet_scratch_bytes", C.c_size_t),
+        ("edge_index", C.c_void_p), ("edge_cell_shift", C.c_void_p), ("triplet_edge_index", C.c_void_p), ("num_triplet_i", C.c_void_p),
+        ("num_triplet_ij", C.c_void_p), ("pos32", C.c_void_p),
+        ("topo", C.c_void_p), ("topo_bytes", C.c_size_t), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class M3GMdResult(C.Structure):   # m3g_md_result
+    _fields_ = [("path", C.c_int32), ("topo_hints", C.c_int32), ("n_edges", C.c_int64), ("n_triplets", C.c_int64),
+                ("max_displacement", C.c_double)]
+
+
+MD_REUSE, MD_REFILL, MD_NEED_SEARCH, MD_UNSUPPORTED = range(4)
+
 # name -> (restype, argtypes); every symbol include/m3gnet_hip.h declares
 SYMBOLS = {
     "m3g_get_info": (C.c_int, [C.POINTER(M3GInfo)]),
@@ -109,6 +129,12 @@ SYMBOLS = {
                                      C.c_void_p]),
     "m3g_debug_read_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "m3g_debug_live_handles": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "m3g_md_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "m3g_md_destroy": (None, [C.c_void_p]),
+    "m3g_md_set_lists": (C.c_int, [C.c_void_p, C.POINTER(M3GMdLists)]),
+    "m3g_md_invalidate": (C.c_int, [C.c_void_p]),
+    "m3g_md_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(M3GMdResult),
+                              C.c_void_p]),
     "m3g_topology_data_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_topology_debug_last_path": (C.c_int, [C.POINTER(C.c_int32)]),
     "m3g_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),

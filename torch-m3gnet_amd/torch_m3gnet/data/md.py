@@ -56,6 +56,7 @@ class VerletGraph:
         self.lattice = torch.tensor(lat, device=self.device)                                    # fp64, as the search works
         self.batch = torch.tensor(np.repeat(np.arange(len(sizes)), sizes), dtype=torch.int64, device=self.device)
         self.atom_types = torch.tensor(z - 1, dtype=torch.long, device=self.device)
+        self._species_range = (int(z.min()) - 1, int(z.max()) - 1) if len(z) else (0, 0)
         self.lattice32 = self.lattice.to(torch.float)
         self.N, self.S = int(len(z)), len(sizes)
         self.graph = None
@@ -70,6 +71,11 @@ class VerletGraph:
         self._pending = None         # positions of a begin() whose verdict has not been read
         self._state_valid = False    # the candidates' membership bytes describe the current lists
         self._max_row = 0
+        self._md = None              # m3g_md handle of `step`
+        self._md_for = None          # the candidate set its buffers were made for
+        self._md_buffers = None
+        self._lists_owner = "py"     # which path wrote cand_state / the lists last: update / evaluate ("py") or step ("c")
+        self._cand_dist = None
         self._test_args = None
         self._graph_constants = {K.ATOM_TYPES: self.atom_types, K.LATTICE: self.lattice32, K.BATCH: self.batch, K.NUM_NODES: self.N,
                                  "num_graphs": self.S}
@@ -92,7 +98,8 @@ class VerletGraph:
 
     # ------------------------------------------------------------------------------------------------ candidates
     def _search(self, pos: torch.Tensor) -> None:
-        ei, shift, _ = neighbor_list_gpu(self.lattice, pos, self.batch, self.cutoff + self.skin, host_lattice=self._host_lattice)
+        ei, shift, dist = neighbor_list_gpu(self.lattice, pos, self.batch, self.cutoff + self.skin, host_lattice=self._host_lattice)
+        self._cand_dist = dist   # (for the triplet capacity of `step`)
         ec = int(ei.size(1))
         rows = torch.empty(self.N + 2, dtype=torch.int32, device=self.device)
         with _cuda.on_device(self.device):
@@ -106,8 +113,15 @@ class VerletGraph:
         self._state_valid = False
         self.stats["search"] += 1
 
+    def _own_lists(self) -> None:
+        """update / evaluate after `step` calls: the membership bytes describe the lists `step` keeps on the C side, not `self.graph`."""
+        if self._lists_owner != "py":
+            self._lists_owner = "py"
+            self.graph, self._pending, self._state_valid = None, None, False
+
     def _queue_test(self, pos: torch.Tensor) -> None:
         """The skin test at `pos`, queued on the current stream together with the copy of its verdict to pinned host memory."""
+        self._own_lists()
         a = self._test_args
         if a is None or a[0] is not self._cand:   # the arguments that change only with a new search, converted once
             ei, shift, rows, state, pos_ref, scratch = self._cand
@@ -248,3 +262,106 @@ class VerletGraph:
         if not self.confirm():
             out = model(self.graph, **kwargs)
         return out
+
+    # ------------------------------------------------------------------------------------------------ one call per step
+    def __del__(self):
+        try:
+            if getattr(self, "_md", None):
+                self.lib.m3g_md_destroy(self._md)
+                self._md = None
+        except Exception:
+            pass
+
+    def _md_prepare(self, engine) -> None:
+        """Buffers of the candidates' capacity for `step` (once per candidate search): list tensors, topology, workspace."""
+        ei, shift, rows, state, pos_ref, scratch = self._cand
+        dev, N, S = self.device, self.N, self.S
+        ec = int(ei.size(1))
+        # every configuration within skin / 2 of the reference positions has its three-body edges among the candidates within
+        # threebody_cutoff + skin: sum_i c_i (c_i - 1) bounds its triplets
+        near = self._cand_dist <= self.threebody_cutoff + self.skin
+        c = torch.bincount(ei[0][near], minlength=N)
+        cap_t = int((c * (c - 1)).sum())
+        nb_topo, nb_work = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.m3g_topology_bytes(N, ec, cap_t, S, C.byref(nb_topo)))
+        _lib.check(self.lib.m3g_workspace_bytes(engine.plan, N, ec, cap_t, S, C.byref(nb_work)))
+        b = {
+            "ei": torch.empty(2 * max(ec, 1), dtype=torch.int64, device=dev), "shift": torch.empty(3 * max(ec, 1), dtype=torch.int32, device=dev),
+            "tei": torch.empty(2 * max(cap_t, 1), dtype=torch.int64, device=dev), "nti": torch.empty(N, dtype=torch.int64, device=dev),
+            "ntij": torch.empty(max(ec, 1), dtype=torch.int32, device=dev), "pos32": torch.empty(N, 3, dtype=torch.float, device=dev),
+            "topo": torch.empty(nb_topo.value, dtype=torch.uint8, device=dev), "work": torch.empty(nb_work.value, dtype=torch.uint8, device=dev),
+            "cap_t": cap_t, "plan_key": (engine.precision, nb_work.value),
+        }
+        lists = _lib.M3GMdLists(
+            n_atoms=N, n_structs=S, n_cand=ec, cap_edges=ec, cap_triplets=cap_t, cutoff=self.cutoff, threebody_cutoff=self.threebody_cutoff,
+            skin=self.skin, pos_ref=pos_ref.data_ptr(), lattice=self.lattice.data_ptr(), lattice32=self.lattice32.data_ptr(),
+            batch=self.batch.data_ptr(), atom_types=self.atom_types.data_ptr(), cand_edge_index=ei.data_ptr(), cand_shift=shift.data_ptr(),
+            cand_row_ptr=rows.data_ptr(), cand_state=state.data_ptr(), verlet_scratch=scratch.data_ptr(), verlet_scratch_bytes=scratch.numel(),
+            edge_index=b["ei"].data_ptr(), edge_cell_shift=b["shift"].data_ptr(), triplet_edge_index=b["tei"].data_ptr(),
+            num_triplet_i=b["nti"].data_ptr(), num_triplet_ij=b["ntij"].data_ptr(), pos32=b["pos32"].data_ptr(), topo=b["topo"].data_ptr(),
+            topo_bytes=nb_topo.value, workspace=b["work"].data_ptr(), workspace_bytes=nb_work.value)
+        if self._md is None:
+            h = C.c_void_p()
+            _lib.check(self.lib.m3g_md_create(C.byref(h)))
+            self._md = h
+        _lib.check(self.lib.m3g_md_set_lists(self._md, C.byref(lists)))
+        self._md_buffers, self._md_for = b, self._cand
+        self._lists_owner = "c"
+
+    def step(self, model, pos: torch.Tensor, forces: bool = True, force: str | None = None) -> dict:
+        """Energies, forces and stresses at `pos` through ONE call of the library per step (m3g_md_step): the skin test, the lists and
+        topology when a pair crossed a cutoff, and the engine are sequenced on the C side, on buffers of the candidates' capacity
+        made once per search -- a refill allocates nothing and the interpreter runs once per step.  `model`: the `Gradient` built by
+        `build_model`.  Returns {total_energy [S], forces [N,3], stresses [S,6]} (new tensors per call), bit-identical to
+        `model(self.update(pos))`.  The current lists are `step_lists()`.  `force="refill"` / `"search"` as in `update`.
+        Mixing `step` with `update` / `evaluate` on one object is allowed (each re-derives the lists when the other wrote them last)."""
+        pos = self._check_pos(pos)
+        eng = model.engine
+        dev = self.device
+        lo, hi = self._species_range
+        if lo < 0 or hi >= eng.cfg.num_types:   # (the reference fails on elemental_energies[atom_types], nn/atom_ref.py:27)
+            raise IndexError(f"atom_types must lie in [0, {eng.cfg.num_types - 1}] (num_types = {eng.cfg.num_types}); got values in [{lo}, {hi}]")
+        sig = eng._signature(dev)
+        with _cuda.on_device(dev):
+            if sig != eng._sig:
+                eng.commit()
+                eng._sig = sig
+            self._pending = None
+            if self._cand is None or force == "search" or self.skin <= 0.0:
+                self._search(pos)
+            f32 = dict(dtype=torch.float, device=dev)
+            e = torch.empty(self.S, **f32)
+            f = torch.empty(self.N, 3, **f32) if forces else None
+            st = torch.empty(self.S, 6, **f32) if forces else None
+            res = _lib.M3GMdResult()
+            for attempt in range(3):
+                b = self._md_buffers
+                if self._md_for is not self._cand or b is None or b["plan_key"][0] != eng.precision:
+                    self._md_prepare(eng)
+                    b = self._md_buffers
+                elif self._lists_owner != "c":       # update / evaluate rewrote the membership bytes since
+                    _lib.check(self.lib.m3g_md_invalidate(self._md))
+                    self._lists_owner = "c"
+                _lib.check(self.lib.m3g_md_step(self._md, eng.plan, _ptr(pos), _ptr(e), _ptr(f), _ptr(st), 1 if force == "refill" else 0,
+                                                C.byref(res), _stream()))
+                if res.path == _lib.MD_NEED_SEARCH:
+                    self._search(pos)
+                    continue
+                break
+            if res.path == _lib.MD_UNSUPPORTED or res.path == _lib.MD_NEED_SEARCH:
+                # candidate rows beyond the two-launch refill, or lists beyond the capacity bound: the general path for this step
+                out = model(self.update(pos), forces=forces, extras=False)
+                return {k: out[k] for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES) if k in out}
+            self.stats["reuse" if res.path == _lib.MD_REUSE else "refill"] += 1
+            self._step_sizes = (int(res.n_edges), int(res.n_triplets))
+        out = {K.TOTAL_ENERGY: e}
+        if forces:
+            out[K.FORCES], out[K.STRESSES] = f, st
+        return out
+
+    def step_lists(self) -> dict:
+        """The lists `step` ran on last, as views of its capacity buffers (valid until the next `step`)."""
+        n_e, n_t = self._step_sizes
+        b = self._md_buffers
+        return {K.EDGE_INDEX: b["ei"][: 2 * n_e].view(2, n_e), K.EDGE_CELL_SHIFT: b["shift"][: 3 * n_e].view(n_e, 3),
+                K.TRIPLET_EDGE_INDEX: b["tei"][: 2 * n_t].view(2, n_t), K.NUM_TRIPLET_I: b["nti"], K.NUM_TRIPLET_IJ: b["ntij"][:n_e]}
