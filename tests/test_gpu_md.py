@@ -428,6 +428,17 @@ def test_step_through_the_c_side_trajectory_object_is_the_update_path_bit_for_bi
         got = a.step(model, p) if step % 2 else model(a.update(p), extras=False)
         for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
             assert torch.equal(got[key], want[key]), (step, key)
+    # buffers kept from an earlier search that turn out too small for the triplets of a new one: the library refuses the refill
+    # (nothing evaluated), `step` makes buffers of the exact capacity and calls again -- same results
+    a._md_buffers["cap_t"] = 8
+    a._md_buffers["tei"] = torch.empty(16, dtype=torch.int64, device=DEV)
+    pos = pos + rng.normal(0.0, 0.02, pos.shape)
+    p = torch.tensor(pos, device=DEV)
+    got = a.step(model, p, force="search")
+    want = model(b.update(p, force="search"), extras=False)
+    assert a._md_buffers["cap_t"] > 8
+    for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+        assert torch.equal(got[key], want[key]), key
     # a species outside the model's table fails as in the reference
     bad = VerletGraph([lats[0]], [np.full(3, 120)], 5.0, 4.0, skin=0.4, device=DEV)
     with pytest.raises(IndexError):

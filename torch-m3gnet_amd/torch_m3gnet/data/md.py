@@ -272,34 +272,45 @@ class VerletGraph:
         except Exception:
             pass
 
-    def _md_prepare(self, engine) -> None:
-        """Buffers of the candidates' capacity for `step` (once per candidate search): list tensors, topology, workspace."""
+    def _md_prepare(self, engine, exact: bool = False) -> None:
+        """Buffers of the candidates' capacity for `step`: list tensors, topology, workspace.  Made when there are none, when the
+        candidates outgrow them, or (`exact`) when m3g_md_step found the triplets beyond their capacity; a new search otherwise keeps
+        the buffers it has (their capacity is checked by the library at every refill) and costs no wait for the device here."""
         ei, shift, rows, state, pos_ref, scratch = self._cand
         dev, N, S = self.device, self.N, self.S
         ec = int(ei.size(1))
-        # every configuration within skin / 2 of the reference positions has its three-body edges among the candidates within
-        # threebody_cutoff + skin: sum_i c_i (c_i - 1) bounds its triplets
-        near = self._cand_dist <= self.threebody_cutoff + self.skin
-        c = torch.bincount(ei[0][near], minlength=N)
-        cap_t = int((c * (c - 1)).sum())
-        nb_topo, nb_work = C.c_size_t(), C.c_size_t()
-        _lib.check(self.lib.m3g_topology_bytes(N, ec, cap_t, S, C.byref(nb_topo)))
-        _lib.check(self.lib.m3g_workspace_bytes(engine.plan, N, ec, cap_t, S, C.byref(nb_work)))
-        b = {
-            "ei": torch.empty(2 * max(ec, 1), dtype=torch.int64, device=dev), "shift": torch.empty(3 * max(ec, 1), dtype=torch.int32, device=dev),
-            "tei": torch.empty(2 * max(cap_t, 1), dtype=torch.int64, device=dev), "nti": torch.empty(N, dtype=torch.int64, device=dev),
-            "ntij": torch.empty(max(ec, 1), dtype=torch.int32, device=dev), "pos32": torch.empty(N, 3, dtype=torch.float, device=dev),
-            "topo": torch.empty(nb_topo.value, dtype=torch.uint8, device=dev), "work": torch.empty(nb_work.value, dtype=torch.uint8, device=dev),
-            "cap_t": cap_t, "plan_key": (engine.precision, nb_work.value),
-        }
+        b = self._md_buffers
+        keep = b is not None and b["plan_key"][0] == engine.precision and ec <= b["cap_e"] and not exact
+        cap_t = b["cap_t"] if keep else 0
+        if not keep:
+            # every configuration within skin / 2 of the reference positions has its three-body edges among the candidates within
+            # threebody_cutoff + skin: sum_i c_i (c_i - 1) bounds its triplets
+            near = self._cand_dist <= self.threebody_cutoff + self.skin
+            c = torch.bincount(ei[0][near], minlength=N)
+            cap_t = int((c * (c - 1)).sum())
+        if not keep or cap_t > b["cap_t"]:
+            # new buffers, with some headroom so that the searches of a trajectory (whose candidate counts drift by a few per cent)
+            # keep them
+            cap_e, cap_t = max(int(ec * 1.1), 1), max(int(cap_t * 1.1), 1)
+            nb_topo, nb_work = C.c_size_t(), C.c_size_t()
+            _lib.check(self.lib.m3g_topology_bytes(N, cap_e, cap_t, S, C.byref(nb_topo)))
+            _lib.check(self.lib.m3g_workspace_bytes(engine.plan, N, cap_e, cap_t, S, C.byref(nb_work)))
+            b = {
+                "ei": torch.empty(2 * cap_e, dtype=torch.int64, device=dev), "shift": torch.empty(3 * cap_e, dtype=torch.int32, device=dev),
+                "tei": torch.empty(2 * cap_t, dtype=torch.int64, device=dev), "nti": torch.empty(N, dtype=torch.int64, device=dev),
+                "ntij": torch.empty(cap_e, dtype=torch.int32, device=dev), "pos32": torch.empty(N, 3, dtype=torch.float, device=dev),
+                "topo": torch.empty(nb_topo.value, dtype=torch.uint8, device=dev), "work": torch.empty(nb_work.value, dtype=torch.uint8, device=dev),
+                "cap_e": cap_e, "cap_t": cap_t, "plan_key": (engine.precision, nb_work.value),
+            }
+        cap_e, cap_t = b["cap_e"], b["cap_t"]
         lists = _lib.M3GMdLists(
-            n_atoms=N, n_structs=S, n_cand=ec, cap_edges=ec, cap_triplets=cap_t, cutoff=self.cutoff, threebody_cutoff=self.threebody_cutoff,
+            n_atoms=N, n_structs=S, n_cand=ec, cap_edges=cap_e, cap_triplets=cap_t, cutoff=self.cutoff, threebody_cutoff=self.threebody_cutoff,
             skin=self.skin, pos_ref=pos_ref.data_ptr(), lattice=self.lattice.data_ptr(), lattice32=self.lattice32.data_ptr(),
             batch=self.batch.data_ptr(), atom_types=self.atom_types.data_ptr(), cand_edge_index=ei.data_ptr(), cand_shift=shift.data_ptr(),
             cand_row_ptr=rows.data_ptr(), cand_state=state.data_ptr(), verlet_scratch=scratch.data_ptr(), verlet_scratch_bytes=scratch.numel(),
             edge_index=b["ei"].data_ptr(), edge_cell_shift=b["shift"].data_ptr(), triplet_edge_index=b["tei"].data_ptr(),
             num_triplet_i=b["nti"].data_ptr(), num_triplet_ij=b["ntij"].data_ptr(), pos32=b["pos32"].data_ptr(), topo=b["topo"].data_ptr(),
-            topo_bytes=nb_topo.value, workspace=b["work"].data_ptr(), workspace_bytes=nb_work.value)
+            topo_bytes=b["topo"].numel(), workspace=b["work"].data_ptr(), workspace_bytes=b["work"].numel())
         if self._md is None:
             h = C.c_void_p()
             _lib.check(self.lib.m3g_md_create(C.byref(h)))
@@ -334,7 +345,8 @@ class VerletGraph:
             f = torch.empty(self.N, 3, **f32) if forces else None
             st = torch.empty(self.S, 6, **f32) if forces else None
             res = _lib.M3GMdResult()
-            for attempt in range(3):
+            searched = exact_done = False
+            while True:
                 b = self._md_buffers
                 if self._md_for is not self._cand or b is None or b["plan_key"][0] != eng.precision:
                     self._md_prepare(eng)
@@ -344,8 +356,13 @@ class VerletGraph:
                     self._lists_owner = "c"
                 _lib.check(self.lib.m3g_md_step(self._md, eng.plan, _ptr(pos), _ptr(e), _ptr(f), _ptr(st), 1 if force == "refill" else 0,
                                                 C.byref(res), _stream()))
-                if res.path == _lib.MD_NEED_SEARCH:
+                if res.path == _lib.MD_NEED_SEARCH and not searched:
                     self._search(pos)
+                    searched = True
+                    continue
+                if res.path == _lib.MD_UNSUPPORTED and not exact_done:
+                    self._md_prepare(eng, exact=True)   # buffers kept from an earlier search may be too small for this one
+                    exact_done = True
                     continue
                 break
             if res.path == _lib.MD_UNSUPPORTED or res.path == _lib.MD_NEED_SEARCH:
