@@ -443,3 +443,23 @@ def test_step_through_the_c_side_trajectory_object_is_the_update_path_bit_for_bi
     bad = VerletGraph([lats[0]], [np.full(3, 120)], 5.0, 4.0, skin=0.4, device=DEV)
     with pytest.raises(IndexError):
         bad.step(model, torch.tensor(pos0[0][:3], device=DEV))
+
+
+@pytest.mark.parametrize("name,pos,z", [("isolated atom", [[1.0, 2.0, 3.0]], [29]),
+                                        ("pair beyond the three-body cutoff", [[1.0, 2.0, 3.0], [5.5, 2.0, 3.0]], [29, 8])])
+def test_step_on_cells_without_edges_or_without_triplets(name, pos, z):
+    """m3g_md_step on a cell with no edge at all, and on one with edges but no triplet (capacity 0 for the triplet buffers): the same
+    energies / forces / stresses as update + model, through the refill and the reuse path."""
+    from torch_m3gnet.data.md import VerletGraph
+
+    K = _K()
+    model = _model()
+    lat, pos, z = np.eye(3) * 20.0, np.asarray(pos), np.asarray(z)
+    a, b = (VerletGraph([lat], [z], 5.0, 4.0, skin=0.4, device=DEV) for _ in range(2))
+    for it in range(3):
+        p = torch.tensor(pos + 0.01 * it, device=DEV)
+        got = a.step(model, p)
+        want = model(b.update(p), extras=False)
+        for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+            assert torch.equal(got[key], want[key]), (name, it, key)
+    assert a.stats == b.stats and a.stats["reuse"] == 2
