@@ -439,6 +439,15 @@ def test_step_through_the_c_side_trajectory_object_is_the_update_path_bit_for_bi
     assert a._md_buffers["cap_t"] > 8
     for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
         assert torch.equal(got[key], want[key]), key
+    # a new cell (variable-cell relaxation): both objects search again in it
+    scale = 1.02
+    lats2 = [l * scale for l in lats]
+    a.set_lattice(lats2)
+    b.set_lattice(lats2)
+    p = torch.tensor(pos * scale, device=DEV)
+    got, want = a.step(model, p), model(b.update(p), extras=False)
+    for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+        assert torch.equal(got[key], want[key]), key
     # a species outside the model's table fails as in the reference
     bad = VerletGraph([lats[0]], [np.full(3, 120)], 5.0, 4.0, skin=0.4, device=DEV)
     with pytest.raises(IndexError):
