@@ -152,8 +152,10 @@ def test_verlet_graph_reuses_everything_on_the_headline_cell():
     assert vg.stats == {"reuse": 3, "refill": 1, "search": 1}, vg.stats
 
 
-def test_nve_trajectory_conserves_energy_across_list_updates():
-    """Physics-level check of the whole trajectory path: velocity-Verlet NVE dynamics of a 108-atom Cu cell on the LJ-FITTED weights
+@pytest.mark.parametrize("driver", ["evaluate", "step"])
+def test_nve_trajectory_conserves_energy_across_list_updates(driver):
+    """(`driver`: VerletGraph.evaluate -- the interpreter sequences skin test, refill, topology, engine -- or VerletGraph.step -- one
+    m3g_md_step call per step.)  Physics-level check of the whole trajectory path: velocity-Verlet NVE dynamics of a 108-atom Cu cell on the LJ-FITTED weights
     (trained by the reference's own code, tests/golden/model_fitted_lj.npz), positions resident on the device, lists maintained by
     VerletGraph.evaluate (no wait in front of the step).  Forces that were not the exact gradient of the energy, a stale or
     mis-ordered list after a refill, or a pair missed by the skin list would show as a drift of the total energy that does not
@@ -189,7 +191,7 @@ def test_nve_trajectory_conserves_energy_across_list_updates():
         vg = VerletGraph([lat], [np.full(108, 29)], rc, r3, skin=0.3, device=DEV)
 
         def energy_forces(p):
-            out = vg.evaluate(model, p, extras=False)
+            out = vg.evaluate(model, p, extras=False) if driver == "evaluate" else vg.step(model, p)
             return out[K.TOTAL_ENERGY].double().sum(), out[K.FORCES].double().clone()
 
         e_pot, f = energy_forces(pos)
@@ -201,7 +203,7 @@ def test_nve_trajectory_conserves_energy_across_list_updates():
             vel = vel + 0.5 * dt * acc_unit / mass * f
             totals.append(float(e_pot + 0.5 * mass / acc_unit * (vel * vel).sum()))
             pots.append(float(e_pot))
-            sizes.add((int(vg.graph[K.NUM_EDGES]), int(vg.graph[K.NUM_TRIPLETS])))
+            sizes.add((int(vg.graph[K.NUM_EDGES]), int(vg.graph[K.NUM_TRIPLETS])) if driver == "evaluate" else vg._step_sizes)
         totals, pots = np.array(totals), np.array(pots)
         return np.abs(totals - totals[0]).max(), pots.max() - pots.min(), sizes, vg.stats
 
