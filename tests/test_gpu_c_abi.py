@@ -71,3 +71,52 @@ def test_c_abi_host_without_torch(tmp_path, case, mode):
     assert rel_err(f, o["forces"]) < 1e-4
     if mode == "ref":   # the reference's own outputs (SURVEY finding 1: three-body term invisible in ref mode)
         assert rel_err(f, expect["out_forces"]) < 1e-4
+
+
+MD_BIN = ROOT / "torch-m3gnet_amd" / "lib" / "m3g_md_check"
+
+
+def test_c_abi_trajectory_loop_without_torch(tmp_path):
+    """tests/c_abi/m3g_md_check.cpp: candidate search, capacity buffers from hipMalloc and one m3g_md_step per frame, in a host that
+    knows nothing about torch -- against VerletGraph.update + model on the same frames: energies and forces bit-identical, the same
+    path (standing lists / re-derived lists / new search) on every frame."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.md import VerletGraph
+
+    if not MD_BIN.exists():
+        pytest.fail(f"{MD_BIN} missing: run `make -C torch-m3gnet_amd` (or __graft_entry__.build())")
+    case, mode, skin = "mix", "doc", 0.4
+    params, cfg, consts, graph, expect, (N, S) = _write_case(tmp_path / "case.bin", case, mode)
+    rng = np.random.default_rng(4)
+    pos = graph["pos"].double().numpy().copy()
+    lat = graph["lattice"].reshape(-1, 3, 3).double().numpy()
+    frames = []
+    for k in range(10):
+        pos = pos + rng.normal(0.0, 1e-9 if k % 4 == 2 else 0.02, pos.shape)
+        if k == 6:
+            pos[1] += lat[0][2]          # a lattice-vector jump: the skin test asks for a new search
+        frames.append(pos.copy())
+    with open(tmp_path / "case.bin", "ab") as fh:
+        fh.write(b"T" + struct.pack("<qd", len(frames), skin) + np.stack(frames).astype(np.float64).tobytes())
+    proc = subprocess.run([str(MD_BIN), str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    raw = (tmp_path / "out.bin").read_bytes()
+    rec = 4 + 4 * S + 4 * 3 * N
+    assert len(raw) == rec * len(frames)
+    model, _ = build_engine_model(case, mode)
+    sizes = np.bincount(graph["batch"].numpy(), minlength=S)
+    z = graph["atom_types"].numpy() + 1
+    vg = VerletGraph(list(lat), np.split(z, np.cumsum(sizes)[:-1]), cfg.cutoff, cfg.threebody_cutoff, skin=skin, device="cuda")
+    paths = {0: 0, 1: 0, 2: 0}
+    for k, p in enumerate(frames):
+        before = dict(vg.stats)
+        out = model(vg.update(torch.tensor(p, device="cuda")), extras=False)
+        want_path = 2 if vg.stats["search"] > before["search"] else (1 if vg.stats["refill"] > before["refill"] else 0)
+        blob = raw[k * rec:(k + 1) * rec]
+        path = struct.unpack("<i", blob[:4])[0]
+        e = torch.tensor(np.frombuffer(blob[4:4 + 4 * S], dtype=np.float32).copy())
+        f = torch.tensor(np.frombuffer(blob[4 + 4 * S:], dtype=np.float32).copy()).reshape(N, 3)
+        assert path == want_path, (k, path, want_path)
+        assert torch.equal(e, out[K.TOTAL_ENERGY].cpu()) and torch.equal(f, out[K.FORCES].cpu()), k
+        paths[path] += 1
+    assert all(v > 0 for v in paths.values()), paths

@@ -252,10 +252,11 @@ def test_torch_free_c_abi_host_is_built_and_links():
     import subprocess
     from pathlib import Path
 
-    binary = Path(__file__).resolve().parent.parent / "torch-m3gnet_amd" / "lib" / "m3g_c_abi_check"
-    assert binary.exists(), "run `make -C torch-m3gnet_amd` (or __graft_entry__.build())"
-    proc = subprocess.run([str(binary)], capture_output=True, text=True, timeout=60)
-    assert proc.returncode == 1 and "usage:" in proc.stderr
+    for name in ("m3g_c_abi_check", "m3g_md_check"):   # (the second: the trajectory loop over m3g_md_*, tests/c_abi/m3g_md_check.cpp)
+        binary = Path(__file__).resolve().parent.parent / "torch-m3gnet_amd" / "lib" / name
+        assert binary.exists(), "run `make -C torch-m3gnet_amd` (or __graft_entry__.build())"
+        proc = subprocess.run([str(binary)], capture_output=True, text=True, timeout=60)
+        assert proc.returncode == 1 and "usage:" in proc.stderr, name
 
 
 class _Lattice:
