@@ -103,8 +103,6 @@ FLOPS_RATIO_NOTE = ("flops_8d / flops_useful = 2: SURVEY.md 8(d) counts W1 [x_i 
 BYTES_8D_PER_STEP = lambda E, T, N: 4008 * E + 48 * T + 3504 * N   # noqa: E731  SURVEY.md 8(d), D = 64, B = 3
 PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16 MFMA peak (same rate as bf16)
 PMC_SQ_FILE = "r05_pmc_sq_counters.json"        # profiles/: per-kernel SQ counters (tools/pmc_sq_json.py), stamped like the traffic set
-# kernels one launch of a stage consists of (csrc/m3g_api.hip: m3g_energy_forces), for `launches_per_step`
-KERNELS_PER_STAGE = {"readout": 2, "geometry_rev_forces": 3}
 PMC_TRAFFIC_FILE = "r05_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py), stamped with
                                                 # the digest of the kernel sources it was collected on
 DEFAULT_PRECISION = "fp32"   # the reference's arithmetic (fp32 end to end): the headline `value` / `dtype` / `roofline`
@@ -169,14 +167,37 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def physical_cores():
+    """Physical cores among the CPUs this process may run on (distinct (package, core) pairs of /proc/cpuinfo inside the affinity
+    mask), clipped by the cgroup quota like host_cores()."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cpu, pkg = set(), None, 0
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            key, _, val = line.partition(":")
+            key = key.strip()
+            if key == "processor":
+                cpu = int(val)
+            elif key == "physical id":
+                pkg = int(val)
+            elif key == "core id" and cpu in allowed:
+                seen.add((pkg, int(val)))
+        if seen:
+            return max(1, min(len(seen), host_cores(cap=1 << 16)))
+    except Exception:
+        pass
+    return host_cores(cap=1 << 16)
+
+
 def cpu_baseline(cells=(10, 10, 25), steps=3):
-    """Oracle (port of the reference's CPU path) on the headline configuration itself: 1 warm-up + `steps` steps at all cores,
-    then 1 step at 1 thread (BASELINE.md "CPU-baseline plan")."""
+    """Oracle (port of the reference's CPU path) on the headline configuration itself, as BASELINE.md's "CPU-baseline plan" prescribes:
+    1 warm-up + `steps` steps at ALL physical host cores (`value`), then 1 step at 16 threads (the per-GPU host share of a box of this
+    pool: the figure of rounds 1-5, kept as `threads_16`) and 1 step at 1 thread."""
     from oracle import m3gnet_oracle as orc   # the checker, used here only as the thing timed (allowed: cpu_baseline leg)
     from torch_m3gnet.config import ModelConfig
     from torch_m3gnet.data.synthetic import fcc_cu_graph
 
-    cores = min(host_cores(), 16)  # the GPU box gives 16 cores per GPU
+    cores = physical_cores()
     torch.manual_seed(0)
     model = ModelConfig().build()
     params = {f"model.{k}": v.detach().clone() for k, v in model.model.state_dict().items()}
@@ -195,19 +216,27 @@ def cpu_baseline(cells=(10, 10, 25), steps=3):
             orc.energy_forces(params, cfg, consts, graph)
         return (time.perf_counter() - t0) / n_steps
 
-    log(f"cpu_baseline: {n} atoms, {cores} threads")
+    log(f"cpu_baseline: {n} atoms, {cores} threads (all physical cores this process may use)")
     dt = run(cores, steps, 1)
-    log(f"cpu_baseline: {dt * 1e3:.0f} ms/step; 1 thread")
-    dt1 = run(1, 1, 0)   # (code and allocator are warm from the runs above)
-    torch.set_num_threads(cores)
-    return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "ms_per_step": dt * 1e3,
-            "threads_1": {"value": n / dt1, "unit": "atom-steps/s", "cores": 1, "ms_per_step": dt1 * 1e3},
-            "threads_note": "deliberately capped at 16 threads = the host-core share a one-GPU box of this pool gives a job (BASELINE.md asks for all "
-                            "physical cores; the port is bandwidth-bound on [3,3,T] tensors: 16 threads are 1.8x one thread)",
-            "sample": f"the headline workload itself: {n}-atom fcc Cu supercell ({'x'.join(map(str, cells))} cells), fp32, {steps} timed "
-                      f"steps after 1 warm-up at {cores} threads -- a deliberate cap, the per-GPU host-core share of the box -- ({dt * 1e3:.0f} ms/step), then 1 timed step at 1 thread "
-                      f"({dt1 * 1e3:.0f} ms/step), torch {torch.__version__} CPU"}
+    log(f"cpu_baseline: {dt * 1e3:.0f} ms/step; 16 threads")
+    rec = {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "ms_per_step": dt * 1e3,
+           "host_logical_cpus": os.cpu_count(), "usable_logical_cpus": host_cores(cap=1 << 16),
+           "cores_note": "cores = physical cores inside this process's affinity mask / cgroup quota: everything the box lets one job use "
+                         "(a one-GPU box of this pool exposes 16 of its host's cores)"}
+    if cores > 16:
+        dt16 = run(16, 1, 0)   # (code and allocator are warm from the runs above)
+        rec["threads_16"] = {"value": n / dt16, "unit": "atom-steps/s", "cores": 16, "ms_per_step": dt16 * 1e3,
+                             "note": "the per-GPU host-core share of a one-GPU box of this pool (the figure rounds 1-5 reported as `value`)"}
+        log(f"cpu_baseline: {dt16 * 1e3:.0f} ms/step; 1 thread")
+    dt1 = run(1, 1, 0)
+    torch.set_num_threads(min(cores, 16))
+    rec["threads_1"] = {"value": n / dt1, "unit": "atom-steps/s", "cores": 1, "ms_per_step": dt1 * 1e3}
+    rec["threads_all"] = {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "ms_per_step": dt * 1e3}   # (= `value`; named for the record)
+    rec["sample"] = (f"the headline workload itself: {n}-atom fcc Cu supercell ({'x'.join(map(str, cells))} cells), fp32, {steps} timed steps after 1 warm-up at "
+                     f"{cores} threads = all physical cores of the host this process may use ({dt * 1e3:.0f} ms/step), then 1 timed step at 16 threads"
+                     f"{' (%.0f ms/step)' % rec['threads_16']['ms_per_step'] if 'threads_16' in rec else ''} and 1 at 1 thread ({dt1 * 1e3:.0f} ms/step), "
+                     f"torch {torch.__version__} CPU")
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------- self launch
@@ -561,6 +590,10 @@ def measure_beside(model, device):
     rec = {"step_ms_32_atom_cu_cell": per_call(lambda: model(small, forces=True, extras=False), 200, warm=20)}
     mid = fcc_cu_graph(6, 6, 6).to(device)
     rec["step_ms_864_atom_cu_cell"] = per_call(lambda: model(mid, forces=True, extras=False), 100, warm=10)
+    for cells in ((8, 8, 8), (10, 10, 10)):   # 2,048 / 4,000 atoms: the sizes between the small-system launches and the headline cell
+        gm = fcc_cu_graph(*cells).to(device)
+        rec[f"step_ms_{4 * cells[0] ** 3}_atom_cu_cell"] = per_call(lambda: model(gm, forces=True, extras=False), 50, warm=5)
+        del gm
     # MD-style iteration on the two small cells (VerletGraph.evaluate, reuse path: what an MD user of a small cell pays per step)
     for n_cells, key in ((2, "md_iteration_ms_32_atom_cell"), (6, "md_iteration_ms_864_atom_cell")):
         gi_s = np.stack(np.meshgrid(np.arange(n_cells), np.arange(n_cells), np.arange(n_cells), indexing="ij"), -1)
@@ -770,7 +803,9 @@ def main():
         ideal = BYTES_8D_PER_STEP(n_edges, n_trip, n_atoms)
         step_bytes = {"traffic": total, "algorithmic_bytes_8d": ideal, "traffic_over_algorithmic": (total / ideal) if total else None,
                       "source": traffic_source["file"] if total else None}
-        launches = sum(cnt * KERNELS_PER_STAGE.get(k, 1) for k, (ms, cnt) in per_launch.items() if ms * cnt > 0.006)   # (empty stages: two bare events, ~5 us)
+        # launches of ONE step as the timed region issues it: counted by the library from a stream capture of the un-profiled call
+        # (m3g_count_launches; the stage profiler above runs a slightly different sequence -- no fused tail launches)
+        launches = model.engine.count_launches(lambda: model(graph, forces=True, extras=False))
         return views[dom], [v for k, v in views.items() if k != dom], stage_ms, step_bytes, launches
 
     timing = series_and_clock(step, args.steps, sample_clock=rank == 0)
@@ -782,13 +817,14 @@ def main():
     if clk:   # the peaks of MI355X_MICROARCH.md are quoted at 2,400 MHz; the card holds less under this load
         roofline["frac_at_measured_clock"] = roofline["frac"] * 2400.0 / clk
     out.update(value=value, ms_per_step=ms_per_step, ms_per_step_min=timing["ms_per_step_min"], ms_per_step_median=timing["ms_per_step_median"],
-               clock_mhz=(timing.get("clock_mhz") or {}).get("median"), step_timing=timing, kernel_launches_per_step=launches, roofline=roofline, roofline_other_kernels=others, step_traffic_bytes=step_bytes,
+               clock_mhz=(timing.get("clock_mhz") or {}).get("median"), step_timing=timing, kernel_launches_per_step=launches[0],
+               other_stream_operations_per_step=launches[1], roofline=roofline, roofline_other_kernels=others, step_traffic_bytes=step_bytes,
                config={"workload": f"single {n_atoms}-atom fcc Cu PBC supercell per GPU ({'x'.join(map(str, args.cells))} cells, "
                                    "a=3.61 A, jitter 0.025 A), r_cut 5 A / 3-body 4 A, default M3GNet (l_max=n_max=3, D=64, "
                                    "3 blocks), energy+forces+stress",
                        "precision": args.precision, **({"engine_options": args.engine_option} if args.engine_option else {}),
                        "atoms_per_gpu": n_atoms, "edges_per_gpu": n_edges, "triplets_per_gpu": n_trip,
-                       "active_edges_per_gpu": n_active, "topology_hints": topo_hints, "first_call_s_incl_topology_build": first_call_s,
+                       "active_edges_per_gpu": n_active, "topology_hints": topo_hints, "kernel_launches_per_step": launches[0], "first_call_s_incl_topology_build": first_call_s,
                        "topology_build_ms": topo_ms, "stage_ms_per_step": stage_ms,
                        "multi_gpu": "replicas (a single cell does not shard; no collective inside the timed steps); config4_sharded below runs the sharded path",
                        **({"replica_energy_rel_spread": replica_spread} if replica_spread is not None else {})})
@@ -810,25 +846,34 @@ def main():
         if world == 1 and tuple(args.cells) == (10, 10, 25):
             out["beside"] = measure_beside(model, device)
             log(f"beside: {out['beside']}")
-        # the secondary figures as ONE flat dict of numbers under `config` (the driver's record keeps `config`; the full sub-records
-        # stay in the top-level keys above)
+        # the secondary figures as SCALAR keys directly under `config` (the driver's record keeps the scalar keys of `config` and drops
+        # nested objects; the full sub-records stay in the top-level keys above)
         bs = out.get("beside", {})
         md = bs.get("md_iteration_ms_10k_atom_cell", {}).get(args.precision, {})
-        out["config"]["secondary"] = {
-            **{f"{m}_ms_per_step": out[m]["ms_per_step"] for m in other_modes if m in out},
-            "config4_ms_per_step": out["config4_sharded"]["ms_per_step"],
-            **{k: bs[k] for k in ("step_ms_32_atom_cu_cell", "step_ms_864_atom_cu_cell", "md_iteration_ms_32_atom_cell",
-                                  "md_iteration_ms_864_atom_cell", "md_refill_iteration_ms_32_atom_cell", "md_refill_iteration_ms_864_atom_cell",
-                                  "md_step_refill_iteration_ms_32_atom_cell", "md_step_refill_iteration_ms_864_atom_cell",
-                                  "step_ms_config5_r3_4A", "step_ms_config5_r3_6A") if k in bs},
-            **({f"md_10k_{args.precision}_{k}_ms": md[k]["total"] for k in ("reuse", "refill", "rebuild", "step_reuse", "step_refill") if k in md}),
-            **({f"md_10k_{args.precision}_reuse_no_wait_ms": md["reuse_verdict_read_after_the_step"]["total"]}
-               if "reuse_verdict_read_after_the_step" in md else {}),
-        }
+        sec = {**{f"sec_{m}_ms": out[m]["ms_per_step"] for m in other_modes if m in out},
+               "sec_config4_ms": out["config4_sharded"]["ms_per_step"]}
+        for key, short in (("step_ms_32_atom_cu_cell", "sec_step_ms_32_atom"), ("step_ms_864_atom_cu_cell", "sec_step_ms_864_atom"),
+                           ("step_ms_2048_atom_cu_cell", "sec_step_ms_2048_atom"), ("step_ms_4000_atom_cu_cell", "sec_step_ms_4000_atom"),
+                           ("md_iteration_ms_32_atom_cell", "sec_md_ms_32_atom"), ("md_iteration_ms_864_atom_cell", "sec_md_ms_864_atom"),
+                           ("md_refill_iteration_ms_32_atom_cell", "sec_md_refill_ms_32_atom"),
+                           ("md_refill_iteration_ms_864_atom_cell", "sec_md_refill_ms_864_atom"),
+                           ("md_step_refill_iteration_ms_32_atom_cell", "sec_md_step_refill_ms_32_atom"),
+                           ("md_step_refill_iteration_ms_864_atom_cell", "sec_md_step_refill_ms_864_atom"),
+                           ("step_ms_config5_r3_4A", "sec_config5_ms"), ("step_ms_config5_r3_6A", "sec_config5_r3_6A_ms")):
+            if key in bs:
+                sec[short] = bs[key]
+        for k, short in (("reuse", "sec_md_10k_reuse_ms"), ("refill", "sec_md_10k_refill_ms"), ("rebuild", "sec_md_10k_search_ms"),
+                         ("step_reuse", "sec_md_10k_step_reuse_ms"), ("step_refill", "sec_md_10k_step_refill_ms"),
+                         ("reuse_verdict_read_after_the_step", "sec_md_10k_reuse_no_wait_ms")):
+            if k in md:
+                sec[short] = md[k]["total"]
+        out["config"].update({k: round(float(v), 4) for k, v in sec.items()})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tuple(args.cells))
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]   # (vs_baseline stays null: nothing published)
+            out["config"]["sec_cpu_all_cores_ms"] = round(out["cpu_baseline"]["ms_per_step"], 1)
+            out["config"]["sec_cpu_cores"] = out["cpu_baseline"]["cores"]
         print(json.dumps(out), flush=True)
     job.close()
 

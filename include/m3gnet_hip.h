@@ -192,7 +192,12 @@ int m3g_topology_debug_last_path(int32_t* path);
  * a caller that passes hints words around must poll this entry point -- once per topology is enough, the bits are sticky (the
  * Python engine does so at the second call with a topology).  Synchronises the stream. */
 #define M3G_TOPO_ERR_HINTS 1
-#define M3G_TOPO_ERR_SYNC 2    /* an in-launch wait between workgroup roles ran into its bound (never expected; results INVALID) */
+#define M3G_TOPO_ERR_SYNC 2    /* an in-launch wait between workgroup roles ran into its bound (never expected; the rows that were waited for
+                                * are replaced by NaN, so the call's forces are NaN as well) */
+#define M3G_TOPO_ERR_SPECIES 4 /* an atom_types entry outside [0, num_types): the reference raises there (IndexError at
+                                * elemental_energies[atom_types], nn/atom_ref.py:27).  The hot call cannot return it without a wait, so it
+                                * never indexes with such a value (clamped), stores NaN as that atom's energy -- its structure's energy is
+                                * then NaN -- and sets this bit.  m3g_md_step checks the species itself and returns M3G_ERR_VALUE. */
 int m3g_topology_status(int64_t n_atoms, int64_t n_edges, int64_t n_triplets, int64_t n_structs, const void* topo,
                         int32_t* host_status, void* stream);
 
@@ -436,10 +441,17 @@ int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
  * event pool).  They are bound to the plan's device: a commit that moves the plan to another device releases all of them. */
 int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out);
 
-#define M3G_ABI_VERSION 5   /* 2: m3g_io.topo_hints, m3g_topology_hints; 3: m3g_verlet_*, m3g_topology_status, hints word certified on the buffer,
+/* Measurement: what ONE m3g_energy_forces call with these arguments puts on a stream -- kernel launches and other operations (memsets,
+ * copies) -- counted by capturing the call's own launch sequence into a HIP graph on an internal stream (nothing executes, no buffer
+ * is touched) and counting the graph's nodes.  The sequence counted is the un-profiled one (the stage profiler changes it). */
+int m3g_count_launches(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes, int32_t* kernel_launches,
+                       int32_t* other_operations);
+
+#define M3G_ABI_VERSION 6   /* 2: m3g_io.topo_hints, m3g_topology_hints; 3: m3g_verlet_*, m3g_topology_status, hints word certified on the buffer,
                              * canonical edge order by the shift relative to the given coordinates, default precision fp32;
                              * 4: m3g_verlet_fill_lists, m3g_topology_build_canonical, M3G_TOPO_ERR_SYNC, options small_tiles / small_launches / fuse_node_tb;
-                             * 5: m3g_topology_build_canonical_begin / _end, m3g_topology_data_bytes, option legendre_backward, m3g_md_* */
+                             * 5: m3g_topology_build_canonical_begin / _end, m3g_topology_data_bytes, option legendre_backward, m3g_md_*;
+                             * 6: M3G_TOPO_ERR_SPECIES (species checked on the library side, m3g_md_step returns M3G_ERR_VALUE), m3g_count_launches */
 
 #ifdef __cplusplus
 }

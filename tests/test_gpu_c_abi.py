@@ -49,6 +49,8 @@ def _write_case(path, case, mode):
     g += graph["edge_index"].long().contiguous().numpy().tobytes() + graph["edge_cell_shift"].to(torch.int32).contiguous().numpy().tobytes()
     g += graph["triplet_edge_index"].long().contiguous().numpy().tobytes() + graph["lattice"].float().contiguous().numpy().tobytes()
     g += graph["batch"].long().numpy().tobytes()
+    global _G_OFFSET
+    _G_OFFSET = sum(map(len, blob))   # where the 'G' record starts (_corrupt_species)
     blob.append(g)
     path.write_bytes(b"".join(blob))
     return params, cfg, consts, graph, expect, (N, S)
@@ -120,3 +122,40 @@ def test_c_abi_trajectory_loop_without_torch(tmp_path):
         assert torch.equal(e, out[K.TOTAL_ENERGY].cpu()) and torch.equal(f, out[K.FORCES].cpu()), k
         paths[path] += 1
     assert all(v > 0 for v in paths.values()), paths
+
+
+def _corrupt_species(path, N, value):
+    """Overwrite atom_types[1] of the 'G' record of a case file (layout: _write_case)."""
+    raw = bytearray(path.read_bytes())
+    g = _G_OFFSET
+    assert raw[g:g + 9] == b"G" + struct.pack("<q", N)   # tag + n_atoms
+    off = g + 1 + 32 + 4 * 3 * N + 8 * 1
+    raw[off:off + 8] = struct.pack("<q", value)
+    path.write_bytes(bytes(raw))
+
+
+@pytest.mark.parametrize("bad", [95, -1, 1 << 40])
+def test_c_abi_out_of_range_species_is_loud_not_out_of_bounds(tmp_path, bad):
+    """A C caller has no Python host in front of it: an atom_types entry outside [0, num_types) -- where the reference raises
+    IndexError (nn/atom_ref.py:25-29) -- must neither index a table out of bounds nor give plausible numbers.  m3g_energy_forces
+    (no wait inside) stores NaN as that atom's energy and sets the sticky M3G_TOPO_ERR_SPECIES bit."""
+    params, cfg, consts, graph, expect, (N, S) = _write_case(tmp_path / "case.bin", "cu32", "doc")
+    _corrupt_species(tmp_path / "case.bin", N, bad)
+    proc = subprocess.run([str(BIN), str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    status = int(proc.stdout.split("topology status")[1].split()[0])
+    assert status & 4, proc.stdout           # M3G_TOPO_ERR_SPECIES
+    out = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    assert np.isnan(out[:S]).all()
+
+
+def test_c_abi_trajectory_step_refuses_out_of_range_species(tmp_path):
+    """m3g_md_step waits for the skin test's verdict anyway: it checks the species behind that wait and returns M3G_ERR_VALUE."""
+    params, cfg, consts, graph, expect, (N, S) = _write_case(tmp_path / "case.bin", "cu32", "doc")
+    _corrupt_species(tmp_path / "case.bin", N, 95)
+    pos = graph["pos"].double().numpy()
+    with open(tmp_path / "case.bin", "ab") as fh:
+        fh.write(b"T" + struct.pack("<qd", 1, 0.4) + pos.astype(np.float64).tobytes())
+    proc = subprocess.run([str(MD_BIN), str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert proc.returncode != 0
+    assert "atom_types must lie in [0, 94]" in proc.stdout + proc.stderr, proc.stdout + proc.stderr

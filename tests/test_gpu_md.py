@@ -474,3 +474,40 @@ def test_step_on_cells_without_edges_or_without_triplets(name, pos, z):
         for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
             assert torch.equal(got[key], want[key]), (name, it, key)
     assert a.stats == b.stats and a.stats["reuse"] == 2
+
+
+def test_evaluate_after_step_after_speculative_evaluates_on_one_object():
+    """evaluate() past `speculate_after` (so the next evaluate takes begin()'s queued-ahead path), then step() (which takes the
+    lists over to the C side and drops `self.graph`), then evaluate() again on the SAME object: the speculative path must fall back
+    to update() instead of writing into a graph that is gone (advisor finding, round 5).  Results equal a second object driven
+    through update() alone, bit for bit."""
+    from torch_m3gnet.data.md import VerletGraph
+
+    K = _K()
+    model = _model()
+    lat, p0, z = random_cell_arrays(24, 7.0, seed=77)
+    a, b = (VerletGraph([lat], [z], 5.0, 4.0, skin=0.6, device=DEV) for _ in range(2))
+    pos = p0.copy()
+    rng = np.random.default_rng(5)
+
+    def both(kind):
+        p = torch.tensor(pos, device=DEV)
+        want = model(b.update(p), extras=False)
+        got = a.step(model, p) if kind == "step" else a.evaluate(model, p, extras=False)
+        for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+            assert torch.equal(got[key], want[key]), (kind, key)
+
+    for _ in range(a.speculate_after + 2):        # frozen cell: every verdict is "unchanged"
+        pos = pos + rng.normal(0.0, 1e-10, pos.shape)
+        both("evaluate")
+    assert a._reuse_streak >= a.speculate_after
+    both("step")
+    pos = pos + rng.normal(0.0, 1e-10, pos.shape)
+    both("evaluate")                              # crashed with TypeError before the fix
+    assert a._reuse_streak < a.speculate_after    # the streak counts verdicts about the current lists only
+    for _ in range(a.speculate_after + 2):
+        pos = pos + rng.normal(0.0, 1e-10, pos.shape)
+        both("evaluate")
+    both("step")
+    pos = pos + rng.normal(0.0, 0.05, pos.shape)  # and one with the lists changed
+    both("evaluate")

@@ -779,3 +779,33 @@ def test_pair_virial_is_invariant_under_lattice_translation_of_an_atom():
         outs.append((pv(g)["stresses"].cpu(), model.cuda()(g)["stresses"].cpu()))
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-6 * float(outs[0][0].abs().max()) + 1e-9)
     assert float((outs[0][1] - outs[1][1]).abs().max()) > 10 * float((outs[0][0] - outs[1][0]).abs().max())
+
+
+@pytest.mark.parametrize("edge_kernel,split_node_tiles", [(1, 128), (1, 0), (0, 128), (2, 128)])
+def test_out_of_range_species_past_the_host_check_give_nan_and_a_sticky_bit(edge_kernel, split_node_tiles):
+    """The library side of the species check (a C caller has no Python host in front of it; reference: IndexError at
+    elemental_energies[atom_types], nn/atom_ref.py:25-29): with the host's own check switched off, every engine -- split / persistent
+    MFMA kernels, vector-ALU baseline, any-size path -- leaves NaN as the offending structure's energy and the sticky
+    M3G_TOPO_ERR_SPECIES bit on the topology, never indexing a table with the value (memory-safe by construction: clamped)."""
+    from torch_m3gnet.data.material_graph import Batch
+    from torch_m3gnet.nn.modules import _Topology
+
+    K = _K()
+    model = _default_model()
+    model.engine.set_option("edge_kernel", edge_kernel)
+    model.engine.set_option("split_node_tiles", split_node_tiles)
+    model.engine._check_species = lambda graph, probe: None
+    cells = [random_cell_graph(12, 6.0, s) for s in range(3)]
+    g = Batch.from_data_list(cells).to(DEV)
+    good = model(g.clone())[K.TOTAL_ENERGY].clone()
+    assert torch.isfinite(good).all()
+    for bad in (95, -3, 1 << 40):
+        h = g.clone()
+        types = h[K.ATOM_TYPES].clone()
+        types[14] = bad              # an atom of the second structure
+        h[K.ATOM_TYPES] = types
+        out = model(h)
+        e = out[K.TOTAL_ENERGY]
+        # (the other structures are untouched; the vector-ALU baseline path adds its per-centre sums with float atomics: not bitwise)
+        assert torch.isnan(e[1]) and torch.allclose(e[[0, 2]], good[[0, 2]], rtol=1e-5, atol=0), (bad, e, good)
+        assert _Topology.of(out).status() & 4

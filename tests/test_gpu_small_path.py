@@ -184,3 +184,136 @@ def test_dp1_rows_in_list_order_are_bit_identical():
                 outs.append({k: g[k].clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES)})
             for k, v in outs[0].items():
                 assert torch.equal(v, outs[1][k]), (c, m, small_tiles, k)
+
+
+# ------------------------------------------------------------------ the size regimes of the kernel selection (round 6)
+# Between the fixtures (<= 128 atoms) and BASELINE configs 2 / 3 the step changes kernels by size (plan options small_tiles /
+# small_tiles_fwd, split_node_tiles; kFusedSumsMaxAtoms, kNodeTbFusedMaxAtoms in csrc/m3g_internal.h).  These cells sit in every
+# regime between the switches.  Reference behaviour held: nn/gradient.py:25-64, tests/test_model.py:59-78.
+REGIME_CELLS = [(5, 5, 5),    # 500 atoms, 1,313 tiles: both edge kernels split, >= 3 tiles per workgroup pass
+                (6, 6, 6),    # 864 atoms, 2,268 tiles: split forward + persistent reverse by default
+                (7, 7, 7)]    # 1,372 atoms, 3,602 tiles: both persistent, fused per-structure sums off
+
+
+def _fitted_model():
+    """The default architecture with the LJ-fitted weights (|F| ~ 1 eV/A: activations away from their linear range), `doc` factors."""
+    model, _ = build_engine_model("cu32fit", "doc")
+    return model
+
+
+def _regime_outputs(model, g0, **options):
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    for name, value in options.items():
+        model.engine.set_option(name, value)
+    g = model(g0.clone())
+    torch.cuda.synchronize()
+    return {k: g[k].clone() for k in (K.TOTAL_ENERGY, K.SCALED_ATOMIC_ENERGIES, K.NODE_FEATURES, K.EDGE_ATTR, K.MID_EDGE_FEATURES,
+                                      K.FORCES, K.STRESSES)}
+
+
+@pytest.mark.parametrize("cells", REGIME_CELLS)
+def test_small_path_equals_large_path_in_every_size_regime(cells):
+    """500 / 864 / 1,372-atom Cu cells with the split-tile kernels forced on (small_tiles = 2^20), forced off (0) and on the
+    DEFAULT selection: forward outputs bit-identical across all three, forces and stresses within 1e-5 of their largest component."""
+    from helpers import fcc_cu_graph
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    g0 = fcc_cu_graph(*cells).to("cuda")
+    forced = _regime_outputs(_fitted_model(), g0, small_tiles=1 << 20)
+    large = _regime_outputs(_fitted_model(), g0, small_tiles=0)
+    default = _regime_outputs(_fitted_model(), g0)
+    for name, other in (("split", forced), ("default", default)):
+        for k in (K.TOTAL_ENERGY, K.SCALED_ATOMIC_ENERGIES, K.NODE_FEATURES, K.EDGE_ATTR, K.MID_EDGE_FEATURES):
+            assert torch.equal(other[k], large[k]), (cells, name, k)
+        assert rel_err(other[K.FORCES], large[K.FORCES]) < 1e-5, (cells, name)
+        assert rel_err(other[K.STRESSES], large[K.STRESSES]) < 1e-5, (cells, name)
+    # the mixed regime itself, whatever the defaults are: split forward + persistent reverse, and the other way round
+    mixed = _regime_outputs(_fitted_model(), g0, small_tiles=0, small_tiles_fwd=1 << 20)
+    assert torch.equal(mixed[K.EDGE_ATTR], large[K.EDGE_ATTR]) and torch.equal(mixed[K.TOTAL_ENERGY], large[K.TOTAL_ENERGY])
+    assert torch.equal(mixed[K.FORCES], large[K.FORCES])   # same reverse kernels on bit-identical saved activations
+    mixed2 = _regime_outputs(_fitted_model(), g0, small_tiles=1 << 20, small_tiles_fwd=0)
+    assert torch.equal(mixed2[K.EDGE_ATTR], large[K.EDGE_ATTR])
+    assert torch.equal(mixed2[K.FORCES], forced[K.FORCES])
+
+
+def _vs_fp64_oracle(model, out, e_tol=1e-5, f_tol=1e-4, m_tol=1e-4):
+    """Engine outputs against the fp64 evaluation of the oracle (exact derivative) on the same inputs and captured constants."""
+    import dataclasses
+
+    from oracle import m3gnet_oracle as orc
+    from test_gpu_properties import _oracle_inputs
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    torch.set_num_threads(8)
+    p, cfg, c, og = _oracle_inputs(model, out)
+    p64 = {k: v.double() for k, v in p.items()}
+    c64 = dataclasses.replace(c, **{f.name: getattr(c, f.name).double() for f in dataclasses.fields(c)})
+    o = orc.energy_forces(p64, cfg, c64, og, legendre_backward="exact")
+    e_err = float(((out[K.TOTAL_ENERGY].double().cpu() - o["total_energy"]).abs() / o["total_energy"].abs()).max())
+    f_err = rel_err(out[K.FORCES], o["forces"])
+    m_err = max(rel_err(out[K.MID_EDGE_FEATURES][b], o[f"mid_edge_features_{b}"]) for b in range(cfg.num_blocks))
+    assert e_err < e_tol and f_err < f_tol and m_err < m_tol, (e_err, f_err, m_err)
+    return e_err, f_err, m_err
+
+
+def test_mid_size_cell_on_the_default_selection_vs_oracle():
+    """The 864-atom Cu cell (the size every mid-size figure is quoted on) with the LJ-fitted weights in `doc` mode on the DEFAULT
+    kernel selection against the CPU oracle: E 1e-5, F 1e-4 of max|F|, mid_edge_features 1e-4 in every block."""
+    from helpers import fcc_cu_graph
+
+    model = _fitted_model()
+    out = model(fcc_cu_graph(6, 6, 6).to("cuda"))
+    margins = _vs_fp64_oracle(model, out)
+    import os
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/mid_size_margins.txt", "a") as fh:
+            fh.write("864-atom cell, default selection vs oracle: E %.2e  F %.2e  mid_edge_features %.2e\n" % margins)
+
+
+def test_many_small_structures_beyond_the_fused_launches_limit_vs_oracle():
+    """One batch of 12 x 64-atom random-species cells (more structures than the fused launches walk, kForceTailMaxStructs = 8:
+    the stand-alone sum kernels run) against the oracle, and batched == per-structure energies (reference tests/test_model.py:59-78)."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.data.material_graph import Batch
+    from torch_m3gnet.model.build import build_model
+
+    torch.manual_seed(3)
+    model = build_model(cutoff=5.0, threebody_cutoff=4.0, l_max=3, n_max=3, num_types=95, embedding_dim=64, num_blocks=3)
+    for m in model.model:
+        if type(m).__name__ == "ThreeBodyInteration":
+            m.nsb.factors = m.nsb.documented_factors()
+    cells = [random_cell_graph(64, 9.1, s) for s in range(12)]
+    out = model(Batch.from_data_list(cells).to("cuda"))
+    assert out[K.TOTAL_ENERGY].numel() == 12
+    _vs_fp64_oracle(model, out)
+    e_all = out[K.TOTAL_ENERGY].clone()
+    for s in (0, 7, 11):
+        one = model(Batch.from_data_list([cells[s]]).to("cuda"))
+        torch.testing.assert_close(one[K.TOTAL_ENERGY], e_all[s:s + 1], rtol=1e-6, atol=1e-6)
+
+
+def test_in_launch_wait_that_runs_out_poisons_the_forces():
+    """k_node_tb_reverse (cells of at most 128 atoms): the node role waits inside the launch for the three-body role's rows.  The
+    launcher takes that form only when the runtime says every workgroup of the launch is resident at once; the wait is bounded all
+    the same, and when it runs out (forced here: option debug_node_tb_polls < 0 makes the node role wait for an increment that never
+    comes) the call must not hand out numbers computed from rows that were never published: forces NaN, sticky M3G_TOPO_ERR_SYNC."""
+    from torch_m3gnet.data import MaterialGraphKey as K
+    from torch_m3gnet.nn.modules import _Topology
+
+    model, _ = build_engine_model("cu32fit", "doc")
+    _, _, _, graph, _ = load_oracle_case("cu32fit", "doc")
+    good = model(engine_graph(graph))
+    f_good = good[K.FORCES].clone()
+    assert torch.isfinite(f_good).all() and _Topology.of(good).status() == 0
+    model.engine.set_option("debug_node_tb_polls", -64)
+    bad = model(engine_graph(graph))
+    assert torch.isnan(bad[K.FORCES]).any()
+    assert torch.equal(bad[K.TOTAL_ENERGY], good[K.TOTAL_ENERGY])   # (the forward pass is untouched)
+    assert _Topology.of(bad).status() & 2
+    model.engine.set_option("debug_node_tb_polls", 0)
+    again = model(engine_graph(graph))
+    assert torch.equal(again[K.FORCES], f_good) and _Topology.of(again).status() == 0
+    # a generous bound on the real wait changes nothing
+    model.engine.set_option("debug_node_tb_polls", 1 << 20)
+    assert torch.equal(model(engine_graph(graph))[K.FORCES], f_good)

@@ -395,6 +395,11 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     drop_graphs(plan);
     return M3G_OK;
   }
+  if (strcmp(name, "debug_node_tb_polls") == 0) {   // test hook: bound (k > 0) or force (k < 0) the time-out of k_node_tb_reverse's in-launch wait
+    plan->debug_node_tb_polls = value;
+    drop_graphs(plan);
+    return M3G_OK;
+  }
   if (strcmp(name, "small_launches") == 0) {   // 0: never fuse the small-system launches (A/B tests; results are bit-identical either way)
     plan->small_launches = value != 0;
     drop_graphs(plan);
@@ -639,6 +644,45 @@ static int energy_forces_graph(const m3g_plan* plan, const m3g_io* io, void* wor
   return join();
 }
 
+// m3g_count_launches: the call's launch sequence captured (not executed) on a stream of its own, nodes counted by type
+extern "C" int m3g_count_launches(const m3g_plan* plan, const m3g_io* io, void* workspace, size_t workspace_bytes, int32_t* kernel_launches,
+                                  int32_t* other_operations) {
+  if (!plan || !io || !kernel_launches) { set_error("m3g_count_launches: null argument"); return M3G_ERR_VALUE; }
+  if (plan->capturing) { set_error("m3g_count_launches: a capture is in progress"); return M3G_ERR_STATE; }
+  hipStream_t s = nullptr;
+  M3G_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { (void)hipStreamDestroy(s); set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e)); return M3G_ERR_HIP; }
+  const bool profile = plan->profile;
+  plan->capturing = true;
+  plan->profile = false;
+  const int rc = m3g_energy_forces(plan, io, workspace, workspace_bytes, (void*)s);
+  plan->capturing = false;
+  plan->profile = profile;
+  e = hipStreamEndCapture(s, &graph);
+  (void)hipStreamDestroy(s);
+  if (rc != M3G_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess || !graph) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return M3G_ERR_HIP; }
+  size_t n = 0;
+  e = hipGraphGetNodes(graph, nullptr, &n);
+  std::vector<hipGraphNode_t> nodes(n);
+  if (e == hipSuccess && n) e = hipGraphGetNodes(graph, nodes.data(), &n);
+  int kernels = 0, other = 0;
+  for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+    hipGraphNodeType ty;
+    e = hipGraphNodeGetType(nodes[i], &ty);
+    if (e != hipSuccess) break;
+    if (ty == hipGraphNodeTypeKernel) ++kernels;
+    else if (ty != hipGraphNodeTypeEmpty) ++other;
+  }
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { set_error("m3g_count_launches: reading the captured graph failed: %s", hipGetErrorString(e)); return M3G_ERR_HIP; }
+  *kernel_launches = kernels;
+  if (other_operations) *other_operations = other;
+  return M3G_OK;
+}
+
 // what the reverse edge kernels of this plan hand to k_node_reverse: the fused kernels write 24-bit rows (floating in the bf16x3 mode,
 // fixed point + scales in the f16x3 mode), everything else fp32 rows
 static int dp1_format(const m3g_plan* plan) {
@@ -787,7 +831,7 @@ extern "C" int m3g_energy_forces(const m3g_plan* plan, const m3g_io* io, void* w
         launch_node_reverse_v_term(c, W, wl.blk[b], t, w, w.v[b], dx_alt, s);
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
       } else if (b > 0 && fused_rev && plan->fuse_node_tb && !plan->profile &&
-                 launch_node_tb_reverse(c, W, wl.blk[b], t, w, w.v[b], /*first=*/b == c.B - 1, dx_cur, dx_alt, dp1_format(plan), b, s, tb_hints)) {
+                 launch_node_tb_reverse(c, W, wl.blk[b], t, w, w.v[b], /*first=*/b == c.B - 1, dx_cur, dx_alt, dp1_format(plan), b, s, tb_hints, plan->debug_node_tb_polls)) {
         // (moment path) three-body reverse and node reverse of the block as two workgroup roles of ONE launch
         float* tmp = dx_cur; dx_cur = dx_alt; dx_alt = tmp;
       } else if (b == 0 && mfma && fused_rev && plan->small_launches && !plan->profile &&

@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(256) g_embed_x(int64_t N, int D, int num_types
   GEN_IDX(N * D);
   const int64_t a = gid / D;
   const int o = (int)(gid % D);
-  x[gid] = W[(int64_t)o * num_types + types[a]];   // one_hot(types) @ W^T, W [D, num_types] (nn/featurizer.py:33-38)
+  bool bad;   // (an out-of-range species is clamped here and reported by g_atomic_energy)
+  x[gid] = W[(int64_t)o * num_types + species_index(types[a], num_types, bad)];   // one_hot(types) @ W^T, W [D, num_types] (nn/featurizer.py:33-38)
 }
 
 // what the reference's LegendreCosPolynomial.backward returns per unit of its grad_output `go` (nn/interaction.py:373-382):
@@ -396,9 +397,12 @@ __global__ void __launch_bounds__(256) g_geometry_rev(int64_t E, int R, const fl
 
 __global__ void __launch_bounds__(256) g_atomic_energy(int64_t N, int num_types, float energy_scale, const int64_t* __restrict__ types,
                                                        const float* __restrict__ elemental, const float* __restrict__ od, const float* __restrict__ og,
-                                                       float* __restrict__ ea) {
+                                                       float* __restrict__ ea, const int32_t* topo_flags) {
   GEN_IDX(N);
-  ea[gid] = elemental[types[gid]] / energy_scale + od[gid] * sigmoid_f(og[gid]);
+  bool bad;   // the reference raises here (nn/atom_ref.py:27): NaN energy + sticky M3G_TOPO_ERR_SPECIES
+  const int64_t ty = species_index(types[gid], num_types, bad);
+  ea[gid] = bad ? __builtin_nanf("") : elemental[ty] / energy_scale + od[gid] * sigmoid_f(og[gid]);
+  if (bad) flag_bad_species(topo_flags);
 }
 __global__ void __launch_bounds__(256) g_readout_seed(int64_t N, float energy_scale, const float* __restrict__ od, const float* __restrict__ og,
                                                       float* __restrict__ d_od, float* __restrict__ d_og) {
@@ -648,7 +652,7 @@ int generic_energy_forces(const m3g_plan* plan, const m3g_io* io, void* workspac
   map(s, N * D, OP_SILU, w.rp2g, w.rh1);
   linear(s, N, 1, D, w.rh0, D, W.rw[0][2], W.rb[0][2], w.rod, 1);
   linear(s, N, 1, D, w.rh1, D, W.rw[1][2], W.rb[1][2], w.rog, 1);
-  if (N > 0) hipLaunchKernelGGL(g_atomic_energy, grid1(N), dim3(256), 0, s, N, c.num_types, c.energy_scale, io->atom_types, W.elemental, w.rod, w.rog, ea);
+  if (N > 0) hipLaunchKernelGGL(g_atomic_energy, grid1(N), dim3(256), 0, s, N, c.num_types, c.energy_scale, io->atom_types, W.elemental, w.rod, w.rog, ea, t.flags);
   M3G_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(float) * S, s));
   launch_energy_sums(cc, t, ea, st, io->total_energy, s);
 

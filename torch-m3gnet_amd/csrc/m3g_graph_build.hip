@@ -1107,7 +1107,7 @@ extern "C" int m3g_verlet_fill_lists(int64_t N, int64_t Ec, int64_t n_edges, int
   hipStream_t s = (hipStream_t)stream_;
   if (N == 0) return M3G_OK;
   if (max_cand_row > kRefillList || N > kRefillMaxAtoms) { set_error("m3g_verlet_fill_lists: candidate rows or atom count beyond its limits"); return M3G_ERR_UNSUPPORTED; }
-  if (!scratch || !cand_row_ptr || !cand_state || (n_edges > 0 && (!edge_index || !edge_cell_shift)) || (n_triplets > 0 && !triplet_edge_index)) {
+  if (!scratch || !cand_row_ptr || (Ec > 0 && !cand_state) || (n_edges > 0 && (!edge_index || !edge_cell_shift)) || (n_triplets > 0 && !triplet_edge_index)) {
     set_error("m3g_verlet_fill_lists: null argument");
     return M3G_ERR_VALUE;
   }

@@ -223,6 +223,7 @@ struct m3g_plan {
                                  // (m3g_node_mfma.hip; measured at 625 tiles: node tables 58 -> 85 us, readout 28 -> 36 us per step -- not beyond)
   int fuse_node_tb = 1;          // option "fuse_node_tb": three-body reverse (moment path) + node reverse of a block as two workgroup roles of
                                  // one launch (k_node_tb_reverse, m3g_threebody.hip)
+  int debug_node_tb_polls = 0;   // option "debug_node_tb_polls" (tests): see launch_node_tb_reverse
   int small_launches = 1;        // option "small_launches": small systems take fused launches (force tail, readout + energy sums, ...)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   bool readout_f16 = false; // option "readout_f16": the readout layers on scaled two-part fp16 chains in the f16x3 mode (5 us faster at 10,000
@@ -465,7 +466,7 @@ void launch_threebody_reverse(const Consts& c, const Topo& t, const Work& w, con
 bool launch_threebody_reverse_final(const Consts& c, const Topo& t, const Work& w, const float* v, bool first, const float* dh, int dh_parts,
                                     hipStream_t s, int topo_hints);
 bool launch_node_tb_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v, bool first,
-                            const float* dx_new, float* dx_out, int dp1_packed, int block, hipStream_t s, int topo_hints);
+                            const float* dx_new, float* dx_out, int dp1_packed, int block, hipStream_t s, int topo_hints, int debug_polls = 0);
 // pack_mfma.hip / edge_mfma.hip
 int pack_mfma_images(m3g_plan* plan);
 void free_mfma_images(m3g_plan* plan);

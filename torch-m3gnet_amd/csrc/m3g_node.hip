@@ -124,10 +124,10 @@ __global__ void __launch_bounds__(256) k_node_pre(int C, int64_t N, const float*
 }
 
 __global__ void __launch_bounds__(256) k_node_reverse(NodeRevArgs a) {
-  node_reverse_body<false>(a, blockIdx.x, [] {});
+  node_reverse_body<false>(a, blockIdx.x, [] { return false; });
 }
 __global__ void __launch_bounds__(256) k_node_reverse_small(NodeRevArgs a) {   // weights of phase 2 requested at entry (small systems)
-  node_reverse_body<false, true>(a, blockIdx.x, [] {});
+  node_reverse_body<false, true>(a, blockIdx.x, [] { return false; });
 }
 
 // the v-gradient share of the node reverse on its own (dx_out += (dv v (1-v)) W1), for when k_node_reverse ran without it
@@ -169,7 +169,7 @@ constexpr int kRA = 4;
 __global__ void __launch_bounds__(256) k_readout(Consts c, int64_t N, const float* __restrict__ W, ReadoutW rw,
                                                  size_t elemental_off, const int64_t* __restrict__ types,
                                                  const float* __restrict__ x, NodeSums ns, float* __restrict__ scaled_atomic,
-                                                 float* __restrict__ dx, float* __restrict__ scaled_total, int64_t S) {
+                                                 float* __restrict__ dx, float* __restrict__ scaled_total, int64_t S, const int32_t* topo_flags) {
   __shared__ float bufA[4][kRA][kDP], bufB[4][kRA][kDP];
   // the per-structure sums are accumulated with atomics by the next kernel: cleared here instead of a memset launch
   if (blockIdx.x == 0) for (int64_t i = threadIdx.x; i < S; i += blockDim.x) scaled_total[i] = 0.f;
@@ -213,9 +213,10 @@ __global__ void __launch_bounds__(256) k_readout(Consts c, int64_t N, const floa
     og[j] += W[rw.b3 + 1];
     sg[j] = sigmoid_f(og[j]);
     if (a0 + j < N && o == 0) {
-      int64_t ty = types[a0 + j];
-      ty = ty < 0 ? 0 : (ty >= c.num_types ? c.num_types - 1 : ty);
-      scaled_atomic[a0 + j] = W[elemental_off + ty] / c.energy_scale + od[j] * sg[j];
+      bool bad;
+      const int64_t ty = species_index(types[a0 + j], c.num_types, bad);
+      scaled_atomic[a0 + j] = bad ? __builtin_nanf("") : W[elemental_off + ty] / c.energy_scale + od[j] * sg[j];
+      if (bad) flag_bad_species(topo_flags);
     }
   }
   if (dx == nullptr) return;  // uniform
@@ -262,9 +263,11 @@ __global__ void __launch_bounds__(256) k_gather_rows(int64_t n, int width, int t
   if (id >= n * width) return;
   int64_t a = id / width;
   int o = (int)(id % width);
-  int64_t r = idx[a];
-  r = r < 0 ? 0 : (r >= table_rows ? table_rows - 1 : r);
-  out[id] = transposed ? table[(int64_t)o * table_stride + r] : table[r * table_stride + o];
+  // (stage entry points m3g_atom_ref / m3g_atom_featurizer: the reference raises on an index outside the table, nn/atom_ref.py:27;
+  //  here the table is never indexed with one and the atom's output row is NaN)
+  bool bad;
+  const int64_t r = species_index(idx[a], table_rows, bad);
+  out[id] = bad ? __builtin_nanf("") : (transposed ? table[(int64_t)o * table_stride + r] : table[r * table_stride + o]);
 }
 
 __global__ void __launch_bounds__(256) k_copy_strided(int64_t rows, int width, const float* __restrict__ in, int in_stride,
@@ -344,7 +347,7 @@ void launch_readout(const Consts& c, const float* W, const WeightLayout& wl, con
   if (t.N == 0) (void)hipMemsetAsync(scaled_total, 0, sizeof(float) * t.S, s);
   if (t.N > 0) {
     hipLaunchKernelGGL(k_readout, grid_for(t.N, 4 * kRA), dim3(256), 0, s, c, t.N, W, wl.ro, wl.elemental, types, x, ns, scaled_atomic,
-                       want_grad ? w.dx : nullptr, scaled_total, t.S);
+                       want_grad ? w.dx : nullptr, scaled_total, t.S, t.flags);
   }
   launch_energy_sums(c, t, scaled_atomic, scaled_total, total, s);
 }

@@ -294,9 +294,10 @@ __global__ void __launch_bounds__(256) k_readout_mfma(Consts c, int64_t N, const
     og = sum_lane_quarters(og) + lds[ReadoutImg::b3 + 1];
     const float sg = fsigmoid(og);
     if (live && q == 0) {
-      int64_t ty = types[atom];
-      ty = ty < 0 ? 0 : (ty >= c.num_types ? c.num_types - 1 : ty);
-      scaled_atomic[atom] = elemental[ty] / c.energy_scale + od * sg;
+      bool bad;
+      const int64_t ty = species_index(types[atom], c.num_types, bad);
+      scaled_atomic[atom] = bad ? __builtin_nanf("") : elemental[ty] / c.energy_scale + od * sg;
+      if (bad) flag_bad_species(rs.flags);
     }
     if (dx == nullptr) continue;   // uniform
     // reverse: dL/d eps = energy_scale
@@ -436,9 +437,10 @@ __global__ void __launch_bounds__(256) k_readout_split(Consts c, int64_t N, cons
     og = sum_lane_quarters(og) + b3g;
     const float sg = fsigmoid(og);
     if (live && q == 0 && w == 0) {
-      int64_t ty = types[atom];
-      ty = ty < 0 ? 0 : (ty >= c.num_types ? c.num_types - 1 : ty);
-      scaled_atomic[atom] = elemental[ty] / c.energy_scale + od * sg;
+      bool bad;
+      const int64_t ty = species_index(types[atom], c.num_types, bad);
+      scaled_atomic[atom] = bad ? __builtin_nanf("") : elemental[ty] / c.energy_scale + od * sg;
+      if (bad) flag_bad_species(rs.flags);
     }
     if constexpr (GRAD) {
       // reverse: dL/d eps = energy_scale

@@ -203,7 +203,7 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
 #ifndef M3G_NR_NO_CHUNK
       if constexpr (DEFER_V) {
         if (args.with_v_term) {
-          wait_for_dgq();
+          const bool never_came = wait_for_dgq();   // (bounded wait ran out: the rows below are stale -- NaN instead, M3G_TOPO_ERR_SYNC)
           // second pass over the in-edge list: dv in the one-pass form's order (chunks of 64 pairs, batches of kNrBatch, pairwise sums)
           for (int kc = ks; kc < k1s; kc += 64) {
             const int cnt = k1s - kc < 64 ? k1s - kc : 64;
@@ -220,6 +220,7 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
               for (int j = 0; j < kNrBatch; j += 4) dv += (g[j] + g[j + 1]) + (g[j + 2] + g[j + 3]);
             }
           }
+          if (never_came) dv = __builtin_nanf("");
         }
       }
 #endif

@@ -15,6 +15,9 @@
 // L2.  Partners outside the staged window (only possible for degrees beyond the LDS budget) fall back to global
 // memory, so correctness does not depend on the window size.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "m3g_internal.h"
 #include "m3g_node_rev.h"
@@ -621,11 +624,16 @@ __global__ void __launch_bounds__(kTbMomThreads) k_threebody_moments_final(Const
 //   * workgroups [0, n_tb) take the three-body role, then publish: device-scope fence + one atomic increment of `done`;
 //   * workgroups [n_tb, ...) take the node role: the dp1 gather needs nothing from the three-body role; its last term (the
 //     v-gradient, from the dL/dg rows the three-body role writes) waits until `done` == n_tb.
-// No deadlock: workgroups are dispatched in index order, so when a node workgroup runs every three-body workgroup has been
-// dispatched, and those never wait for anything.  The wait is bounded all the same (a sticky error bit instead of a hang).
+// No deadlock: the launcher takes this form only when EVERY workgroup of the launch is resident at once (n_tb + n_node <= what the
+// device holds of this kernel at its LDS footprint, asked of the runtime -- launch_node_tb_reverse; otherwise the two launches), so
+// the three-body workgroups a node workgroup waits for are running, and those never wait for anything.  The wait is bounded all the
+// same: when it runs out the node role replaces the v-gradient term it waited for by NaN (forces of the call: NaN) and sets the
+// sticky M3G_TOPO_ERR_SYNC bit -- never stale rows.
 struct NodeTbArgs {
   int n_tb;          // workgroups of the three-body role
   int32_t* done;     // Work::sync word of this block (cleared at the start of every step)
+  int max_polls;     // bound of the node role's wait (2^22 polls ~ 2 s; tests shrink it through option "debug_node_tb_polls")
+  int wait_extra;    // tests: the node role waits for this many increments MORE than will ever come (its time-out path)
 };
 template <int L, int R>
 __global__ void __launch_bounds__(256) k_node_tb_reverse(Consts c, TbMomArgs ta, int cap_rows, int cap_atoms, NodeRevArgs na, NodeTbArgs f) {
@@ -643,14 +651,16 @@ __global__ void __launch_bounds__(256) k_node_tb_reverse(Consts c, TbMomArgs ta,
   node_reverse_body<true, true>(na, (int64_t)blockIdx.x - f.n_tb, [&] {
     // ONE lane per wave polls (64 lanes polling one word from every waiting wave starve the increments they wait for: 73 us
     // instead of 24 on the 864-atom cell), ~0.5 us apart
+    int never_came = 0;
     if ((threadIdx.x & 63) == 0) {
       int spins = 0;
-      while (__hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.n_tb) {
+      while (__hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.n_tb + f.wait_extra) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1 << 22)) { atomicOr(ta.flags + 8, M3G_TOPO_ERR_SYNC); break; }   // (cannot happen: see above)
+        if (++spins > f.max_polls) { atomicOr(ta.flags + 8, M3G_TOPO_ERR_SYNC); never_came = 1; break; }   // (cannot happen: see above)
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows read below are the ones published before the increments
+    return __builtin_amdgcn_readfirstlane(never_came) != 0;
   });
 }
 
@@ -704,10 +714,40 @@ void launch_threebody(const Consts& c, const Topo& t, const Work& w, const float
   else { M3G_DISPATCH_LR(c.L, c.R, hipLaunchKernelGGL((k_threebody_fwd<L, R, kTbListShort, kTbCapShort, kTbLprShort>), grid_rows(t.E), dim3(kTbRows * kTbLprShort), 0, s, c, a)); }
 }
 
+// The in-launch wait of k_node_tb_reverse is deadlock-free only when all workgroups of the launch are resident together: ask the
+// runtime how many this kernel fits per CU at this LDS footprint (cached per instantiation, device and footprint); false = take the
+// two launches.
+template <int L, int R>
+static bool node_tb_launch(const Consts& c, const TbMomArgs& a, int rows, int atoms, const NodeRevArgs& na, int n_tb, int n_node, int32_t* done,
+                           int debug_polls, hipStream_t s) {
+  const size_t lds = mom_lds_bytes<L, R, true>(rows, atoms);
+  static std::mutex mu;
+  static std::map<std::pair<int, size_t>, int> resident;   // (device, dynamic LDS bytes) -> workgroups the device holds at once
+  int dev = 0, cap = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = resident.find(std::make_pair(dev, lds));
+    if (it == resident.end()) {
+      int per_cu = 0, cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_node_tb_reverse<L, R>, 256, lds) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        per_cu = cus = 0;
+      it = resident.emplace(std::make_pair(dev, lds), per_cu * cus).first;
+    }
+    cap = it->second;
+  }
+  if (n_tb + n_node > cap) return false;
+  // (debug_polls, tests only: k > 0 bounds the wait at k polls; k < 0 makes the node role wait for an increment that never comes, |k| polls)
+  const NodeTbArgs f{n_tb, done, debug_polls > 0 ? debug_polls : debug_polls < 0 ? -debug_polls : 1 << 22, debug_polls < 0 ? 1 : 0};
+  hipLaunchKernelGGL((k_node_tb_reverse<L, R>), dim3((unsigned)(n_tb + n_node)), dim3(256), lds, s, c, a, rows, atoms, na, f);
+  return true;
+}
+
 // three-body reverse + node reverse of a block in one launch (k_node_tb_reverse); false: not applicable (list kernels, no atoms, no
 // sync words) -- the caller then launches the two kernels
 bool launch_node_tb_reverse(const Consts& c, const float* W, const BlockW& bw, const Topo& t, const Work& w, const float* v, bool first,
-                            const float* dx_new, float* dx_out, int dp1_packed, int block, hipStream_t s, int topo_hints) {
+                            const float* dx_new, float* dx_out, int dp1_packed, int block, hipStream_t s, int topo_hints, int debug_polls) {
   // Small cells only.  Measured: 32 atoms 20.7 -> 15.8 us for the pair, 108 atoms a gain, 256 atoms a small loss, 864 atoms 24 -> 47 us,
   // 10,000 atoms 2.40 -> 2.62 ms per step: publishing costs an L2 write-back per three-body workgroup and an L2 invalidate per
   // waiting wave (the XCDs' L2s are not coherent with each other), which a launch boundary does once for everybody.
@@ -720,10 +760,9 @@ bool launch_node_tb_reverse(const Consts& c, const float* W, const BlockW& bw, c
   // its XCD's L2 (one per row block -- 284 on the 864-atom cell -- cost 59 us instead of the 24 us of the two separate kernels);
   // beside the node role's gather a longer walk costs nothing
   const int n_tb = (int)std::min<unsigned>(grid_rows(t.E).x, 128u), n_node = (int)((t.N + kNodesRev - 1) / kNodesRev);
-  const NodeTbArgs f{n_tb, w.sync + kSyncNodeRev + block};
-  M3G_DISPATCH_LR3(c.L, c.R, hipLaunchKernelGGL((k_node_tb_reverse<L, R>), dim3((unsigned)(n_tb + n_node)), dim3(256), (mom_lds_bytes<L, R, true>(rows, atoms)), s, c, a,
-                                                 rows, atoms, na, f));
-  return true;
+  bool launched = false;
+  M3G_DISPATCH_LR3(c.L, c.R, launched = (node_tb_launch<L, R>(c, a, rows, atoms, na, n_tb, n_node, w.sync + kSyncNodeRev + block, debug_polls, s)));
+  return launched;
 }
 
 // the step's last three-body reverse + the geometry reverse (dE/dr of every edge) in one launch; false: not the moment path / no

@@ -10,7 +10,7 @@ _PKG_ROOT = Path(__file__).resolve().parent.parent  # .../torch-m3gnet_amd
 LIB_PATH = _PKG_ROOT / "lib" / "libm3gnet_hip.so"
 
 M3G_OK, M3G_ERR_VALUE, M3G_ERR_STATE, M3G_ERR_SIZE, M3G_ERR_HIP, M3G_ERR_UNSUPPORTED = range(6)
-ABI_VERSION = 5
+ABI_VERSION = 6
 VERLET_FILL_LISTS_MAX_ROW = 1024   # M3G_VERLET_FILL_LISTS_MAX_ROW (include/m3gnet_hip.h)
 
 
@@ -137,6 +137,7 @@ SYMBOLS = {
                               C.c_void_p]),
     "m3g_topology_data_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_topology_debug_last_path": (C.c_int, [C.POINTER(C.c_int32)]),
+    "m3g_count_launches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "m3g_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "m3g_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                    C.POINTER(C.c_int32)]),

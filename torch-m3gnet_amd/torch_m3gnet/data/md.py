@@ -118,6 +118,7 @@ class VerletGraph:
         if self._lists_owner != "py":
             self._lists_owner = "py"
             self.graph, self._pending, self._state_valid = None, None, False
+            self._reuse_streak = 0   # (evaluate's speculation counted verdicts about lists that are no longer the current ones)
 
     def _queue_test(self, pos: torch.Tensor) -> None:
         """The skin test at `pos`, queued on the current stream together with the copy of its verdict to pinned host memory."""
@@ -228,6 +229,7 @@ class VerletGraph:
     def begin(self, pos: torch.Tensor) -> Batch:
         """Queue the skin test at `pos` and return the CURRENT graph with `pos` written into it, on the assumption that the lists
         are unchanged; `confirm()` says whether that held.  (No graph yet: falls back to `update`.)"""
+        self._own_lists()   # (`step` wrote the lists last: `self.graph` is gone, take the update path)
         if self._cand is None or self.graph is None or self.skin <= 0.0:
             return self.update(pos)
         pos = self._check_pos(pos)

@@ -81,6 +81,7 @@ class Engine:
         self.topology_hints = True
         self._species_host = None   # pinned [min, max] of the last species check
         self._out_cache = {}
+        self._count_next, self.last_launch_count = False, None
 
     def __del__(self):
         try:
@@ -167,6 +168,13 @@ class Engine:
     def profile(self, enable: bool) -> None:
         _lib.check(self.lib.m3g_profile_enable(self.plan, 1 if enable else 0))
 
+    def count_launches(self, call) -> tuple:
+        """(kernel launches, other stream operations) of ONE m3g_energy_forces call as `call()` issues it -- the un-profiled launch
+        sequence, counted by the library from a stream capture of the call itself (m3g_count_launches)."""
+        self._count_next, self.last_launch_count = True, None
+        call()
+        return self.last_launch_count
+
     def profile_read(self) -> dict:
         """{stage: (total_ms, launches)} from the HIP events recorded since the last read."""
         n = C.c_int32()
@@ -241,6 +249,11 @@ class Engine:
                 raise RuntimeError(f"m3g_energy_forces flagged topology error bits {topo.status():#x} on the previous call with this "
                                    "graph: its results were invalid (m3g_topology_status, include/m3gnet_hip.h)")
             topo._engine_calls = calls + 1
+            if self._count_next:   # measurement (count_launches): this call's launch sequence, captured beside the call -- nothing executes twice
+                self._count_next = False
+                k, o = C.c_int32(), C.c_int32()
+                _lib.check(self.lib.m3g_count_launches(self.plan, C.byref(io), p(self._workspace), self._workspace.numel(), C.byref(k), C.byref(o)))
+                self.last_launch_count = (int(k.value), int(o.value))
             _lib.check(self.lib.m3g_energy_forces(self.plan, C.byref(io), p(self._workspace), self._workspace.numel(), M._stream()))
         for key, val in out.items():
             graph[key] = val
