@@ -441,6 +441,13 @@ int m3g_debug_read_stamps(m3g_plan* plan, uint64_t* host_out);
  * event pool).  They are bound to the plan's device: a commit that moves the plan to another device releases all of them. */
 int m3g_debug_live_handles(const m3g_plan* plan, int32_t* out);
 
+/* Test hooks for the library's own device-wide exclusive scan and stable radix sort (csrc/m3g_prims.h: the primitives behind the
+ * neighbour search and the list / topology construction).  elem_bytes / key_bytes: 4 or 8 (integers); in == out allowed for the
+ * scan; the sort works in place on `keys` (+ `vals`, int32, may be NULL) over the key bits [begin_bit, end_bit).  Both allocate their
+ * temporary storage and wait for the stream: diagnostics only. */
+int m3g_debug_exclusive_scan(int32_t elem_bytes, int64_t n, const void* in, void* out, void* stream);
+int m3g_debug_radix_sort(int32_t key_bytes, int64_t n, void* keys, int32_t* vals, int32_t begin_bit, int32_t end_bit, void* stream);
+
 /* Measurement: what ONE m3g_energy_forces call with these arguments puts on a stream -- kernel launches and other operations (memsets,
  * copies) -- counted by capturing the call's own launch sequence into a HIP graph on an internal stream (nothing executes, no buffer
  * is touched) and counting the graph's nodes.  The sequence counted is the un-profiled one (the stage profiler changes it). */
@@ -451,7 +458,8 @@ int m3g_count_launches(const m3g_plan* plan, const m3g_io* io, void* workspace, 
                              * canonical edge order by the shift relative to the given coordinates, default precision fp32;
                              * 4: m3g_verlet_fill_lists, m3g_topology_build_canonical, M3G_TOPO_ERR_SYNC, options small_tiles / small_launches / fuse_node_tb;
                              * 5: m3g_topology_build_canonical_begin / _end, m3g_topology_data_bytes, option legendre_backward, m3g_md_*;
-                             * 6: M3G_TOPO_ERR_SPECIES (species checked on the library side, m3g_md_step returns M3G_ERR_VALUE), m3g_count_launches */
+                             * 6: M3G_TOPO_ERR_SPECIES (species checked on the library side, m3g_md_step returns M3G_ERR_VALUE), m3g_count_launches,
+                             *    m3g_debug_exclusive_scan / m3g_debug_radix_sort (the library's own scan and sort: no hipCUB) */
 
 #ifdef __cplusplus
 }

@@ -373,3 +373,60 @@ def test_canonical_topology_build_falls_back_on_lists_that_are_not_canonical():
     g = batch_from_arrays([lat], [frac @ lat], [np.full(7, 28)], 9.0, 3.0, device="cuda")
     (a, ha, fa), (b, hb, fb), path = _topology_buffers(g)
     assert path == 0 and fa == 0 and fb == 0 and ha == hb and torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ the library's own scan and sort (csrc/m3g_prims.h)
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 2047, 2048, 2049, 4096, 100_003, 2048 * 2048 + 5])
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+def test_device_exclusive_scan_against_cumsum(n, dtype):
+    """The exclusive scan behind the neighbour search and the list builders (tiles of 2,048, recursive tile totals): every length
+    around the tile and recursion boundaries, both integer widths, in place and out of place -- integer results, bit-exact."""
+    import ctypes as C
+
+    from torch_m3gnet import _lib
+
+    lib = _lib.load_library()
+    gen = torch.Generator().manual_seed(n + (7 if dtype == torch.int64 else 0))
+    x = torch.randint(0, 5 if dtype == torch.int32 else 1 << 33, (n,), dtype=dtype, generator=gen).cuda()
+    want = torch.cumsum(x, 0) - x if n else x.clone()
+    out = torch.full_like(x, -1)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.m3g_debug_exclusive_scan(x.element_size(), n, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), s))
+    assert torch.equal(out, want)
+    y = x.clone()
+    _lib.check(lib.m3g_debug_exclusive_scan(y.element_size(), n, C.c_void_p(y.data_ptr()), C.c_void_p(y.data_ptr()), s))
+    assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 8), (255, 5), (256, 8), (257, 13), (4096, 16), (4097, 17), (70_001, 24), (1_000_003, 32)])
+def test_device_radix_sort_is_a_stable_sort(n, bits):
+    """The LSD radix sort of the general topology build (incoming-edge lists of asymmetric graphs, unsorted triplet lists): 32-bit
+    keys with values -- stability checked through the values (a stable sort of (key, original position) pairs is unique) -- and
+    64-bit keys, key bits [0, bits) and a window that does not start at bit 0."""
+    import ctypes as C
+
+    from torch_m3gnet import _lib
+
+    lib = _lib.load_library()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator().manual_seed(n)
+    keys = torch.randint(0, 1 << min(bits, 31), (n,), dtype=torch.int64, generator=gen)
+    if bits < 16:
+        keys = keys % 7        # many duplicates
+    k32 = keys.to(torch.int32).cuda()
+    vals = torch.arange(n, dtype=torch.int32).cuda()
+    _lib.check(lib.m3g_debug_radix_sort(4, n, C.c_void_p(k32.data_ptr()), C.c_void_p(vals.data_ptr()), 0, min(bits, 31), s))
+    want_k, want_i = torch.sort(keys, stable=True)
+    assert torch.equal(k32.cpu().long(), want_k) and torch.equal(vals.cpu().long(), want_i)
+    # 64-bit keys (triplet keys: (first edge << 32) | second edge), keys only
+    hi = torch.randint(0, 1 << 20, (n,), dtype=torch.int64, generator=gen)
+    k64 = ((hi << 32) | keys).cuda()
+    want64 = torch.sort(k64.cpu())[0]
+    _lib.check(lib.m3g_debug_radix_sort(8, n, C.c_void_p(k64.data_ptr()), None, 0, 52, s))
+    assert torch.equal(k64.cpu(), want64)
+    # a window of key bits that starts above bit 0: ordered by those bits only, ties in input order
+    k = ((hi << 32) | keys).cuda()
+    v = torch.arange(n, dtype=torch.int32).cuda()
+    _lib.check(lib.m3g_debug_radix_sort(8, n, C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), 32, 52, s))
+    _, want_i = torch.sort(hi, stable=True)
+    assert torch.equal(v.cpu().long(), want_i)

@@ -274,6 +274,7 @@ def test_mid_size_cell_on_the_default_selection_vs_oracle():
 def test_many_small_structures_beyond_the_fused_launches_limit_vs_oracle():
     """One batch of 12 x 64-atom random-species cells (more structures than the fused launches walk, kForceTailMaxStructs = 8:
     the stand-alone sum kernels run) against the oracle, and batched == per-structure energies (reference tests/test_model.py:59-78)."""
+    from helpers import random_cell_graph
     from torch_m3gnet.data import MaterialGraphKey as K
     from torch_m3gnet.data.material_graph import Batch
     from torch_m3gnet.model.build import build_model

@@ -102,9 +102,27 @@ __global__ void __launch_bounds__(kStructThreads) k_struct_stress(const int32_t*
                                                        const float* __restrict__ forces, float* __restrict__ stresses,
                                                        const float* __restrict__ ea, float energy_scale, float* __restrict__ scaled_total,
                                                        float* __restrict__ total) {
-  __shared__ float part[kStructThreads * 6];
-  if (ea) struct_energy<kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, ea, energy_scale, scaled_total, total, part);
-  struct_stress<kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, pos, lattice, forces, stresses, part);
+  __shared__ float part[kStructThreads * 7];
+  if (!ea) {
+    struct_stress<kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, pos, lattice, forces, stresses, part);
+    return;
+  }
+  // energy and virial in ONE pass over the structure's atoms (seven independent sums, each in struct_reduce's order: the same
+  // bits as struct_energy followed by struct_stress, half the barriers and one wait per atom instead of two)
+  float tot[7];
+  struct_reduce<7, kStructThreads>(blockIdx.x, struct_ptr, flags, n_atoms, batch, tot, part, [&](int a, int ss, float* v) {
+    const float inv = inv_volume(lattice + (int64_t)ss * 9);
+    const float px = pos[a * 3], py = pos[a * 3 + 1], pz = pos[a * 3 + 2];
+    const float fx = forces[a * 3], fy = forces[a * 3 + 1], fz = forces[a * 3 + 2];
+    v[0] = px * fx * inv; v[1] = py * fy * inv; v[2] = pz * fz * inv;
+    v[3] = py * fz * inv; v[4] = pz * fx * inv; v[5] = px * fy * inv;
+    v[6] = ea[a];
+  });
+  if (threadIdx.x < 6) stresses[(int64_t)blockIdx.x * 6 + threadIdx.x] = tot[threadIdx.x];
+  if (threadIdx.x == 0) {
+    scaled_total[blockIdx.x] = tot[6];
+    total[blockIdx.x] = energy_scale * tot[6];
+  }
 }
 __global__ void __launch_bounds__(kStructThreads) k_struct_stress_pair(const int32_t* __restrict__ struct_ptr, const int32_t* __restrict__ flags,
                                                             int64_t n_atoms, const int32_t* __restrict__ batch,

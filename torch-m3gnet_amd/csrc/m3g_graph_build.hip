@@ -11,13 +11,16 @@
 // skin list (m3g_verlet_*) reproduce a fresh build bit for bit --, then neighbour index: the same order
 // torch_m3gnet/data/neighbors.py produces, so both builders can be compared element by element.
 // Geometry in fp64 like pymatgen (inclusion d <= cutoff is decided in double; the stored tensors are narrowed by
-// the caller).  Linked cells: atoms are radix-sorted (hipCUB) into bins at least one cutoff wide, and one wave per atom
-// walks its periodic images, testing only the bins of an image within reach -- O(N) pair tests for large cells, and
-// the plain all-images x all-atoms search when the cell is smaller than the cutoff (one bin).  Integer/byte work,
-// L2-bound.  Count -> exclusive scan (hipCUB) -> fill, so no atomics and a deterministic result.
-#include <hipcub/hipcub.hpp>
+// the caller).  Linked cells: atoms are put into bins at least one cutoff wide by a counting sort (per-bin integer counters, one
+// scan, one scatter), and one wave per atom walks its periodic images, testing only the bins of an image within reach -- O(N)
+// pair tests for large cells, and the plain all-images x all-atoms search when the cell is smaller than the cutoff (one bin).
+// Integer/byte work, L2-bound.  Count -> exclusive scan (m3g_prims.h) -> fill: no float atomics and a deterministic result.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
 
 #include "m3g_internal.h"
+#include "m3g_prims.h"
 
 namespace m3g {
 
@@ -85,8 +88,8 @@ struct NbScratch {
   double* pos_w;          // [N,3] wrapped into the home cell
   int32_t* wrap;          // [N,3] integer offset removed by the wrap
   int32_t* binc;          // [N,3] bin coordinates of each atom
-  int32_t *bin_key, *bin_key_s, *iota, *perm;   // [N] global bin id per atom, sorted copy, atom ids, atoms ordered by bin
-  int32_t* bin_start;     // [Bmax+1] first slot of each bin in perm
+  int32_t *bin_key, *bin_rank, *perm;   // [N] global bin id per atom, its arrival rank inside that bin, atoms ordered by bin
+  int32_t* bin_start;     // [Bmax+2] atoms per bin (counted by k_wrap_positions), then the first slot of each bin in perm
   double* pos_s;          // [N,3] wrapped positions in bin order
   int64_t* counts;        // [N*M + 1] matches per (atom, image), then exclusive offsets
   int64_t* tri;           // [N + 1] triplets per centre d (d - 1) (m3g_neighbor_count_triplets), [N] = their sum
@@ -108,21 +111,15 @@ static NbScratch nb_carve(int64_t N, int64_t S, int64_t M, void* base) {
   w.wrap = (int32_t*)take(sizeof(int32_t) * 3 * (size_t)(N + 1));
   w.binc = (int32_t*)take(sizeof(int32_t) * 3 * (size_t)(N + 1));
   w.bin_key = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
-  w.bin_key_s = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
-  w.iota = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
+  w.bin_rank = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
   w.perm = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
   w.bin_start = (int32_t*)take(sizeof(int32_t) * (size_t)(w.max_bins + 2));
   w.pos_s = (double*)take(sizeof(double) * 3 * (size_t)(N + 1));
   w.counts = (int64_t*)take(sizeof(int64_t) * (size_t)(N * M + 2));
   w.tri = (int64_t*)take(sizeof(int64_t) * (size_t)(N + 2));
-  size_t t1 = 0, t2 = 0, t3 = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const int64_t*)nullptr, (int64_t*)nullptr, (int)(N * M + 1));
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const int64_t*)nullptr, (int64_t*)nullptr, (int)(S + 1));
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t3, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr,
-                                           (int32_t*)nullptr, (int)N);
-  size_t t4 = 0;
-  (void)hipcub::DeviceReduce::Sum(nullptr, t4, (const int64_t*)nullptr, (int64_t*)nullptr, (int)std::max<int64_t>(N, 1));
-  w.tmp_bytes = std::max(std::max(t1, t4), std::max(t2, t3));
+  // scratch of the three scans (counts per (atom, image); bins per structure; atoms per bin), m3g_prims.h
+  w.tmp_bytes = std::max(std::max(prims::scan_tmp_bytes<int64_t>(N * M + 1), prims::scan_tmp_bytes<int64_t>(S + 1)),
+                         prims::scan_tmp_bytes<int32_t>(w.max_bins + 2));
   w.tmp = take(w.tmp_bytes);
   w.total = off;
   return w;
@@ -130,9 +127,9 @@ static NbScratch nb_carve(int64_t N, int64_t S, int64_t M, void* base) {
 
 // one thread per structure: inverse lattice, image ranges, bin grid, atom range (batch must be sorted/contiguous)
 __global__ void k_struct_info(int64_t N, int64_t S, const double* __restrict__ lattice, const int64_t* __restrict__ batch,
-                              double cutoff, StructInfo* info, int64_t* nbins, int* flags) {
+                              double cutoff, StructInfo* info, int64_t* nbins, int* flags, int64_t* tri_total) {
   int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (s == 0) nbins[S] = 0;
+  if (s == 0) { nbins[S] = 0; *tri_total = 0; }
   if (s >= S) return;
   StructInfo si;
   const double* L = lattice + s * 9;
@@ -173,7 +170,7 @@ __global__ void k_struct_info(int64_t N, int64_t S, const double* __restrict__ l
 
 __global__ void k_wrap_positions(int64_t N, int64_t S, const double* __restrict__ pos, const int64_t* __restrict__ batch,
                                  const StructInfo* __restrict__ info, const int64_t* __restrict__ bin_off, double* pos_w,
-                                 int32_t* wrap, int32_t* binc, int32_t* bin_key, int32_t* iota, int* flags) {
+                                 int32_t* wrap, int32_t* binc, int32_t* bin_key, int32_t* bin_cnt, int32_t* bin_rank, int* flags) {
   int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (a >= N) return;
   int64_t s = batch[a];
@@ -189,22 +186,21 @@ __global__ void k_wrap_positions(int64_t N, int64_t S, const double* __restrict_
     binc[a * 3 + p] = b[p];
   }
   for (int c = 0; c < 3; ++c) pos_w[a * 3 + c] = pw[c];
-  bin_key[a] = (int32_t)(bin_off[s] + ((int64_t)b[0] * si.nb[1] + b[1]) * si.nb[2] + b[2]);
-  iota[a] = (int32_t)a;
+  const int32_t key = (int32_t)(bin_off[s] + ((int64_t)b[0] * si.nb[1] + b[1]) * si.nb[2] + b[2]);
+  bin_key[a] = key;
+  // counting sort of the atoms by bin: the bin's counter hands out the slots.  The order of arrival inside a bin is not fixed, and
+  // nothing depends on it: every consumer of `perm` (k_neighbors) ranks its matches by neighbour index before it writes them.
+  bin_rank[a] = atomicAdd(&bin_cnt[key], 1);
 }
 
-// bin_start[g] = first slot of bin g in the bin-sorted atom list; also gathers the wrapped positions in that order
-__global__ void k_bin_ranges(int64_t N, int64_t S, const int64_t* __restrict__ bin_off, const int32_t* __restrict__ keys_sorted,
-                             const int32_t* __restrict__ perm, const double* __restrict__ pos_w, int32_t* bin_start, double* pos_s) {
-  int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (g < N) {
-    const int64_t a = perm[g];
-    pos_s[g * 3] = pos_w[a * 3]; pos_s[g * 3 + 1] = pos_w[a * 3 + 1]; pos_s[g * 3 + 2] = pos_w[a * 3 + 2];
-  }
-  if (g > bin_off[S]) return;
-  int64_t lo = 0, hi = N;
-  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < g) lo = mid + 1; else hi = mid; }
-  bin_start[g] = (int32_t)lo;
+// atoms into their bins' slot ranges (bin_start: exclusive scan of the per-bin counts) + the wrapped positions in that order
+__global__ void k_bin_scatter(int64_t N, const int32_t* __restrict__ bin_key, const int32_t* __restrict__ bin_rank, const int32_t* __restrict__ bin_start,
+                              const double* __restrict__ pos_w, int32_t* __restrict__ perm, double* __restrict__ pos_s) {
+  const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const int64_t g = bin_start[bin_key[a]] + bin_rank[a];
+  perm[g] = (int32_t)a;
+  pos_s[g * 3] = pos_w[a * 3]; pos_s[g * 3 + 1] = pos_w[a * 3 + 1]; pos_s[g * 3 + 2] = pos_w[a * 3 + 2];
 }
 
 // One wave per atom i.  The wave walks the atom's periodic images in order; for an image it visits the bins that can hold a
@@ -345,7 +341,10 @@ __global__ void __launch_bounds__(256) k_neighbors(int64_t N, int64_t M, const i
   }
   if (!FILL && tri) {
     const int64_t d = __reduce_add_sync(~0ull, my3);
-    if (lane == 0) tri[i] = d * (d - 1);
+    if (lane == 0) {
+      tri[i] = d * (d - 1);
+      atomicAdd(reinterpret_cast<unsigned long long*>(tri + N), (unsigned long long)(d * (d - 1)));   // (integers: the total does not depend on the order)
+    }
   }
 }
 
@@ -462,8 +461,7 @@ static VerletScratch verlet_carve(int64_t N, int64_t Ec, void* base) {
   w.dist = (double*)take(sizeof(double) * (size_t)(Ec + 1));
   w.row_keep = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 2));
   w.row_tri = (int64_t*)take(sizeof(int64_t) * (size_t)(N + 1));
-  size_t tmp = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(N + 1));
+  const size_t tmp = prims::scan_tmp_bytes<int32_t>(N + 1);
   w.scan_tmp_bytes = tmp;
   w.scan_tmp = take(tmp);
   w.acc = (unsigned long long*)take(sizeof(unsigned long long) * 8);   // [4]: workgroup counter of the one-launch update (small cells)
@@ -838,8 +836,7 @@ static TbScratch tb_carve(int64_t N, int64_t E, void* base) {
   w.deg = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 1));
   w.row_ptr = (int32_t*)take(sizeof(int32_t) * (size_t)(N + 2));
   w.counts = (int64_t*)take(sizeof(int64_t) * (size_t)(E + 2));
-  size_t tmp = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const int64_t*)nullptr, (int64_t*)nullptr, (int)(E + 1));
+  const size_t tmp = prims::scan_tmp_bytes<int64_t>(E + 1);
   w.scan_tmp_bytes = tmp;
   w.scan_tmp = take(tmp);
   w.total = off;
@@ -959,24 +956,23 @@ extern "C" int m3g_neighbor_count_triplets(int64_t N, int64_t S, int64_t max_ima
   M3G_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int), s));
   *host_n_edges = 0;
   if (N == 0 || S == 0) return M3G_OK;
-  hipLaunchKernelGGL(k_struct_info, g_for(S), dim3(256), 0, s, N, S, lattice, batch, cutoff, w.info, w.bin_off, flags);
-  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, w.bin_off, w.bin_off, (int)(S + 1), s));
+  hipLaunchKernelGGL(k_struct_info, g_for(S), dim3(256), 0, s, N, S, lattice, batch, cutoff, w.info, w.bin_off, flags, w.tri + N);
+  M3G_HIP_CHECK(prims::exclusive_scan<int64_t>(w.bin_off, w.bin_off, S + 1, w.tmp, s));
+  // atoms sorted by bin: a counting sort (bin ids are < max_bins) -- per-bin counters filled while the positions are wrapped, one
+  // scan, one scatter
+  M3G_HIP_CHECK(hipMemsetAsync(w.bin_start, 0, sizeof(int32_t) * (size_t)(w.max_bins + 2), s));
   hipLaunchKernelGGL(k_wrap_positions, g_for(N), dim3(256), 0, s, N, S, pos, batch, w.info, w.bin_off, w.pos_w, w.wrap, w.binc, w.bin_key,
-                     w.iota, flags);
-  int key_bits = 1;   // bin ids are < max_bins
-  while ((int64_t(1) << key_bits) <= w.max_bins) ++key_bits;
-  M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w.tmp, w.tmp_bytes, w.bin_key, w.bin_key_s, w.iota, w.perm, (int)N, 0, key_bits, s));
-  hipLaunchKernelGGL(k_bin_ranges, g_for(w.max_bins + 1), dim3(256), 0, s, N, S, w.bin_off, w.bin_key_s, w.perm, w.pos_w, w.bin_start, w.pos_s);
+                     w.bin_start, w.bin_rank, flags);
+  M3G_HIP_CHECK(prims::exclusive_scan<int32_t>(w.bin_start, w.bin_start, w.max_bins + 2, w.tmp, s));
+  hipLaunchKernelGGL(k_bin_scatter, g_for(N), dim3(256), 0, s, N, w.bin_key, w.bin_rank, w.bin_start, w.pos_w, w.perm, w.pos_s);
   const int64_t NM = N * max_images;
   hipLaunchKernelGGL((k_neighbors<false>), g_for(N * 64), dim3(256), 0, s, N, max_images, batch, w.info, w.bin_off, w.bin_start, w.perm, w.pos_s,
                      w.pos_w, w.binc, w.wrap, cutoff, w.counts, (int64_t)0, nullptr, nullptr, nullptr, threebody_cutoff, host_n_triplets ? w.tri : nullptr);
   M3G_HIP_CHECK(hipMemsetAsync(w.counts + NM, 0, sizeof(int64_t), s));
-  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, w.counts, w.counts, (int)(NM + 1), s));
+  M3G_HIP_CHECK(prims::exclusive_scan<int64_t>(w.counts, w.counts, NM + 1, w.tmp, s));
   int h_flags = 0;
-  if (host_n_triplets) {
-    M3G_HIP_CHECK(hipcub::DeviceReduce::Sum(w.tmp, w.tmp_bytes, w.tri, w.tri + N, (int)N, s));
+  if (host_n_triplets)   // (summed by k_neighbors itself: an integer atomic per centre)
     M3G_HIP_CHECK(hipMemcpyAsync(host_n_triplets, w.tri + N, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  }
   M3G_HIP_CHECK(hipMemcpyAsync(host_n_edges, w.counts + NM, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipMemcpyAsync(&h_flags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipStreamSynchronize(s));
@@ -1089,7 +1085,7 @@ extern "C" int m3g_verlet_fill(int64_t N, int64_t Ec, int64_t n_edges, void* scr
   }
   VerletScratch w = verlet_carve(N, Ec, scratch);
   M3G_HIP_CHECK(hipMemsetAsync(w.row_keep + N, 0, sizeof(int32_t), s));
-  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, w.scan_tmp_bytes, w.row_keep, w.row_keep, (int)(N + 1), s));
+  M3G_HIP_CHECK(prims::exclusive_scan<int32_t>(w.row_keep, w.row_keep, N + 1, w.scan_tmp, s));
   hipLaunchKernelGGL(k_verlet_fill, g_for(N * 64), dim3(256), 0, s, N, Ec, n_edges, cand_edge_index, cand_shift, cand_row_ptr, w.row_keep, w.state,
                      w.dist, edge_index, edge_cell_shift, distances, cand_state);
   M3G_HIP_CHECK(hipGetLastError());
@@ -1141,7 +1137,7 @@ extern "C" int m3g_threebody_count(int64_t N, int64_t E, const int64_t* edge_ind
   hipLaunchKernelGGL(k_rows_from_sorted, g_for(N + 1), dim3(256), 0, s, N, E, edge_index, w.row_ptr, flags);
   hipLaunchKernelGGL(k_rank_valid, g_for(N * 64), dim3(256), 0, s, N, w.row_ptr, distances, threebody_cutoff, w.rank, w.deg, w.counts);
   M3G_HIP_CHECK(hipMemsetAsync(w.counts + E, 0, sizeof(int64_t), s));
-  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, w.scan_tmp_bytes, w.counts, w.counts, (int)(E + 1), s));
+  M3G_HIP_CHECK(prims::exclusive_scan<int64_t>(w.counts, w.counts, E + 1, w.scan_tmp, s));
   int h_flags = 0;
   M3G_HIP_CHECK(hipMemcpyAsync(host_n_triplets, w.counts + E, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   M3G_HIP_CHECK(hipMemcpyAsync(&h_flags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1167,7 +1163,7 @@ extern "C" int m3g_threebody_build(int64_t N, int64_t E, const int64_t* edge_ind
   hipLaunchKernelGGL(k_rows_from_sorted, g_for(N + 1), dim3(256), 0, s, N, E, edge_index, w.row_ptr, flags);
   hipLaunchKernelGGL(k_rank_valid, g_for(N * 64), dim3(256), 0, s, N, w.row_ptr, distances, threebody_cutoff, w.rank, w.deg, w.counts);
   M3G_HIP_CHECK(hipMemsetAsync(w.counts + E, 0, sizeof(int64_t), s));
-  M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(w.scan_tmp, w.scan_tmp_bytes, w.counts, w.counts, (int)(E + 1), s));
+  M3G_HIP_CHECK(prims::exclusive_scan<int64_t>(w.counts, w.counts, E + 1, w.scan_tmp, s));
   hipLaunchKernelGGL(k_fill_triplets, g_for(N * 64), dim3(256), 0, s, N, E, n_triplets, w.row_ptr, w.rank, w.deg, w.counts, triplet_edge_index,
                      num_triplet_i, num_triplet_ij);
   M3G_HIP_CHECK(hipGetLastError());
@@ -1183,5 +1179,44 @@ extern "C" int m3g_threebody_fill(int64_t N, int64_t E, const int64_t* edge_inde
   hipLaunchKernelGGL(k_fill_triplets, g_for(N * 64), dim3(256), 0, s, N, E, n_triplets, w.row_ptr, w.rank, w.deg, w.counts, triplet_edge_index,
                      num_triplet_i, num_triplet_ij);
   M3G_HIP_CHECK(hipGetLastError());
+  return M3G_OK;
+}
+
+// ---- test hooks for the scan / sort primitives of m3g_prims.h (tests/test_gpu_graph_build.py) ----------------------------
+// Temporary storage from hipMalloc, a wait at the end: diagnostics, not product paths.
+extern "C" int m3g_debug_exclusive_scan(int32_t elem_bytes, int64_t n, const void* in, void* out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if ((elem_bytes != 4 && elem_bytes != 8) || n < 0 || (n > 0 && (!in || !out))) { set_error("m3g_debug_exclusive_scan: bad argument"); return M3G_ERR_VALUE; }
+  void* tmp = nullptr;
+  M3G_HIP_CHECK(hipMalloc(&tmp, elem_bytes == 4 ? prims::scan_tmp_bytes<int32_t>(n) : prims::scan_tmp_bytes<int64_t>(n)));
+  hipError_t e = elem_bytes == 4 ? prims::exclusive_scan<int32_t>((const int32_t*)in, (int32_t*)out, n, tmp, s)
+                                 : prims::exclusive_scan<int64_t>((const int64_t*)in, (int64_t*)out, n, tmp, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) { set_error("m3g_debug_exclusive_scan: %s", hipGetErrorString(e)); return M3G_ERR_HIP; }
+  return M3G_OK;
+}
+// keys (and vals, may be NULL) are sorted in place by the key bits [begin_bit, end_bit); stable
+extern "C" int m3g_debug_radix_sort(int32_t key_bytes, int64_t n, void* keys, int32_t* vals, int32_t begin_bit, int32_t end_bit, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if ((key_bytes != 4 && key_bytes != 8) || n < 0 || (n > 0 && !keys) || begin_bit < 0 || end_bit > 8 * key_bytes || begin_bit > end_bit) {
+    set_error("m3g_debug_radix_sort: bad argument");
+    return M3G_ERR_VALUE;
+  }
+  if (n == 0) return M3G_OK;
+  void *tmp = nullptr, *kb = nullptr, *vb = nullptr;
+  M3G_HIP_CHECK(hipMalloc(&tmp, prims::sort_tmp_bytes(n)));
+  M3G_HIP_CHECK(hipMalloc(&kb, (size_t)n * key_bytes));
+  if (vals) M3G_HIP_CHECK(hipMalloc(&vb, (size_t)n * sizeof(int32_t)));
+  const int where = key_bytes == 4 ? prims::radix_sort<uint32_t, int32_t>((uint32_t*)keys, (uint32_t*)kb, vals, (int32_t*)vb, n, begin_bit, end_bit, tmp, s)
+                                   : prims::radix_sort<uint64_t, int32_t>((uint64_t*)keys, (uint64_t*)kb, vals, (int32_t*)vb, n, begin_bit, end_bit, tmp, s);
+  hipError_t e = where < 0 ? hipErrorUnknown : hipSuccess;
+  if (where == 1) {
+    e = hipMemcpyAsync(keys, kb, (size_t)n * key_bytes, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && vals) e = hipMemcpyAsync(vals, vb, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp); (void)hipFree(kb); if (vb) (void)hipFree(vb);
+  if (e != hipSuccess) { set_error("m3g_debug_radix_sort failed"); return M3G_ERR_HIP; }
   return M3G_OK;
 }

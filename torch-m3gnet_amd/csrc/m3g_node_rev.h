@@ -19,6 +19,10 @@ constexpr int kNodesRev = M3G_NODES_REV;
 #define M3G_NR_BATCH 8   // 768-byte nontemporal rows, index pairs handed out by v_readlane: 4 -> 0.172, 8 -> 0.166, 12 -> 0.171 ms per step
 #endif
 constexpr int kNrBatch = M3G_NR_BATCH;   // rows in flight per wave in the dp1 gather (multiple of 4)
+#ifndef M3G_NR_BATCH_SMALL
+#define M3G_NR_BATCH_SMALL 16   // ... of the small-system instantiation (PRELOAD): the launch is a chain of round trips there, not bandwidth
+#endif
+constexpr int kNrBatchSmall = M3G_NR_BATCH_SMALL;
 struct NodeRevArgs {
   int C;
   int64_t N;
@@ -44,6 +48,9 @@ struct NodeRevArgs {
 // lives on the waves it can keep resident.
 template <bool DEFER_V, bool PRELOAD = false, class WAIT>
 __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64_t vblock, WAIT wait_for_dgq) {
+  // rows in flight per wave.  The sums do not depend on it: row r of an atom's list goes to accumulator r mod 4 and the dL/dg terms are
+  // added four at a time in list order whatever the batch length (padding rows add +0)
+  constexpr int NB = PRELOAD ? kNrBatchSmall : kNrBatch;
   const int C = args.C;
   const int64_t N = args.N;
   const float* __restrict__ W = args.W;
@@ -85,6 +92,17 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
     if (i < N) {
       const int e1 = row_ptr[i + 1];
       int e = row_ptr[i];
+      // small systems: the in-edge list's bounds and its first 64 (edge, three-body row) pairs are requested BEFORE the partial-row
+      // sums below are waited for -- two dependent round trips less in a launch that is a chain of them (at 10,000 atoms, where the
+      // gather is bandwidth, it changes nothing: 0.2035 vs 0.2042 ms per step)
+      int k = 0, k1 = 0;
+      int2 mine_first = make_int2(-1, -1);
+      if constexpr (PRELOAD) {
+        k1 = in_ptr[i + 1];
+        k = in_ptr[i];
+        const int ks0 = __builtin_amdgcn_readfirstlane(k), k1s0 = __builtin_amdgcn_readfirstlane(k1);
+        if (ks0 + ln < k1s0) mine_first = in_pair[ks0 + ln];
+      }
       if (seg_head) {
         // the fused reverse kernel already summed the rows of each centre inside its tiles: add the partial rows
         // (run starting mid-tile + first runs of the tiles whose column 0 belongs to this centre)
@@ -108,11 +126,13 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
       }
       // in-edge rows: 8 whole 1-KB rows in flight per wave (random rows: latency-bound unless enough bytes are in
       // flight); lanes 0-15 also pick up the matching dL/dg row elements for the v-gradient (same edge list)
-      const int k1 = in_ptr[i + 1];
-      int k = in_ptr[i];
+      if constexpr (!PRELOAD) {
+        k1 = in_ptr[i + 1];
+        k = in_ptr[i];
+      }
       float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f), b3 = b2;
       const int cq = ln & 15;
-      // kNrBatch whole 1-KB rows in flight per wave, the remainder in one guarded batch as well (a row-at-a-time tail
+      // NB whole 1-KB rows in flight per wave, the remainder in one guarded batch as well (a row-at-a-time tail
       // is a dependent round trip per row)
 #ifndef M3G_NR_NO_CHUNK
       // the (edge, three-body row) pairs of up to 64 in-edges arrive in ONE coalesced load, a lane each, and are handed
@@ -120,54 +140,54 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
       const int ks = __builtin_amdgcn_readfirstlane(k), k1s = __builtin_amdgcn_readfirstlane(k1);
       for (int kc = ks; kc < k1s; kc += 64) {
         const int cnt = k1s - kc < 64 ? k1s - kc : 64;
-        const int2 mine = ln < cnt ? in_pair[kc + ln] : make_int2(-1, -1);
-      for (int b = 0; b < cnt; b += kNrBatch) {
-        int2 f[kNrBatch];   // (edge id, compact three-body row or -1)
-        float4 u[kNrBatch];
-        float g[kNrBatch];
+        const int2 mine = (PRELOAD && kc == ks) ? mine_first : (ln < cnt ? in_pair[kc + ln] : make_int2(-1, -1));
+      for (int b = 0; b < cnt; b += NB) {
+        int2 f[NB];   // (edge id, compact three-body row or -1)
+        float4 u[NB];
+        float g[NB];
 #pragma unroll
-        for (int j = 0; j < kNrBatch; ++j) {
+        for (int j = 0; j < NB; ++j) {
           const int src = b + j < 64 ? b + j : 63;   // lanes >= cnt hold (-1, -1)
           f[j].x = b + j < 64 ? __builtin_amdgcn_readlane(mine.x, src) : -1;
           f[j].y = b + j < 64 ? __builtin_amdgcn_readlane(mine.y, src) : -1;
           if (args.dp1_by_dst && f[j].x >= 0) f[j].x = kc + b + j;   // rows stored in list order: a stream, not a gather
         }
 #else
-      for (; k < k1; k += kNrBatch) {
-        int2 f[kNrBatch];   // (edge id, compact three-body row or -1)
-        float4 u[kNrBatch];
-        float g[kNrBatch];
+      for (; k < k1; k += NB) {
+        int2 f[NB];   // (edge id, compact three-body row or -1)
+        float4 u[NB];
+        float g[NB];
 #pragma unroll
-        for (int j = 0; j < kNrBatch; ++j) f[j] = k + j < k1 ? in_pair[k + j] : make_int2(-1, -1);
+        for (int j = 0; j < NB; ++j) f[j] = k + j < k1 ? in_pair[k + j] : make_int2(-1, -1);
 #endif
 #ifndef M3G_DP1_F32
         if (dp1_packed == kDp1Fixed) {   // rows of the fused f16x3 reverse kernel: 24-bit fixed point + a scale per 64 columns (pack24_fixed)
-          u32x3 pk[kNrBatch];
-          float sc[kNrBatch];
+          u32x3 pk[NB];
+          float sc[NB];
 #pragma unroll
-          for (int j = 0; j < kNrBatch; ++j) {
+          for (int j = 0; j < NB; ++j) {
             pk[j] = f[j].x >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(reinterpret_cast<const unsigned*>(dp1) +
                                                                    (int64_t)f[j].x * kDp1PackedDwords + 3 * ln))
                                 : u32x3{0u, 0u, 0u};   // (any bytes decode to finite numbers; the zero scale makes them 0)
             sc[j] = f[j].x >= 0 ? dp1_scale[(int64_t)f[j].x * 4 + (ln >> 4)] : 0.f;
           }
 #pragma unroll
-          for (int j = 0; j < kNrBatch; ++j) {
+          for (int j = 0; j < NB; ++j) {
             const f32x4 t = unpack24_fixed(pk[j], sc[j]);
             u[j] = make_float4(t[0], t[1], t[2], t[3]);
             g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
           }
         } else if (dp1_packed) {   // rows written by the fused bf16x3 reverse kernel: 24-bit values, 12 B per lane (m3g_mfma_common.h: pack24)
-          u32x3 pk[kNrBatch];
+          u32x3 pk[NB];
 #pragma unroll
-          for (int j = 0; j < kNrBatch; ++j)
+          for (int j = 0; j < NB; ++j)
             // nontemporal: every row is read exactly once, and keeping it out of L2 leaves the cache to the weights and
             // partial rows (node reverse 0.218 -> 0.187 ms per step)
             pk[j] = f[j].x >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(reinterpret_cast<const unsigned*>(dp1) +
                                                                    (int64_t)f[j].x * kDp1PackedDwords + 3 * ln))
                                 : u32x3{0u, 0u, 0u};
 #pragma unroll
-          for (int j = 0; j < kNrBatch; ++j) {
+          for (int j = 0; j < NB; ++j) {
             const f32x4 t = unpack24(pk[j]);
             u[j] = make_float4(t[0], t[1], t[2], t[3]);
             g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
@@ -175,7 +195,7 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
         } else
 #endif
 #pragma unroll
-        for (int j = 0; j < kNrBatch; ++j) {
+        for (int j = 0; j < NB; ++j) {
           // fp32 rows (fp32 mode, split reverse kernels): read once -> nontemporal, like the packed rows
           if (f[j].x >= 0) {
             const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dp1) + (int64_t)f[j].x * 64 + ln);
@@ -187,7 +207,7 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
           g[j] = (with_v_term && f[j].y >= 0) ? dgq[(int64_t)f[j].y * kCP + cq] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < kNrBatch; j += 4) {
+        for (int j = 0; j < NB; j += 4) {
           b0.x += u[j].x; b0.y += u[j].y; b0.z += u[j].z; b0.w += u[j].w;
           b1.x += u[j + 1].x; b1.y += u[j + 1].y; b1.z += u[j + 1].z; b1.w += u[j + 1].w;
           b2.x += u[j + 2].x; b2.y += u[j + 2].y; b2.z += u[j + 2].z; b2.w += u[j + 2].w;
@@ -204,20 +224,20 @@ __device__ __forceinline__ void node_reverse_body(const NodeRevArgs& args, int64
       if constexpr (DEFER_V) {
         if (args.with_v_term) {
           const bool never_came = wait_for_dgq();   // (bounded wait ran out: the rows below are stale -- NaN instead, M3G_TOPO_ERR_SYNC)
-          // second pass over the in-edge list: dv in the one-pass form's order (chunks of 64 pairs, batches of kNrBatch, pairwise sums)
+          // second pass over the in-edge list: dv in the one-pass form's order (chunks of 64 pairs, batches of NB, pairwise sums)
           for (int kc = ks; kc < k1s; kc += 64) {
             const int cnt = k1s - kc < 64 ? k1s - kc : 64;
             const int2 mine = ln < cnt ? in_pair[kc + ln] : make_int2(-1, -1);
-            for (int b = 0; b < cnt; b += kNrBatch) {
-              float g[kNrBatch];
+            for (int b = 0; b < cnt; b += NB) {
+              float g[NB];
 #pragma unroll
-              for (int j = 0; j < kNrBatch; ++j) {
+              for (int j = 0; j < NB; ++j) {
                 const int src = b + j < 64 ? b + j : 63;
                 const int ar = b + j < 64 ? __builtin_amdgcn_readlane(mine.y, src) : -1;
                 g[j] = ar >= 0 ? dgq[(int64_t)ar * kCP + cq] : 0.f;   // (written by other workgroups of this launch: read after the acquire in wait_for_dgq)
               }
 #pragma unroll
-              for (int j = 0; j < kNrBatch; j += 4) dv += (g[j] + g[j + 1]) + (g[j + 2] + g[j + 3]);
+              for (int j = 0; j < NB; j += 4) dv += (g[j] + g[j + 1]) + (g[j + 2] + g[j + 3]);
             }
           }
           if (never_came) dv = __builtin_nanf("");

@@ -71,6 +71,55 @@ __device__ __forceinline__ void struct_reduce(int s, const int32_t* __restrict__
     __syncthreads();                                                          // (`part` is free for the next structure)
     return;
   }
+  if constexpr (REAL == kStructThreads) {
+    // One real thread per virtual thread (the stand-alone kernels; one large cell is ONE workgroup, so this is a chain of dependent
+    // waits on a single CU).  Same sums in the same order, with fewer waits: the strided loop requests four atoms' values before it
+    // adds them (in order), tree levels 512 .. 64 cross waves through LDS (one barrier each), levels 32 .. 1 are lane shifts in
+    // wave 0 -- lane v adds lane v + off exactly as part[v] += part[v + off] does.
+    const int vt = (int)threadIdx.x;
+    float acc[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[k] = 0.f;
+    if (sorted) {
+      for (int a = a0 + vt; a < a1; a += 4 * kStructThreads) {
+        float v[4][W];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int aj = a + j * kStructThreads;
+          per_atom(aj < a1 ? aj : a, s, v[j]);   // (an index past the range re-reads atom a: its values are not added)
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (a + j * kStructThreads < a1)
+#pragma unroll
+            for (int k = 0; k < W; ++k) acc[k] += v[j][k];
+      }
+    } else {
+      strided_sum(vt, acc);
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) part[vt * W + k] = acc[k];
+    __syncthreads();
+    for (int off = kStructThreads / 2; off >= 64; off >>= 1) {
+      if (vt < off)
+#pragma unroll
+        for (int k = 0; k < W; ++k) part[vt * W + k] += part[(vt + off) * W + k];
+      __syncthreads();
+    }
+    if (vt < 64) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        float x = part[vt * W + k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);   // lanes >= off add values nobody reads
+        if (vt == 0) part[k] = x;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < W; ++k) total[k] = part[k];   // every thread holds the sums
+    __syncthreads();                                  // (`part` is free for the next structure)
+    return;
+  }
   for (int vt = (int)threadIdx.x; vt < kStructThreads; vt += REAL) {
     float acc[W];
     strided_sum(vt, acc);

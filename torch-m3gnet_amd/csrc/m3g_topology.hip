@@ -9,9 +9,9 @@
 // Index-only integer work: HBM-bound radix sorts (hipCUB) + binary searches; not on the per-step path
 // while the neighbour list is unchanged.
 #include <cstdlib>
-#include <hipcub/hipcub.hpp>
 
 #include "m3g_internal.h"
+#include "m3g_prims.h"
 
 namespace m3g {
 
@@ -19,15 +19,10 @@ static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a
 
 size_t topo_sort_tmp_bytes(int64_t E, int64_t T) {
   size_t m = (size_t)std::max<int64_t>(std::max<int64_t>(E, T), 1);
-  size_t cub = 0, scan = 0;
-  size_t pairs = 0;
-  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)m, 0, 64, 0);
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, pairs, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
-                                           (int)std::max<int64_t>(E, 1), 0, 32, 0);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(E + 1));
-  // (+ E + 1: the certificate's per-row flags live behind the two key arrays, launch_hint_kernels; the library's own temporary
-  // sizes fall below that on graphs of a few hundred edges, which then never got their certificate)
-  return align_up(std::max(std::max(std::max(cub, pairs), scan), (size_t)E + 1)) + 2 * align_up(m * sizeof(uint64_t));
+  // scratch of the radix sorts (general lists only) and of the active-edge scan (m3g_prims.h); + E + 1: the certificate's per-row
+  // flags live behind the two key arrays (launch_hint_kernels)
+  const size_t sort = prims::sort_tmp_bytes((int64_t)m), scan = prims::scan_tmp_bytes<int32_t>(E + 1);
+  return align_up(std::max(std::max(sort, scan), (size_t)E + 1)) + 2 * align_up(m * sizeof(uint64_t));
 }
 
 Topo topo_carve(int64_t N, int64_t E, int64_t T, int64_t S, void* base) {
@@ -755,7 +750,6 @@ static int topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int6
   uint64_t* keysA = (uint64_t*)tmp;
   uint64_t* keysB = (uint64_t*)(tmp + align_up(m * sizeof(uint64_t)));
   void* cub_tmp = tmp + 2 * align_up(m * sizeof(uint64_t));
-  size_t cub_bytes = t.sort_tmp_bytes - 2 * align_up(m * sizeof(uint64_t));
 
   if (N > 0) hipLaunchKernelGGL(k_convert_batch, grid(N), dim3(TPB), 0, s, N, S, batch, t.batch, t.flags);
   // incoming-edge lists: edges ordered by (neighbour atom, edge id).  A symmetric edge list (any full neighbour list) gets them
@@ -765,9 +759,14 @@ static int topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int6
   int32_t* dst_sorted = (int32_t*)keysA;
   int32_t* edge_ids = (int32_t*)keysB;
   auto sort_in_edges = [&]() -> int {
-    hipLaunchKernelGGL(k_iota32, grid(E), dim3(TPB), 0, s, E, edge_ids);
-    M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, t.dst, dst_sorted, edge_ids, t.in_edge, (int)E, 0, bits_for(N + 1), s));
-    hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, dst_sorted, t.in_ptr);
+    // (keys, values) ping-pong between the halves of the two key arrays: [dst copy | spare] and [edge ids | spare]
+    int32_t *ka = dst_sorted, *kb = dst_sorted + E, *va = edge_ids, *vb = edge_ids + E;   // (each key array holds max(E, T) 8-byte words)
+    hipLaunchKernelGGL(k_iota32, grid(E), dim3(TPB), 0, s, E, va);
+    M3G_HIP_CHECK(hipMemcpyAsync(ka, t.dst, sizeof(int32_t) * E, hipMemcpyDeviceToDevice, s));
+    const int where = prims::radix_sort<int32_t, int32_t>(ka, kb, va, vb, E, 0, bits_for(N + 1), cub_tmp, s);
+    if (where < 0) { set_error("radix sort of the incoming edges failed: %s", hipGetErrorString(hipGetLastError())); return M3G_ERR_HIP; }
+    M3G_HIP_CHECK(hipMemcpyAsync(t.in_edge, where ? vb : va, sizeof(int32_t) * E, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_lower_bound32, grid(N + 1), dim3(TPB), 0, s, N, E, where ? kb : ka, t.in_ptr);
     return M3G_OK;
   };
   if (E > 0) hipLaunchKernelGGL(k_convert_edges, grid(E), dim3(TPB), 0, s, N, E, edge_index, t.src, t.dst, edge_ids, t.flags);
@@ -782,7 +781,7 @@ static int topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int6
   // windows, compacted partner lists, byte-sized partner ids
   auto downstream = [&](bool symmetric, const uint64_t* t1_keys) -> int {
     hipLaunchKernelGGL(k_active_flags, grid(E + 1), dim3(TPB), 0, s, E, t.t1_ptr, t.t2_ptr, t.act_scan);
-    M3G_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, t.act_scan, t.act_scan, (int)(E + 1), s));
+    M3G_HIP_CHECK(prims::exclusive_scan<int32_t>(t.act_scan, t.act_scan, E + 1, cub_tmp, s));
     hipLaunchKernelGGL(k_active_scatter, grid(std::max(E, N) + 1), dim3(TPB), 0, s, N, E, t.t1_ptr, t.t2_ptr, t.act_scan, t.row_ptr, t.dst, t.act_list,
                        t.act_dst, t.act_id, t.arow_ptr, t.n_act);
     hipLaunchKernelGGL(k_tb_windows, grid(E / kTbRows + 1), dim3(TPB), 0, s, E / kTbRows + 1, t.n_act, t.act_list, t.src, t.arow_ptr, t.t1_ptr, t.t2_ptr,
@@ -845,8 +844,9 @@ static int topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int6
       hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, keysA, 0, t.flags, order);
       uint64_t* sorted = keysA;
       if (h[1] & 1) {      // not sorted: radix sort, then rows, partners and the mirror check again
-        M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keysA, keysB, (int)T, 0, 32 + bits_for(E + 1), s));
-        sorted = keysB;
+        const int where = prims::radix_sort<uint64_t, int32_t>(keysA, keysB, nullptr, nullptr, T, 0, 32 + bits_for(E + 1), cub_tmp, s);
+        if (where < 0) { set_error("radix sort of the triplet keys failed: %s", hipGetErrorString(hipGetLastError())); return M3G_ERR_HIP; }
+        sorted = where ? keysB : keysA;
       }
       hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, sorted, t.t1_e2);
       hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, sorted, t.t1_ptr);
@@ -867,8 +867,10 @@ static int topology_build(int64_t N, int64_t E, int64_t T, int64_t S, const int6
       } else {
         uint64_t* other = sorted == keysA ? keysB : keysA;   // the t1 keys are no longer needed
         hipLaunchKernelGGL(k_convert_triplets, grid(T), dim3(TPB), 0, s, E, T, triplet_edge_index, t.src, other, 1, t.flags, order);
-        uint64_t* out = other == keysA ? keysB : keysA;
-        M3G_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, other, out, (int)T, 0, 32 + bits_for(E + 1), s));
+        uint64_t* spare = other == keysA ? keysB : keysA;
+        const int where = prims::radix_sort<uint64_t, int32_t>(other, spare, nullptr, nullptr, T, 0, 32 + bits_for(E + 1), cub_tmp, s);
+        if (where < 0) { set_error("radix sort of the triplet keys failed: %s", hipGetErrorString(hipGetLastError())); return M3G_ERR_HIP; }
+        uint64_t* out = where ? spare : other;
         hipLaunchKernelGGL(k_low_word, grid(T), dim3(TPB), 0, s, T, out, t.t2_e1);
         hipLaunchKernelGGL(k_lower_bound64, grid(E + 1), dim3(TPB), 0, s, E, T, out, t.t2_ptr);
       }

@@ -137,6 +137,8 @@ SYMBOLS = {
                               C.c_void_p]),
     "m3g_topology_data_bytes": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     "m3g_topology_debug_last_path": (C.c_int, [C.POINTER(C.c_int32)]),
+    "m3g_debug_exclusive_scan": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "m3g_debug_radix_sort": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "m3g_count_launches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "m3g_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "m3g_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_float),
