@@ -318,3 +318,29 @@ def test_in_launch_wait_that_runs_out_poisons_the_forces():
     # a generous bound on the real wait changes nothing
     model.engine.set_option("debug_node_tb_polls", 1 << 20)
     assert torch.equal(model(engine_graph(graph))[K.FORCES], f_good)
+
+
+@pytest.mark.parametrize("cells,mode", [((6, 6, 6), 1), ((8, 8, 8), 1), ((5, 5, 5), 2), ((9, 9, 9), 2)])
+def test_split_tail_of_the_persistent_reverse_kernel(cells, mode):
+    """Option split_tail (default 1): the single tile a workgroup of the persistent reverse kernel cannot share out over its four SIMDs
+    goes through the four-way split once its whole tiles are done (rev_split_run inside k_edge_rev_f32).  864 atoms: 9 tiles per
+    workgroup -> 8 whole + 1 split; 2,048 atoms: 21 -> 20 + 1.  Mode 2 (opt-in) also takes two left-over tiles, one per group of four
+    waves: 500 atoms (persistent kernels forced) 6 -> 4 + 2, 2,916 atoms 30 -> 28 + 2.  Forward outputs do not depend on the option;
+    forces and stresses agree with the all-whole-tiles kernel to 1e-5 of their largest component (the split associates dL/dh and dL/dm
+    per wave); every setting deterministic."""
+    from helpers import fcc_cu_graph
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    g0 = fcc_cu_graph(*cells).to("cuda")
+    with_tail = _regime_outputs(_fitted_model(), g0, small_tiles=0, split_tail=mode)
+    whole = _regime_outputs(_fitted_model(), g0, small_tiles=0, split_tail=0)
+    for k in (K.TOTAL_ENERGY, K.SCALED_ATOMIC_ENERGIES, K.NODE_FEATURES, K.EDGE_ATTR, K.MID_EDGE_FEATURES):
+        assert torch.equal(with_tail[k], whole[k]), (cells, k)
+    f_err, s_err = rel_err(with_tail[K.FORCES], whole[K.FORCES]), rel_err(with_tail[K.STRESSES], whole[K.STRESSES])
+    assert 0.0 < f_err < 1e-5 and s_err < 1e-5, (cells, f_err, s_err)   # (> 0: the tail really ran)
+    again = _regime_outputs(_fitted_model(), g0, small_tiles=0, split_tail=mode)
+    assert torch.equal(again[K.FORCES], with_tail[K.FORCES]) and torch.equal(again[K.STRESSES], with_tail[K.STRESSES])
+    import os
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/small_vs_large_margins.txt", "a") as fh:
+            fh.write(f"split tail, {4 * cells[0] ** 3} atoms: forward bit-identical; F {f_err:.2e} of max|F|, stress {s_err:.2e}\n")

@@ -20,6 +20,8 @@ if os.environ.get("M3G_SMALL_TILES"):   # threshold of the split-tile edge kerne
     model.engine.set_option("small_tiles", int(os.environ["M3G_SMALL_TILES"]))
 if os.environ.get("M3G_SMALL_TILES_FWD"):   # ... of the forward kernel alone
     model.engine.set_option("small_tiles_fwd", int(os.environ["M3G_SMALL_TILES_FWD"]))
+for opt in filter(None, os.environ.get("M3G_ENGINE_OPTIONS", "").split(",")):   # e.g. split_tail=0
+    model.engine.set_option(opt.split("=")[0], int(opt.split("=")[1]))
 for n in ([int(v) for v in sys.argv[2:]] or (2, 3, 4, 6, 8, 10)):
     g = fcc_cu_graph(n, n, n).to("cuda")
     for _ in range(40):   # (the host-side graph build in front of this leaves the GPU idle: 5 warm-up steps were not enough for its clocks)

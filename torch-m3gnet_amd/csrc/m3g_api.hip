@@ -400,6 +400,12 @@ extern "C" int m3g_plan_set_option(m3g_plan* plan, const char* name, int32_t val
     drop_graphs(plan);
     return M3G_OK;
   }
+  if (strcmp(name, "split_tail") == 0) {   // 0: the persistent reverse kernel runs every tile whole (A/B tests; forward outputs bit-identical either way)
+    if (value < 0 || value > 2) { set_error("split_tail must be 0 (never), 1 (a single left-over tile) or 2 (one or two)"); return M3G_ERR_VALUE; }
+    plan->split_tail = value;
+    drop_graphs(plan);
+    return M3G_OK;
+  }
   if (strcmp(name, "small_launches") == 0) {   // 0: never fuse the small-system launches (A/B tests; results are bit-identical either way)
     plan->small_launches = value != 0;
     drop_graphs(plan);

@@ -523,6 +523,7 @@ struct RevArgs {
   float w_inv;          // f16x3 mode: 1 / the model's weight scale (plan->w_scale_inv), else 1
   float* dp1_scale;     // f16x3 fused kernel: [E][4] inverse scales (x 2^-9) of the 24-bit fixed-point dp1 rows (pack24_fixed)
   const int32_t* in_pos;   // fp32 fused kernels: row of edge e in the dp1 array = in_pos[e] (Topo::in_pos); nullptr: row = e
+  int split_tail;          // k_edge_rev_f32: the tiles a workgroup cannot share out evenly over its SIMDs go through the four-way split (option "split_tail")
 };
 
 // x summed over the four lane quarters (lanes l, l^16, l^32, l^48), result in every lane.  v_permlane16/32_swap

@@ -15,6 +15,7 @@
 //     the rows themselves leave as fp32 (this mode keeps every hand-over in fp32).
 // One persistent workgroup per CU, waves pull 16-edge tiles from an LDS counter (TileQueue); XCD-aware chunking.
 #include "m3g_edge_common.h"
+#include "m3g_edge_split_rev.h"
 
 namespace m3g {
 
@@ -160,15 +161,25 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
   load_image(lds, a.img, kRevF32Floats, q_head);
   const int lane = threadIdx.x & 63, qd = lane >> 4;
   TileQueue queue(a.tiles, q_head);
+  // The tail.  A workgroup's `count` tiles go to 4 SIMDs as whole tiles, so count mod 4 = 1 ends with ONE SIMD running a whole tile
+  // (12 us) while the other three idle -- at 2-10 tiles per SIMD (cells of 500 - 4,000 atoms) that is 5-15 % of the launch.  That tile
+  // is taken out of the queue and worked on by four waves, one per SIMD, once the whole tiles are done (rev_split_run, the body of the
+  // small-system kernel: ~8 us).  Measured (profiles/r06_split_tail_sweep.txt): 864 atoms 0.389 -> 0.377 ms per step, 2,048 atoms
+  // 0.629 -> 0.614, 2,916 atoms 0.827 -> 0.820; sizes whose count mod 4 is not 1 unchanged.  split_tail = 2 also takes count mod 4 = 2
+  // (two tiles, both groups of four waves): a gain of 20-27 us per step at 30 tiles per workgroup (2,916 atoms, BASELINE config 5) but a
+  // loss of as much at 6 and at 42 -- the pair has to wait for the slowest whole-tile wave, and two SIMDs' worth of work gains little
+  // from four -- so the default is 1.
+  int tail = 0;
+  if constexpr (SAVED_P2 && WAVES == 8) tail = (queue.count & 3) >= 1 && (queue.count & 3) <= a.split_tail ? (queue.count & 3) : 0;   // split_tail: 0 never, 1: one tile, 2: one or two
+  const int count_a = queue.count - tail;
   int ticket = queue.fetch(lane);
-  if (ticket >= queue.count) return;
-  int ci_i, cj_i;
-  load_ends(a.src, nullptr, queue.base + ticket, a.E, lane, ci_i, cj_i);
+  int ci_i = 0, cj_i;
+  if (ticket < count_a) load_ends(a.src, nullptr, queue.base + ticket, a.E, lane, ci_i, cj_i);
   constexpr bool FIRST = !NEED_DP1;   // block 0: its input is the edge embedding e0 = SiLU(W_adj h), reversed here
-  for (;;) {
+  while (ticket < count_a) {
     const int64_t tile = queue.base + ticket;
     ticket = queue.fetch(lane);  // next tile's ticket and centre atoms one tile ahead
-    const bool has_next = ticket < queue.count;
+    const bool has_next = ticket < count_a;
     int nci = 0, ncj = 0;
     if (has_next) load_ends(a.src, nullptr, queue.base + ticket, a.E, lane, nci, ncj);
     int lv = lane;               // opaque per tile: keeps the loop-invariant LDS weight reads inside the loop
@@ -258,8 +269,14 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
     chain_f32<1, 8>(lds + L.tbT, d8, dmv, lv);
     store_dh(a.dh, edge, a.E, dhv, qd);
     if (edge < a.E && arow >= 0) *(f32x4*)(a.dm + (int64_t)arow * kCP + 4 * qd) = dmv[0];
-    if (!has_next) break;
     ci_i = nci;
+  }
+  if constexpr (SAVED_P2 && WAVES == 8) {
+    if (tail) {   // (uniform over the workgroup.  The weight image in LDS is dead once every wave has left the loop above: rev_split_run's
+                  //  first barrier; its exchange buffers then take the image's place)
+      const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+      rev_split_run<TBS, NEED_DP1>(a, L, lds /* the operands come from the LDS copy of the image */, lds, 2, wave >> 2, wave & 3, lane, queue.base + count_a + (wave >> 2), queue.base + queue.count, 2);
+    }
   }
 }
 
@@ -273,7 +290,8 @@ void launch_edge_rev_f32(const m3g_plan* plan, const Consts& c, const Topo& t, c
   const float* img = plan->d_mfma_revf32 + (size_t)b * L.total;
   RevArgs ar{t.E, tiles, img, t.src, t.dst, w.h, w.m[b], dx_new, t.act_id, nullptr, nullptr, nullptr, nullptr, w.de_soa, nullptr,
              de_is_zero ? 1 : 0, w.dm, w.dh_parts + (size_t)b * t.E * kRP, w.dp1, nullptr, w.seg_head, w.seg_first, w.p1_blk[b],
-             saves_p2(plan) ? w.p2_blk[b] : nullptr, 1.f, nullptr, dp1_rows_by_dst(plan) ? t.in_pos : nullptr};
+             saves_p2(plan) ? w.p2_blk[b] : nullptr, 1.f, nullptr, dp1_rows_by_dst(plan) ? t.in_pos : nullptr, plan->split_tail};
+  static_assert(2 * kRevSplitGroupFloats + kRevSplitTabFloats <= kRevF32Floats, "the split tail's exchange buffers must fit in the image's LDS");
   constexpr int WV = kWavesRevF32;
   dim3 grid(grid_for_tiles(tiles, WV)), block(64 * WV);
   const bool p2 = saves_p2(plan);

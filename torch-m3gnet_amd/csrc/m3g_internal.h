@@ -224,6 +224,7 @@ struct m3g_plan {
   int fuse_node_tb = 1;          // option "fuse_node_tb": three-body reverse (moment path) + node reverse of a block as two workgroup roles of
                                  // one launch (k_node_tb_reverse, m3g_threebody.hip)
   int debug_node_tb_polls = 0;   // option "debug_node_tb_polls" (tests): see launch_node_tb_reverse
+  int split_tail = 1;            // option "split_tail": see k_edge_rev_f32 (the tiles of a workgroup's last, part-filled round through the four-way split)
   int small_launches = 1;        // option "small_launches": small systems take fused launches (force tail, readout + energy sums, ...)
   int rev_kernel = 1;            // MFMA path: 1 = fused reverse kernel per block, 0 = node-MLP + edge-MLP kernel pair
   bool readout_f16 = false; // option "readout_f16": the readout layers on scaled two-part fp16 chains in the f16x3 mode (5 us faster at 10,000
