@@ -102,8 +102,8 @@ FLOPS_RATIO_NOTE = ("flops_8d / flops_useful = 2: SURVEY.md 8(d) counts W1 [x_i 
                     "per atom and block, 42 x fewer rows than edges)")
 BYTES_8D_PER_STEP = lambda E, T, N: 4008 * E + 48 * T + 3504 * N   # noqa: E731  SURVEY.md 8(d), D = 64, B = 3
 PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16 MFMA peak (same rate as bf16)
-PMC_SQ_FILE = "r05_pmc_sq_counters.json"        # profiles/: per-kernel SQ counters (tools/pmc_sq_json.py), stamped like the traffic set
-PMC_TRAFFIC_FILE = "r05_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py), stamped with
+PMC_SQ_FILE = "r06_pmc_sq_counters.json"        # profiles/: per-kernel SQ counters (tools/pmc_sq_json.py), stamped like the traffic set
+PMC_TRAFFIC_FILE = "r06_pmc_hbm_traffic.json"   # profiles/: per-kernel FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py), stamped with
                                                 # the digest of the kernel sources it was collected on
 DEFAULT_PRECISION = "fp32"   # the reference's arithmetic (fp32 end to end): the headline `value` / `dtype` / `roofline`
 DTYPE = {"fp32": "f32",
@@ -812,7 +812,7 @@ def main():
     roofline, others, stage_ms, step_bytes, launches = record(args.precision, ms_per_step)
     roofline["formula"] = ("achieved = algorithmic_flops (fp32) or executed_mfma_flops (split modes) / avg_launch_ms; frac = achieved / peak; "
                            "avg_launch_ms = HIP events around the kernel's launches on the launch stream, inside the library (m3g_profile_*), "
-                           "which the rocprofv3 average of profiles/r05_<mode>_kernel_stats.csv must agree with")
+                           "which the rocprofv3 average of profiles/r06_<mode>_kernel_stats.csv must agree with")
     clk = (timing.get("clock_mhz") or {}).get("median")
     if clk:   # the peaks of MI355X_MICROARCH.md are quoted at 2,400 MHz; the card holds less under this load
         roofline["frac_at_measured_clock"] = roofline["frac"] * 2400.0 / clk

@@ -260,6 +260,9 @@ struct TileQueue {
     return __builtin_amdgcn_readfirstlane(v);
   }
 };
+// (Round 6, measured and dropped: the final PART round of a workgroup handed out statically, tile j to wave j, so that its tiles land on
+//  different SIMDs -- 1,372 atoms -4 us per step, but 4,000 / 5,324 / 6,912 atoms +15 .. +40 us and the 10,000-atom reverse kernel +2 %:
+//  the dynamic counter gives the last tiles to the waves that finish FIRST, which matters more than which SIMD they sit on.)
 
 // streamed-once tile loads: nontemporal, so they do not evict the node tables the gathers re-use from L2
 // (forward 0.425 -> 0.418 ms, fused reverse 0.892 -> 0.884 per step)

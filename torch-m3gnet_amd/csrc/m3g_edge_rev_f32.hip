@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
   int tail = 0;
   if constexpr (SAVED_P2 && WAVES == 8) tail = (queue.count & 3) >= 1 && (queue.count & 3) <= a.split_tail ? (queue.count & 3) : 0;   // split_tail: 0 never, 1: one tile, 2: one or two
   const int count_a = queue.count - tail;
+  const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int ticket = queue.fetch(lane);
   int ci_i = 0, cj_i;
   if (ticket < count_a) load_ends(a.src, nullptr, queue.base + ticket, a.E, lane, ci_i, cj_i);
@@ -274,8 +275,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_edge_rev_f32(RevArgs a, MfmaRevF
   if constexpr (SAVED_P2 && WAVES == 8) {
     if (tail) {   // (uniform over the workgroup.  The weight image in LDS is dead once every wave has left the loop above: rev_split_run's
                   //  first barrier; its exchange buffers then take the image's place)
-      const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-      rev_split_run<TBS, NEED_DP1>(a, L, lds /* the operands come from the LDS copy of the image */, lds, 2, wave >> 2, wave & 3, lane, queue.base + count_a + (wave >> 2), queue.base + queue.count, 2);
+      rev_split_run<TBS, NEED_DP1>(a, L, lds /* the operands come from the LDS copy of the image */, lds, 2, wave_id >> 2, wave_id & 3, lane,
+                                   queue.base + count_a + (wave_id >> 2), queue.base + queue.count, 2);
     }
   }
 }
