@@ -233,8 +233,8 @@ def cpu_baseline(cells=(10, 10, 25), steps=3):
     rec["threads_1"] = {"value": n / dt1, "unit": "atom-steps/s", "cores": 1, "ms_per_step": dt1 * 1e3}
     rec["threads_all"] = {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "ms_per_step": dt * 1e3}   # (= `value`; named for the record)
     rec["sample"] = (f"the headline workload itself: {n}-atom fcc Cu supercell ({'x'.join(map(str, cells))} cells), fp32, {steps} timed steps after 1 warm-up at "
-                     f"{cores} threads = all physical cores of the host this process may use ({dt * 1e3:.0f} ms/step), then 1 timed step at 16 threads"
-                     f"{' (%.0f ms/step)' % rec['threads_16']['ms_per_step'] if 'threads_16' in rec else ''} and 1 at 1 thread ({dt1 * 1e3:.0f} ms/step), "
+                     f"{cores} threads = all physical cores of the host this process may use ({dt * 1e3:.0f} ms/step), then "
+                     f"{'1 timed step at 16 threads (%.0f ms/step) and ' % rec['threads_16']['ms_per_step'] if 'threads_16' in rec else ''}1 timed step at 1 thread ({dt1 * 1e3:.0f} ms/step), "
                      f"torch {torch.__version__} CPU")
     return rec
 

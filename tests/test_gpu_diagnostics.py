@@ -64,3 +64,32 @@ def test_readout_f16_option_agrees_with_the_exact_readout():
     assert float((f1 - f0).abs().max() / f0.abs().max()) < 1e-5
     out = model(g)
     assert torch.equal(out[K.FORCES], f0)
+
+
+def test_launch_count_comes_from_a_capture_of_the_unprofiled_call():
+    """m3g_count_launches (what bench.py reports as kernel_launches_per_step): the launch sequence of ONE m3g_energy_forces call is
+    captured on a stream of the library's own -- nothing executes, no buffer is touched -- and its nodes are counted.  The counted call
+    and the calls around it return identical bits; the 32-atom cell takes the 17 launches of DESIGN.md section 2a, an energy-only call
+    fewer, and the stage profiler (which runs a slightly different sequence) does not disturb the count."""
+    import torch
+
+    from helpers import build_engine_model, engine_graph, load_oracle_case
+    from torch_m3gnet.data import MaterialGraphKey as K
+
+    model, _ = build_engine_model("cu32fit", "doc")
+    _, _, _, graph, _ = load_oracle_case("cu32fit", "doc")
+    g = engine_graph(graph)
+    before = {k: model(g, extras=False)[k].clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES)}
+    kernels, other = model.engine.count_launches(lambda: model(g, extras=False))
+    during = {k: g[k].clone() for k in before}
+    after = {k: model(g, extras=False)[k].clone() for k in before}
+    for k in before:
+        assert torch.equal(before[k], during[k]) and torch.equal(before[k], after[k]), k
+    assert kernels == 17 and other == 0, (kernels, other)
+    k_energy, _ = model.engine.count_launches(lambda: model(g, forces=False, extras=False))
+    assert 0 < k_energy < kernels
+    model.engine.profile(True)
+    try:
+        assert model.engine.count_launches(lambda: model(g, extras=False)) == (kernels, other)
+    finally:
+        model.engine.profile(False)
