@@ -77,6 +77,7 @@ def test_launch_count_comes_from_a_capture_of_the_unprofiled_call():
     from torch_m3gnet.data import MaterialGraphKey as K
 
     model, _ = build_engine_model("cu32fit", "doc")
+    model.engine.set_precision("fp32")   # (the count below is the exact-fp32 sequence's, whatever M3G_PRECISION says)
     _, _, _, graph, _ = load_oracle_case("cu32fit", "doc")
     g = engine_graph(graph)
     before = {k: model(g, extras=False)[k].clone() for k in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES)}
