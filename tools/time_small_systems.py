@@ -22,8 +22,13 @@ if os.environ.get("M3G_SMALL_TILES_FWD"):   # ... of the forward kernel alone
     model.engine.set_option("small_tiles_fwd", int(os.environ["M3G_SMALL_TILES_FWD"]))
 for opt in filter(None, os.environ.get("M3G_ENGINE_OPTIONS", "").split(",")):   # e.g. split_tail=0
     model.engine.set_option(opt.split("=")[0], int(opt.split("=")[1]))
-for n in ([int(v) for v in sys.argv[2:]] or (2, 3, 4, 6, 8, 10)):
-    g = fcc_cu_graph(n, n, n).to("cuda")
+def _cells(tok):   # "6" -> (6, 6, 6); "6,7,8" -> (6, 7, 8)
+    v = [int(x) for x in str(tok).split(",")]
+    return tuple(v) if len(v) == 3 else (v[0],) * 3
+
+
+for cells in ([_cells(v) for v in sys.argv[2:]] or [(n,) * 3 for n in (2, 3, 4, 6, 8, 10)]):
+    g = fcc_cu_graph(*cells).to("cuda")
     for _ in range(40):   # (the host-side graph build in front of this leaves the GPU idle: 5 warm-up steps were not enough for its clocks)
         model(g, forces=True, extras=False)
     torch.cuda.synchronize()
@@ -33,5 +38,5 @@ for n in ([int(v) for v in sys.argv[2:]] or (2, 3, 4, 6, 8, 10)):
         model(g, forces=True, extras=False)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    atoms = 4 * n ** 3
+    atoms = 4 * cells[0] * cells[1] * cells[2]
     print(f"{atoms:6d} atoms  {int(g['edge_index'].shape[1]):8d} edges: {ms:.3f} ms/step = {atoms / ms * 1e3 / 1e6:.3f} M atom-steps/s", flush=True)
