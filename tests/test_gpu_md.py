@@ -511,3 +511,32 @@ def test_evaluate_after_step_after_speculative_evaluates_on_one_object():
     both("step")
     pos = pos + rng.normal(0.0, 0.05, pos.shape)  # and one with the lists changed
     both("evaluate")
+
+
+def test_trajectory_step_reports_sticky_error_bits_of_the_previous_step():
+    """m3g_md_step reads the sticky error word of its topology buffer behind the wait for the skin test's verdict (the word rides to
+    pinned host memory with the fp32 copy of the positions): a step whose in-launch wait ran out (forced: option
+    debug_node_tb_polls < 0 -> forces NaN + M3G_TOPO_ERR_SYNC) makes the NEXT step fail with M3G_ERR_STATE instead of handing out more
+    numbers from that buffer; the step after that re-derives lists and topology (which clears the word) and is clean again."""
+    from torch_m3gnet.data.md import VerletGraph
+
+    K = _K()
+    model = _model()
+    lat, p0, z = random_cell_arrays(40, 8.0, seed=11)   # <= 128 atoms: the node + three-body reverse of a block share a launch
+    vg = VerletGraph([lat], [z], 5.0, 4.0, skin=0.6, device=DEV)
+    ref = VerletGraph([lat], [z], 5.0, 4.0, skin=0.6, device=DEV)
+    pos = torch.tensor(p0, device=DEV)
+    good = vg.step(model, pos)
+    assert torch.isfinite(good[K.FORCES]).all()
+    model.engine.set_option("debug_node_tb_polls", -64)
+    try:
+        bad = vg.step(model, pos)                      # standing lists: the same topology buffer
+        assert torch.isnan(bad[K.FORCES]).any()        # loud already: the term that was waited for is NaN
+    finally:
+        model.engine.set_option("debug_node_tb_polls", 0)
+    with pytest.raises(RuntimeError, match="error bits"):
+        vg.step(model, pos)
+    again = vg.step(model, pos)                        # lists and topology re-derived: clean
+    want = model(ref.update(pos), extras=False)
+    for key in (K.TOTAL_ENERGY, K.FORCES, K.STRESSES):
+        assert torch.equal(again[key], want[key]), key
