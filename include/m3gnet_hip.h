@@ -419,7 +419,12 @@ void m3g_md_destroy(m3g_md* md);
 int m3g_md_set_lists(m3g_md* md, const m3g_md_lists* lists);
 int m3g_md_invalidate(m3g_md* md);   /* the caller has rewritten cand_state / the list buffers through other calls: re-derive at the next step */
 /* pos: [N,3] fp64 device positions (unwrapped).  forces / stresses may be NULL (energies only).  force_refill != 0: re-derive the
- * lists whatever the verdict says (tests, timing).  Waits for `stream` (verdict) -- the outputs are queued, not waited for. */
+ * lists whatever the verdict says (tests, timing).  Waits for `stream` (verdict) -- the outputs are queued, not waited for.
+ * Behind that one wait the call also learns (ABI 6): whether atom_types lies in [0, num_types) of `plan` -- checked once per list set
+ * and model; M3G_ERR_VALUE otherwise, as the reference raises IndexError (nn/atom_ref.py:25-29) -- and whether an EARLIER step left
+ * sticky error bits on the topology buffer (M3G_TOPO_ERR_*): M3G_ERR_STATE, nothing evaluated, the next call re-derives lists and
+ * topology.  M3G_MD_UNSUPPORTED also answers a workspace that has become too small for the plan's current options (the caller makes
+ * buffers again).  cand_state and the list buffers may be NULL when n_cand == 0. */
 int m3g_md_step(m3g_md* md, const m3g_plan* plan, const double* pos, float* total_energy, float* forces, float* stresses,
                 int32_t force_refill, m3g_md_result* host_result, void* stream);
 

@@ -1205,9 +1205,12 @@ extern "C" int m3g_debug_radix_sort(int32_t key_bytes, int64_t n, void* keys, in
   }
   if (n == 0) return M3G_OK;
   void *tmp = nullptr, *kb = nullptr, *vb = nullptr;
-  M3G_HIP_CHECK(hipMalloc(&tmp, prims::sort_tmp_bytes(n)));
-  M3G_HIP_CHECK(hipMalloc(&kb, (size_t)n * key_bytes));
-  if (vals) M3G_HIP_CHECK(hipMalloc(&vb, (size_t)n * sizeof(int32_t)));
+  if (hipMalloc(&tmp, prims::sort_tmp_bytes(n)) != hipSuccess || hipMalloc(&kb, (size_t)n * key_bytes) != hipSuccess ||
+      (vals && hipMalloc(&vb, (size_t)n * sizeof(int32_t)) != hipSuccess)) {
+    (void)hipFree(tmp); (void)hipFree(kb); (void)hipFree(vb);
+    set_error("m3g_debug_radix_sort: out of device memory");
+    return M3G_ERR_HIP;
+  }
   const int where = key_bytes == 4 ? prims::radix_sort<uint32_t, int32_t>((uint32_t*)keys, (uint32_t*)kb, vals, (int32_t*)vb, n, begin_bit, end_bit, tmp, s)
                                    : prims::radix_sort<uint64_t, int32_t>((uint64_t*)keys, (uint64_t*)kb, vals, (int32_t*)vb, n, begin_bit, end_bit, tmp, s);
   hipError_t e = where < 0 ? hipErrorUnknown : hipSuccess;
